@@ -1,0 +1,642 @@
+// libcude_hip.so -- host side of the C ABI declared in include/cude.h.
+// Owns the device-resident population (subject-major SoA), the solver tables, the HIP stream,
+// and (optionally) an RCCL communicator for the one all-reduce per optimiser step.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/cude.h"
+#include "cude_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int32_t fail(int32_t code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(CUDE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+// ---------------------------------------------------------------------------------- solver tables
+const double TA7[6] = {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+                       2.324710524099774};
+const double TC[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+const double TR[7][4] = {{1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
+                         {0.0, 0.13169999999999998, -0.2234, 0.1017},
+                         {0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253},
+                         {0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902},
+                         {0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928},
+                         {0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661},
+                         {0.0, 1.5, -4.0, 2.5}};
+
+void interp_weights(double th, double* w) {
+    if (std::fabs(th - 1.0) < 1e-12) {
+        for (int j = 0; j < 6; j++) w[j] = TA7[j];
+        w[6] = 0.0;
+        return;
+    }
+    for (int i = 0; i < 7; i++) w[i] = ((TR[i][3] * th + TR[i][2]) * th + TR[i][1]) * th * th + TR[i][0] * th;
+}
+
+// observation tau lies in step n with t_n < tau <= t_{n+1}  (tau = t_0 -> step 0, theta 0)
+void locate_obs(const std::vector<double>& tp, int S, std::vector<int32_t>& step, std::vector<double>& w) {
+    const int T = (int)tp.size();
+    const double t0 = tp[0], h = (tp[T - 1] - tp[0]) / S;
+    step.resize(T);
+    w.resize((size_t)T * 7);
+    for (int i = 0; i < T; i++) {
+        const double x = (tp[i] - t0) / h;
+        int n = (int)std::ceil(x - 1e-9) - 1;
+        if (n < 0) n = 0;
+        if (n > S - 1) n = S - 1;
+        step[i] = n;
+        interp_weights((tp[i] - (t0 + n * h)) / h, &w[(size_t)i * 7]);
+    }
+}
+
+// glucose segment + fraction for the 5 distinct stage times of every step (c2..c5 and 1)
+void glucose_tables(const std::vector<double>& tp, int S, std::vector<int32_t>& seg, std::vector<double>& phi) {
+    const int T = (int)tp.size();
+    const double t0 = tp[0], h = (tp[T - 1] - tp[0]) / S;
+    seg.resize((size_t)S * 5);
+    phi.resize((size_t)S * 5);
+    for (int n = 0; n < S; n++) {
+        for (int s = 0; s < 5; s++) {
+            const double t = (s < 4) ? (t0 + n * h) + TC[s + 1] * h : t0 + (n + 1) * h;
+            int j = 0;
+            while (j + 1 < T && tp[j + 1] <= t) j++;
+            if (j > T - 2) j = T - 2;
+            seg[(size_t)n * 5 + s] = j;
+            phi[(size_t)n * 5 + s] = (t - tp[j]) / (tp[j + 1] - tp[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- RCCL (dlopen)
+typedef struct { char internal[CUDE_UNIQUE_ID_BYTES]; } nccl_uid;
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(nccl_uid*) = nullptr;
+    int (*CommInitRank)(void**, int, nccl_uid, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int32_t load_rccl() {
+    if (g_rccl.handle) return CUDE_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {   // reuse a copy already in the process (e.g. PyTorch's) first
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+    }
+    if (!h)
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+    if (!h) return fail(CUDE_ERR_COMM, std::string("cannot load librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (int (*)(nccl_uid*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, nccl_uid, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce =
+        (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(CUDE_ERR_COMM, "librccl lacks a required symbol");
+    g_rccl.handle = h;
+    return CUDE_OK;
+}
+
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        int _r = (expr);                                                                           \
+        if (_r != 0)                                                                               \
+            return fail(CUDE_ERR_COMM, std::string(#expr) + ": " +                                 \
+                                           (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t resize(size_t count) {
+        if (count == n) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+struct cude_ctx {
+    cude_config cfg;
+    cude::NetShape net;
+    int P = 0;
+    hipStream_t stream = nullptr;
+    int64_t N = 0;          // local subjects
+    double n_global = 0;    // subjects over all ranks
+    int T = 0;
+    std::vector<double> tp;
+    bool have_pop = false, have_nn = false, have_cond = false;
+    // population (CPEP)
+    DevBuf<double> k0, k1, k2, c0, dG, obs, age;
+    // population (SUPP)
+    DevBuf<double> data, ckpt;
+    double scale[3] = {1, 1, 1};
+    // tables
+    DevBuf<int32_t> seg, obs_step;
+    DevBuf<double> phi, obs_w;
+    // parameters / gradients / optimiser
+    DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;
+    DevBuf<double> m_nn, v_nn, m_cond, v_cond;
+    int64_t nblocks = 0;
+    double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    int64_t adam_t = 0;
+    bool adam_ready = false;
+    int64_t last_failed = 0;
+    // comm
+    void* comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    // timing of the dominant kernel
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double host_red[3];
+};
+
+namespace {
+
+int32_t bind(cude_ctx* c) {
+    if (!c) return fail(CUDE_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return CUDE_OK;
+}
+
+int32_t allreduce_dev(cude_ctx* c, double* buf, size_t count) {
+    if (!c->comm) return CUDE_OK;
+    RCCL_TRY(g_rccl.AllReduce(buf, buf, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
+    return CUDE_OK;
+}
+
+int32_t alloc_common(cude_ctx* c) {
+    const int64_t N = c->N;
+    c->nblocks = (N + cude::kBlock - 1) / cude::kBlock;
+    HIP_TRY(c->cond.resize(N));
+    HIP_TRY(c->g_cond.resize(N));
+    HIP_TRY(c->sse.resize(N));
+    HIP_TRY(c->partials.resize((size_t)c->nblocks * (c->P + 2)));
+    HIP_TRY(c->m_cond.resize(N));
+    HIP_TRY(c->v_cond.resize(N));
+    HIP_TRY(hipMemsetAsync(c->cond.p, 0, N * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->m_cond.p, 0, N * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->v_cond.p, 0, N * sizeof(double), c->stream));
+    c->have_cond = false;
+    c->adam_t = 0;
+    return CUDE_OK;
+}
+
+int32_t upload_tables(cude_ctx* c, bool glucose) {
+    std::vector<int32_t> step;
+    std::vector<double> w;
+    locate_obs(c->tp, c->cfg.n_steps, step, w);
+    HIP_TRY(c->obs_step.resize(step.size()));
+    HIP_TRY(c->obs_w.resize(w.size()));
+    HIP_TRY(hipMemcpyAsync(c->obs_step.p, step.data(), step.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->obs_w.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (glucose) {
+        std::vector<int32_t> seg;
+        std::vector<double> phi;
+        glucose_tables(c->tp, c->cfg.n_steps, seg, phi);
+        HIP_TRY(c->seg.resize(seg.size()));
+        HIP_TRY(c->phi.resize(phi.size()));
+        HIP_TRY(hipMemcpyAsync(c->seg.p, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->phi.p, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));   // host vectors die here
+    return CUDE_OK;
+}
+
+int32_t check_times(int32_t n_obs, const double* tp) {
+    if (n_obs < 2 || n_obs > cude::kMaxObs) return fail(CUDE_ERR_ARG, "n_obs must be in [2, 32]");
+    for (int t = 1; t < n_obs; t++)
+        if (!(tp[t] > tp[t - 1])) return fail(CUDE_ERR_ARG, "timepoints must be strictly increasing");
+    return CUDE_OK;
+}
+
+// launches the ensemble kernel + second-stage reduction (+ all-reduce, + L2 term)
+int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev) {
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (!c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "parameters not set");
+    const int S = c->cfg.n_steps;
+    const double h = (c->tp.back() - c->tp.front()) / S;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing && grad) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            c->ev_pool.emplace_back(a, b);
+        }
+        e0 = c->ev_pool[c->ev_used].first;
+        e1 = c->ev_pool[c->ev_used].second;
+        c->ev_used++;
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    if (c->cfg.model == CUDE_MODEL_CPEP) {
+        cude::CpepArgs a{};
+        a.N = c->N;
+        a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
+        a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+        a.cond = c->cond.p; a.nn = c->nn.p;
+        a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+        a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+        a.sse = c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
+        a.g_cond = c->g_cond.p; a.partials = c->partials.p;
+        HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, grad, a, c->stream));
+    } else {
+        cude::SuppArgs a{};
+        a.N = c->N;
+        a.data = c->data.p; a.cond = c->cond.p; a.nn = c->nn.p;
+        a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+        a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+        for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+        a.ckpt = c->ckpt.p; a.sse = c->sse.p; a.traj = traj_dev;
+        a.g_cond = c->g_cond.p; a.partials = c->partials.p;
+        HIP_TRY(cude::launch_supp(c->net, grad, a, c->stream));
+    }
+    if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+    const int P = c->P;
+    if (grad) HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream));
+    else HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+    if (c->comm) {
+        int32_t rc = grad ? allreduce_dev(c, c->g_nn.p, P + 2) : allreduce_dev(c, c->g_nn.p + P, 2);
+        if (rc) return rc;
+    }
+    if (c->cfg.lambda != 0.0) {
+        if (!grad) HIP_TRY(hipMemsetAsync(c->g_nn.p, 0, P * sizeof(double), c->stream));
+        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream));
+    }
+    return CUDE_OK;
+}
+
+// copies [loss_sum, n_failed] (and optionally g_nn) back and forms the reference's loss value
+int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
+    const int P = c->P;
+    std::vector<double> tmp(P + 2);
+    if (g_nn_host) {
+        HIP_TRY(hipMemcpyAsync(tmp.data(), c->g_nn.p, (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(tmp.data() + P, c->g_nn.p + P, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_failed = (int64_t)std::llround(tmp[P + 1]);
+    if (g_nn_host) std::memcpy(g_nn_host, tmp.data(), P * sizeof(double));
+    if (loss) *loss = (c->last_failed > 0 || !std::isfinite(tmp[P])) ? std::numeric_limits<double>::infinity()
+                                                                     : tmp[P] / c->n_global;
+    return CUDE_OK;
+}
+
+}  // namespace
+
+// =============================================================================== exported ABI
+extern "C" {
+
+const char* cude_last_error(void) { return g_err.c_str(); }
+
+int32_t cude_device_count(int32_t* count) {
+    if (!count) return fail(CUDE_ERR_ARG, "null count");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    *count = n;
+    return CUDE_OK;
+}
+
+int32_t cude_n_params(int32_t nn_in, int32_t nn_width, int32_t nn_depth) {
+    if (nn_in < 1 || nn_width < 1 || nn_depth < 1) return fail(CUDE_ERR_ARG, "bad network shape");
+    cude::NetShape n{nn_in, nn_width, nn_depth};
+    return n.n_params();
+}
+
+int32_t cude_create(const cude_config* cfg, cude_ctx** out) {
+    if (!cfg || !out) return fail(CUDE_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->n_steps < 1 || cfg->n_steps > 100000) return fail(CUDE_ERR_ARG, "n_steps out of range");
+    if (cfg->nn_in < 1 || cfg->nn_width < 1 || cfg->nn_depth < 1) return fail(CUDE_ERR_ARG, "bad network shape");
+    cude::NetShape net{cfg->nn_in, cfg->nn_width, cfg->nn_depth};
+    if (cfg->model == CUDE_MODEL_CPEP) {
+        if (!cude::cpep_shape_supported(net, cfg->n_state))
+            return fail(CUDE_ERR_UNSUPPORTED, "c-peptide kernel not compiled for this (nn_in,width,depth,n_state)");
+    } else if (cfg->model == CUDE_MODEL_SUPP) {
+        if (cfg->n_state != 3 || !cude::supp_shape_supported(net))
+            return fail(CUDE_ERR_UNSUPPORTED, "suppression kernel not compiled for this (width,depth)");
+    } else {
+        return fail(CUDE_ERR_ARG, "unknown model id");
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(CUDE_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+    cude_ctx* c = new (std::nothrow) cude_ctx();
+    if (!c) return fail(CUDE_ERR_ARG, "out of host memory");
+    c->cfg = *cfg;
+    c->net = net;
+    c->P = net.n_params();
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(CUDE_ERR_HIP, hipGetErrorString(e)); }
+    const int P = c->P;
+    if (c->nn.resize(P) || c->g_nn.resize(P + 2) || c->m_nn.resize(P) || c->v_nn.resize(P)) {
+        cude_destroy(c);
+        return fail(CUDE_ERR_HIP, "hipMalloc failed");
+    }
+    (void)hipMemsetAsync(c->g_nn.p, 0, (P + 2) * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->m_nn.p, 0, P * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->v_nn.p, 0, P * sizeof(double), c->stream);
+    *out = c;
+    return CUDE_OK;
+}
+
+int32_t cude_destroy(cude_ctx* c) {
+    if (!c) return CUDE_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return CUDE_OK;
+}
+
+int32_t cude_set_population_cpep(cude_ctx* c, int64_t N, int32_t n_obs, const double* timepoints,
+                                 const double* glucose, const double* cpeptide, int64_t ld_subject, int64_t ld_time,
+                                 const double* age, const uint8_t* t2dm) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (c->cfg.model != CUDE_MODEL_CPEP) return fail(CUDE_ERR_STATE, "context is not a c-peptide model");
+    if (N < 1 || !timepoints || !glucose || !cpeptide || !age || !t2dm) return fail(CUDE_ERR_ARG, "null/empty input");
+    if ((rc = check_times(n_obs, timepoints))) return rc;
+    const int T = n_obs;
+    c->have_pop = false;
+    c->N = N;
+    c->T = T;
+    c->tp.assign(timepoints, timepoints + T);
+    // stage as [T][N] (subject fastest) so every device access is coalesced
+    std::vector<double> g((size_t)T * N), cp((size_t)T * N);
+    for (int t = 0; t < T; t++)
+        for (int64_t i = 0; i < N; i++) {
+            g[(size_t)t * N + i] = glucose[i * ld_subject + t * ld_time];
+            cp[(size_t)t * N + i] = cpeptide[i * ld_subject + t * ld_time];
+        }
+    DevBuf<double> gdev;
+    DevBuf<uint8_t> t2dev;
+    HIP_TRY(gdev.resize((size_t)T * N));
+    HIP_TRY(t2dev.resize(N));
+    HIP_TRY(c->obs.resize((size_t)T * N));
+    HIP_TRY(c->dG.resize((size_t)T * N));
+    HIP_TRY(c->k0.resize(N)); HIP_TRY(c->k1.resize(N)); HIP_TRY(c->k2.resize(N)); HIP_TRY(c->c0.resize(N));
+    HIP_TRY(c->age.resize(N));
+    HIP_TRY(c->auc.resize(c->cfg.n_state == 3 ? N : 0));
+    HIP_TRY(hipMemcpyAsync(gdev.p, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->obs.p, cp.data(), cp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->age.p, age, N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t2dev.p, t2dm, N * sizeof(uint8_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(cude::launch_prepare_cpep(N, T, gdev.p, c->obs.p, c->age.p, t2dev.p, c->k0.p, c->k1.p, c->k2.p, c->c0.p,
+                                      c->dG.p, c->stream));
+    if ((rc = alloc_common(c))) return rc;
+    if ((rc = upload_tables(c, true))) return rc;
+    c->n_global = (double)N;
+    if (c->comm) {
+        double v[1] = {(double)N};
+        if ((rc = cude_comm_allreduce_host(c, v, 1))) return rc;
+        c->n_global = v[0];
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_pop = true;
+    return CUDE_OK;
+}
+
+int32_t cude_set_population_supp(cude_ctx* c, int64_t N, int32_t n_obs, const double* timepoints, const double* data) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (c->cfg.model != CUDE_MODEL_SUPP) return fail(CUDE_ERR_STATE, "context is not a suppression model");
+    if (N < 1 || !timepoints || !data) return fail(CUDE_ERR_ARG, "null/empty input");
+    if ((rc = check_times(n_obs, timepoints))) return rc;
+    const int T = n_obs;
+    c->have_pop = false;
+    c->N = N;
+    c->T = T;
+    c->tp.assign(timepoints, timepoints + T);
+    std::vector<double> d((size_t)3 * T * N);
+    double ssum[4] = {0, 0, 0, (double)N};
+    for (int64_t i = 0; i < N; i++)
+        for (int s = 0; s < 3; s++) {
+            double m = -std::numeric_limits<double>::infinity();
+            for (int t = 0; t < T; t++) {
+                const double v = data[s + 3 * (t + (int64_t)T * i)];
+                d[((size_t)s * T + t) * N + i] = v;
+                if (v > m) m = v;
+            }
+            ssum[s] += m;
+        }
+    if (c->comm && (rc = cude_comm_allreduce_host(c, ssum, 4))) return rc;
+    c->n_global = ssum[3];
+    for (int s = 0; s < 3; s++) c->scale[s] = ssum[s] / ssum[3];
+    HIP_TRY(c->data.resize(d.size()));
+    HIP_TRY(c->ckpt.resize((size_t)c->cfg.n_steps * 3 * N));
+    HIP_TRY(hipMemcpyAsync(c->data.p, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = alloc_common(c))) return rc;
+    if ((rc = upload_tables(c, false))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_pop = true;
+    return CUDE_OK;
+}
+
+int32_t cude_set_params(cude_ctx* c, const double* nn, const double* cond) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (nn) {
+        HIP_TRY(hipMemcpyAsync(c->nn.p, nn, c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->have_nn = true;
+    }
+    if (cond) {
+        if (!c->have_pop) return fail(CUDE_ERR_STATE, "set the population before the conditional parameters");
+        HIP_TRY(hipMemcpyAsync(c->cond.p, cond, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->have_cond = true;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
+int32_t cude_get_params(cude_ctx* c, double* nn, double* cond) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (nn) HIP_TRY(hipMemcpyAsync(nn, c->nn.p, c->P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (cond) {
+        if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+        HIP_TRY(hipMemcpyAsync(cond, c->cond.p, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
+int32_t cude_forward(cude_ctx* c, double* loss, double* per_subject_sse, double* traj) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    double* traj_dev = nullptr;
+    if (traj) {
+        if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+        HIP_TRY(c->traj.resize((size_t)c->cfg.n_state * c->T * c->N));
+        traj_dev = c->traj.p;
+    }
+    if ((rc = run_ensemble(c, false, traj_dev))) return rc;
+    if (per_subject_sse)
+        HIP_TRY(hipMemcpyAsync(per_subject_sse, c->sse.p, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (traj)
+        HIP_TRY(hipMemcpyAsync(traj, c->traj.p, c->traj.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return finish_loss(c, loss, nullptr);
+}
+
+int32_t cude_loss_grad(cude_ctx* c, double* loss, double* g_nn, double* g_cond) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if ((rc = run_ensemble(c, true, nullptr))) return rc;
+    if (g_cond)
+        HIP_TRY(hipMemcpyAsync(g_cond, c->g_cond.p, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> tmp;
+    return finish_loss(c, loss, g_nn);
+}
+
+int32_t cude_n_failed(cude_ctx* c, int64_t* n_failed) {
+    if (!c || !n_failed) return fail(CUDE_ERR_ARG, "null argument");
+    *n_failed = c->last_failed;
+    return CUDE_OK;
+}
+
+int32_t cude_adam_init(cude_ctx* c, double lr, double beta1, double beta2, double eps) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
+        return fail(CUDE_ERR_ARG, "bad Adam hyper-parameters");
+    c->lr = lr; c->b1 = beta1; c->b2 = beta2; c->eps = eps;
+    c->adam_t = 0;
+    HIP_TRY(hipMemsetAsync(c->m_nn.p, 0, c->P * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->v_nn.p, 0, c->P * sizeof(double), c->stream));
+    if (c->have_pop) {
+        HIP_TRY(hipMemsetAsync(c->m_cond.p, 0, c->N * sizeof(double), c->stream));
+        HIP_TRY(hipMemsetAsync(c->v_cond.p, 0, c->N * sizeof(double), c->stream));
+    }
+    c->adam_ready = true;
+    return CUDE_OK;
+}
+
+int32_t cude_adam_step(cude_ctx* c, double* loss) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
+    if ((rc = run_ensemble(c, true, nullptr))) return rc;
+    c->adam_t += 1;
+    cude::AdamArgs a{};
+    a.N = c->N; a.P = c->P;
+    a.cond = c->cond.p; a.m_cond = c->m_cond.p; a.v_cond = c->v_cond.p; a.g_cond = c->g_cond.p;
+    a.nn = c->nn.p; a.m_nn = c->m_nn.p; a.v_nn = c->v_nn.p; a.g_nn = c->g_nn.p;
+    a.lr = c->lr; a.b1 = c->b1; a.b2 = c->b2; a.eps = c->eps;
+    a.c1 = 1.0 - std::pow(c->b1, (double)c->adam_t);
+    a.c2 = 1.0 - std::pow(c->b2, (double)c->adam_t);
+    if (loss) {
+        // read the loss of this iterate before the update kernel is queued behind it
+        if ((rc = finish_loss(c, loss, nullptr))) return rc;
+    }
+    HIP_TRY(cude::launch_adam(a, c->stream));
+    return CUDE_OK;
+}
+
+int32_t cude_synchronize(cude_ctx* c) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
+int32_t cude_set_kernel_timing(cude_ctx* c, int32_t enabled) {
+    if (!c) return fail(CUDE_ERR_ARG, "null context");
+    c->timing = enabled != 0;
+    c->ev_used = 0;
+    return CUDE_OK;
+}
+
+int32_t cude_kernel_time_ms(cude_ctx* c, double* avg_ms, int64_t* launches) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!avg_ms) return fail(CUDE_ERR_ARG, "null output");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t k = 0; k < c->ev_used; k++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
+        tot += ms;
+    }
+    *avg_ms = c->ev_used ? tot / (double)c->ev_used : 0.0;
+    if (launches) *launches = (int64_t)c->ev_used;
+    c->ev_used = 0;
+    return CUDE_OK;
+}
+
+int32_t cude_comm_unique_id(uint8_t id[CUDE_UNIQUE_ID_BYTES]) {
+    if (!id) return fail(CUDE_ERR_ARG, "null id");
+    int32_t rc = load_rccl();
+    if (rc) return rc;
+    nccl_uid u;
+    RCCL_TRY(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, u.internal, CUDE_UNIQUE_ID_BYTES);
+    return CUDE_OK;
+}
+
+int32_t cude_comm_init(cude_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t id[CUDE_UNIQUE_ID_BYTES]) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !id) return fail(CUDE_ERR_ARG, "bad communicator arguments");
+    if (c->comm) return fail(CUDE_ERR_STATE, "communicator already attached");
+    if ((rc = load_rccl())) return rc;
+    nccl_uid u;
+    std::memcpy(u.internal, id, CUDE_UNIQUE_ID_BYTES);
+    RCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    return CUDE_OK;
+}
+
+int32_t cude_comm_allreduce_host(cude_ctx* c, double* values, int32_t count) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!values || count < 1) return fail(CUDE_ERR_ARG, "bad buffer");
+    if (!c->comm) return CUDE_OK;   // single rank: identity
+    DevBuf<double> tmp;
+    HIP_TRY(tmp.resize(count));
+    HIP_TRY(hipMemcpyAsync(tmp.p, values, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = allreduce_dev(c, tmp.p, count))) return rc;
+    HIP_TRY(hipMemcpyAsync(values, tmp.p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
+}  // extern "C"

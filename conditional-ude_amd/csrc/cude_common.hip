@@ -1,0 +1,115 @@
+// Small support kernels: population preparation (van Cauter kinetics, glucose increments),
+// deterministic second-stage reduction of the per-workgroup partials, L2 term, and Adam.
+//
+// Replaces (reference repo paths):
+//   van_cauter_parameters     src/c-peptide-models.jl:30-42 (dup src/saem.jl:7-21)
+//   Optimisers.Adam update    used at src/parameter-estimation.jl:176, suppression_model.jl:164, saem.jl:128
+//   lambda*sum(abs2, neural)  suppression/src/suppression_model.jl:128
+#include "cude_device.h"
+#include "cude_kernels.h"
+
+namespace cude {
+
+// glucose_tn / cpep_tn are already [T][N] (subject fastest).
+__global__ void prepare_cpep_kernel(int64_t N, int T, const double* __restrict__ glucose_tn,
+                                    const double* __restrict__ cpep_tn, const double* __restrict__ age,
+                                    const uint8_t* __restrict__ t2dm, double* __restrict__ k0, double* __restrict__ k1,
+                                    double* __restrict__ k2, double* __restrict__ c0, double* __restrict__ dG) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const bool d = t2dm[i] != 0;
+    const double ln2 = 0.693147180559945309417232121458;
+    const double sh = d ? 4.52 : 4.95, fr = d ? 0.78 : 0.76, lo = 0.14 * age[i] + 29.2;
+    const double kk1 = fr * (ln2 / lo) + (1.0 - fr) * (ln2 / sh);
+    const double kk0 = (ln2 / sh) * (ln2 / lo) / kk1;
+    const double kk2 = (ln2 / sh) + (ln2 / lo) - kk0 - kk1;
+    k0[i] = kk0;
+    k1[i] = kk1;
+    k2[i] = kk2;
+    c0[i] = cpep_tn[i];
+    const double g0 = glucose_tn[i];
+    for (int t = 0; t < T; t++) dG[(int64_t)t * N + i] = glucose_tn[(int64_t)t * N + i] - g0;
+}
+
+hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const double* cpep_tn, const double* age,
+                               const uint8_t* t2dm, double* k0, double* k1, double* k2, double* c0, double* dG,
+                               hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(prepare_cpep_kernel, dim3((unsigned)((N + bs - 1) / bs)), dim3(bs), 0, s, N, T, glucose_tn,
+                       cpep_tn, age, t2dm, k0, k1, k2, c0, dG);
+    return hipGetLastError();
+}
+
+// One workgroup per column; fixed-shape tree => bitwise reproducible for a given nblocks.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
+                                                              int stride, int col0, double* __restrict__ out) {
+    __shared__ double s[256];
+    const int q = col0 + blockIdx.x;
+    double v = 0.0;
+    for (int64_t b = threadIdx.x; b < nblocks; b += 256) v += partials[b * stride + q];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[q] = s[0];
+}
+
+// reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
+hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol), dim3(256), 0, s, partials, nblocks, stride, col0, out);
+    return hipGetLastError();
+}
+
+__global__ void l2_term_kernel(const double* __restrict__ nn, int P, double lambda, double n_global,
+                               double* __restrict__ out) {
+    // single wave
+    const int lane = threadIdx.x;
+    double ss = 0.0;
+    for (int q = lane; q < P; q += 64) {
+        const double w = nn[q];
+        ss = fma(w, w, ss);
+        out[q] = fma(2.0 * lambda, w, out[q]);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) out[P] = fma(lambda * n_global, ss, out[P]);
+}
+
+hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(l2_term_kernel, dim3(1), dim3(64), 0, s, nn, P, lambda, n_global, out);
+    return hipGetLastError();
+}
+
+// Adam exactly as Optimisers.jl: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// x -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).  Skipped when any subject failed
+// (g_nn[P+1] > 0): the reference's optimiser would see an Inf objective there.
+__global__ void adam_kernel(AdamArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.g_nn[a.P + 1] > 0.0) return;
+    double *x, *m, *v;
+    double g;
+    if (idx < a.N) {
+        x = a.cond + idx; m = a.m_cond + idx; v = a.v_cond + idx; g = a.g_cond[idx];
+    } else if (idx < a.N + a.P) {
+        const int64_t q = idx - a.N;
+        x = a.nn + q; m = a.m_nn + q; v = a.v_nn + q; g = a.g_nn[q];
+    } else {
+        return;
+    }
+    const double mm = fma(a.b1, *m, (1.0 - a.b1) * g);
+    const double vv = fma(a.b2, *v, (1.0 - a.b2) * g * g);
+    *m = mm;
+    *v = vv;
+    *x -= a.lr * (mm / a.c1) / (sqrt(vv / a.c2) + a.eps);
+}
+
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
+    const int bs = 256;
+    const int64_t n = a.N + a.P;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cude

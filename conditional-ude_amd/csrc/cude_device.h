@@ -1,0 +1,238 @@
+// Device-side building blocks shared by the gfx950 kernels: Tsit5 tableau, fp64 activations,
+// and the tiny tanh/softplus MLP (forward and weighted reverse sweep) with the shared weights
+// read through the scalar unit.
+//
+// Reference behaviour being replaced (paths relative to the reference repo):
+//   softplus            src/neural-network.jl:13-15
+//   SimpleChains MLP    src/neural-network.jl:42-58  -- params per layer [vec_colmajor(W); b]
+//   Tsit5               OrdinaryDiffEq (third-party, not vendored); tableau: Tsitouras 2011
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cude_math.h"
+
+namespace cude {
+
+// ------------------------------------------------------------------------------------ Tsit5
+// compile-time copy for fully unrolled code (immediates / SGPR literals instead of loads)
+struct Tab {
+    static constexpr double a(int i, int j) {
+        constexpr double A[7][6] = {
+            {0, 0, 0, 0, 0, 0},
+            {0.161, 0, 0, 0, 0, 0},
+            {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+            {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+            {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+            {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+            {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+             2.324710524099774}};
+        return A[i][j];
+    }
+    static constexpr double c(int i) {
+        constexpr double C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+        return C[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------ math
+// Scalar (wave-uniform) read of a network parameter: the constant address space makes the
+// compiler emit s_load_* for uniform addresses, so weights live in SGPRs and feed v_fma_f64 as
+// the scalar operand -- no VGPRs, no LDS bandwidth for the 37-67 shared doubles.
+typedef const __attribute__((address_space(4))) double* cptr_t;
+typedef const __attribute__((address_space(4))) int32_t* ciptr_t;
+__device__ __forceinline__ cptr_t as_const(const double* p) {
+    return (cptr_t)(uintptr_t)p;
+}
+__device__ __forceinline__ ciptr_t as_const(const int32_t* p) {
+    return (ciptr_t)(uintptr_t)p;
+}
+
+// Makes the compiler forget what it knows about *p so that the (cheap, asynchronous) scalar loads
+// of the weights are re-issued per network evaluation instead of being hoisted out of the time
+// loop, where 55+ doubles exceed the 102-SGPR budget and spill to VGPR lanes.
+__device__ __forceinline__ cptr_t launder(cptr_t p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+__device__ __forceinline__ double act_tanh(double x) { return m_tanh(x); }
+// softplus(x) = log(1+exp(x)) (reference form, evaluated stably); *sig receives the logistic derivative.
+__device__ __forceinline__ double act_softplus(double x, double* sig) { return m_softplus(x, sig); }
+__device__ __forceinline__ double act_softplus_val(double x) { return m_softplus_val(x); }
+
+// ------------------------------------------------------------------------------------ MLP
+// Network NIN -> W (tanh) x D -> 1 (softplus).  The first NV inputs vary per evaluation; the
+// remaining NIN-NV inputs are constant per subject (exp(conditional) [, age]) and are folded
+// into a per-subject first-layer offset  c_j = b1_j + sum_{i>=NV} W1[j,i]*cst_i.
+template <int NIN, int W, int D, int NV>
+struct Mlp {
+    static constexpr int NC = NIN - NV;
+    static constexpr int L1 = W * NIN + W;          // first layer params
+    static constexpr int LH = W * W + W;            // each further hidden layer
+    static constexpr int OUT = L1 + (D - 1) * LH;   // output layer offset
+    static constexpr int P = OUT + W + 1;
+    // accumulator layout for the reverse sweep
+    static constexpr int G_W1V = 0;                 // [NV][W]  d/dW1[j,i], i<NV
+    static constexpr int G_C = G_W1V + NV * W;      // [W]      d/dc_j
+    static constexpr int G_H = G_C + W;             // (D-1) x (W*W + W)
+    static constexpr int G_OUT = G_H + (D - 1) * LH;  // [W] + 1
+    static constexpr int NACC = G_OUT + W + 1;
+
+    __device__ static __forceinline__ void first_layer_offset(cptr_t p, const double (&cst)[NC > 0 ? NC : 1],
+                                                              double (&c)[W]) {
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            double z = p[W * NIN + j];
+#pragma unroll
+            for (int i = 0; i < NC; i++) z = fma(p[j + W * (NV + i)], cst[i], z);
+            c[j] = z;
+        }
+    }
+
+    // 0 when every parameter is finite, NaN otherwise.  The clamped activations above swallow
+    // NaN/Inf, so non-finite inputs are tracked explicitly to honour the reference's failure
+    // convention (non-finite solve => loss = Inf).
+    __device__ static __forceinline__ double param_check(cptr_t p) {
+        double chk = 0.0;
+#pragma unroll 1
+        for (int q = 0; q < P; q++) chk = fma(p[q], 0.0, chk);
+        return chk;
+    }
+
+    // value only
+    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[W], const double (&x)[NV]) {
+        p = launder(p);
+        double h[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            double z = c[j];
+#pragma unroll
+            for (int i = 0; i < NV; i++) z = fma(p[j + W * i], x[i], z);
+            h[j] = act_tanh(z);
+        }
+#pragma unroll
+        for (int l = 1; l < D; l++) {
+            const int o = L1 + (l - 1) * LH;
+            double g[W];
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                double z = p[o + W * W + j];
+#pragma unroll
+                for (int i = 0; i < W; i++) z = fma(p[o + j + W * i], h[i], z);
+                g[j] = act_tanh(z);
+            }
+#pragma unroll
+            for (int j = 0; j < W; j++) h[j] = g[j];
+        }
+        double z = p[OUT + W];
+#pragma unroll
+        for (int i = 0; i < W; i++) z = fma(p[OUT + i], h[i], z);
+        return act_softplus_val(z);
+    }
+
+    // value + weighted reverse sweep:  acc += wgt * d(out)/d(params);  if WANT_DX,
+    // dx[i] += wgt * d(out)/dx_i.  Returns the network output.
+    template <bool WANT_DX>
+    __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[W], const double (&x)[NV],
+                                                       double wgt, double (&acc)[NACC], double (&dx)[NV]) {
+        p = launder(p);
+        double h[D][W];
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            double z = c[j];
+#pragma unroll
+            for (int i = 0; i < NV; i++) z = fma(p[j + W * i], x[i], z);
+            h[0][j] = act_tanh(z);
+        }
+#pragma unroll
+        for (int l = 1; l < D; l++) {
+            const int o = L1 + (l - 1) * LH;
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                double z = p[o + W * W + j];
+#pragma unroll
+                for (int i = 0; i < W; i++) z = fma(p[o + j + W * i], h[l - 1][i], z);
+                h[l][j] = act_tanh(z);
+            }
+        }
+        double z = p[OUT + W];
+#pragma unroll
+        for (int i = 0; i < W; i++) z = fma(p[OUT + i], h[D - 1][i], z);
+        double sig;
+        const double y = act_softplus(z, &sig);
+
+        // reverse
+        const double dz = wgt * sig;
+        acc[G_OUT + W] += dz;
+        double dh[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            acc[G_OUT + i] = fma(dz, h[D - 1][i], acc[G_OUT + i]);
+            dh[i] = dz * p[OUT + i];
+        }
+#pragma unroll
+        for (int l = D - 1; l >= 1; l--) {
+            const int o = L1 + (l - 1) * LH;
+            const int go = G_H + (l - 1) * LH;
+            double dprev[W];
+#pragma unroll
+            for (int i = 0; i < W; i++) dprev[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const double d = dh[j] * fma(-h[l][j], h[l][j], 1.0);
+                acc[go + W * W + j] += d;
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+                    acc[go + j + W * i] = fma(d, h[l - 1][i], acc[go + j + W * i]);
+                    dprev[i] = fma(p[o + j + W * i], d, dprev[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < W; i++) dh[i] = dprev[i];
+        }
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const double d = dh[j] * fma(-h[0][j], h[0][j], 1.0);
+            acc[G_C + j] += d;
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                acc[G_W1V + i * W + j] = fma(d, x[i], acc[G_W1V + i * W + j]);
+                if (WANT_DX) dx[i] = fma(p[j + W * i], d, dx[i]);
+            }
+        }
+        return y;
+    }
+
+    // Expand the accumulators into the SimpleChains parameter order; also d/d(conditional) through
+    // cst[0] = exp(conditional):  dcond = cst0 * sum_j dc_j * W1[j,NV].
+    __device__ static __forceinline__ void expand(cptr_t p, const double (&acc)[NACC],
+                                                  const double (&cst)[NC > 0 ? NC : 1], double (&g)[P], double* dcond) {
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) g[j + W * i] = acc[G_W1V + i * W + j];
+#pragma unroll
+            for (int i = 0; i < NC; i++) g[j + W * (NV + i)] = acc[G_C + j] * cst[i];
+            g[W * NIN + j] = acc[G_C + j];
+        }
+#pragma unroll
+        for (int q = 0; q < (D - 1) * LH + W + 1; q++) g[L1 + q] = acc[G_H + q];
+        double s = 0.0;
+        if (NC > 0) {
+#pragma unroll
+            for (int j = 0; j < W; j++) s = fma(acc[G_C + j], p[j + W * NV], s);
+            s *= cst[0];
+        }
+        *dcond = s;
+    }
+};
+
+// ------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace cude

@@ -1,0 +1,84 @@
+// Kernel argument blocks and host-side launch entry points (implemented in the .hip files).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cude {
+
+constexpr int kBlock = 64;     // one wave per workgroup: no cross-wave barrier on the path
+constexpr int kMaxObs = 32;
+
+struct NetShape {
+    int nin, width, depth;
+    int n_params() const {
+        int p = 0, fan = nin;
+        for (int l = 0; l < depth; l++) { p += width * fan + width; fan = width; }
+        return p + fan + 1;
+    }
+};
+
+// c-peptide cUDE (linear kinetics + state-independent NN forcing)
+struct CpepArgs {
+    int64_t N;
+    const double* k0; const double* k1; const double* k2; const double* c0;   // [N]
+    const double* dG;        // [T][N]  glucose(t_j) - glucose(t_0)
+    const double* obs;       // [T][N]
+    const double* age;       // [N] (covariate model) or nullptr
+    const double* cond;      // [N]
+    const double* nn;        // [P]
+    const int32_t* seg;      // [S*5]  glucose segment of each distinct stage time
+    const double* phi;       // [S*5]  fraction inside the segment
+    const int32_t* obs_step; // [T]
+    const double* obs_w;     // [T][7] h-free dense-output weights b_i(theta)
+    int32_t T, S;
+    double h, inv_n;
+    double* sse;             // [N] or nullptr
+    double* traj;            // [NS x T x N] column-major or nullptr
+    double* auc;             // [N] or nullptr (NS == 3: cumulative secretion at t_end)
+    double* g_cond;          // [N] (grad)
+    double* partials;        // [nblocks][P+2]
+};
+
+// suppression cUDE (nonlinear: NN input is the state)
+struct SuppArgs {
+    int64_t N;
+    const double* data;      // [3][T][N]
+    const double* cond;      // [N]
+    const double* nn;        // [P]
+    const int32_t* obs_step; // [T]
+    const double* obs_w;     // [T][7]
+    int32_t T, S;
+    double h, inv_n;
+    double iscale2[3];       // 1/scale_s^2
+    double* ckpt;            // [S][3][N] step-state checkpoints (grad)
+    double* sse;             // [N] or nullptr (already divided by scale^2)
+    double* traj;            // [3 x T x N] column-major or nullptr
+    double* g_cond;          // [N]
+    double* partials;        // [nblocks][P+2]
+};
+
+// returns hipSuccess, or hipErrorInvalidValue when the shape is not compiled in
+hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepArgs& a, hipStream_t s);
+hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
+bool cpep_shape_supported(const NetShape& net, int n_state);
+bool supp_shape_supported(const NetShape& net);
+
+// common kernels
+// out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol)
+hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
+                              hipStream_t s);
+// g_nn[q] += 2*lambda*nn[q];  out[P] += lambda*sum(nn^2)*n_global   (so that loss = out[P]/n_global)
+hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s);
+struct AdamArgs {
+    int64_t N; int P;
+    double* cond; double* m_cond; double* v_cond; const double* g_cond;
+    double* nn; double* m_nn; double* v_nn; const double* g_nn;   // g_nn[P+1] = n_failed
+    double lr, b1, b2, eps, c1, c2;   // c1 = 1-b1^t, c2 = 1-b2^t
+};
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
+// population preparation
+hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const double* cpep_tn, const double* age,
+                               const uint8_t* t2dm, double* k0, double* k1, double* k2, double* c0, double* dG,
+                               hipStream_t s);
+
+}  // namespace cude

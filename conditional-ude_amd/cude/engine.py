@@ -1,0 +1,175 @@
+"""Thin object wrapper over the C ABI: one Engine = one cude_ctx = one GPU.
+
+Holds no numerics: every number comes from libcude_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODEL_CPEP, MODEL_SUPP, CudeError, check
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def n_params(nn_in, width, depth):
+    return check(_lib.load().cude_n_params(nn_in, width, depth))
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(_lib.load().cude_device_count(C.byref(n)))
+    return n.value
+
+
+class Engine:
+    """model: 'cpep' | 'supp'.  arch = (nn_in, width, depth)."""
+
+    def __init__(self, model, arch, n_steps=30, n_state=None, lam=0.0, device=0):
+        self._lib = _lib.load()
+        self.model = {"cpep": MODEL_CPEP, "supp": MODEL_SUPP}[model]
+        self.arch = tuple(int(v) for v in arch)
+        if n_state is None:
+            n_state = 2 if self.model == MODEL_CPEP else 3
+        cfg = _lib.Config(self.model, n_state, self.arch[0], self.arch[1], self.arch[2], int(n_steps), int(device), 0,
+                          float(lam))
+        h = C.c_void_p()
+        check(self._lib.cude_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.n_state = n_state
+        self.P = n_params(*self.arch)
+        self.N = 0
+        self.T = 0
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cude_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- population
+    def set_population_cpep(self, timepoints, glucose, cpeptide, age, t2dm):
+        """glucose, cpeptide: (N, T) arrays (any strides are honoured without a host copy when
+        they are element-strided float64)."""
+        tp = _f64(timepoints)
+        g = np.asarray(glucose, dtype=np.float64)
+        cp = np.asarray(cpeptide, dtype=np.float64)
+        if g.shape != cp.shape or g.ndim != 2 or g.shape[1] != tp.size:
+            raise ValueError("glucose/cpeptide must be (N, T) with T = len(timepoints)")
+        if g.strides != cp.strides or g.strides[0] % 8 or g.strides[1] % 8:
+            g, cp = np.ascontiguousarray(g), np.ascontiguousarray(cp)
+        N, T = g.shape
+        age = _f64(age)
+        t2 = np.ascontiguousarray(t2dm, dtype=np.uint8)
+        if age.size != N or t2.size != N:
+            raise ValueError("age/t2dm must have N entries")
+        check(self._lib.cude_set_population_cpep(self._h, N, T, _ptr(tp), _ptr(g), _ptr(cp), g.strides[0] // 8,
+                                                 g.strides[1] // 8, _ptr(age), _ptr(t2)))
+        self.N, self.T = N, T
+
+    def set_population_supp(self, timepoints, data):
+        """data: (3, T, N) array (Julia individual_data); passed in Julia column-major order."""
+        tp = _f64(timepoints)
+        d = np.asarray(data, dtype=np.float64)
+        if d.ndim != 3 or d.shape[0] != 3 or d.shape[1] != tp.size:
+            raise ValueError("data must be (3, T, N)")
+        dcol = np.ascontiguousarray(d.transpose(2, 1, 0))
+        N, T = d.shape[2], d.shape[1]
+        check(self._lib.cude_set_population_supp(self._h, N, T, _ptr(tp), _ptr(dcol)))
+        self.N, self.T = N, T
+
+    # -- parameters
+    def set_params(self, nn=None, cond=None):
+        nn_a = None if nn is None else _f64(nn)
+        cd_a = None if cond is None else _f64(cond).reshape(-1)
+        if nn_a is not None and nn_a.size != self.P:
+            raise ValueError(f"expected {self.P} network parameters, got {nn_a.size}")
+        if cd_a is not None and cd_a.size != self.N:
+            raise ValueError(f"expected {self.N} conditional parameters, got {cd_a.size}")
+        check(self._lib.cude_set_params(self._h, _ptr(nn_a), _ptr(cd_a)))
+
+    def get_params(self):
+        nn = np.empty(self.P)
+        cond = np.empty(self.N)
+        check(self._lib.cude_get_params(self._h, _ptr(nn), _ptr(cond)))
+        return nn, cond
+
+    # -- evaluation
+    def forward(self, want_sse=False, want_traj=False):
+        loss = C.c_double()
+        sse = np.empty(self.N) if want_sse else None
+        traj = np.empty((self.N, self.T, self.n_state)) if want_traj else None
+        check(self._lib.cude_forward(self._h, C.byref(loss), _ptr(sse), _ptr(traj)))
+        out = {"loss": loss.value}
+        if want_sse:
+            out["sse"] = sse
+        if want_traj:
+            out["traj"] = traj.transpose(2, 1, 0)     # -> (n_state, T, N), the Julia Array(sol) shape
+        return out
+
+    def loss_grad(self, want_cond_grad=True):
+        loss = C.c_double()
+        g_nn = np.empty(self.P)
+        g_cond = np.empty(self.N) if want_cond_grad else None
+        check(self._lib.cude_loss_grad(self._h, C.byref(loss), _ptr(g_nn), _ptr(g_cond)))
+        return loss.value, g_nn, g_cond
+
+    def n_failed(self):
+        n = C.c_int64()
+        check(self._lib.cude_n_failed(self._h, C.byref(n)))
+        return n.value
+
+    # -- optimiser
+    def adam_init(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        check(self._lib.cude_adam_init(self._h, lr, beta1, beta2, eps))
+
+    def adam_step(self, want_loss=True):
+        if want_loss:
+            loss = C.c_double()
+            check(self._lib.cude_adam_step(self._h, C.byref(loss)))
+            return loss.value
+        check(self._lib.cude_adam_step(self._h, None))
+        return None
+
+    def synchronize(self):
+        check(self._lib.cude_synchronize(self._h))
+
+    def set_kernel_timing(self, enabled):
+        check(self._lib.cude_set_kernel_timing(self._h, int(bool(enabled))))
+
+    def kernel_time_ms(self):
+        ms = C.c_double()
+        n = C.c_int64()
+        check(self._lib.cude_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- communicator
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+        check(_lib.load().cude_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        check(self._lib.cude_comm_init(self._h, n_ranks, rank, buf))
+
+    def allreduce_host(self, values):
+        v = _f64(values).copy()
+        check(self._lib.cude_comm_allreduce_host(self._h, _ptr(v), v.size))
+        return v
+
+
+__all__ = ["Engine", "CudeError", "n_params", "device_count"]

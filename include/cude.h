@@ -1,0 +1,133 @@
+/* cude.h -- C ABI of libcude_hip.so: the MI355X (gfx950) population ensemble ODE solve +
+ * discrete adjoint for conditional universal differential equations.
+ *
+ * This is the drop-in boundary for ONE hot path of Computational-Biology-TUe/conditional-ude:
+ * everything Optimization.jl calls as `f(theta, p)` / its gradient while training a cUDE.
+ * The reference has no FFI layer (it is pure Julia); each entry point below names the
+ * reference function(s) (paths relative to the reference repo root) whose arithmetic it
+ * replaces, so a maintainer can bind it with `ccall` (INTEGRATION.md has the Julia stubs).
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = ok, <0 = error (CUDE_ERR_*); the message is
+ *     available from cude_last_error() (thread-local).  No exceptions, no abort().
+ *   - fp64 throughout.  The caller owns every host buffer; the library copies on set_* and
+ *     never retains host pointers.  All device memory is owned by the context.
+ *   - a context is bound to one HIP device and one stream; it is not thread-safe.
+ *   - solver failure convention of the reference (src/parameter-estimation.jl:61-64,134-136):
+ *     a non-finite trajectory in any subject makes the returned loss +Inf with status 0;
+ *     cude_n_failed() tells how many subjects failed.
+ *   - discretisation: fixed-step Tsit5, n_steps uniform steps over [t[0], t[T-1]],
+ *     observations by the Tsit5 dense-output interpolant (DESIGN.md "numerical contract").
+ */
+#ifndef CUDE_H
+#define CUDE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUDE_OK 0
+#define CUDE_ERR_ARG (-1)         /* bad argument / size */
+#define CUDE_ERR_HIP (-2)         /* HIP runtime error (message has hipGetErrorString) */
+#define CUDE_ERR_STATE (-3)       /* call order (e.g. loss before set_population) */
+#define CUDE_ERR_UNSUPPORTED (-4) /* network shape / model not compiled in */
+#define CUDE_ERR_COMM (-5)        /* RCCL error or librccl not loadable */
+
+#define CUDE_MODEL_CPEP 0 /* c-peptide cUDE: src/c-peptide-models.jl:7-14,86-94,170-194 */
+#define CUDE_MODEL_SUPP 1 /* suppression cUDE: suppression/src/suppression_model.jl:88-95 */
+
+#define CUDE_UNIQUE_ID_BYTES 128
+
+typedef struct cude_ctx cude_ctx;
+
+/* Replaces the per-script constants + `chain(width, depth, tanh; input_dims)`
+ * (src/neural-network.jl:105-107; suppression_model.jl:78-85) that fix the model shape. */
+typedef struct cude_config {
+    int32_t model;    /* CUDE_MODEL_* */
+    int32_t n_state;  /* CPEP: 2, or 3 = +cumulative-secretion quadrature state (zero loss weight); SUPP: 3 */
+    int32_t nn_in;    /* CPEP: 2 = [dG, exp(beta)], 3 = [dG, exp(beta), age] (covariate model,
+                         src/c-peptide-models.jl:96-104); SUPP: 4 = [u1,u2,u3,exp(theta)] */
+    int32_t nn_width; /* hidden width */
+    int32_t nn_depth; /* number of tanh hidden layers; output layer is softplus, 1 unit */
+    int32_t n_steps;  /* fixed Tsit5 steps over the time span */
+    int32_t device;   /* HIP device ordinal */
+    int32_t reserved;
+    double lambda;    /* L2 weight on the network parameters (suppression_loss :128); 0 for CPEP */
+} cude_config;
+
+const char* cude_last_error(void);
+int32_t cude_device_count(int32_t* count);
+/* Number of network parameters for a shape: SimpleChains layout, per layer
+ * [vec_colmajor(W out x in); b] (src/neural-network.jl:52-56). */
+int32_t cude_n_params(int32_t nn_in, int32_t nn_width, int32_t nn_depth);
+
+int32_t cude_create(const cude_config* cfg, cude_ctx** out);
+int32_t cude_destroy(cude_ctx* ctx);
+
+/* --- population (replaces the CPeptideConditionalUDEModel constructor loop,
+ * src/c-peptide-models.jl:170-194 incl. van_cauter_parameters :30-42, u0, tspan and the
+ * LinearInterpolation of glucose :181; c-peptide/02-conditional.jl:26-28).
+ * glucose / cpeptide are N x T matrices addressed as base[i*ld_subject + t*ld_time]
+ * (Julia column-major N x T: ld_subject = 1, ld_time = N; numpy C-order: ld_subject = T, ld_time = 1).
+ * age[N], t2dm[N] (0/1).  timepoints[T] are shared by all subjects and are also the glucose knots.
+ * If a communicator is attached (cude_comm_init) the global subject count is all-reduced here. */
+int32_t cude_set_population_cpep(cude_ctx* ctx, int64_t n_subjects, int32_t n_obs, const double* timepoints,
+                                 const double* glucose, const double* cpeptide, int64_t ld_subject,
+                                 int64_t ld_time, const double* age, const uint8_t* t2dm);
+
+/* suppression model population: data is the Julia array individual_data[3 x T x N] in
+ * column-major order (data[s + 3*(t + T*i)]); u0 = data[:,1,:]; scale = mean_i max_t data
+ * (suppression_model.jl:119,126). */
+int32_t cude_set_population_supp(cude_ctx* ctx, int64_t n_subjects, int32_t n_obs, const double* timepoints,
+                                 const double* data);
+
+/* theta = ComponentArray(neural = nn[P], conditional = cond[N]) (parameter-estimation.jl:354-357).
+ * Either pointer may be NULL to leave that part unchanged. */
+int32_t cude_set_params(cude_ctx* ctx, const double* nn, const double* cond);
+int32_t cude_get_params(cude_ctx* ctx, double* nn, double* cond);
+
+/* Forward-only population loss: `loss(theta, (models, timepoints, data))`
+ * (src/parameter-estimation.jl:126-140, per-subject :56-68) / `suppression_loss` without AD
+ * (suppression_model.jl:117-130) / `simul` (:107-115).
+ * per_subject_sse[N] (optional) is the un-normalised SSE of each subject (the quantity
+ * loss_sigma :70-75 and individual_log_likelihood saem.jl:55-66 are built from).
+ * traj (optional) receives the interpolated states as [n_state x T x N] column-major
+ * (Julia Array(sol) layout of simul). */
+int32_t cude_forward(cude_ctx* ctx, double* loss, double* per_subject_sse, double* traj);
+
+/* Loss and gradient: replaces ForwardDiff.gradient(loss, theta) under AutoForwardDiff()
+ * (parameter-estimation.jl:370; suppression_model.jl:155; saem.jl:120) by a discrete adjoint
+ * of the same fixed-step map.  g_nn[P]; g_cond[N] may be NULL (stays on the device). */
+int32_t cude_loss_grad(cude_ctx* ctx, double* loss, double* g_nn, double* g_cond);
+int32_t cude_n_failed(cude_ctx* ctx, int64_t* n_failed);
+
+/* Optimisers.Adam(eta) state (parameter-estimation.jl:176; suppression_model.jl:164; saem.jl:128).
+ * Resets the moments and the step counter. */
+int32_t cude_adam_init(cude_ctx* ctx, double lr, double beta1, double beta2, double eps);
+/* One fused optimiser iteration on device-resident parameters: loss + gradient + (all-reduce of
+ * [g_nn; sum loss; n_failed] when a communicator is attached) + Adam update of nn (replicated)
+ * and cond (sharded).  loss may be NULL: then nothing is copied back and the call does not
+ * synchronise (use cude_synchronize). The reported loss is the one BEFORE the update. */
+int32_t cude_adam_step(cude_ctx* ctx, double* loss);
+int32_t cude_synchronize(cude_ctx* ctx);
+
+/* Average device time (ms) of the dominant kernel (forward+adjoint) over the launches since the
+ * last call, measured with HIP events on the context's stream; resets the accumulator. */
+int32_t cude_kernel_time_ms(cude_ctx* ctx, double* avg_ms, int64_t* launches);
+/* Enable(1)/disable(0) the per-launch event timing used by cude_kernel_time_ms. */
+int32_t cude_set_kernel_timing(cude_ctx* ctx, int32_t enabled);
+
+/* --- multi-GPU: subjects are sharded, one context (process) per GPU; the only exchange is one
+ * sum all-reduce of P+2 doubles per optimiser step (the reference has no distributed path; this
+ * is the data-parallel form of EnsembleThreads, suppression_model.jl:113,123).
+ * rank 0 creates the id, the host distributes its bytes, every rank calls cude_comm_init. */
+int32_t cude_comm_unique_id(uint8_t id[CUDE_UNIQUE_ID_BYTES]);
+int32_t cude_comm_init(cude_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[CUDE_UNIQUE_ID_BYTES]);
+/* Sum all-reduce of a host vector through the communicator (used for population statistics
+ * such as SAEM's mean/var of the random effects, saem.jl:204-205). */
+int32_t cude_comm_allreduce_host(cude_ctx* ctx, double* values, int32_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDE_H */

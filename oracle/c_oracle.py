@@ -1,0 +1,90 @@
+"""ctypes binding of oracle/libcude_oracle.so (TEST INFRASTRUCTURE ONLY; see cude_oracle.c)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _n_params(nin, width, depth):
+    p, fan = 0, nin
+    for _ in range(depth):
+        p += width * fan + width
+        fan = width
+    return p + fan + 1
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libcude_oracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _LIB = C.CDLL(path)
+        _LIB.cude_oracle_num_threads.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads():
+    return lib().cude_oracle_num_threads()
+
+
+def cpep(timepoints, glucose, cpeptide, age, t2dm, arch, nn, beta, n_steps, n_state=2,
+         want_grad=True, want_traj=False, covariate=False, nthreads=0):
+    """Returns dict(loss, sse, g_nn, g_beta, traj, n_failed)."""
+    glucose = np.ascontiguousarray(glucose, dtype=np.float64)
+    cpeptide = np.ascontiguousarray(cpeptide, dtype=np.float64)
+    N, T = glucose.shape
+    tp = np.ascontiguousarray(timepoints, dtype=np.float64)
+    age = np.ascontiguousarray(age, dtype=np.float64)
+    t2 = np.ascontiguousarray(t2dm, dtype=np.uint8)
+    nn = np.ascontiguousarray(nn, dtype=np.float64)
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    nin, width, depth = arch
+    P = _n_params(*arch)
+    assert nn.size == P and beta.size == N
+    loss = C.c_double(0.0)
+    sse = np.zeros(N)
+    g_nn = np.zeros(P) if want_grad else None
+    g_beta = np.zeros(N) if want_grad else None
+    traj = np.zeros((N, T, n_state)) if want_traj else None
+    rc = lib().cude_oracle_cpep(C.c_int(N), C.c_int(T), _p(tp), _p(glucose), _p(cpeptide), _p(age), _p(t2),
+                                C.c_int(int(covariate)), C.c_int(nin), C.c_int(width), C.c_int(depth),
+                                _p(nn), _p(beta), C.c_int(n_steps), C.c_int(n_state), C.c_int(int(want_grad)),
+                                C.c_int(nthreads), C.byref(loss), _p(sse), _p(g_nn), _p(g_beta), _p(traj))
+    if rc < 0:
+        raise ValueError("cude_oracle_cpep: unsupported size")
+    return dict(loss=loss.value, sse=sse, g_nn=g_nn, g_beta=g_beta, traj=traj, n_failed=rc)
+
+
+def supp(timepoints, data, arch, nn, theta, lam, n_steps, want_grad=True, want_traj=False, nthreads=0):
+    """data: 3 x T x N numpy array (any layout; converted to Julia column-major)."""
+    data = np.asarray(data, dtype=np.float64)
+    _, T, N = data.shape
+    dcol = np.ascontiguousarray(data.transpose(2, 1, 0))      # memory: i slowest, s fastest
+    tp = np.ascontiguousarray(timepoints, dtype=np.float64)
+    nn = np.ascontiguousarray(nn, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    nin, width, depth = arch
+    assert nin == 4
+    P = _n_params(*arch)
+    assert nn.size == P and theta.size == N
+    loss = C.c_double(0.0)
+    sse = np.zeros(N)
+    g_nn = np.zeros(P) if want_grad else None
+    g_th = np.zeros(N) if want_grad else None
+    traj = np.zeros((N, T, 3)) if want_traj else None
+    rc = lib().cude_oracle_supp(C.c_int(N), C.c_int(T), _p(tp), _p(dcol), C.c_int(width), C.c_int(depth),
+                                _p(nn), _p(theta), C.c_double(lam), C.c_int(n_steps), C.c_int(int(want_grad)),
+                                C.c_int(nthreads), C.byref(loss), _p(sse), _p(g_nn), _p(g_th), _p(traj))
+    if rc < 0:
+        raise ValueError("cude_oracle_supp: unsupported size")
+    if traj is not None:
+        traj = traj.transpose(2, 1, 0)                         # -> 3 x T x N
+    return dict(loss=loss.value, sse=sse, g_nn=g_nn, g_theta=g_th, traj=traj, n_failed=rc)

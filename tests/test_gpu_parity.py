@@ -1,0 +1,108 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64): loss rtol 1e-10, gradients 1e-9 relative to the gradient's max-norm.  The
+north-star bar is rtol <= 1e-6; the discrete adjoint and the oracle's forward-mode duals are two
+different algorithms for the same derivative, so agreement is expected near round-off.
+"""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (imported first so PyTorch and libcude_hip share one HIP runtime)
+
+from conftest import make_cpep_case, make_supp_case
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-10
+GRAD_RTOL = 1e-9
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("arch,n_state,N", [((2, 6, 2), 3, 1000), ((2, 6, 2), 2, 333), ((2, 4, 2), 2, 64),
+                                             ((2, 4, 2), 3, 65), ((3, 4, 2), 2, 200), ((2, 8, 2), 2, 130),
+                                             ((2, 4, 3), 2, 77), ((2, 6, 2), 3, 1)])
+def test_cpep_loss_and_gradient(arch, n_state, N):
+    import c_oracle as co
+    from cude.engine import Engine
+    c = make_cpep_case(N, arch)
+    ref = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], c["beta"], c["n_steps"], n_state,
+                  want_grad=True, want_traj=True, covariate=(arch[0] == 3))
+    eng = Engine("cpep", arch, n_steps=c["n_steps"], n_state=n_state)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(c["nn"], c["beta"])
+    f = eng.forward(want_sse=True, want_traj=True)
+    assert abs(f["loss"] - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"])
+    assert _rel(f["sse"], ref["sse"]) < 1e-10
+    assert _rel(f["traj"], ref["traj"].transpose(2, 1, 0)) < 1e-11
+    loss, g_nn, g_cond = eng.loss_grad()
+    assert abs(loss - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"])
+    assert _rel(g_nn, ref["g_nn"]) < GRAD_RTOL
+    assert _rel(g_cond, ref["g_beta"]) < GRAD_RTOL
+    assert eng.n_failed() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("arch,N,lam", [((4, 3, 5), 500, 0.01), ((4, 3, 5), 37, 0.0), ((4, 3, 2), 64, 0.1),
+                                         ((4, 6, 2), 129, 0.0)])
+def test_supp_loss_and_gradient(arch, N, lam):
+    import c_oracle as co
+    from cude.engine import Engine
+    c = make_supp_case(N, arch)
+    ref = co.supp(c["tp"], c["data"], arch, c["nn"], c["theta"], lam, c["n_steps"], want_grad=True, want_traj=True)
+    eng = Engine("supp", arch, n_steps=c["n_steps"], lam=lam)
+    eng.set_population_supp(c["tp"], c["data"])
+    eng.set_params(c["nn"], c["theta"])
+    f = eng.forward(want_sse=True, want_traj=True)
+    assert abs(f["loss"] - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"])
+    assert _rel(f["sse"], ref["sse"]) < 1e-10
+    assert _rel(f["traj"], ref["traj"]) < 1e-11
+    loss, g_nn, g_cond = eng.loss_grad()
+    assert abs(loss - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"])
+    assert _rel(g_nn, ref["g_nn"]) < GRAD_RTOL
+    assert _rel(g_cond, ref["g_theta"]) < GRAD_RTOL
+    eng.close()
+
+
+def test_adam_steps_match_oracle():
+    """10 fused device Adam steps vs oracle gradient + restated Optimisers.Adam on the host."""
+    import c_oracle as co
+    import cude_oracle as o
+    from cude.engine import Engine
+    arch, N = (2, 6, 2), 300
+    c = make_cpep_case(N, arch)
+    eng = Engine("cpep", arch, n_steps=30, n_state=3)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(c["nn"], c["beta"])
+    eng.adam_init(1e-2)
+    nn, beta = c["nn"].copy(), c["beta"].copy()
+    m_n, v_n, m_b, v_b = np.zeros_like(nn), np.zeros_like(nn), np.zeros_like(beta), np.zeros_like(beta)
+    for t in range(1, 11):
+        ref = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, nn, beta, 30, 3)
+        loss = eng.adam_step()
+        assert abs(loss - ref["loss"]) <= 1e-9 * abs(ref["loss"])
+        nn, m_n, v_n = o.adam_update(nn, ref["g_nn"], m_n, v_n, t, 1e-2)
+        beta, m_b, v_b = o.adam_update(beta, ref["g_beta"], m_b, v_b, t, 1e-2)
+    nn_d, beta_d = eng.get_params()
+    assert np.max(np.abs(nn_d - nn)) < 1e-8
+    assert np.max(np.abs(beta_d - beta)) < 1e-8
+    eng.close()
+
+
+def test_failure_convention():
+    """A non-finite trajectory gives +Inf with status 0 (parameter-estimation.jl:61-64,134-136)."""
+    from cude.engine import Engine
+    arch, N = (2, 4, 2), 70
+    c = make_cpep_case(N, arch)
+    eng = Engine("cpep", arch)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    beta = c["beta"].copy()
+    beta[5] = np.nan
+    eng.set_params(c["nn"], beta)
+    out = eng.forward()
+    assert out["loss"] == np.inf
+    assert eng.n_failed() == 1
+    loss, _, _ = eng.loss_grad()
+    assert loss == np.inf
+    eng.close()
