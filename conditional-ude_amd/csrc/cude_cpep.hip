@@ -21,28 +21,6 @@
 
 namespace cude {
 
-constexpr int kRedRows = 16;   // rows of the LDS transpose used by the wave reduction
-
-// Sum v[0..NV) over the 64 lanes of the (single-wave) workgroup and store the sums to out[0..NV).
-// Chunked LDS transpose: rolled code (small i-cache footprint), fixed order (deterministic).
-template <int NV>
-__device__ __forceinline__ void block_reduce_store(const double (&v)[NV], double* s_red, double* out, int lane) {
-#pragma unroll
-    for (int c0 = 0; c0 < NV; c0 += kRedRows) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kRedRows; r++)
-            if (c0 + r < NV) s_red[r * kBlock + lane] = v[c0 + r];
-        __syncthreads();
-        if (lane < kRedRows && c0 + lane < NV) {
-            double acc = 0.0;
-#pragma unroll 8
-            for (int l = 0; l < kBlock; l++) acc += s_red[lane * kBlock + ((l + lane) & (kBlock - 1))];
-            out[c0 + lane] = acc;
-        }
-    }
-}
-
 template <int NIN, int W, int D, int NS, bool GRAD>
 __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     using Net = Mlp<NIN, W, D, 1>;

@@ -15,6 +15,16 @@
 namespace cude {
 
 // ------------------------------------------------------------------------------------ Tsit5
+// wave-uniform table for rolled stage loops (scalar loads with a run-time stage index)
+__device__ __constant__ const double TS_A[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {0.161, 0, 0, 0, 0, 0},
+    {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+
 // compile-time copy for fully unrolled code (immediates / SGPR literals instead of loads)
 struct Tab {
     static constexpr double a(int i, int j) {
@@ -229,6 +239,29 @@ struct Mlp {
 };
 
 // ------------------------------------------------------------------------------------ reductions
+constexpr int kBlockLanes = 64;
+constexpr int kRedRows = 16;   // rows of the LDS transpose used by the wave reduction
+
+// Sum v[0..NV) over the 64 lanes of the (single-wave) workgroup and store the sums to out[0..NV).
+// Chunked LDS transpose: rolled code (small i-cache footprint), fixed order (deterministic).
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(const double (&v)[NV], double* s_red, double* out, int lane) {
+#pragma unroll
+    for (int c0 = 0; c0 < NV; c0 += kRedRows) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRedRows; r++)
+            if (c0 + r < NV) s_red[r * kBlockLanes + lane] = v[c0 + r];
+        __syncthreads();
+        if (lane < kRedRows && c0 + lane < NV) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < kBlockLanes; l++) acc += s_red[lane * kBlockLanes + ((l + lane) & (kBlockLanes - 1))];
+            out[c0 + lane] = acc;
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

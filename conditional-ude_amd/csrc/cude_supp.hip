@@ -35,12 +35,22 @@ struct SuppRhs {
     }
 };
 
+// LDS rows of kBlock doubles (one per lane):
+//   s_K [7][3]  stage derivatives k_i (forward) / their adjoints (reverse)
+//   s_Y [7][3]  stage inputs Y_i of the step being reversed (also the reduction scratch)
+//   s_res[T][3] residuals kept for the reverse sweep
+constexpr int kSuppRowsFixed = 42;
+
 template <int W, int D, bool GRAD>
 __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     using R = SuppRhs<W, D>;
     using Net = typename R::Net;
     constexpr int P = Net::P;
-    extern __shared__ double s_res[];   // [T][3][kBlock]
+    extern __shared__ double smem[];
+    double* s_K = smem;
+    double* s_Y = smem + 21 * kBlock;
+    double* s_res = smem + 42 * kBlock;
+    double* s_red = s_Y;
 
     const int lane = threadIdx.x;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
@@ -52,6 +62,8 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     ciptr_t obs_step = as_const(a.obs_step);
     const int S = a.S, T = a.T;
     const double h = a.h;
+#define KROW(j, s) s_K[((j) * 3 + (s)) * kBlock + lane]
+#define YROW(j, s) s_Y[((j) * 3 + (s)) * kBlock + lane]
 
     double cst[1] = {exp(a.cond[i])};
     double c[W];
@@ -62,150 +74,198 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     for (int s = 0; s < 3; s++) y[s] = a.data[((int64_t)s * T + 0) * N + i];
     const double y0[3] = {y[0], y[1], y[2]};
 
-    double K[7][3];
-    R::f(p, c, y, K[0]);
+    // ------------------------------------------------------------------ forward
+    // One network call site: evaluation e = 0 is k_1 of step 0; e = 6n+st (st = 1..6) is stage
+    // st+1 of step n (st = 6: k_7 = f(y_{n+1}), reused as k_1 of the next step).
     double sse = fma(cst[0], 0.0, Net::param_check(p));   // NaN iff a parameter / theta is non-finite
-    int oi = 0;
-    for (int n = 0; n < S; n++) {
-        if (GRAD) {
+    int oi = 0, n = 0, st = 0;
+#pragma unroll 1
+    for (int e = 0; e <= 6 * S; e++) {
+        double u[3];
+        if (st == 0) {
 #pragma unroll
-            for (int s = 0; s < 3; s++) a.ckpt[((int64_t)n * 3 + s) * N + i] = y[s];
-        }
-        double Y[3];
+            for (int s = 0; s < 3; s++) u[s] = y[s];
+            if (GRAD) {
 #pragma unroll
-        for (int st = 1; st < 7; st++) {
-#pragma unroll
-            for (int s = 0; s < 3; s++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < st; j++) acc = fma(Tab::a(st, j), K[j][s], acc);
-                Y[s] = fma(h, acc, y[s]);
+                for (int s = 0; s < 3; s++) a.ckpt[(int64_t)s * N + i] = y[s];        // y_0
             }
-            R::f(p, c, Y, K[st]);
+        } else {
+            double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int j = 0; j < st; j++) {
+                const double aj = TS_A[st][j];
+#pragma unroll
+                for (int s = 0; s < 3; s++) t[s] = fma(aj, KROW(j, s), t[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++) u[s] = fma(h, t[s], y[s]);
         }
+        double du[3];
+        R::f(p, c, u, du);
+#pragma unroll
+        for (int s = 0; s < 3; s++) KROW(st, s) = du[s];
+        if (e == 0) { st = 1; continue; }
+        if (st < 6) { st++; continue; }
+        // ---- end of step n: u = y_{n+1}, KROW(6) = k_7
         while (oi < T && obs_step[oi] == n) {
+            double o[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int j = 0; j < 7; j++) {
+                const double w = obs_w[oi * 7 + j];
+#pragma unroll
+                for (int s = 0; s < 3; s++) o[s] = fma(w, KROW(j, s), o[s]);
+            }
 #pragma unroll
             for (int s = 0; s < 3; s++) {
-                double o = 0.0;
-#pragma unroll
-                for (int j = 0; j < 7; j++) o = fma(obs_w[oi * 7 + j], K[j][s], o);
-                o = fma(h, o, y[s]);
-                const double r = o - a.data[((int64_t)s * T + oi) * N + i];
+                const double ov = fma(h, o[s], y[s]);
+                const double r = ov - a.data[((int64_t)s * T + oi) * N + i];
                 sse = fma(r * a.iscale2[s], r, sse);
                 if (GRAD) s_res[(oi * 3 + s) * kBlock + lane] = r;
-                if (a.traj != nullptr && active) a.traj[s + 3 * (oi + (int64_t)T * i)] = o;
+                if (a.traj != nullptr && active) a.traj[s + 3 * (oi + (int64_t)T * i)] = ov;
             }
             oi++;
         }
 #pragma unroll
-        for (int s = 0; s < 3; s++) { y[s] = Y[s]; K[0][s] = K[6][s]; }
+        for (int s = 0; s < 3; s++) { y[s] = u[s]; KROW(0, s) = du[s]; }
+        st = 1;
+        n++;
+        if (GRAD && n < S) {
+#pragma unroll
+            for (int s = 0; s < 3; s++) a.ckpt[((int64_t)n * 3 + s) * N + i] = y[s];  // y_n
+        }
     }
     const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);
     if (active && a.sse != nullptr) a.sse[i] = sse;
-    double red_loss = active ? sse : 0.0;
-    double red_fail = (active && failed) ? 1.0 : 0.0;
+    const double red_loss = active ? sse : 0.0;
+    const double red_fail = (active && failed) ? 1.0 : 0.0;
     double* out = a.partials + (int64_t)blockIdx.x * (P + 2);
 
     if (!GRAD) {
-        red_loss = wave_sum(red_loss);
-        red_fail = wave_sum(red_fail);
-        if (lane == 0) { out[P] = red_loss; out[P + 1] = red_fail; }
+        const double v2[2] = {red_loss, red_fail};
+        block_reduce_store<2>(v2, s_red, out + P, lane);
         return;
     } else {
+        // -------------------------------------------------------------- reverse sweep
         double acc[Net::NACC];
 #pragma unroll
         for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
         double lam[3] = {0.0, 0.0, 0.0};   // adjoint of y_{n+1}
         double kap[3] = {0.0, 0.0, 0.0};   // adjoint of k_7 of step n from step n+1's use as k_1
+        double yb[3] = {0.0, 0.0, 0.0};
         const double gs = 2.0 * a.inv_n;
         oi = T - 1;
-        for (int n = S - 1; n >= 0; n--) {
-            double yn[3];
+        n = S - 1;
+        st = 6;
+        // VJP evaluations in reverse order: idx = 6n+st (st = 6..1) is stage st+1 of step n;
+        // idx = 0 is k_1 of step 0 = f(y_0).
+#pragma unroll 1
+        for (int idx = 6 * S; idx >= 0; idx--) {
+            if (idx > 0 && st == 6) {
+                // ---- recompute the stage inputs of step n from the checkpoint
+                double yn[3];
 #pragma unroll
-            for (int s = 0; s < 3; s++) yn[s] = a.ckpt[((int64_t)n * 3 + s) * N + i];
-            // recompute the stage states of this step
-            double Ys[6][3];                 // Ys[st-1] = input of stage st+1 (st = 1..6; last = y_{n+1})
-            {
-                double Kf[6][3];
-                R::f(p, c, yn, Kf[0]);
+                for (int s = 0; s < 3; s++) { yn[s] = a.ckpt[((int64_t)n * 3 + s) * N + i]; YROW(0, s) = yn[s]; }
+#pragma unroll 1
+                for (int r = 0; r < 6; r++) {
+                    double u[3], du[3];
 #pragma unroll
-                for (int st = 1; st < 7; st++) {
+                    for (int s = 0; s < 3; s++) u[s] = YROW(r, s);
+                    R::f(p, c, u, du);
+#pragma unroll
+                    for (int s = 0; s < 3; s++) KROW(r, s) = du[s];
+                    double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+                    for (int j = 0; j <= r; j++) {
+                        const double aj = TS_A[r + 1][j];
+#pragma unroll
+                        for (int s = 0; s < 3; s++) t[s] = fma(aj, KROW(j, s), t[s]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 3; s++) YROW(r + 1, s) = fma(h, t[s], yn[s]);
+                }
+                // ---- seed the stage adjoints (stored over the stage derivatives)
+#pragma unroll 1
+                for (int j = 0; j < 6; j++) {
+#pragma unroll
+                    for (int s = 0; s < 3; s++) KROW(j, s) = 0.0;
+                }
+#pragma unroll
+                for (int s = 0; s < 3; s++) { KROW(6, s) = kap[s]; yb[s] = 0.0; }
+                while (oi >= 0 && obs_step[oi] == n) {
+                    double hg[3];
 #pragma unroll
                     for (int s = 0; s < 3; s++) {
-                        double t = 0.0;
-#pragma unroll
-                        for (int j = 0; j < st; j++) t = fma(Tab::a(st, j), Kf[j][s], t);
-                        Ys[st - 1][s] = fma(h, t, yn[s]);
+                        const double g = gs * a.iscale2[s] * s_res[(oi * 3 + s) * kBlock + lane];
+                        yb[s] += g;
+                        hg[s] = h * g;
                     }
-                    if (st < 6) R::f(p, c, Ys[st - 1], Kf[st]);
+#pragma unroll 1
+                    for (int j = 0; j < 7; j++) {
+                        const double w = obs_w[oi * 7 + j];
+#pragma unroll
+                        for (int s = 0; s < 3; s++) KROW(j, s) = fma(w, hg[s], KROW(j, s));
+                    }
+                    oi--;
                 }
             }
-            double kb[7][3];
+            double u[3], kb[3], ub[3];
+            if (idx > 0) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) { kb[j][0] = 0.0; kb[j][1] = 0.0; kb[j][2] = 0.0; }
+                for (int s = 0; s < 3; s++) { u[s] = YROW(st, s); kb[s] = KROW(st, s); }
+            } else {
 #pragma unroll
-            for (int s = 0; s < 3; s++) kb[6][s] = kap[s];
-            double yb[3] = {0.0, 0.0, 0.0};
-            while (oi >= 0 && obs_step[oi] == n) {
-#pragma unroll
-                for (int s = 0; s < 3; s++) {
-                    const double g = gs * a.iscale2[s] * s_res[(oi * 3 + s) * kBlock + lane];
-                    yb[s] += g;
-                    const double hg = h * g;
-#pragma unroll
-                    for (int j = 0; j < 7; j++) kb[j][s] = fma(obs_w[oi * 7 + j], hg, kb[j][s]);
-                }
-                oi--;
+                for (int s = 0; s < 3; s++) { u[s] = y0[s]; kb[s] = kap[s]; }
             }
-            // stage 7 at y_{n+1}
-            R::vjp(p, c, Ys[5], kb[6], lam, acc);
+            if (idx > 0 && st == 6) {
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
-                yb[s] += lam[s];
-                const double hl = h * lam[s];
+                for (int s = 0; s < 3; s++) ub[s] = lam[s];     // stage 7 adds into the adjoint of y_{n+1}
+            } else {
 #pragma unroll
-                for (int j = 0; j < 6; j++) kb[j][s] = fma(Tab::a(6, j), hl, kb[j][s]);
+                for (int s = 0; s < 3; s++) ub[s] = 0.0;
             }
+            R::vjp(p, c, u, kb, ub, acc);
+            if (idx == 0) break;
+            // propagate ub through  Y_st = y_n + h sum_{j<st} a(st,j) k_j
 #pragma unroll
-            for (int st = 5; st >= 1; st--) {
-                double Yb[3] = {0.0, 0.0, 0.0};
-                R::vjp(p, c, Ys[st - 1], kb[st], Yb, acc);
+            for (int s = 0; s < 3; s++) yb[s] += ub[s];
+            const int nj = st < 6 ? st : 6;
+#pragma unroll 1
+            for (int j = 0; j < nj; j++) {
+                const double aj = h * TS_A[st][j];
 #pragma unroll
-                for (int s = 0; s < 3; s++) {
-                    yb[s] += Yb[s];
-                    const double hy = h * Yb[s];
-#pragma unroll
-                    for (int j = 0; j < st; j++) kb[j][s] = fma(Tab::a(st, j), hy, kb[j][s]);
-                }
+                for (int s = 0; s < 3; s++) KROW(j, s) = fma(aj, ub[s], KROW(j, s));
             }
+            if (st > 1) {
+                st--;
+            } else {
 #pragma unroll
-            for (int s = 0; s < 3; s++) { lam[s] = yb[s]; kap[s] = kb[0][s]; }
+                for (int s = 0; s < 3; s++) { lam[s] = yb[s]; kap[s] = KROW(0, s); }
+                st = 6;
+                n--;
+            }
         }
-        // k_1 of step 0 = f(y_0): y_0 is data, but the network parameters and exp(theta) enter
-        {
-            double ub[3] = {0.0, 0.0, 0.0};
-            R::vjp(p, c, y0, kap, ub, acc);
-        }
-        double g[P];
+        double g[P + 2];
         double dcond;
-        Net::expand(p, acc, cst, g, &dcond);
-        if (active) a.g_cond[i] = dcond;
-        const double keep = active ? 1.0 : 0.0;
+        {
+            double gp[P];
+            Net::expand(p, acc, cst, gp, &dcond);
+            const double keep = active ? 1.0 : 0.0;
 #pragma unroll
-        for (int q = 0; q < P; q++) {
-            const double v = wave_sum(g[q] * keep);
-            if (lane == 0) out[q] = v;
+            for (int q = 0; q < P; q++) g[q] = gp[q] * keep;
         }
-        red_loss = wave_sum(red_loss);
-        red_fail = wave_sum(red_fail);
-        if (lane == 0) { out[P] = red_loss; out[P + 1] = red_fail; }
+        g[P] = red_loss;
+        g[P + 1] = red_fail;
+        if (active) a.g_cond[i] = dcond;
+        block_reduce_store<P + 2>(g, s_red, out, lane);
     }
+#undef KROW
+#undef YROW
 }
 
 template <int W, int D, bool GRAD>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
-    const size_t lds = GRAD ? sizeof(double) * (size_t)a.T * 3 * kBlock : 0;
+    const size_t lds = sizeof(double) * (size_t)(kSuppRowsFixed + (GRAD ? 3 * a.T : 0)) * kBlock;
     hipLaunchKernelGGL((supp_kernel<W, D, GRAD>), dim3((unsigned)nblocks), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }

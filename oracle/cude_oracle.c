@@ -76,6 +76,7 @@ static void locate_obs(const double* tp, int T, int S, int* step, double* theta)
 }
 
 /* ---------------------------------------------------------------- dual arithmetic */
+static inline void d_copy(dual* r, const dual* x, int np) { r->v = x->v; for (int i = 0; i < np; i++) r->d[i] = x->d[i]; }
 static inline void d_const(dual* r, double v, int np) { r->v = v; for (int i = 0; i < np; i++) r->d[i] = 0.0; }
 static inline void d_axpy(dual* r, double a, const dual* x, int np) { /* r += a*x */
     r->v += a * x->v; for (int i = 0; i < np; i++) r->d[i] += a * x->d[i]; }
@@ -92,7 +93,7 @@ static inline void d_softplus(dual* r, const dual* x, int np) {
 static void mlp_dual(dual* out, const dual* in, int nin, int width, int depth, const double* nn, int seed, int np) {
     dual h[MAXW], g[MAXW], z;
     int fan = nin, off = 0;
-    for (int i = 0; i < nin; i++) h[i] = in[i];
+    for (int i = 0; i < nin; i++) d_copy(&h[i], &in[i], np);
     for (int l = 0; l < depth; l++) {
         for (int j = 0; j < width; j++) {
             int bi = off + fan * width + j;
@@ -104,7 +105,7 @@ static void mlp_dual(dual* out, const dual* in, int nin, int width, int depth, c
             }
             d_tanh(&g[j], &z, np);
         }
-        for (int j = 0; j < width; j++) h[j] = g[j];
+        for (int j = 0; j < width; j++) d_copy(&h[j], &g[j], np);
         off += fan * width + width;
         fan = width;
     }
@@ -144,11 +145,11 @@ static void rhs_eval(const rhs_ctx* c, double t, const dual* u, dual* du) {
     if (c->model == 0) {
         double dG = lin_interp(c->tp, c->G, c->T, t) - lin_interp(c->tp, c->G, c->T, c->tp[0]);
         dual in[3], a, b;
-        d_const(&in[0], dG, np); in[1] = c->eb; d_const(&in[2], c->age, np);
+        d_const(&in[0], dG, np); d_copy(&in[1], &c->eb, np); d_const(&in[2], c->age, np);
         mlp_dual(&a, in, c->nin, c->width, c->depth, c->nn, c->seed, np);
         d_const(&in[0], 0.0, np);
         mlp_dual(&b, in, c->nin, c->width, c->depth, c->nn, c->seed, np);
-        dual prod = a; d_axpy(&prod, -1.0, &b, np);
+        dual prod; d_copy(&prod, &a, np); d_axpy(&prod, -1.0, &b, np);
         d_const(&du[0], c->k0 * c->c0, np);
         d_axpy(&du[0], -(c->k0 + c->k2), &u[0], np);
         d_axpy(&du[0], c->k1, &u[1], np);
@@ -156,14 +157,14 @@ static void rhs_eval(const rhs_ctx* c, double t, const dual* u, dual* du) {
         d_const(&du[1], 0.0, np);
         d_axpy(&du[1], -c->k1, &u[1], np);
         d_axpy(&du[1], c->k2, &u[0], np);
-        if (c->ns == 3) du[2] = prod;
+        if (c->ns == 3) d_copy(&du[2], &prod, np);
     } else {
         dual in[4], uh;
-        in[0] = u[0]; in[1] = u[1]; in[2] = u[2]; in[3] = c->eb;
+        d_copy(&in[0], &u[0], np); d_copy(&in[1], &u[1], np); d_copy(&in[2], &u[2], np); d_copy(&in[3], &c->eb, np);
         mlp_dual(&uh, in, 4, c->width, c->depth, c->nn, c->seed, np);
         d_const(&du[0], 0.0, np); d_axpy(&du[0], -0.4, &u[0], np);
         d_const(&du[1], 0.0, np); d_axpy(&du[1], 0.4, &u[0], np); d_axpy(&du[1], -1.0, &uh, np);
-        du[2] = uh; d_axpy(&du[2], -0.3, &u[2], np);
+        d_copy(&du[2], &uh, np); d_axpy(&du[2], -0.3, &u[2], np);
     }
 }
 
@@ -173,7 +174,7 @@ static void solve_fixed(const rhs_ctx* c, const dual* u0, const double* tp, int 
     int ns = c->ns, np = c->np;
     double t0 = tp[0], h = (tp[T - 1] - tp[0]) / S;
     dual y[3], ynew[3], Y[3], k[7][3];
-    for (int s = 0; s < ns; s++) y[s] = u0[s];
+    for (int s = 0; s < ns; s++) d_copy(&y[s], &u0[s], np);
     rhs_eval(c, t0, y, k[0]);
     for (int n = 0; n < S; n++) {
         double tn = t0 + n * h;
@@ -181,20 +182,20 @@ static void solve_fixed(const rhs_ctx* c, const dual* u0, const double* tp, int 
             for (int s = 0; s < ns; s++) {
                 dual acc; d_const(&acc, 0.0, np);
                 for (int j = 0; j < i; j++) d_axpy(&acc, TA[i][j], &k[j][s], np);
-                Y[s] = y[s]; d_axpy(&Y[s], h, &acc, np);
+                d_copy(&Y[s], &y[s], np); d_axpy(&Y[s], h, &acc, np);
             }
             if (i < 6) rhs_eval(c, tn + TC[i] * h, Y, k[i]);
-            else { for (int s = 0; s < ns; s++) ynew[s] = Y[s]; rhs_eval(c, t0 + (n + 1) * h, ynew, k[6]); }
+            else { for (int s = 0; s < ns; s++) d_copy(&ynew[s], &Y[s], np); rhs_eval(c, t0 + (n + 1) * h, ynew, k[6]); }
         }
         for (int ti = 0; ti < T; ti++) if (ostep[ti] == n) {
             double w[7]; interp_weights(otheta[ti], w);
             for (int s = 0; s < ns; s++) {
                 dual acc; d_const(&acc, 0.0, np);
                 for (int j = 0; j < 7; j++) d_axpy(&acc, w[j], &k[j][s], np);
-                out[ti * ns + s] = y[s]; d_axpy(&out[ti * ns + s], h, &acc, np);
+                d_copy(&out[ti * ns + s], &y[s], np); d_axpy(&out[ti * ns + s], h, &acc, np);
             }
         }
-        for (int s = 0; s < ns; s++) { y[s] = ynew[s]; k[0][s] = k[6][s]; }
+        for (int s = 0; s < ns; s++) { d_copy(&y[s], &ynew[s], np); d_copy(&k[0][s], &k[6][s], np); }
     }
 }
 
