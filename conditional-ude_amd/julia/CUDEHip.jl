@@ -1,0 +1,60 @@
+# Julia shim over the C ABI of libcude_hip.so (see INTEGRATION.md).  Written, not executed in this pipeline
+# (Julia is not installed in the build image); mirrors conditional-ude_amd/cude/engine.py 1:1.
+module CUDEHip
+const LIB = "libcude_hip.so"
+struct Config
+    model::Int32; n_state::Int32; nn_in::Int32; nn_width::Int32; nn_depth::Int32
+    n_steps::Int32; device::Int32; reserved::Int32; lambda::Float64
+end
+check(st) = st < 0 ? error(unsafe_string(ccall((:cude_last_error, LIB), Cstring, ()))) : st
+
+mutable struct Ctx; h::Ptr{Cvoid}; P::Int; N::Int; end
+function Ctx(cfg::Config)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:cude_create, LIB), Int32, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, h))
+    P = ccall((:cude_n_params, LIB), Int32, (Int32, Int32, Int32), cfg.nn_in, cfg.nn_width, cfg.nn_depth)
+    c = Ctx(h[], P, 0); finalizer(x -> ccall((:cude_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), c); c
+end
+
+# models' data as Julia column-major N×T matrices: ld_subject = 1, ld_time = N (no host copy)
+function set_population!(c::Ctx, timepoints::Vector{Float64}, glucose::Matrix{Float64}, cpeptide::Matrix{Float64},
+                         ages::Vector{Float64}, t2dm::Vector{UInt8})
+    N, T = size(glucose)
+    GC.@preserve timepoints glucose cpeptide ages t2dm check(ccall((:cude_set_population_cpep, LIB), Int32,
+        (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{UInt8}),
+        c.h, N, T, timepoints, glucose, cpeptide, 1, N, ages, t2dm))
+    c.N = N
+end
+
+# drop-in for `loss(θ, (models, timepoints, cpeptide_data))`  (src/parameter-estimation.jl:126-140)
+function loss(c::Ctx, θ)
+    nn = Vector{Float64}(θ.neural); cond = vec(Matrix{Float64}(θ.conditional)); l = Ref{Float64}()
+    GC.@preserve nn cond begin
+        check(ccall((:cude_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond))
+        check(ccall((:cude_forward, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}), c.h, l, C_NULL, C_NULL))
+    end
+    l[]
+end
+
+# gradient hook:  OptimizationFunction((θ,p)->loss(ctx,θ); grad = (G,θ,p)->grad!(G,ctx,θ))
+function grad!(G, c::Ctx, θ)
+    nn = Vector{Float64}(θ.neural); cond = vec(Matrix{Float64}(θ.conditional))
+    gnn = Vector{Float64}(undef, c.P); gcond = Vector{Float64}(undef, c.N); l = Ref{Float64}()
+    GC.@preserve nn cond gnn gcond begin
+        check(ccall((:cude_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond))
+        check(ccall((:cude_loss_grad, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}), c.h, l, gnn, gcond))
+    end
+    G.neural .= gnn; G.conditional .= reshape(gcond, size(G.conditional)); G
+end
+
+# fast path replacing Optimization.solve(prob, Optimisers.Adam(η), maxiters=K): parameters stay on the GPU
+function adam!(c::Ctx, θ0, η, iters; callback = (l)->false)
+    loss(c, θ0); check(ccall((:cude_adam_init, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Float64, Float64), c.h, η, 0.9, 0.999, 1e-8))
+    l = Ref{Float64}()
+    for _ in 1:iters
+        check(ccall((:cude_adam_step, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}), c.h, l)); callback(l[]) && break
+    end
+    nn = Vector{Float64}(undef, c.P); cond = Vector{Float64}(undef, c.N)
+    check(ccall((:cude_get_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond)); (nn, cond, l[])
+end
+end

@@ -1,0 +1,115 @@
+"""Soft pins of the CPU oracle against the reference's STORED results (tests/golden/*.npz).
+
+The reference has no tests and cannot run here (Julia), so parity is formally unpinned; these checks
+tie the restated equations, unit conversions, van Cauter constants, MLP parameter layout and loss
+definitions to numbers the reference itself produced.  Tolerances are the adaptive-solver level
+(reference: reltol 1e-3), not the 1e-6 kernel-parity level.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _argmin_1d(f, lo, hi, n_grid=71, iters=45):
+    """Vectorised bounded 1-D minimisation (grid + golden section) of f: (N,) -> (N,)."""
+    grid = np.linspace(lo, hi, n_grid)
+    vals = np.stack([f(np.full_like(lo_, g)) for g, lo_ in ((g, np.zeros(f.n)) for g in grid)])
+    k = np.clip(np.argmin(vals, axis=0), 1, n_grid - 2)
+    a, b = grid[k - 1], grid[k + 1]
+    gr = (np.sqrt(5) - 1) / 2
+    c, d = b - gr * (b - a), a + gr * (b - a)
+    fc, fd = f(c), f(d)
+    for _ in range(iters):
+        left = fc < fd
+        b = np.where(left, d, b)
+        a = np.where(left, a, c)
+        c2, d2 = b - gr * (b - a), a + gr * (b - a)
+        fc, fd = f(c2), f(d2)
+        c, d = c2, d2
+    x = 0.5 * (a + b)
+    return x, f(x)
+
+
+class _Sse:
+    def __init__(self, fn, n):
+        self.fn, self.n = fn, n
+
+    def __call__(self, x):
+        return self.fn(x)
+
+
+def _cpep_refit(nn, g):
+    import c_oracle as co
+    N = g["glucose"].shape[0]
+
+    def sse(beta):
+        return co.cpep(g["timepoints"], g["glucose"], g["cpeptide"], g["ages"], g["t2dm"], (2, 4, 2), nn, beta, 30,
+                       2, want_grad=False)["sse"]
+    return _argmin_1d(_Sse(sse, N), -4.0, 3.0)
+
+
+def test_cpeptide_stored_betas_are_recovered():
+    """With stored model k=0 (37 weights, SimpleChains column-major layout) the per-subject refit of beta on
+    the 117 Ohashi subjects reproduces each of the 57 stored training betas."""
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    nn, stored = g["nn_2x4x4x1"][0], g["betas_train"][0]
+    beta_hat, sse = _cpep_refit(nn, g)
+    cost = np.abs(stored[:, None] - beta_hat[None, :])
+    r, c = linear_sum_assignment(cost)
+    d = cost[r, c]
+    assert np.median(d) < 5e-3, np.median(d)
+    assert np.quantile(d, 0.9) < 3e-2, np.quantile(d, 0.9)
+    assert np.mean(sse[c]) < 0.5           # nmol^2/L^2; SURVEY probe: mean 0.31, median 0.16
+    assert np.median(sse[c]) < 0.3
+
+
+def test_cpeptide_row_major_layout_is_rejected():
+    """Negative control: reading the weight matrices row-major destroys the match (pins the layout)."""
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    nn = g["nn_2x4x4x1"][0].copy()
+    w1 = nn[0:8].reshape(2, 4).T.copy()     # stored column-major 4x2 -> reinterpret as row-major
+    w2 = nn[12:28].reshape(4, 4).T.copy()
+    nn[0:8], nn[12:28] = w1.reshape(-1), w2.reshape(-1)
+    beta_hat, sse = _cpep_refit(nn, g)
+    cost = np.abs(g["betas_train"][0][:, None] - beta_hat[None, :])
+    r, c = linear_sum_assignment(cost)
+    assert np.median(cost[r, c]) > 0.05 or np.mean(sse[c]) > 1.0
+
+
+def test_cpeptide_stationarity_of_stored_optimum():
+    """At (stored nn, refit betas of the matched subjects) the population gradient w.r.t. beta vanishes and
+    the gradient w.r.t. the network is small relative to its size at a perturbed point."""
+    import c_oracle as co
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    nn, stored = g["nn_2x4x4x1"][0], g["betas_train"][0]
+    beta_hat, _ = _cpep_refit(nn, g)
+    cost = np.abs(stored[:, None] - beta_hat[None, :])
+    _, c = linear_sum_assignment(cost)
+    sel = np.sort(c)
+    args = (g["timepoints"], g["glucose"][sel], g["cpeptide"][sel], g["ages"][sel], g["t2dm"][sel], (2, 4, 2))
+    at = co.cpep(*args, nn, beta_hat[sel], 30, 2)
+    off = co.cpep(*args, nn * 1.1, beta_hat[sel] + 0.2, 30, 2)
+    assert np.max(np.abs(at["g_beta"])) < 1e-6
+    assert np.linalg.norm(at["g_nn"]) < 0.05 * np.linalg.norm(off["g_nn"])
+
+
+@pytest.mark.parametrize("model", [0, 3, 7])
+def test_suppression_stored_losses(model):
+    """min_theta dataterm(theta, stored nn_n) must be <= and close to the stored final loss
+    (lambda = 0; theta was not saved by the reference: suppression/suppression.jl:76-91)."""
+    import c_oracle as co
+    g = dict(np.load(os.path.join(GOLD, "suppression_lambda0.npz")))
+    nn, data, tp = g["nn_4x3x5x1"][model], g["group_data"], g["timepoints"]
+    N = data.shape[2]
+
+    def sse(theta):
+        return co.supp(tp, data, (4, 3, 5), nn, theta, 0.0, 60, want_grad=False)["sse"]
+    _, best = _argmin_1d(_Sse(sse, N), -6.0, 4.0, n_grid=101)
+    loss = best.sum() / N
+    stored = g["losses"][model]
+    assert loss <= stored * 1.02
+    assert loss >= stored * 0.80
