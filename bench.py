@@ -44,9 +44,11 @@ def executed_flops_per_trajectory(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS):
     """fp64 flops the forward+adjoint kernel actually executes per subject (FMA = 2), counted from
     the kernel's structure (DESIGN.md "flop accounting"): evaluations x per-evaluation counts."""
     nin, w, d = arch
-    tanh_fl = 19 * 2 + 9           # m_tanh: 19 FMA + 9 other VALU ops
-    softplus_fl = 28 * 2 + 22      # m_softplus incl. logistic derivative
-    fwd_eval = 2 * (w * 1 + (d - 1) * w * w + w) + d * w * tanh_fl + softplus_fl
+    # m_tanh_vec per neuron: min, mul, rndne, cvt, ldexp, add, bfi (7 x 1 flop) + 13 FMA (2 reduction, 10 Horner,
+    # 1 final) ; per layer: one reciprocal (rcp + 3 FMA) + 3(W-1) multiplies
+    tanh_layer_fl = w * (7 + 13 * 2) + (1 + 3 * 2) + 3 * (w - 1)
+    softplus_fl = 26 * 2 + 22      # exp (12 FMA) + shared reciprocal (3 FMA) + atanh series (11 FMA) + 22 other ops
+    fwd_eval = 2 * (w * 1 + (d - 1) * w * w + w) + d * tanh_layer_fl + softplus_fl
     bwd_eval = (2 * w + w + 2) + (d - 1) * w * (4 + 4 * w) + w * 6
     n_eval = 5 * n_steps + 1
     stage_fwd = 2 * (2 * 21 + 2 * 6 + 7 * 4) + 2 * 6          # stage sums, Y, A*Y+g, quadrature

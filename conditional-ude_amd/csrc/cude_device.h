@@ -75,6 +75,28 @@ __device__ __forceinline__ double act_softplus_val(double x) { return m_softplus
 // Network NIN -> W (tanh) x D -> 1 (softplus).  The first NV inputs vary per evaluation; the
 // remaining NIN-NV inputs are constant per subject (exp(conditional) [, age]) and are folded
 // into a per-subject first-layer offset  c_j = b1_j + sum_{i>=NV} W1[j,i]*cst_i.
+//
+// Weight traffic: the shared parameters are wave-uniform, so they are read with scalar loads and
+// used as SGPR operands.  A 2-6-6-1 network has 55 doubles per evaluation (110 SGPRs) which does
+// not fit next to the activation constants in the 102-SGPR budget; left alone, the scheduler
+// hoists every s_load to the top of the evaluation and spills ~60 SGPRs to VGPR lanes
+// (v_writelane/v_readlane = 25 % extra VALU instructions in the reverse sweep).  Therefore the
+// weights are streamed one SimpleChains column (W contiguous doubles) at a time and
+// sched_barriers keep each column's loads next to its W independent FMAs.
+template <int W>
+struct SCol {
+    double v[W];
+};
+template <int W>
+__device__ __forceinline__ SCol<W> ld_col(cptr_t p, int off) {
+    p = launder(p);   // opaque base per column: keeps the IR from merging/hoisting the column loads
+    SCol<W> c;
+#pragma unroll
+    for (int j = 0; j < W; j++) c.v[j] = p[off + j];
+    return c;
+}
+#define CUDE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 template <int NIN, int W, int D, int NV>
 struct Mlp {
     static constexpr int NC = NIN - NV;
@@ -100,7 +122,7 @@ struct Mlp {
         }
     }
 
-    // 0 when every parameter is finite, NaN otherwise.  The clamped activations above swallow
+    // 0 when every parameter is finite, NaN otherwise.  The clamped activations swallow
     // NaN/Inf, so non-finite inputs are tracked explicitly to honour the reference's failure
     // convention (non-finite solve => loss = Inf).
     __device__ static __forceinline__ double param_check(cptr_t p) {
@@ -110,35 +132,52 @@ struct Mlp {
         return chk;
     }
 
-    // value only
-    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[W], const double (&x)[NV]) {
-        p = launder(p);
-        double h[W];
+    // hidden activations of all layers: h[l][j]; returns the output pre-activation
+    __device__ static __forceinline__ double forward(cptr_t p, const double (&c)[W], const double (&x)[NV],
+                                                     double (&h)[D][W]) {
+        double z[W];
 #pragma unroll
-        for (int j = 0; j < W; j++) {
-            double z = c[j];
+        for (int i = 0; i < NV; i++) {
+            const SCol<W> col = ld_col<W>(p, W * i);
 #pragma unroll
-            for (int i = 0; i < NV; i++) z = fma(p[j + W * i], x[i], z);
-            h[j] = act_tanh(z);
+            for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
         }
+        m_tanh_vec<W>(z, h[0]);
 #pragma unroll
         for (int l = 1; l < D; l++) {
             const int o = L1 + (l - 1) * LH;
-            double g[W];
+            CUDE_FENCE();
+            {
+                const SCol<W> b = ld_col<W>(p, o + W * W);
 #pragma unroll
-            for (int j = 0; j < W; j++) {
-                double z = p[o + W * W + j];
-#pragma unroll
-                for (int i = 0; i < W; i++) z = fma(p[o + j + W * i], h[i], z);
-                g[j] = act_tanh(z);
+                for (int j = 0; j < W; j++) z[j] = b.v[j];
             }
 #pragma unroll
-            for (int j = 0; j < W; j++) h[j] = g[j];
-        }
-        double z = p[OUT + W];
+            for (int i = 0; i < W; i++) {
+                CUDE_FENCE();
+                const SCol<W> col = ld_col<W>(p, o + W * i);
 #pragma unroll
-        for (int i = 0; i < W; i++) z = fma(p[OUT + i], h[i], z);
-        return act_softplus_val(z);
+                for (int j = 0; j < W; j++) z[j] = fma(col.v[j], h[l - 1][i], z[j]);
+            }
+            CUDE_FENCE();
+            m_tanh_vec<W>(z, h[l]);
+        }
+        CUDE_FENCE();
+        const SCol<W> wo = ld_col<W>(p, OUT);
+        double z0 = p[OUT + W], z1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (i & 1) z1 = fma(wo.v[i], h[D - 1][i], z1);
+            else z0 = fma(wo.v[i], h[D - 1][i], z0);
+        }
+        return z0 + z1;
+    }
+
+    // value only
+    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[W], const double (&x)[NV]) {
+        p = launder(p);
+        double h[D][W];
+        return act_softplus_val(forward(p, c, x, h));
     }
 
     // value + weighted reverse sweep:  acc += wgt * d(out)/d(params);  if WANT_DX,
@@ -148,67 +187,68 @@ struct Mlp {
                                                        double wgt, double (&acc)[NACC], double (&dx)[NV]) {
         p = launder(p);
         double h[D][W];
-#pragma unroll
-        for (int j = 0; j < W; j++) {
-            double z = c[j];
-#pragma unroll
-            for (int i = 0; i < NV; i++) z = fma(p[j + W * i], x[i], z);
-            h[0][j] = act_tanh(z);
-        }
-#pragma unroll
-        for (int l = 1; l < D; l++) {
-            const int o = L1 + (l - 1) * LH;
-#pragma unroll
-            for (int j = 0; j < W; j++) {
-                double z = p[o + W * W + j];
-#pragma unroll
-                for (int i = 0; i < W; i++) z = fma(p[o + j + W * i], h[l - 1][i], z);
-                h[l][j] = act_tanh(z);
-            }
-        }
-        double z = p[OUT + W];
-#pragma unroll
-        for (int i = 0; i < W; i++) z = fma(p[OUT + i], h[D - 1][i], z);
+        const double zo = forward(p, c, x, h);
         double sig;
-        const double y = act_softplus(z, &sig);
+        const double y = act_softplus(zo, &sig);
 
         // reverse
         const double dz = wgt * sig;
         acc[G_OUT + W] += dz;
         double dh[W];
+        CUDE_FENCE();
+        {
+            const SCol<W> wo = ld_col<W>(p, OUT);
 #pragma unroll
-        for (int i = 0; i < W; i++) {
-            acc[G_OUT + i] = fma(dz, h[D - 1][i], acc[G_OUT + i]);
-            dh[i] = dz * p[OUT + i];
+            for (int i = 0; i < W; i++) {
+                acc[G_OUT + i] = fma(dz, h[D - 1][i], acc[G_OUT + i]);
+                dh[i] = dz * wo.v[i];
+            }
         }
 #pragma unroll
         for (int l = D - 1; l >= 1; l--) {
             const int o = L1 + (l - 1) * LH;
             const int go = G_H + (l - 1) * LH;
-            double dprev[W];
-#pragma unroll
-            for (int i = 0; i < W; i++) dprev[i] = 0.0;
+            double d[W];
 #pragma unroll
             for (int j = 0; j < W; j++) {
-                const double d = dh[j] * fma(-h[l][j], h[l][j], 1.0);
-                acc[go + W * W + j] += d;
-#pragma unroll
-                for (int i = 0; i < W; i++) {
-                    acc[go + j + W * i] = fma(d, h[l - 1][i], acc[go + j + W * i]);
-                    dprev[i] = fma(p[o + j + W * i], d, dprev[i]);
-                }
+                d[j] = dh[j] * fma(-h[l][j], h[l][j], 1.0);
+                acc[go + W * W + j] += d[j];
             }
 #pragma unroll
-            for (int i = 0; i < W; i++) dh[i] = dprev[i];
+            for (int i = 0; i < W; i++) {
+                CUDE_FENCE();
+                const SCol<W> col = ld_col<W>(p, o + W * i);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < W; j++) {
+                    acc[go + j + W * i] = fma(d[j], h[l - 1][i], acc[go + j + W * i]);
+                    if (j & 1) s1 = fma(col.v[j], d[j], s1);
+                    else s0 = fma(col.v[j], d[j], s0);
+                }
+                dh[i] = s0 + s1;
+            }
+            CUDE_FENCE();
         }
 #pragma unroll
         for (int j = 0; j < W; j++) {
             const double d = dh[j] * fma(-h[0][j], h[0][j], 1.0);
+            dh[j] = d;
             acc[G_C + j] += d;
 #pragma unroll
+            for (int i = 0; i < NV; i++) acc[G_W1V + i * W + j] = fma(d, x[i], acc[G_W1V + i * W + j]);
+        }
+        if (WANT_DX) {
+#pragma unroll
             for (int i = 0; i < NV; i++) {
-                acc[G_W1V + i * W + j] = fma(d, x[i], acc[G_W1V + i * W + j]);
-                if (WANT_DX) dx[i] = fma(p[j + W * i], d, dx[i]);
+                CUDE_FENCE();
+                const SCol<W> col = ld_col<W>(p, W * i);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < W; j++) {
+                    if (j & 1) s1 = fma(col.v[j], dh[j], s1);
+                    else s0 = fma(col.v[j], dh[j], s0);
+                }
+                dx[i] += s0 + s1;
             }
         }
         return y;

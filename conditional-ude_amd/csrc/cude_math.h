@@ -3,14 +3,18 @@
 // The path is bound by fp64 VALU issue and ~70 % of the arithmetic is tanh/softplus
 // (SURVEY.md 8(d)).  The ROCm device-library tanh/exp/log keep <1 ulp over the whole double
 // range with double-double arithmetic (~250 VALU ops per tanh on gfx950); the network only
-// needs ABSOLUTE accuracy ~1e-16 on outputs that are O(1), so these versions use
-//   exp : Cody-Waite reduction + degree-12 polynomial + v_ldexp_f64            (~18 ops)
-//   1/d : v_rcp_f64 + two Newton steps (d is in [1, 2.4e17], no scaling needed)   (5 ops)
-//   tanh(x)     = sign(x) * (1 - 2/(exp(2|x|)+1))
-//   softplus(x) = max(x,0) + log1p(exp(-|x|)),  sigmoid from the same exponential
+// needs ABSOLUTE accuracy ~1e-15 on outputs that are O(1).  Measured issue costs on MI355X
+// (tools/ubench/valu_rates.hip): every fp64 VALU op (fma, mul, add, min, rndne, cvt, ldexp)
+// takes one 1.71 ns SIMD slot per wave-instruction, v_rcp_f64 takes four.  Hence:
+//   exp(2s) : Cody-Waite reduction to |s| <= ln2/4 + degree-10 near-minimax polynomial
+//             (tools/fit_exp_poly.py, max rel err 3.8e-16) + v_ldexp_f64           (16 slots)
+//   1/d     : v_rcp_f64 + one cubic Newton step r0*(1+e+e^2)                          (7 slots)
+//   tanh    : sign(x)*(1 - 2/(exp(2|x|)+1)); the W reciprocals of a layer share ONE v_rcp_f64
+//             through prefix products (3(W-1) multiplies)
+//   softplus(x) = max(x,0) + log1p(exp(-|x|)); logistic derivative from the same exponential
 // Reference semantics: softplus(x) = log(1+exp(x)) (src/neural-network.jl:13-15); the stable form
 // differs from it by rounding only (and does not overflow for x > 709).
-// Max abs error vs libm (tests/test_math_host.py): tanh 2.3e-16, softplus 3e-16, sigmoid 2e-16.
+// Max abs error vs libm is asserted in tests/test_math_host.py.
 #pragma once
 #include <math.h>
 #if defined(__HIPCC__)
@@ -22,55 +26,87 @@
 
 namespace cude {
 
+// 1/d for d in [1, 1e290]
 CUDE_HD double m_rcp(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(d);
+    const double r0 = __builtin_amdgcn_rcp(d);       // ~2^-23 relative
 #else
-    double r = (double)(1.0f / (float)d);   // host model of a low-precision seed
+    double r0 = 1.0 / d;                              // host model of a low-precision seed:
+    {                                                 // keep 23 mantissa bits of the exact quotient
+        unsigned long long u;
+        __builtin_memcpy(&u, &r0, 8);
+        u &= ~((1ull << 29) - 1ull);
+        __builtin_memcpy(&r0, &u, 8);
+    }
 #endif
-    double e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-#if !defined(__HIP_DEVICE_COMPILE__)
-    e = fma(-d, r, 1.0);                    // float seed needs one more step than v_rcp_f64
-    r = fma(r, e, r);
-#endif
-    return r;
+    const double e = fma(-d, r0, 1.0);
+    const double t = fma(e, e, e);                    // e + e^2 ; error after the step is e^3
+    return fma(r0, t, r0);
 }
 
-// exp(y) for y in [-708, 708]
-CUDE_HD double m_exp(double y) {
-    const double n = rint(y * 1.4426950408889634074);             // log2(e)
-    double r = fma(n, -6.93147180369123816490e-01, y);             // ln2 hi
-    r = fma(n, -1.90821492927058770002e-10, r);                    // ln2 lo
-    double p = 2.08767569878680989792e-09;                         // 1/12!
-    p = fma(p, r, 2.50521083854417187751e-08);                     // 1/11!
-    p = fma(p, r, 2.75573192239858906526e-07);                     // 1/10!
-    p = fma(p, r, 2.75573192239858906526e-06);                     // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);                     // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);                     // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);                     // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);                     // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);                     // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);                     // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+// exp(2 x) for x in [-354, 354]
+CUDE_HD double m_exp2x(double x) {
+    const double n = rint(x * 2.88539008177792681472);                  // 2*log2(e)
+    double s = fma(n, -3.46573590184561908245e-01, x);                   // ln2/2 hi
+    s = fma(n, -9.54107464635293850010e-11, s);                          // ln2/2 lo ; |s| <= ln2/4
+    double p = 2.82893898152419560454e-04;
+    p = fma(p, s, 1.41517725676594432853e-03);
+    p = fma(p, s, 6.34918511283140765689e-03);
+    p = fma(p, s, 2.53966979461632859361e-02);
+    p = fma(p, s, 8.88888891679270320978e-02);
+    p = fma(p, s, 2.66666668341369039741e-01);
+    p = fma(p, s, 6.66666666665170271067e-01);
+    p = fma(p, s, 1.33333333332435244323e+00);
+    p = fma(p, s, 2.00000000000000222045e+00);
+    p = fma(p, s, 2.00000000000001332268e+00);
+    p = fma(p, s, 1.0);
     return ldexp(p, (int)n);
 }
 
+CUDE_HD double m_exp(double y) { return m_exp2x(0.5 * y); }
+
+// denominators exp(2|z|)+1 of tanh, clamped so that products of up to 8 of them stay finite
+CUDE_HD double m_tanh_den(double z) { return m_exp2x(fmin(fabs(z), 20.0)) + 1.0; }
+
 CUDE_HD double m_tanh(double x) {
-    const double y = fmin(fabs(x) * 2.0, 40.0);
-    const double r = m_rcp(m_exp(y) + 1.0);
+    const double r = m_rcp(m_tanh_den(x));
     return copysign(fma(-2.0, r, 1.0), x);
 }
 
-// log(u) for u in [1, 2]
-CUDE_HD double m_log_1_2(double u) {
-    const bool big = u > 1.41421356237309504880;
-    const double v = big ? 0.5 * u : u;
-    const double s = (v - 1.0) * m_rcp(v + 1.0);
+// t[j] = tanh(z[j]) for a whole layer with ONE reciprocal (prefix-product trick).
+// (A lock-step variant that interleaves the W Horner chains was measured 5 % slower: two waves per
+// SIMD already cover the FMA latency and the extra live registers cost more than they buy.)
+template <int W>
+CUDE_HD void m_tanh_vec(const double (&z)[W], double (&t)[W]) {
+    static_assert(W <= 8, "batched reciprocal: product of denominators must stay below 1e308");
+    double d[W], pre[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) d[j] = m_tanh_den(z[j]);
+    pre[0] = d[0];
+#pragma unroll
+    for (int j = 1; j < W; j++) pre[j] = pre[j - 1] * d[j];
+    double r = m_rcp(pre[W - 1]);
+#pragma unroll
+    for (int j = W - 1; j >= 1; j--) {
+        const double inv = r * pre[j - 1];
+        r = r * d[j];
+        t[j] = copysign(fma(-2.0, inv, 1.0), z[j]);
+    }
+    t[0] = copysign(fma(-2.0, r, 1.0), z[0]);
+}
+
+// softplus value and logistic derivative
+CUDE_HD double m_softplus(double x, double* sig) {
+    const double e = m_exp2x(fmax(-0.5 * fabs(x), -350.0));     // exp(-|x|) in (0, 1]
+    const double d = 1.0 + e;                                    // in (1, 2]
+    // log(d) = 2 atanh(s), s = (v-1)/(v+1), v = d or d/2 so that v in [1/sqrt2, sqrt2]
+    const bool big = d > 1.41421356237309504880;
+    const double num = big ? e - 1.0 : e;
+    const double den = big ? e + 3.0 : e + 2.0;
+    const double rp = m_rcp(d * den);                            // one reciprocal for 1/d and 1/den
+    const double inv_d = rp * den;
+    const double s = num * (rp * d);
+    *sig = x >= 0.0 ? inv_d : e * inv_d;
     const double z = s * s;
     double p = 1.0 / 21.0;
     p = fma(p, z, 1.0 / 19.0);
@@ -84,21 +120,12 @@ CUDE_HD double m_log_1_2(double u) {
     p = fma(p, z, 1.0 / 3.0);
     p = fma(p, z, 1.0);
     const double l = 2.0 * s * p;
-    return big ? l + 0.693147180559945309417 : l;
-}
-
-// softplus value and logistic derivative
-CUDE_HD double m_softplus(double x, double* sig) {
-    const double e = m_exp(fmax(-fabs(x), -700.0));      // in (0, 1]
-    const double d = 1.0 + e;
-    const double r = m_rcp(d);
-    *sig = x >= 0.0 ? r : e * r;
-    return fmax(x, 0.0) + m_log_1_2(d);
+    return fmax(x, 0.0) + (big ? l + 0.693147180559945309417 : l);
 }
 
 CUDE_HD double m_softplus_val(double x) {
-    const double e = m_exp(fmax(-fabs(x), -700.0));
-    return fmax(x, 0.0) + m_log_1_2(1.0 + e);
+    double sig;
+    return m_softplus(x, &sig);
 }
 
 }  // namespace cude
