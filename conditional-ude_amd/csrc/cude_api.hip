@@ -245,7 +245,7 @@ int32_t check_times(int32_t n_obs, const double* tp) {
 }
 
 // launches the ensemble kernel + second-stage reduction (+ all-reduce, + L2 term)
-int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev) {
+int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only = false) {
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "parameters not set");
     const int S = c->cfg.n_steps;
@@ -289,6 +289,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev) {
     const int P = c->P;
     if (grad) HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream));
     else HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+    if (local_only) return CUDE_OK;   // the caller reduces across ranks and applies the L2 term
     if (c->comm) {
         int32_t rc = grad ? allreduce_dev(c, c->g_nn.p, P + 2) : allreduce_dev(c, c->g_nn.p + P, 2);
         if (rc) return rc;
@@ -566,6 +567,62 @@ int32_t cude_adam_step(cude_ctx* c, double* loss) {
         // read the loss of this iterate before the update kernel is queued behind it
         if ((rc = finish_loss(c, loss, nullptr))) return rc;
     }
+    HIP_TRY(cude::launch_adam(a, c->stream));
+    return CUDE_OK;
+}
+
+int32_t cude_set_global_subjects(cude_ctx* c, double n_global, const double* scale3) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (!(n_global >= (double)c->N)) return fail(CUDE_ERR_ARG, "global subject count smaller than the local one");
+    c->n_global = n_global;
+    if (scale3) {
+        for (int s = 0; s < 3; s++) {
+            if (!(scale3[s] > 0)) return fail(CUDE_ERR_ARG, "scale must be positive");
+            c->scale[s] = scale3[s];
+        }
+    }
+    return CUDE_OK;
+}
+
+int32_t cude_get_scale(cude_ctx* c, double* scale3, double* n_global) {
+    if (!c || !scale3 || !n_global) return fail(CUDE_ERR_ARG, "null argument");
+    for (int s = 0; s < 3; s++) scale3[s] = c->scale[s];
+    *n_global = c->n_global;
+    return CUDE_OK;
+}
+
+int32_t cude_loss_grad_partial(cude_ctx* c, double* partial, double* g_cond) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!partial) return fail(CUDE_ERR_ARG, "null output");
+    if ((rc = run_ensemble(c, true, nullptr, /*local_only=*/true))) return rc;
+    if (g_cond)
+        HIP_TRY(hipMemcpyAsync(g_cond, c->g_cond.p, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(partial, c->g_nn.p, (c->P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
+int32_t cude_adam_apply(cude_ctx* c, const double* reduced, double* loss) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
+    if (!reduced) return fail(CUDE_ERR_ARG, "null input");
+    const int P = c->P;
+    HIP_TRY(hipMemcpyAsync(c->g_nn.p, reduced, (P + 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (c->cfg.lambda != 0.0)
+        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream));
+    c->adam_t += 1;
+    cude::AdamArgs a{};
+    a.N = c->N; a.P = P;
+    a.cond = c->cond.p; a.m_cond = c->m_cond.p; a.v_cond = c->v_cond.p; a.g_cond = c->g_cond.p;
+    a.nn = c->nn.p; a.m_nn = c->m_nn.p; a.v_nn = c->v_nn.p; a.g_nn = c->g_nn.p;
+    a.lr = c->lr; a.b1 = c->b1; a.b2 = c->b2; a.eps = c->eps;
+    a.c1 = 1.0 - std::pow(c->b1, (double)c->adam_t);
+    a.c2 = 1.0 - std::pow(c->b2, (double)c->adam_t);
+    if ((rc = finish_loss(c, loss, nullptr))) return rc;   // also synchronises: `reduced` may be freed after return
     HIP_TRY(cude::launch_adam(a, c->stream));
     return CUDE_OK;
 }

@@ -45,6 +45,10 @@ _SIGNATURES = {
     "cude_adam_init": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "cude_adam_step": (C.c_int32, [C.c_void_p, _dp]),
     "cude_synchronize": (C.c_int32, [C.c_void_p]),
+    "cude_set_global_subjects": (C.c_int32, [C.c_void_p, C.c_double, C.c_void_p]),
+    "cude_get_scale": (C.c_int32, [C.c_void_p, C.c_void_p, _dp]),
+    "cude_loss_grad_partial": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cude_adam_apply": (C.c_int32, [C.c_void_p, C.c_void_p, _dp]),
     "cude_kernel_time_ms": (C.c_int32, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
     "cude_set_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cude_comm_unique_id": (C.c_int32, [C.c_void_p]),

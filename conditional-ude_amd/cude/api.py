@@ -1,0 +1,502 @@
+"""Host-side mirror of the reference's Julia API for the accelerated path (same names, argument
+meaning and error behaviour), implemented on top of the C ABI (libcude_hip.so).  No numerics live
+here except optimiser bookkeeping on small vectors; every loss, gradient and trajectory comes from
+the HIP kernels, and a missing library / GPU raises CudeError (there is no CPU fallback).
+
+Reference items mirrored (paths relative to the reference repo):
+  chain / softplus                         src/neural-network.jl:13-15,42-58,85-87,105-107
+  neural_network_model                     suppression/src/suppression_model.jl:78-85
+  CPeptideConditionalUDEModel (+Covariate) src/c-peptide-models.jl:170-220, src/types.jl:16-19
+  loss / loss_sigma (3 methods each)       src/parameter-estimation.jl:56-75,93-109,126-140
+  initial_parameters                       src/parameter-estimation.jl:22-24,36-38
+  train (population / fixed-NN), train_with_sigma, evaluate_model
+                                           src/parameter-estimation.jl:272-307,340-433
+  suppression_loss / simul / fit_suppression_model
+                                           suppression/src/suppression_model.jl:107-177
+  individual_log_likelihood / mcmc_step / total_nll / update_population_parameters / SAEM
+                                           src/saem.jl:55-66,86-131,134-237
+  likelihood_profile                       src/likelihood-profiles.jl:4-17
+Differences that are deliberate and documented in DESIGN.md: the ODE is solved with FIXED-step Tsit5
+(`n_steps`, default 30) instead of the adaptive default; gradients are a discrete adjoint instead of
+ForwardDiff; the per-subject 1-D fits use a bracketing search instead of Fminbox(LBFGS).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+
+from .engine import Engine
+from .lbfgs import lbfgs
+
+DEFAULT_STEPS = 30
+
+
+# ----------------------------------------------------------------------------- network
+def softplus(x):
+    return np.log1p(np.exp(-np.abs(x))) + np.maximum(x, 0.0)
+
+
+class Chain:
+    """SimpleChain(static(input_dims), TurboDense{true}(tanh, width) x depth, TurboDense{true}(softplus, 1))."""
+
+    def __init__(self, input_dims, width, depth):
+        self.input_dims, self.width, self.depth = int(input_dims), int(width), int(depth)
+
+    @property
+    def arch(self):
+        return (self.input_dims, self.width, self.depth)
+
+    @property
+    def n_params(self):
+        p, fan = 0, self.input_dims
+        for _ in range(self.depth):
+            p += self.width * fan + self.width
+            fan = self.width
+        return p + fan + 1
+
+
+def chain(width, depth=None, activation="tanh", *, input_dims=2, output_dims=1, output_activation="softplus"):
+    """chain(width, depth, tanh) / chain(widths::Vector, tanh).  Only what the kernels implement is accepted:
+    equal hidden widths, tanh hidden layers, one softplus output (every network the reference builds)."""
+    if isinstance(width, (list, tuple, np.ndarray)):
+        widths = list(width)
+        if depth is not None and not isinstance(depth, (int, np.integer)):
+            activation = depth
+        if len(widths) == 0:
+            raise ValueError("Input widths must be non-empty.")
+        if isinstance(activation, (list, tuple)):
+            if len(activation) != len(widths):
+                raise ValueError("The number of widths must match the number of activation functions.")
+            if any(_act_name(a) != "tanh" for a in activation):
+                raise NotImplementedError("only tanh hidden layers are compiled into the HIP kernels")
+            activation = "tanh"
+        if len(set(widths)) != 1:
+            raise NotImplementedError("only equal hidden widths are compiled into the HIP kernels")
+        width, depth = widths[0], len(widths)
+    if _act_name(activation) != "tanh" or _act_name(output_activation) != "softplus" or output_dims != 1:
+        raise NotImplementedError("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
+    return Chain(input_dims, width, depth)
+
+
+def _act_name(a):
+    return a if isinstance(a, str) else getattr(a, "__name__", str(a))
+
+
+def neural_network_model(depth, width, *, input_dims=2):
+    return Chain(input_dims, width, depth)
+
+
+def init_params(net, rng=None):
+    """SimpleChains.init_params restated: Glorot-normal weights, zero biases, SimpleChains layout."""
+    rng = np.random.default_rng() if rng is None else rng
+    parts, fan = [], net.input_dims
+    for _ in range(net.depth):
+        parts += [rng.standard_normal(net.width * fan) * math.sqrt(2.0 / (fan + net.width)), np.zeros(net.width)]
+        fan = net.width
+    parts += [rng.standard_normal(fan) * math.sqrt(2.0 / (fan + 1)), np.zeros(1)]
+    return np.concatenate(parts)
+
+
+def ComponentArray(**kw):
+    """ComponentArrays.ComponentArray stand-in: attribute access to named parts (neural, conditional, ...)."""
+    return SimpleNamespace(**{k: (np.array(v, dtype=np.float64) if not np.isscalar(v) else float(v)) for k, v in kw.items()})
+
+
+class OptimizationSolution(SimpleNamespace):
+    """Fields used downstream of `train` in the reference: .u (ComponentArray) and .objective."""
+
+
+# ----------------------------------------------------------------------------- c-peptide models
+class CPeptideConditionalUDEModel:
+    """CPeptideConditionalUDEModel(glucose, timepoints, age, chain, cpeptide, t2dm) -- holds one subject's data;
+    the ODE problem itself lives on the GPU once the subject is part of a population."""
+
+    def __init__(self, glucose_data, glucose_timepoints, age, network, cpeptide_data, t2dm, *, covariate=False):
+        self.glucose = np.asarray(glucose_data, dtype=np.float64)
+        self.timepoints = np.asarray(glucose_timepoints, dtype=np.float64)
+        self.age = float(age)
+        self.chain = network
+        self.cpeptide = np.asarray(cpeptide_data, dtype=np.float64)
+        self.t2dm = bool(t2dm)
+        self.covariate = covariate
+        if self.glucose.shape != self.timepoints.shape or self.cpeptide.shape != self.timepoints.shape:
+            raise ValueError("glucose, cpeptide and timepoints must have the same length")
+        if network.input_dims != (3 if covariate else 2):
+            raise ValueError("network input_dims does not match the model (2: [dG, beta]; 3: [dG, beta, age])")
+
+
+CPeptideCUDEModel = CPeptideConditionalUDEModel        # name used in the reference's docstrings / stale script
+
+
+def CPeptideConditionalCovariateUDEModel(glucose_data, glucose_timepoints, age, network, cpeptide_data, t2dm):
+    return CPeptideConditionalUDEModel(glucose_data, glucose_timepoints, age, network, cpeptide_data, t2dm,
+                                       covariate=True)
+
+
+class _Pop:
+    """Device-resident population built from a list of models (cached per list object)."""
+
+    def __init__(self, models, timepoints, cpeptide_data, n_steps, n_state, device):
+        net = models[0].chain
+        self.engine = Engine("cpep", net.arch, n_steps=n_steps, n_state=n_state, device=device)
+        G = np.stack([m.glucose for m in models])
+        cp = np.asarray(cpeptide_data, dtype=np.float64).reshape(len(models), -1)
+        self.engine.set_population_cpep(np.asarray(timepoints, dtype=np.float64), G, cp, [m.age for m in models],
+                                        [m.t2dm for m in models])
+        self.models = models          # keeps id(models) alive
+        self.N, self.T = cp.shape
+
+
+_CACHE = {}
+_DEVICE = 0
+
+
+def set_device(device):
+    global _DEVICE
+    _DEVICE = int(device)
+
+
+def clear_cache():
+    for p in _CACHE.values():
+        p.engine.close()
+    _CACHE.clear()
+
+
+def _population(models, timepoints, cpeptide_data, n_steps=None, n_state=2):
+    n_steps = DEFAULT_STEPS if n_steps is None else n_steps
+    cp = np.asarray(cpeptide_data, dtype=np.float64)
+    key = (id(models), len(models), n_steps, n_state, cp.tobytes()[:256], cp.shape)
+    pop = _CACHE.get(key)
+    if pop is None:
+        pop = _Pop(models, timepoints, cp, n_steps, n_state, _DEVICE)
+        _CACHE[key] = pop
+    return pop
+
+
+def _is_model(x):
+    return isinstance(x, CPeptideConditionalUDEModel)
+
+
+def loss(theta, args, *, n_steps=None):
+    """loss(theta, (models, timepoints, cpeptide_data))            population, mean SSE (:126-140)
+       loss(theta, (model, timepoints, cpeptide_data))             single subject SSE (:56-68)
+       loss(beta,  (model, timepoints, cpeptide_data, nn_params))  single subject, fixed network (:93-99)
+    Returns +Inf when any trajectory is non-finite (the reference's solver-failure convention)."""
+    if len(args) == 4:
+        model, timepoints, data, nn = args
+        pop = _population([model], timepoints, np.asarray(data)[None, :], n_steps)
+        pop.engine.set_params(nn, np.atleast_1d(np.asarray(theta, dtype=np.float64))[:1])
+        out = pop.engine.forward(want_sse=True)
+        return out["sse"][0] if np.isfinite(out["loss"]) else np.inf
+    models, timepoints, data = args
+    if _is_model(models):
+        pop = _population([models], timepoints, np.asarray(data)[None, :], n_steps)
+        pop.engine.set_params(theta.neural, np.atleast_1d(theta.conditional)[:1])
+        return pop.engine.forward()["loss"]           # N = 1: mean SSE == SSE
+    pop = _population(models, timepoints, data, n_steps)
+    pop.engine.set_params(theta.neural, np.asarray(theta.conditional).reshape(-1)[:pop.N])
+    return pop.engine.forward()["loss"]
+
+
+def loss_sigma(theta, args, *, n_steps=None):
+    """(n/2) log sigma^2 + SSE / (2 sigma^2)   (src/parameter-estimation.jl:70-75,101-109)."""
+    n = len(args[1])
+    if len(args) == 4:
+        err = loss(theta.ode, args, n_steps=n_steps)
+    else:
+        err = loss(theta, args, n_steps=n_steps)
+    return (n / 2) * math.log(theta.sigma ** 2) + err / (2 * theta.sigma ** 2)
+
+
+def loss_and_gradient(theta, args, *, n_steps=None):
+    """Replaces ForwardDiff.gradient(loss, theta) (AutoForwardDiff, :370) for the population loss."""
+    models, timepoints, data = args
+    pop = _population(models, timepoints, data, n_steps)
+    pop.engine.set_params(theta.neural, np.asarray(theta.conditional).reshape(-1)[:pop.N])
+    val, g_nn, g_cond = pop.engine.loss_grad()
+    return val, ComponentArray(neural=g_nn, conditional=g_cond.reshape(np.asarray(theta.conditional).shape))
+
+
+def initial_parameters(*args, rng=None):
+    """initial_parameters(chain, n_initials; rng) -> list of network parameter vectors
+       initial_parameters(n_models, lhs_lb, lhs_ub, n_initials, rng) -> (n_models x n_initials) Latin hypercube."""
+    if isinstance(args[0], Chain):
+        net, n = args[0], args[1]
+        return [init_params(net, rng) for _ in range(n)]
+    n_models, lb, ub, n = args[:4]
+    rng = args[4] if len(args) > 4 else (np.random.default_rng() if rng is None else rng)
+    # QuasiMonteCarlo.LatinHypercubeSample: one stratified draw per interval and dimension, shuffled
+    u = (rng.permuted(np.tile(np.arange(n), (n_models, 1)), axis=1) + rng.random((n_models, n))) / n
+    return lb + (ub - lb) * u
+
+
+# ----------------------------------------------------------------------------- training drivers
+def _adam_then_lbfgs(eng, nn0, cond0, adam_iters, lbfgs_iters, lr, callback=None):
+    eng.set_params(nn0, cond0)
+    eng.adam_init(lr)
+    last = np.inf
+    for _ in range(adam_iters):
+        last = eng.adam_step()
+        if callback is not None and callback(None, last):
+            break
+        if not np.isfinite(last):
+            raise FloatingPointError("solver failure (non-finite loss) during Adam")
+    nn, cond = eng.get_params()
+    P = nn.size
+
+    def fg(x):
+        eng.set_params(x[:P], x[P:])
+        val, g_nn, g_cond = eng.loss_grad()
+        return val, np.concatenate([g_nn, g_cond])
+
+    res = lbfgs(fg, np.concatenate([nn, cond]), maxiters=lbfgs_iters, callback=callback)
+    return res["x"][:P], res["x"][P:], res["f"]
+
+
+def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_000, selected_initials=25,
+          lhs_lower_bound=-2.0, lhs_upper_bound=0.0, n_conditional_parameters=1, number_of_iterations_adam=1000,
+          number_of_iterations_lbfgs=1000, learning_rate_adam=1e-2, initial_beta=-2.0, lbfgs_lower_bound=-4.0,
+          lbfgs_upper_bound=1.0, lbfgs_iterations=1000, n_steps=None):
+    """Two methods of the reference, selected by the 4th argument as Julia's dispatch does:
+    * rng (numpy Generator): population training, unknown network (:340-386): LHS + init screening of
+      `initial_guesses` candidates (forward-only), best `selected_initials` -> Adam -> L-BFGS.
+    * array of network parameters: per-subject estimation of the conditional parameter with the network
+      frozen (:272-288)."""
+    if isinstance(rng_or_nn, np.random.Generator):
+        rng = rng_or_nn
+        pop = _population(models, timepoints, cpeptide_data, n_steps)
+        eng, N = pop.engine, pop.N
+        nn_inits = initial_parameters(models[0].chain, initial_guesses, rng=rng)
+        ode_inits = initial_parameters(N, lhs_lower_bound, lhs_upper_bound, initial_guesses, rng)
+        losses = np.empty(initial_guesses)
+        for k in range(initial_guesses):                      # screening (:362-366)
+            eng.set_params(nn_inits[k], ode_inits[:, k])
+            losses[k] = eng.forward()["loss"]
+        order = np.argsort(losses, kind="stable")[:selected_initials]
+        sols = []
+        for k in order:
+            try:
+                nn, cond, obj = _adam_then_lbfgs(eng, nn_inits[k], ode_inits[:, k], number_of_iterations_adam,
+                                                 number_of_iterations_lbfgs, learning_rate_adam)
+                sols.append(OptimizationSolution(
+                    u=ComponentArray(neural=nn, conditional=np.repeat(cond[:, None], n_conditional_parameters, 1)),
+                    objective=obj))
+            except FloatingPointError:
+                print("Optimization failed... Skipping")
+        return sols
+    nn = np.asarray(rng_or_nn, dtype=np.float64)
+    beta, sse = estimate_conditional(models, timepoints, cpeptide_data, nn, initial_beta=initial_beta,
+                                     lower=lbfgs_lower_bound, upper=lbfgs_upper_bound, n_steps=n_steps)
+    return [OptimizationSolution(u=np.array([b]), objective=s) for b, s in zip(beta, sse)]
+
+
+def estimate_conditional(models, timepoints, cpeptide_data, nn, *, initial_beta=-2.0, lower=-4.0, upper=1.0,
+                         n_steps=None, n_grid=41, iters=48):
+    """All N independent 1-D problems min_beta SSE_i(beta) at once: every probe is ONE forward launch over
+    the population.  Box [lower, upper]; infinite bounds are replaced by initial_beta -/+ 6."""
+    pop = _population(models, timepoints, cpeptide_data, n_steps)
+    eng, N = pop.engine, pop.N
+    lo = lower if np.isfinite(lower) else np.min(initial_beta) - 6.0
+    hi = upper if np.isfinite(upper) else np.max(initial_beta) + 6.0
+    eng.set_params(nn, np.full(N, lo))
+
+    def sse(b):
+        eng.set_params(None, b)
+        return eng.forward(want_sse=True)["sse"]
+    grid = np.linspace(lo, hi, n_grid)
+    vals = np.stack([sse(np.full(N, g)) for g in grid])
+    vals = np.where(np.isfinite(vals), vals, np.inf)
+    k = np.clip(np.argmin(vals, axis=0), 1, n_grid - 2)
+    a, b = grid[k - 1], grid[k + 1]
+    gr = (math.sqrt(5) - 1) / 2
+    c, d = b - gr * (b - a), a + gr * (b - a)
+    fc, fd = sse(c), sse(d)
+    for _ in range(iters):
+        left = fc < fd
+        b = np.where(left, d, b)
+        a = np.where(left, a, c)
+        c, d = b - gr * (b - a), a + gr * (b - a)
+        fc, fd = sse(c), sse(d)
+    x = 0.5 * (a + b)
+    return x, sse(x)
+
+
+def train_with_sigma(models, timepoints, cpeptide_data, nn, *, initial_beta=-2.0, lbfgs_lower_bound=-4.0,
+                     lbfgs_upper_bound=1.0, lbfgs_iterations=1000, n_steps=None):
+    """Joint (beta, sigma) estimate per subject (:290-307).  For fixed beta the NLL is minimised by
+    sigma^2 = SSE/n, and beta minimises SSE, so the 2-D problem separates."""
+    beta, sse = estimate_conditional(models, timepoints, cpeptide_data, nn, initial_beta=initial_beta,
+                                     lower=lbfgs_lower_bound, upper=lbfgs_upper_bound, n_steps=n_steps)
+    n = len(timepoints)
+    sigma = np.sqrt(np.maximum(sse, 1e-300) / n)
+    obj = (n / 2) * np.log(sigma ** 2) + sse / (2 * sigma ** 2)
+    return [OptimizationSolution(u=ComponentArray(ode=np.array([b]), sigma=s), objective=o)
+            for b, s, o in zip(beta, sigma, obj)]
+
+
+def evaluate_model(models, timepoints, cpeptide_data, neural_network_parameters, betas_train, *, n_steps=None):
+    """Validation objectives of every candidate network (:406-433): (n_subjects x n_networks)."""
+    cols = []
+    for betas, p_nn in zip(betas_train, neural_network_parameters):
+        try:
+            sols = train(models, timepoints, cpeptide_data, np.asarray(p_nn), initial_beta=float(np.mean(betas)),
+                         lbfgs_lower_bound=-np.inf, lbfgs_upper_bound=np.inf, n_steps=n_steps)
+            cols.append([s.objective for s in sols])
+        except Exception:
+            cols.append([np.inf] * len(models))
+    return np.array(cols).T
+
+
+def likelihood_profile(beta, neural_network_parameters, model, timepoints, cpeptide_data, lower_bound, upper_bound,
+                       sigma, *, steps=1000, n_steps=None):
+    """src/likelihood-profiles.jl:4-17 -- the `steps` probes run as ONE population of copies of the subject."""
+    copies = [model] * steps
+    data = np.tile(np.asarray(cpeptide_data, dtype=np.float64), (steps, 1))
+    pop = _population(copies, timepoints, data, n_steps)
+    values = np.linspace(lower_bound, upper_bound, steps)
+    pop.engine.set_params(neural_network_parameters, values)
+    nll = pop.engine.forward(want_sse=True)["sse"] / (2 * sigma ** 2)
+    nll_min = loss(beta, (model, timepoints, cpeptide_data, neural_network_parameters), n_steps=n_steps) / (2 * sigma ** 2)
+    return nll, nll_min, values
+
+
+# ----------------------------------------------------------------------------- suppression model
+class _SuppPop:
+    def __init__(self, data, timepoints, net, lam, n_steps, device):
+        self.engine = Engine("supp", net.arch, n_steps=n_steps, lam=lam, device=device)
+        self.engine.set_population_supp(np.asarray(timepoints, dtype=np.float64), data)
+        self.data = data
+
+
+def _supp_population(prob, data, timepoints, lam, n_steps=None):
+    n_steps = DEFAULT_STEPS if n_steps is None else n_steps
+    data = np.asarray(data, dtype=np.float64)
+    key = ("supp", id(prob), data.shape, data.tobytes()[:256], float(lam), n_steps)
+    pop = _CACHE.get(key)
+    if pop is None:
+        pop = _SuppPop(data, timepoints, prob.network, lam, n_steps, _DEVICE)
+        _CACHE[key] = pop
+    return pop
+
+
+def SuppressionProblem(network):
+    """Stand-in for `ODEProblem(ude_lsup!, [10,0,0], (0,30))` with the network closed over
+    (suppression/suppression.jl:18-20): carries the network shape; u0 comes from the data (:119)."""
+    return SimpleNamespace(network=network)
+
+
+def suppression_loss(p, args, *, n_steps=None):
+    """suppression_loss(p, (prob, individual_data, timepoints, lambda)) with p.theta[N], p.neural[P] (:117-130)."""
+    prob, data, timepoints, lam = args
+    pop = _supp_population(prob, data, timepoints, lam, n_steps)
+    pop.engine.set_params(p.neural, p.theta)
+    return pop.engine.forward()["loss"]
+
+
+def suppression_loss_and_gradient(p, args, *, n_steps=None):
+    prob, data, timepoints, lam = args
+    pop = _supp_population(prob, data, timepoints, lam, n_steps)
+    pop.engine.set_params(p.neural, p.theta)
+    val, g_nn, g_th = pop.engine.loss_grad()
+    return val, ComponentArray(theta=g_th, neural=g_nn)
+
+
+def simul(p, prob, individual_data, timepoints, *, n_steps=None):
+    """simul(p, prob, data, timepoints) -> 3 x T x N array (:107-115)."""
+    pop = _supp_population(prob, individual_data, timepoints, 0.0, n_steps)
+    pop.engine.set_params(p.neural, p.theta)
+    return pop.engine.forward(want_traj=True)["traj"]
+
+
+def fit_suppression_model(p_init, prob, data, timepoints, lam, *, select_best_n=1, adam_iters=2000, lbfgs_iters=2000,
+                          n_steps=None):
+    """fit_suppression_model (:132-177): screen all initials, keep the best n, Adam() [eta = 1e-3] then L-BFGS."""
+    pop = _supp_population(prob, data, timepoints, lam, n_steps)
+    eng = pop.engine
+    init_losses = np.array([suppression_loss(p, (prob, data, timepoints, lam), n_steps=n_steps) for p in p_init])
+    best = np.argsort(init_losses, kind="stable")[:max(1, select_best_n)]
+    sols, traces = [], []
+    for k in best:
+        trace = []
+        try:
+            nn, th, obj = _adam_then_lbfgs(eng, p_init[k].neural, p_init[k].theta, adam_iters, lbfgs_iters, 1e-3,
+                                           callback=lambda _x, l: trace.append(l) and False)
+            sols.append(OptimizationSolution(u=ComponentArray(theta=th, neural=nn), objective=obj))
+        except FloatingPointError:
+            print("Optimization failed")
+        traces.append(trace)
+    return sols, traces
+
+
+# ----------------------------------------------------------------------------- SAEM
+def individual_log_likelihood(sse, n_obs, sigma):
+    """-(n/2) log sigma^2 - SSE/(2 sigma^2), -Inf on solver failure (src/saem.jl:55-66)."""
+    ll = -(n_obs / 2) * math.log(sigma ** 2) - sse / (2 * sigma ** 2)
+    return np.where(np.isfinite(sse), ll, -np.inf)
+
+
+def _log_normal(x, mu, sd):
+    return -0.5 * ((x - mu) / sd) ** 2 - math.log(sd) - 0.5 * math.log(2 * math.pi)
+
+
+def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0, prior_eta=0.0, prior_omega=1.0,
+         iterations=500, n_burnin_iterations=100, proposal_std=0.1, proposal_std_bounds=(1e-3, 1.0), alpha=0.7,
+         n_mcmc_steps=1, initial_mcmc_steps=None, target_acceptance_rate=0.25, initial_temperature=10.0,
+         temperature_decay=0.05, omega_learning_rate=0.04, rng=None, n_steps=None, m_step_iters=5, m_step_lr=1e-2):
+    """SAEM(individuals, initial_neural_params, network; ...) (src/saem.jl:134-237) with the population on the
+    GPU: every Metropolis step evaluates all subjects in one forward launch; the M-step's 5 Adam iterations on
+    (network, sigma) use the device gradient.  Quirks of the reference are preserved: the 'current' likelihood
+    is re-evaluated each step, the stochastic-approximation update is applied inside the chain (:185), Omega is
+    updated as a variance but used as a standard deviation (:91,:204)."""
+    rng = np.random.default_rng() if rng is None else rng
+    initial_mcmc_steps = n_mcmc_steps if initial_mcmc_steps is None else initial_mcmc_steps
+    pop = _population(models, timepoints, cpeptide_data, n_steps)
+    eng, N, T = pop.engine, pop.N, pop.T
+    p_ind = np.full(N, float(prior_eta))
+    p_nn = np.array(initial_neural_params, dtype=np.float64)
+    omega = float(prior_omega)
+    nll_values, acc_rates = [], []
+
+    def sse_of(beta):
+        eng.set_params(p_nn, beta)
+        return eng.forward(want_sse=True)["sse"]
+
+    for it in range(1, iterations + 1):
+        gamma = 1.0 if it <= n_burnin_iterations else 1.0 / (it - n_burnin_iterations) ** alpha
+        steps = initial_mcmc_steps if it <= n_burnin_iterations else n_mcmc_steps
+        temperature = max(1.0, initial_temperature * math.exp(-temperature_decay * it))
+        accepted = 0
+        for _ in range(steps):                                     # E-step (:177-186)
+            prop = p_ind + rng.standard_normal(N) * proposal_std
+            prior_ratio = _log_normal(prop, prior_eta, omega) - _log_normal(p_ind, prior_eta, omega)
+            ll_new = individual_log_likelihood(sse_of(prop), T, sigma)
+            ll_cur = individual_log_likelihood(sse_of(p_ind), T, sigma)
+            acc = np.log(rng.random(N)) < prior_ratio + (ll_new - ll_cur) / temperature
+            accepted += int(acc.sum())
+            p_ind = (1 - gamma) * p_ind + gamma * np.where(acc, prop, p_ind)
+        sse = sse_of(p_ind)
+        loglik = float(individual_log_likelihood(sse, T, sigma).sum())
+        # M-step (:118-131): 5 Adam iterations on (neural, sigma), random effects fixed
+        x = np.concatenate([p_nn, [sigma]])
+        m, v = np.zeros_like(x), np.zeros_like(x)
+        for t in range(1, m_step_iters + 1):
+            eng.set_params(x[:-1], p_ind)
+            mean_sse, g_nn, _ = eng.loss_grad(want_cond_grad=False)   # mean SSE and its network gradient
+            sse_t = mean_sse * N
+            s = x[-1]
+            g = np.concatenate([g_nn * N / (2 * s * s), [N * T / s - sse_t / s ** 3]])
+            m = 0.9 * m + 0.1 * g
+            v = 0.999 * v + 0.001 * g * g
+            x = x - m_step_lr * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
+        sigma = float(x[-1])
+        p_nn = (1 - gamma) * p_nn + gamma * x[:-1]
+        omega = (1 - omega_learning_rate) * omega + omega_learning_rate * float(np.var(p_ind, ddof=1))
+        prior_eta = (1 - omega_learning_rate) * prior_eta + omega_learning_rate * float(np.mean(p_ind))
+        rate = accepted / (N * steps)
+        nll_values.append(-loglik)
+        acc_rates.append(rate)
+        if it > n_burnin_iterations:
+            proposal_std = float(np.clip(math.exp(math.log(proposal_std) + gamma * (rate - target_acceptance_rate)),
+                                         proposal_std_bounds[0], proposal_std_bounds[1]))
+    return SimpleNamespace(p_neural=p_nn, p_individuals=p_ind, Omega=omega, sigma=sigma, eta=prior_eta,
+                           total_nll_values=nll_values, acceptance_rates=acc_rates)

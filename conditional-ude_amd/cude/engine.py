@@ -143,6 +143,30 @@ class Engine:
         check(self._lib.cude_adam_step(self._h, None))
         return None
 
+    # -- bring-your-own collective
+    def set_global_subjects(self, n_global, scale=None):
+        sc = None if scale is None else _f64(scale)
+        check(self._lib.cude_set_global_subjects(self._h, float(n_global), _ptr(sc)))
+
+    def get_scale(self):
+        sc = np.empty(3)
+        n = C.c_double()
+        check(self._lib.cude_get_scale(self._h, _ptr(sc), C.byref(n)))
+        return sc, n.value
+
+    def loss_grad_partial(self, want_cond_grad=False):
+        """This rank's un-reduced [g_nn; sum sse; n_failed] (and optionally dL/dcond of its subjects)."""
+        part = np.empty(self.P + 2)
+        g_cond = np.empty(self.N) if want_cond_grad else None
+        check(self._lib.cude_loss_grad_partial(self._h, _ptr(part), _ptr(g_cond)))
+        return part, g_cond
+
+    def adam_apply(self, reduced):
+        r = _f64(reduced)
+        loss = C.c_double()
+        check(self._lib.cude_adam_apply(self._h, _ptr(r), C.byref(loss)))
+        return loss.value
+
     def synchronize(self):
         check(self._lib.cude_synchronize(self._h))
 

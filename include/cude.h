@@ -111,6 +111,17 @@ int32_t cude_adam_init(cude_ctx* ctx, double lr, double beta1, double beta2, dou
 int32_t cude_adam_step(cude_ctx* ctx, double* loss);
 int32_t cude_synchronize(cude_ctx* ctx);
 
+/* --- bring-your-own collective (MPI.jl, gloo, ...) instead of the built-in RCCL path.
+ * cude_loss_grad_partial returns this rank's un-reduced [g_nn(P); sum_i sse_i; n_failed] (gradient entries
+ * already carry the 1/N_global factor, the L2 term is NOT included); the host sums the vectors of all
+ * ranks and hands the result to cude_adam_apply, which adds the L2 term, forms the loss and runs the Adam
+ * update.  cude_set_global_subjects tells the context the global subject count (and, for the suppression
+ * model, the globally averaged `scale`, suppression_model.jl:126) when no communicator is attached. */
+int32_t cude_set_global_subjects(cude_ctx* ctx, double n_global, const double* scale3 /* or NULL */);
+int32_t cude_get_scale(cude_ctx* ctx, double* scale3, double* n_global);
+int32_t cude_loss_grad_partial(cude_ctx* ctx, double* partial /* P+2 */, double* g_cond /* N or NULL */);
+int32_t cude_adam_apply(cude_ctx* ctx, const double* reduced /* P+2 */, double* loss);
+
 /* Average device time (ms) of the dominant kernel (forward+adjoint) over the launches since the
  * last call, measured with HIP events on the context's stream; resets the accumulator. */
 int32_t cude_kernel_time_ms(cude_ctx* ctx, double* avg_ms, int64_t* launches);

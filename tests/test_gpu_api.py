@@ -1,0 +1,182 @@
+"""GPU tests of the reference-API mirror (cude.api) and of the sharded training step, all through the C ABI.
+They read like the reference's call sites (c-peptide/02-conditional.jl, suppression/suppression.jl, src/saem.jl)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (first: shared HIP runtime)
+
+from conftest import make_cpep_case, make_supp_case
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _ohashi_models(api, net, n=None):
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    n = g["glucose"].shape[0] if n is None else n
+    models = [api.CPeptideConditionalUDEModel(g["glucose"][i], g["timepoints"], g["ages"][i], net, g["cpeptide"][i],
+                                              g["t2dm"][i]) for i in range(n)]
+    return g, models
+
+
+def test_population_loss_and_gradient_on_ohashi_data():
+    """loss(theta, (models, timepoints, cpeptide)) and its gradient on the real 117-subject data with the
+    reference's stored trained weights, vs the oracle."""
+    import c_oracle as co
+    from cude import api
+    net = api.chain(4, 2, "tanh")
+    g, models = _ohashi_models(api, net)
+    N = len(models)
+    rng = np.random.default_rng(0)
+    theta = api.ComponentArray(neural=g["nn_2x4x4x1"][0], conditional=rng.uniform(-2, 0, (N, 1)))
+    args = (models, g["timepoints"], g["cpeptide"])
+    val = api.loss(theta, args)
+    ref = co.cpep(g["timepoints"], g["glucose"], g["cpeptide"], g["ages"], g["t2dm"], (2, 4, 2), theta.neural,
+                  theta.conditional[:, 0], 30, 2)
+    assert abs(val - ref["loss"]) < 1e-10 * ref["loss"]
+    val2, grad = api.loss_and_gradient(theta, args)
+    assert abs(val2 - ref["loss"]) < 1e-10 * ref["loss"]
+    assert np.max(np.abs(grad.neural - ref["g_nn"])) < 1e-9 * np.max(np.abs(ref["g_nn"]))
+    assert np.max(np.abs(grad.conditional[:, 0] - ref["g_beta"])) < 1e-9 * np.max(np.abs(ref["g_beta"]))
+    # single-subject methods
+    single = api.loss(api.ComponentArray(neural=theta.neural, conditional=theta.conditional[3]),
+                      (models[3], g["timepoints"], g["cpeptide"][3]))
+    fixed = api.loss(theta.conditional[3], (models[3], g["timepoints"], g["cpeptide"][3], theta.neural))
+    assert abs(single - ref["sse"][3]) < 1e-10 and abs(fixed - ref["sse"][3]) < 1e-10
+    th = api.ComponentArray(ode=theta.conditional[3], sigma=0.7)
+    nll = api.loss_sigma(th, (models[3], g["timepoints"], g["cpeptide"][3], theta.neural))
+    assert abs(nll - (2.5 * np.log(0.49) + ref["sse"][3] / 0.98)) < 1e-9
+    api.clear_cache()
+
+
+def test_fixed_network_beta_estimation_recovers_stored_betas():
+    """train(models, timepoints, data, nn) -- the per-subject conditional-parameter fit with frozen network
+    (parameter-estimation.jl:272-288) on the GPU reproduces the reference's stored training betas."""
+    from scipy.optimize import linear_sum_assignment
+    from cude import api
+    net = api.chain(4, 2, "tanh")
+    g, models = _ohashi_models(api, net)
+    sols = api.train(models, g["timepoints"], g["cpeptide"], g["nn_2x4x4x1"][0], lbfgs_lower_bound=-4.0,
+                     lbfgs_upper_bound=3.0)
+    beta_hat = np.array([s.u[0] for s in sols])
+    cost = np.abs(g["betas_train"][0][:, None] - beta_hat[None, :])
+    r, c = linear_sum_assignment(cost)
+    assert np.median(cost[r, c]) < 5e-3 and np.quantile(cost[r, c], 0.9) < 3e-2
+    ws = api.train_with_sigma(models[:10], g["timepoints"], g["cpeptide"][:10], g["nn_2x4x4x1"][0],
+                              lbfgs_upper_bound=3.0)
+    assert abs(ws[0].u.sigma - np.sqrt(sols[0].objective / 5)) < 1e-6
+    api.clear_cache()
+
+
+def test_population_training_decreases_loss():
+    """train(models, timepoints, data, rng): screening -> Adam -> L-BFGS (parameter-estimation.jl:340-386)."""
+    from cude import api
+    net = api.chain(4, 2, "tanh")
+    g, models = _ohashi_models(api, net, n=40)
+    rng = np.random.default_rng(5)
+    sols = api.train(models, g["timepoints"], g["cpeptide"][:40], rng, initial_guesses=200, selected_initials=2,
+                     number_of_iterations_adam=150, number_of_iterations_lbfgs=40)
+    assert len(sols) == 2
+    for s in sols:
+        assert np.isfinite(s.objective) and s.objective < 1.5          # untrained screening losses are ~5-50
+        assert s.u.neural.shape == (37,) and s.u.conditional.shape == (40, 1)
+        assert abs(api.loss(s.u, (models, g["timepoints"], g["cpeptide"][:40])) - s.objective) < 1e-9
+    api.clear_cache()
+
+
+def test_suppression_api_matches_oracle_and_fits():
+    import c_oracle as co
+    from cude import api
+    g = dict(np.load(os.path.join(GOLD, "suppression_lambda0.npz")))
+    net = api.neural_network_model(5, 3, input_dims=4)
+    prob = api.SuppressionProblem(net)
+    data, tp = g["group_data"], g["timepoints"]
+    rng = np.random.default_rng(1)
+    p = api.ComponentArray(theta=rng.standard_normal(37), neural=g["nn_4x3x5x1"][0])
+    for lam in (0.0, 0.01):
+        ref = co.supp(tp, data, (4, 3, 5), p.neural, p.theta, lam, 30, want_traj=True)
+        assert abs(api.suppression_loss(p, (prob, data, tp, lam)) - ref["loss"]) < 1e-10 * ref["loss"]
+        val, grad = api.suppression_loss_and_gradient(p, (prob, data, tp, lam))
+        assert np.max(np.abs(grad.neural - ref["g_nn"])) < 1e-9 * np.max(np.abs(ref["g_nn"]))
+        assert np.max(np.abs(grad.theta - ref["g_theta"])) < 1e-9 * np.max(np.abs(ref["g_theta"]))
+    sims = api.simul(p, prob, data, tp)
+    assert sims.shape == (3, 8, 37) and np.max(np.abs(sims - ref["traj"])) < 1e-10
+    # short fit from the stored network: theta only needs to move; loss must approach the stored final loss
+    inits = [api.ComponentArray(theta=rng.standard_normal(37), neural=g["nn_4x3x5x1"][0]) for _ in range(4)]
+    sols, _ = api.fit_suppression_model(inits, prob, data, tp, 0.0, select_best_n=1, adam_iters=300, lbfgs_iters=60)
+    assert sols and sols[0].objective < 0.75 * min(api.suppression_loss(q, (prob, data, tp, 0.0)) for q in inits)
+    api.clear_cache()
+
+
+def test_saem_runs_and_improves_likelihood():
+    from cude import api
+    net = api.chain(4, 2, "tanh")
+    g, models = _ohashi_models(api, net, n=30)
+    res = api.SAEM(models, g["timepoints"], g["cpeptide"][:30], g["nn_2x4x4x1"][0], sigma=0.5, prior_eta=-0.6,
+                   prior_omega=1.0, iterations=6, n_burnin_iterations=3, proposal_std=0.5, n_mcmc_steps=5,
+                   rng=np.random.default_rng(2))
+    assert len(res.total_nll_values) == 6 and np.all(np.isfinite(res.total_nll_values))
+    assert res.total_nll_values[-1] < res.total_nll_values[0]
+    assert 0.0 < res.acceptance_rates[-1] <= 1.0 and res.p_individuals.shape == (30,)
+    api.clear_cache()
+
+
+def test_likelihood_profile_shape_and_minimum():
+    from cude import api
+    net = api.chain(4, 2, "tanh")
+    g, models = _ohashi_models(api, net, n=1)
+    nn = g["nn_2x4x4x1"][0]
+    sol = api.train(models, g["timepoints"], g["cpeptide"][:1], nn, lbfgs_upper_bound=3.0)[0]
+    nll, nll_min, values = api.likelihood_profile(sol.u[0], nn, models[0], g["timepoints"], g["cpeptide"][0], -4.0, 3.0,
+                                                  0.3, steps=500)
+    assert nll.shape == (500,) and nll.min() >= nll_min - 1e-9 and abs(values[np.argmin(nll)] - sol.u[0]) < 0.02
+    api.clear_cache()
+
+
+# ------------------------------------------------------------------ two ranks sharing the one GPU of the test box
+def _gpu_rank(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "conditional-ude_amd"), os.path.join(here, "..", "oracle"), here):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from cude.engine import Engine
+    from cude.parallel import ShardedTrainer, TorchCollective, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = make_cpep_case(n_total, (2, 6, 2))
+    lo, hi = shard_bounds(n_total, world, rank)
+    eng = Engine("cpep", (2, 6, 2), n_steps=30, n_state=3, device=0)
+    eng.set_population_cpep(c["tp"], c["G"][lo:hi], c["obs"][lo:hi], c["age"][lo:hi], c["t2dm"][lo:hi])
+    eng.set_params(c["nn"], c["beta"][lo:hi])
+    tr = ShardedTrainer(eng, TorchCollective(dist), transport="host")
+    tr.sync_population_statistics()
+    tr.adam_init(1e-2)
+    losses = [tr.adam_step() for _ in range(5)]
+    cond = tr.gather_conditional(n_total)
+    nn, _ = eng.get_params()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=losses, cond=cond, nn=nn)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_training_matches_single_engine(tmp_path):
+    import torch.multiprocessing as mp
+    from cude.engine import Engine
+    n_total, world = 333, 2
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_gpu_rank, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["losses"], r1["losses"]) and np.array_equal(r0["nn"], r1["nn"])
+    c = make_cpep_case(n_total, (2, 6, 2))
+    eng = Engine("cpep", (2, 6, 2), n_steps=30, n_state=3)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(c["nn"], c["beta"])
+    eng.adam_init(1e-2)
+    ref = [eng.adam_step() for _ in range(5)]
+    nn, cond = eng.get_params()
+    eng.close()
+    assert np.allclose(r0["losses"], ref, rtol=1e-10)          # loss trajectory over 5 Adam steps
+    assert np.allclose(r0["nn"], nn, rtol=0, atol=1e-10) and np.allclose(r0["cond"], cond, rtol=0, atol=1e-10)

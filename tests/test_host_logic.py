@@ -1,0 +1,157 @@
+"""Host-side logic that needs no GPU: API mirror argument handling, Latin hypercube initials, subject sharding,
+L-BFGS + backtracking, and the data-parallel training step over a 2-rank gloo group (driven with an
+oracle-backed stand-in engine: the product engine itself needs a GPU and never falls back)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import make_cpep_case
+
+
+def test_chain_mirrors_reference_argument_errors():
+    from cude import api
+    assert api.chain(4, 2, "tanh").n_params == 37
+    assert api.chain(6, 2, np.tanh).arch == (2, 6, 2)
+    assert api.chain([3, 3, 3, 3, 3], "tanh", input_dims=4).n_params == 67
+    assert api.neural_network_model(5, 3, input_dims=4).n_params == 67
+    with pytest.raises(ValueError):
+        api.chain([], "tanh")
+    with pytest.raises(ValueError):
+        api.chain([4, 4], ["tanh"])
+    with pytest.raises(NotImplementedError):
+        api.chain([4, 5], "tanh")
+    with pytest.raises(NotImplementedError):
+        api.chain(4, 2, "relu")
+    net = api.chain(4, 2, "tanh")
+    with pytest.raises(ValueError):
+        api.CPeptideConditionalUDEModel([1, 2, 3], [0, 1, 2], 40, net, [1, 2], False)
+    m = api.CPeptideCUDEModel([5.0, 6.0, 7.0], [0.0, 30.0, 60.0], 40, net, [1.0, 2.0, 1.5], True)
+    assert m.t2dm and m.age == 40.0
+
+
+def test_init_params_and_latin_hypercube():
+    from cude import api
+    rng = np.random.default_rng(3)
+    net = api.chain(6, 2, "tanh")
+    p = api.init_params(net, rng)
+    assert p.size == 67 and np.all(p[12:18] == 0) and np.all(p[54:60] == 0) and p[66] == 0
+    lhs = api.initial_parameters(7, -2.0, 0.0, 50, rng)
+    assert lhs.shape == (7, 50) and lhs.min() >= -2.0 and lhs.max() <= 0.0
+    for row in lhs:       # exactly one sample per stratum
+        assert sorted(np.floor((row + 2.0) / 2.0 * 50).astype(int)) == list(range(50))
+
+
+def test_shard_bounds_cover_and_balance():
+    from cude.parallel import shard_bounds
+    for n, w in [(10, 3), (1000000, 8), (5, 8), (64, 2)]:
+        b = [shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_lbfgs_and_backtracking():
+    from cude.lbfgs import lbfgs
+
+    def rosen(x):
+        f = 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2
+        g = np.array([-400 * x[0] * (x[1] - x[0] ** 2) - 2 * (1 - x[0]), 200 * (x[1] - x[0] ** 2)])
+        return f, g
+    r = lbfgs(rosen, np.array([-1.2, 1.0]), maxiters=200)
+    assert r["f"] < 1e-12 and np.allclose(r["x"], [1.0, 1.0], atol=1e-5)
+    A = np.diag(np.arange(1.0, 21.0))
+    r = lbfgs(lambda x: (0.5 * x @ A @ x, A @ x), np.ones(20), maxiters=100)
+    assert r["f"] < 1e-14
+
+    def with_inf(x):                       # solver-failure region: +Inf must be backed away from
+        if x[0] > 2.0:
+            return np.inf, np.zeros(1)
+        return (x[0] - 1.5) ** 2, np.array([2 * (x[0] - 1.5)])
+    r = lbfgs(with_inf, np.array([-30.0]), maxiters=50)
+    assert abs(r["x"][0] - 1.5) < 1e-6
+
+
+# ------------------------------------------------------------------ 2-rank gloo data-parallel step
+class OracleEngine:
+    """Test stand-in with the Engine interface used by ShardedTrainer (numerics from the CPU oracle)."""
+
+    def __init__(self, case, lo, hi):
+        import c_oracle as co
+        self.co, self.c, self.lo, self.hi = co, case, lo, hi
+        self.N, self.P = hi - lo, case["nn"].size
+        self.nn, self.cond = case["nn"].copy(), case["beta"][lo:hi].copy()
+        self.n_global = float(self.N)
+
+    def set_global_subjects(self, n, scale=None):
+        self.n_global = float(n)
+
+    def loss_grad_partial(self, want_cond_grad=False):
+        c, s = self.c, slice(self.lo, self.hi)
+        r = self.co.cpep(c["tp"], c["G"][s], c["obs"][s], c["age"][s], c["t2dm"][s], c["arch"], self.nn, self.cond,
+                         30, 3)
+        self.g_cond = r["g_beta"] * self.N / self.n_global
+        part = np.concatenate([r["g_nn"] * self.N / self.n_global, [r["sse"].sum(), float(r["n_failed"])]])
+        return part, (self.g_cond if want_cond_grad else None)
+
+    def adam_init(self, lr):
+        self.lr, self.t = lr, 0
+        self.m_n = np.zeros(self.P); self.v_n = np.zeros(self.P)
+        self.m_c = np.zeros(self.N); self.v_c = np.zeros(self.N)
+
+    def adam_apply(self, reduced):
+        import cude_oracle as o
+        self.t += 1
+        self.nn, self.m_n, self.v_n = o.adam_update(self.nn, reduced[:self.P], self.m_n, self.v_n, self.t, self.lr)
+        self.cond, self.m_c, self.v_c = o.adam_update(self.cond, self.g_cond, self.m_c, self.v_c, self.t, self.lr)
+        return reduced[self.P] / self.n_global
+
+    def get_params(self):
+        return self.nn.copy(), self.cond.copy()
+
+
+def _rank_main(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "conditional-ude_amd"), os.path.join(here, "..", "oracle"), here):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from cude.parallel import ShardedTrainer, TorchCollective, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = make_cpep_case(n_total, (2, 6, 2))
+    lo, hi = shard_bounds(n_total, world, rank)
+    tr = ShardedTrainer(OracleEngine(case, lo, hi), TorchCollective(dist), transport="host")
+    tr.sync_population_statistics()
+    tr.adam_init(1e-2)
+    losses = [tr.adam_step() for _ in range(4)]
+    cond = tr.gather_conditional(n_total)
+    nn, _ = tr.engine.get_params()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=losses, cond=cond, nn=nn)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_training_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    import c_oracle as co
+    import cude_oracle as o
+    n_total, world = 23, 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["losses"], r1["losses"]) and np.array_equal(r0["nn"], r1["nn"])
+    # single-process reference: the same 4 Adam steps on the whole population
+    c = make_cpep_case(n_total, (2, 6, 2))
+    nn, beta = c["nn"].copy(), c["beta"].copy()
+    m_n, v_n, m_b, v_b = np.zeros_like(nn), np.zeros_like(nn), np.zeros_like(beta), np.zeros_like(beta)
+    ref_losses = []
+    for t in range(1, 5):
+        r = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], c["arch"], nn, beta, 30, 3)
+        ref_losses.append(r["loss"])
+        nn, m_n, v_n = o.adam_update(nn, r["g_nn"], m_n, v_n, t, 1e-2)
+        beta, m_b, v_b = o.adam_update(beta, r["g_beta"], m_b, v_b, t, 1e-2)
+    assert np.allclose(r0["losses"], ref_losses, rtol=1e-12)
+    assert np.allclose(r0["nn"], nn, rtol=0, atol=1e-12)
+    assert np.allclose(r0["cond"], beta, rtol=0, atol=1e-12)
