@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -568,6 +569,70 @@ int32_t cude_adam_step(cude_ctx* c, double* loss) {
         if ((rc = finish_loss(c, loss, nullptr))) return rc;
     }
     HIP_TRY(cude::launch_adam(a, c->stream));
+    return CUDE_OK;
+}
+
+int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_sets, const double* cond_sets,
+                                double* losses) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (n_sets < 1 || !nn_sets || !cond_sets || !losses) return fail(CUDE_ERR_ARG, "null/empty input");
+    const int P = c->P;
+    const int64_t N = c->N, nb = c->nblocks;
+    // chunk so that one launch stays below 2^16-1 grid rows and ~256 MB of partials
+    int64_t chunk = std::min<int64_t>(n_sets, 32768);
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, (int64_t)(256e6 / ((double)nb * (P + 2) * 8.0))));
+    DevBuf<double> d_nn, d_cond, d_part, d_out;
+    HIP_TRY(d_nn.resize((size_t)chunk * P));
+    HIP_TRY(d_cond.resize((size_t)chunk * N));
+    HIP_TRY(d_part.resize((size_t)chunk * nb * (P + 2)));
+    HIP_TRY(d_out.resize((size_t)chunk * 2));
+    std::vector<double> h_out((size_t)chunk * 2);
+    const int S = c->cfg.n_steps;
+    const double h = (c->tp.back() - c->tp.front()) / S;
+    double reg = 0.0;
+    for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
+        const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
+        HIP_TRY(hipMemcpyAsync(d_nn.p, nn_sets + k0 * P, kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_cond.p, cond_sets + k0 * N, kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (c->cfg.model == CUDE_MODEL_CPEP) {
+            cude::CpepArgs a{};
+            a.N = N;
+            a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
+            a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+            a.cond = d_cond.p; a.nn = d_nn.p;
+            a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+            a.partials = d_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
+        } else {
+            cude::SuppArgs a{};
+            a.N = N;
+            a.data = c->data.p; a.cond = d_cond.p; a.nn = d_nn.p;
+            a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+            for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+            a.partials = d_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
+        }
+        HIP_TRY(cude::launch_reduce_sets(d_part.p, (int)kn, nb, P + 2, P, d_out.p, c->stream));
+        if (c->comm && (rc = allreduce_dev(c, d_out.p, (size_t)kn * 2))) return rc;
+        HIP_TRY(hipMemcpyAsync(h_out.data(), d_out.p, kn * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int64_t k = 0; k < kn; k++) {
+            reg = 0.0;
+            if (c->cfg.lambda != 0.0) {
+                const double* w = nn_sets + (k0 + k) * P;
+                for (int q = 0; q < P; q++) reg += w[q] * w[q];
+            }
+            const double sum = h_out[2 * k], nf = h_out[2 * k + 1];
+            losses[k0 + k] = (nf > 0.0 || !std::isfinite(sum)) ? std::numeric_limits<double>::infinity()
+                                                             : sum / c->n_global + c->cfg.lambda * reg;
+        }
+    }
     return CUDE_OK;
 }
 

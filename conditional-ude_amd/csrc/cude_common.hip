@@ -63,6 +63,29 @@ hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int strid
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(64) void reduce_sets_kernel(const double* __restrict__ partials, int64_t nblocks, int stride,
+                                                         int col0, double* __restrict__ out) {
+    const int64_t k = blockIdx.x;
+    const double* base = partials + k * nblocks * stride + col0;
+    double a = 0.0, b = 0.0;
+    for (int64_t r = threadIdx.x; r < nblocks; r += 64) {
+        a += base[r * stride];
+        b += base[r * stride + 1];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) {
+        out[2 * k] = a;
+        out[2 * k + 1] = b;
+    }
+}
+
+hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(reduce_sets_kernel, dim3(n_sets), dim3(64), 0, s, partials, nblocks, stride, col0, out);
+    return hipGetLastError();
+}
+
 __global__ void l2_term_kernel(const double* __restrict__ nn, int P, double lambda, double n_global,
                                double* __restrict__ out) {
     // single wave

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     const bool active = gid < a.N;
     const int64_t i = active ? gid : a.N - 1;
     const int64_t N = a.N;
-    cptr_t p = as_const(a.nn);
+    // multi-start screening: blockIdx.y selects one of n_sets (network, conditional) parameter sets
+    const int64_t set = blockIdx.y;
+    cptr_t p = as_const(a.nn + set * a.set_stride_nn);
     cptr_t phi = as_const(a.phi);
     cptr_t obs_w = as_const(a.obs_w);
     ciptr_t seg = as_const(a.seg);
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     const double k0 = a.k0[i], k1 = a.k1[i], k2 = a.k2[i], c0 = a.c0[i];
     const double a11 = -(k0 + k2), a12 = k1, a21 = k2, a22 = -k1, f0 = k0 * c0;
     double cst[NC];
-    cst[0] = exp(a.cond[i]);
+    cst[0] = exp(a.cond[set * a.set_stride_cond + i]);
     if (NC > 1) cst[1] = a.age[i];
     double c[W];
     Net::first_layer_offset(p, cst, c);
@@ -150,12 +152,12 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     sse += chk;
     const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);   // NaN or Inf
     if (active) {
-        if (a.sse != nullptr) a.sse[i] = sse;
+        if (a.sse != nullptr) a.sse[set * a.set_stride_cond + i] = sse;
         if (NS == 3 && a.auc != nullptr) a.auc[i] = y3;
     }
     const double red_loss = active ? sse : 0.0;
     const double red_fail = (active && failed) ? 1.0 : 0.0;
-    double* out = a.partials + (int64_t)blockIdx.x * (P + 2);
+    double* out = a.partials + ((int64_t)set * gridDim.x + blockIdx.x) * (P + 2);
 
     if (!GRAD) {
         const double v2[2] = {red_loss, red_fail};
@@ -273,7 +275,8 @@ template <int NIN, int W, int D, int NS, bool GRAD>
 static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(5 + kRedRows + (GRAD ? a.T : 0)) * kBlock;
-    hipLaunchKernelGGL((cpep_kernel<NIN, W, D, NS, GRAD>), dim3((unsigned)nblocks), dim3(kBlock), lds, s, a);
+    const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
+    hipLaunchKernelGGL((cpep_kernel<NIN, W, D, NS, GRAD>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
 

@@ -36,7 +36,11 @@ struct CpepArgs {
     double* traj;            // [NS x T x N] column-major or nullptr
     double* auc;             // [N] or nullptr (NS == 3: cumulative secretion at t_end)
     double* g_cond;          // [N] (grad)
-    double* partials;        // [nblocks][P+2]
+    double* partials;        // [n_sets][nblocks][P+2]
+    // multi-start screening (forward only): n_sets parameter sets, set k reads nn + k*set_stride_nn and
+    // cond + k*set_stride_cond (and writes sse + k*set_stride_cond); 0/0/0 for the single-set path
+    int32_t n_sets;
+    int64_t set_stride_nn, set_stride_cond;
 };
 
 // suppression cUDE (nonlinear: NN input is the state)
@@ -54,7 +58,9 @@ struct SuppArgs {
     double* sse;             // [N] or nullptr (already divided by scale^2)
     double* traj;            // [3 x T x N] column-major or nullptr
     double* g_cond;          // [N]
-    double* partials;        // [nblocks][P+2]
+    double* partials;        // [n_sets][nblocks][P+2]
+    int32_t n_sets;          // multi-start screening (forward only), as CpepArgs
+    int64_t set_stride_nn, set_stride_cond;
 };
 
 // returns hipSuccess, or hipErrorInvalidValue when the shape is not compiled in
@@ -66,6 +72,9 @@ bool supp_shape_supported(const NetShape& net);
 // common kernels
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol)
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
+                              hipStream_t s);
+// out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
+hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s);
 // g_nn[q] += 2*lambda*nn[q];  out[P] += lambda*sum(nn^2)*n_global   (so that loss = out[P]/n_global)
 hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s);

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     const bool active = gid < a.N;
     const int64_t i = active ? gid : a.N - 1;
     const int64_t N = a.N;
-    cptr_t p = as_const(a.nn);
+    const int64_t set = blockIdx.y;      // multi-start screening: one parameter set per grid row
+    cptr_t p = as_const(a.nn + set * a.set_stride_nn);
     cptr_t obs_w = as_const(a.obs_w);
     ciptr_t obs_step = as_const(a.obs_step);
     const int S = a.S, T = a.T;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
 #define KROW(j, s) s_K[((j) * 3 + (s)) * kBlock + lane]
 #define YROW(j, s) s_Y[((j) * 3 + (s)) * kBlock + lane]
 
-    double cst[1] = {exp(a.cond[i])};
+    double cst[1] = {exp(a.cond[set * a.set_stride_cond + i])};
     double c[W];
     Net::first_layer_offset(p, cst, c);
 
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
         }
     }
     const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);
-    if (active && a.sse != nullptr) a.sse[i] = sse;
+    if (active && a.sse != nullptr) a.sse[set * a.set_stride_cond + i] = sse;
     const double red_loss = active ? sse : 0.0;
     const double red_fail = (active && failed) ? 1.0 : 0.0;
-    double* out = a.partials + (int64_t)blockIdx.x * (P + 2);
+    double* out = a.partials + ((int64_t)set * gridDim.x + blockIdx.x) * (P + 2);
 
     if (!GRAD) {
         const double v2[2] = {red_loss, red_fail};
@@ -266,7 +267,8 @@ template <int W, int D, bool GRAD>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(kSuppRowsFixed + (GRAD ? 3 * a.T : 0)) * kBlock;
-    hipLaunchKernelGGL((supp_kernel<W, D, GRAD>), dim3((unsigned)nblocks), dim3(kBlock), lds, s, a);
+    const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
+    hipLaunchKernelGGL((supp_kernel<W, D, GRAD>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
 

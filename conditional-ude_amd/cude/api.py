@@ -268,10 +268,8 @@ def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_00
         eng, N = pop.engine, pop.N
         nn_inits = initial_parameters(models[0].chain, initial_guesses, rng=rng)
         ode_inits = initial_parameters(N, lhs_lower_bound, lhs_upper_bound, initial_guesses, rng)
-        losses = np.empty(initial_guesses)
-        for k in range(initial_guesses):                      # screening (:362-366)
-            eng.set_params(nn_inits[k], ode_inits[:, k])
-            losses[k] = eng.forward()["loss"]
+        # screening (:362-366): all candidates in one multi-start launch
+        losses = eng.multistart_forward(np.stack(nn_inits), np.ascontiguousarray(ode_inits.T))
         order = np.argsort(losses, kind="stable")[:selected_initials]
         sols = []
         for k in order:
@@ -413,7 +411,7 @@ def fit_suppression_model(p_init, prob, data, timepoints, lam, *, select_best_n=
     """fit_suppression_model (:132-177): screen all initials, keep the best n, Adam() [eta = 1e-3] then L-BFGS."""
     pop = _supp_population(prob, data, timepoints, lam, n_steps)
     eng = pop.engine
-    init_losses = np.array([suppression_loss(p, (prob, data, timepoints, lam), n_steps=n_steps) for p in p_init])
+    init_losses = eng.multistart_forward(np.stack([p.neural for p in p_init]), np.stack([p.theta for p in p_init]))
     best = np.argsort(init_losses, kind="stable")[:max(1, select_best_n)]
     sols, traces = [], []
     for k in best:

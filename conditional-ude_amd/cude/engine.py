@@ -119,6 +119,17 @@ class Engine:
             out["traj"] = traj.transpose(2, 1, 0)     # -> (n_state, T, N), the Julia Array(sol) shape
         return out
 
+    def multistart_forward(self, nn_sets, cond_sets):
+        """Losses of K candidate (network, conditional) parameter sets in one launch.
+        nn_sets: (K, P); cond_sets: (K, N)."""
+        nn = _f64(nn_sets)
+        cd = _f64(cond_sets)
+        if nn.ndim != 2 or nn.shape[1] != self.P or cd.shape != (nn.shape[0], self.N):
+            raise ValueError(f"expected nn_sets (K, {self.P}) and cond_sets (K, {self.N})")
+        losses = np.empty(nn.shape[0])
+        check(self._lib.cude_multistart_forward(self._h, nn.shape[0], _ptr(nn), _ptr(cd), _ptr(losses)))
+        return losses
+
     def loss_grad(self, want_cond_grad=True):
         loss = C.c_double()
         g_nn = np.empty(self.P)

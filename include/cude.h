@@ -95,6 +95,14 @@ int32_t cude_get_params(cude_ctx* ctx, double* nn, double* cond);
  * (Julia Array(sol) layout of simul). */
 int32_t cude_forward(cude_ctx* ctx, double* loss, double* per_subject_sse, double* traj);
 
+/* Multi-start screening: forward-only loss of n_sets candidate parameter sets over the resident
+ * population in one launch (first phase of `train`, src/parameter-estimation.jl:351-366;
+ * fit_suppression_model suppression_model.jl:135; c-peptide/06-saem.jl:41-42).
+ * nn_sets[n_sets][P], cond_sets[n_sets][N] row-major; losses[n_sets] (+Inf for a set with a failed subject).
+ * Does not touch the context's current parameters. */
+int32_t cude_multistart_forward(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
+                                double* losses);
+
 /* Loss and gradient: replaces ForwardDiff.gradient(loss, theta) under AutoForwardDiff()
  * (parameter-estimation.jl:370; suppression_model.jl:155; saem.jl:120) by a discrete adjoint
  * of the same fixed-step map.  g_nn[P]; g_cond[N] may be NULL (stays on the device). */

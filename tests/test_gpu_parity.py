@@ -106,3 +106,38 @@ def test_failure_convention():
     loss, _, _ = eng.loss_grad()
     assert loss == np.inf
     eng.close()
+
+
+@pytest.mark.parametrize("model", ["cpep", "supp"])
+def test_multistart_forward_matches_individual_evaluations(model):
+    """cude_multistart_forward (screening loop of train / fit_suppression_model) == K separate forward calls
+    == oracle, including a candidate that fails (+Inf) without disturbing the others."""
+    import c_oracle as co
+    from cude.engine import Engine
+    import cude_oracle as o
+    rng = np.random.default_rng(11)
+    K = 37
+    if model == "cpep":
+        arch, N = (2, 4, 2), 57
+        c = make_cpep_case(N, arch)
+        eng = Engine("cpep", arch)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        ref = lambda nn, cd: co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, nn, cd, 30, 2,
+                                     want_grad=False)["loss"]
+    else:
+        arch, N = (4, 3, 5), 70
+        c = make_supp_case(N, arch)
+        eng = Engine("supp", arch, lam=0.01)
+        eng.set_population_supp(c["tp"], c["data"])
+        ref = lambda nn, cd: co.supp(c["tp"], c["data"], arch, nn, cd, 0.01, 30, want_grad=False)["loss"]
+    nn_sets = np.stack([o.glorot_params(arch, 100 + k) for k in range(K)])
+    cond_sets = rng.uniform(-2, 0, (K, N))
+    cond_sets[5, 3] = np.nan
+    losses = eng.multistart_forward(nn_sets, cond_sets)
+    assert losses[5] == np.inf
+    for k in (0, 1, 17, 36):
+        r = ref(nn_sets[k], cond_sets[k])
+        assert abs(losses[k] - r) <= 1e-10 * abs(r)
+        eng.set_params(nn_sets[k], cond_sets[k])
+        assert abs(eng.forward()["loss"] - losses[k]) <= 1e-13 * abs(r)
+    eng.close()
