@@ -95,7 +95,11 @@ __device__ __forceinline__ SCol<W> ld_col(cptr_t p, int off) {
     for (int j = 0; j < W; j++) c.v[j] = p[off + j];
     return c;
 }
+#ifndef CUDE_NO_FENCE
 #define CUDE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CUDE_FENCE()
+#endif
 
 template <int NIN, int W, int D, int NV>
 struct Mlp {

@@ -141,3 +141,97 @@ def test_multistart_forward_matches_individual_evaluations(model):
         eng.set_params(nn_sets[k], cond_sets[k])
         assert abs(eng.forward()["loss"] - losses[k]) <= 1e-13 * abs(r)
     eng.close()
+
+
+def test_full_size_properties_1e5_subjects():
+    """BASELINE configs[2] size (1e5 subjects): properties that need no oracle run at that size --
+    (i) shard additivity: loss/gradient of the whole population = N-weighted combination of two shards,
+    (ii) bitwise determinism of repeated evaluations, (iii) directional derivative vs central differences,
+    (iv) an oracle spot check on a random subset of subjects (per-subject SSE and dL/dbeta)."""
+    import c_oracle as co
+    from cude.engine import Engine
+    arch, N = (2, 6, 2), 100000
+    c = make_cpep_case(N, arch)
+    eng = Engine("cpep", arch, n_steps=30, n_state=3)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(c["nn"], c["beta"])
+    loss, g_nn, g_cond = eng.loss_grad()
+    loss2, g_nn2, g_cond2 = eng.loss_grad()
+    assert loss == loss2 and np.array_equal(g_nn, g_nn2) and np.array_equal(g_cond, g_cond2)      # (ii)
+    sse = eng.forward(want_sse=True)["sse"]
+    assert abs(sse.sum() / N - loss) < 1e-12 * loss
+    # (i) two shards of unequal size
+    cut = 37123
+    parts = []
+    for lo, hi in ((0, cut), (cut, N)):
+        e2 = Engine("cpep", arch, n_steps=30, n_state=3)
+        e2.set_population_cpep(c["tp"], c["G"][lo:hi], c["obs"][lo:hi], c["age"][lo:hi], c["t2dm"][lo:hi])
+        e2.set_params(c["nn"], c["beta"][lo:hi])
+        l, gn, gc = e2.loss_grad()
+        parts.append((hi - lo, l, gn, gc))
+        e2.close()
+    w = np.array([p[0] for p in parts]) / N
+    assert abs(w[0] * parts[0][1] + w[1] * parts[1][1] - loss) < 1e-12 * loss
+    assert np.max(np.abs(w[0] * parts[0][2] + w[1] * parts[1][2] - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
+    assert np.max(np.abs(np.concatenate([w[0] * parts[0][3], w[1] * parts[1][3]]) - g_cond)) < 1e-15
+    # (iii) directional derivative
+    rng = np.random.default_rng(0)
+    d_nn, d_b = rng.standard_normal(g_nn.size), rng.standard_normal(N)
+    eps = 1e-6
+    eng.set_params(c["nn"] + eps * d_nn, c["beta"] + eps * d_b); lp = eng.forward()["loss"]
+    eng.set_params(c["nn"] - eps * d_nn, c["beta"] - eps * d_b); lm = eng.forward()["loss"]
+    assert abs((lp - lm) / (2 * eps) - (g_nn @ d_nn + g_cond @ d_b)) < 1e-7 * abs(g_nn @ d_nn + g_cond @ d_b)
+    # (iv) oracle on 400 random subjects: per-subject SSE and dL/dbeta (which are local to a subject)
+    idx = np.sort(rng.choice(N, 400, replace=False))
+    ref = co.cpep(c["tp"], c["G"][idx], c["obs"][idx], c["age"][idx], c["t2dm"][idx], arch, c["nn"], c["beta"][idx],
+                  30, 3)
+    assert np.max(np.abs(sse[idx] - ref["sse"])) < 1e-11
+    assert np.max(np.abs(g_cond[idx] * N - ref["g_beta"] * 400)) < 1e-9 * np.max(np.abs(ref["g_beta"] * 400))
+    eng.close()
+
+
+@pytest.mark.parametrize("n_steps,tp", [(30, [0.0, 30.0, 60.0, 90.0, 120.0]), (17, [0.0, 10.0, 45.0, 50.0, 120.0]),
+                                         (60, [0.0, 15.0, 30.0, 45.0, 60.0, 75.0, 90.0, 120.0]), (5, [0.0, 120.0]),
+                                         (1, [0.0, 60.0, 120.0])])
+def test_cpep_general_time_grids(n_steps, tp):
+    """Irregular observation times / step counts: observations inside, at the end of, and sharing a step; T=2;
+    a single step holding every observation."""
+    import c_oracle as co
+    import cude_oracle as o
+    from cude.engine import Engine
+    arch, N = (2, 4, 2), 129
+    rng = np.random.default_rng(4)
+    tp = np.array(tp)
+    age, t2 = rng.uniform(20, 79, N), rng.random(N) < 0.4
+    G = 5.0 + np.abs(rng.standard_normal((N, tp.size))).cumsum(1)
+    obs = 0.5 + rng.random((N, tp.size))
+    nn, beta = o.glorot_params(arch, 9), rng.normal(-0.6, 0.5, N)
+    ref = co.cpep(tp, G, obs, age, t2, arch, nn, beta, n_steps, 2, want_traj=True)
+    eng = Engine("cpep", arch, n_steps=n_steps, n_state=2)
+    eng.set_population_cpep(tp, G, obs, age, t2)
+    eng.set_params(nn, beta)
+    f = eng.forward(want_traj=True)
+    assert np.max(np.abs(f["traj"] - ref["traj"].transpose(2, 1, 0))) < 1e-11 * np.max(np.abs(ref["traj"]))
+    loss, g_nn, g_cond = eng.loss_grad()
+    assert abs(loss - ref["loss"]) < 1e-10 * ref["loss"]
+    assert np.max(np.abs(g_nn - ref["g_nn"])) < 1e-9 * np.max(np.abs(ref["g_nn"]))
+    assert np.max(np.abs(g_cond - ref["g_beta"])) < 1e-9 * np.max(np.abs(ref["g_beta"]))
+    eng.close()
+
+
+def test_argument_errors_are_statuses():
+    from cude.engine import Engine
+    from cude._lib import CudeError
+    with pytest.raises(CudeError):
+        Engine("cpep", (2, 5, 2))                      # shape not compiled in -> CUDE_ERR_UNSUPPORTED
+    eng = Engine("cpep", (2, 4, 2))
+    with pytest.raises(CudeError):
+        eng.forward()                                  # population not set
+    with pytest.raises(CudeError):
+        eng.set_population_cpep([0.0, 30.0, 30.0], np.ones((3, 3)), np.ones((3, 3)), np.ones(3), np.zeros(3))
+    eng.set_population_cpep([0.0, 30.0, 60.0], np.ones((3, 3)) * 5, np.ones((3, 3)), np.ones(3) * 40, np.zeros(3))
+    with pytest.raises(CudeError):
+        eng.forward()                                  # parameters not set
+    with pytest.raises(CudeError):
+        eng.adam_step()                                # adam_init missing
+    eng.close()
