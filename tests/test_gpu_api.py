@@ -180,3 +180,29 @@ def test_two_rank_sharded_training_matches_single_engine(tmp_path):
     eng.close()
     assert np.allclose(r0["losses"], ref, rtol=1e-10)          # loss trajectory over 5 Adam steps
     assert np.allclose(r0["nn"], nn, rtol=0, atol=1e-10) and np.allclose(r0["cond"], cond, rtol=0, atol=1e-10)
+
+
+def test_builtin_rccl_path_single_rank():
+    """The built-in communicator (dlopen'ed RCCL: unique id, ncclCommInitRank by-value id, in-place all-reduce on
+    the context's stream) exercised with a 1-rank communicator: results must equal the no-communicator path."""
+    from cude.engine import Engine
+    c = make_cpep_case(300, (2, 6, 2))
+
+    def run(with_comm):
+        eng = Engine("cpep", (2, 6, 2), n_steps=30, n_state=3)
+        if with_comm:
+            uid = Engine.comm_unique_id()
+            assert len(uid) == 128 and any(uid)
+            eng.comm_init(1, 0, uid)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], c["beta"])
+        fwd = eng.forward()["loss"]
+        eng.adam_init(1e-2)
+        losses = [eng.adam_step() for _ in range(3)]
+        nn, cond = eng.get_params()
+        red = eng.allreduce_host([1.5, 2.5])
+        eng.close()
+        return fwd, losses, nn, cond, red
+    a, b = run(False), run(True)
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert np.array_equal(b[4], [1.5, 2.5])
