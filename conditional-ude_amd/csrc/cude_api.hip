@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -169,6 +170,10 @@ struct cude_ctx {
     DevBuf<double> phi, obs_w;
     // parameters / gradients / optimiser
     DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;
+    // chunked gradient path (cude_cpep2.hip)
+    int chunks = 1;
+    DevBuf<int32_t> chunk_start;
+    DevBuf<double> hom_M, hom_obs, fsum, res, g_cond_part, partials2;
     DevBuf<double> m_nn, v_nn, m_cond, v_cond;
     int64_t nblocks = 0;
     double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-8;
@@ -245,6 +250,57 @@ int32_t check_times(int32_t n_obs, const double* tp) {
     return CUDE_OK;
 }
 
+cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base) {
+    cude::Cpep2Args a2{};
+    a2.base = base;
+    a2.L = c->chunks;
+    a2.chunk_start = c->chunk_start.p;
+    a2.hom_M = c->hom_M.p; a2.hom_obs = c->hom_obs.p; a2.fsum = c->fsum.p; a2.res = c->res.p;
+    a2.g_cond_part = c->g_cond_part.p; a2.partials2 = c->partials2.p;
+    return a2;
+}
+
+// Chunking of the step range for the time-split gradient path: L = min(3, S) contiguous chunks (0 <-> disabled
+// by CUDE_CPEP_PATH=1 or an unsupported shape).  Precomputes the kinetics-only chunk transfer matrices.
+int32_t setup_chunks(cude_ctx* c) {
+    c->chunks = 1;
+    const char* env = getenv("CUDE_CPEP_PATH");
+    if (env && env[0] == '1') return CUDE_OK;
+    if (!cude::cpep2_shape_supported(c->net, c->cfg.n_state)) return CUDE_OK;
+    const int S = c->cfg.n_steps;
+    // Largest divisor L of S that keeps nblocks*L within ~2.5 waves per SIMD (1024 SIMDs): measured optimum on
+    // MI355X (tools/quick_bench.py): 57 subjects L=30 (0.43 -> 0.08 ms per step), 1e4 subjects L=6..15
+    // (0.43 -> 0.12 ms), >= 1e5 subjects L=1 (the one-lane-per-subject kernel already fills the chip).
+    int L = 1;
+    for (int d = 1; d <= S; d++)
+        if (S % d == 0 && c->nblocks * d <= 2560) L = d;
+    if (env && env[0] == '2' && env[1] == ':') L = atoi(env + 2);
+    if (L > S) L = S;
+    if (L < 2) return CUDE_OK;
+    std::vector<int32_t> cs(L + 1);
+    for (int k = 0; k <= L; k++) cs[k] = (int32_t)((int64_t)k * S / L);
+    const int64_t N = c->N;
+    const int T = c->T;
+    HIP_TRY(c->chunk_start.resize(L + 1));
+    HIP_TRY(c->hom_M.resize((size_t)L * 4 * N));
+    HIP_TRY(c->hom_obs.resize((size_t)T * 2 * N));
+    HIP_TRY(c->fsum.resize((size_t)L * (3 + T) * N));
+    HIP_TRY(c->res.resize((size_t)T * N));
+    HIP_TRY(c->g_cond_part.resize((size_t)L * N));
+    HIP_TRY(c->partials2.resize((size_t)L * c->nblocks * c->P));
+    HIP_TRY(hipMemcpyAsync(c->chunk_start.p, cs.data(), (L + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    c->chunks = L;
+    cude::CpepArgs a{};
+    a.N = N;
+    a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
+    a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+    a.T = T; a.S = S; a.h = (c->tp.back() - c->tp.front()) / S;
+    cude::Cpep2Args a2 = chunk_args(c, a);
+    HIP_TRY(cude::launch_cpep2_homog(a2, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // cs (host vector) dies here
+    return CUDE_OK;
+}
+
 // launches the ensemble kernel + second-stage reduction (+ all-reduce, + L2 term)
 int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only = false) {
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
@@ -274,7 +330,12 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
         a.sse = c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
-        HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, grad, a, c->stream));
+        if (c->chunks > 1 && (grad || traj_dev == nullptr)) {
+            cude::Cpep2Args a2 = chunk_args(c, a);
+            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
+        } else {
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, grad, a, c->stream));
+        }
     } else {
         cude::SuppArgs a{};
         a.N = c->N;
@@ -288,8 +349,14 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     }
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
     const int P = c->P;
-    if (grad) HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream));
-    else HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+    if (grad && c->cfg.model == CUDE_MODEL_CPEP && c->chunks > 1) {
+        HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+    } else if (grad) {
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream));
+    } else {
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+    }
     if (local_only) return CUDE_OK;   // the caller reduces across ranks and applies the L2 term
     if (c->comm) {
         int32_t rc = grad ? allreduce_dev(c, c->g_nn.p, P + 2) : allreduce_dev(c, c->g_nn.p + P, 2);
@@ -426,6 +493,7 @@ int32_t cude_set_population_cpep(cude_ctx* c, int64_t N, int32_t n_obs, const do
                                       c->dG.p, c->stream));
     if ((rc = alloc_common(c))) return rc;
     if ((rc = upload_tables(c, true))) return rc;
+    if ((rc = setup_chunks(c))) return rc;
     c->n_global = (double)N;
     if (c->comm) {
         double v[1] = {(double)N};

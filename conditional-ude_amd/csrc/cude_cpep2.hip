@@ -1,0 +1,442 @@
+// Chunked ("time-split") c-peptide cUDE loss+gradient path for gfx950.
+//
+// Same mathematics as cude_cpep.hip (fixed-step Tsit5 + discrete adjoint of the c-peptide cUDE,
+// reference: src/c-peptide-models.jl:7-14,86-94; src/parameter-estimation.jl:56-68,126-140,370), but
+// each subject's S steps are split into L contiguous chunks that run in DIFFERENT lanes (grid row =
+// chunk), which (a) triples the number of waves -- at the benchmark size one lane per subject gives only
+// 1.9 waves per SIMD -- and (b) lets the forward sweep (131 VGPRs) run at its own, higher occupancy
+// instead of inheriting the reverse sweep's 229 VGPRs.
+//
+// Why this is possible: the network input [dG(t), e^beta] does not depend on the state, so the ODE is
+// f = A u + [k0 c0 + q(t); 0] with constant A.  Hence
+//   * the state at the end of a chunk is AFFINE in the state at its start: y_out = M y_in + v, where
+//     M (and the response H_tau of every observation to y_in) depend only on the subject's kinetics and
+//     are precomputed once per population (cpep2_homog_kernel), and v / the forced observation parts
+//     come from running the chunk from a ZERO entry state with the network forcing (cpep2_fwd_kernel);
+//   * a tiny per-subject scan stitches the chunks and forms the residuals (cpep2_scan_kernel);
+//   * the adjoint recursion needs no network evaluation and no forward state (J_f = A), so the lane of
+//     chunk c replays the (cheap) stage-adjoint algebra from the last step down to its own chunk and
+//     evaluates the network reverse sweeps only for its own stage times (cpep2_rev_kernel).
+#include "cude_device.h"
+#include "cude_kernels.h"
+
+namespace cude {
+
+// ---------------------------------------------------------------------------------- shared pieces
+struct Kin {
+    double a11, a12, a21, a22, f0;
+};
+
+// One fixed Tsit5 step of  y' = A y + [g_i; 0]  given k_1 (FSAL); g[i] is the forcing of stage i+1.
+// Returns y_{n+1} in (Y1,Y2) and all stage derivatives in K.
+__device__ __forceinline__ void rk_step(const Kin& k, double h, double y1, double y2, const double (&g)[7],
+                                        double (&K)[7][2], double& Y1, double& Y2) {
+#pragma unroll
+    for (int st = 1; st < 7; st++) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < st; j++) {
+            t1 = fma(Tab::a(st, j), K[j][0], t1);
+            t2 = fma(Tab::a(st, j), K[j][1], t2);
+        }
+        Y1 = fma(h, t1, y1);
+        Y2 = fma(h, t2, y2);
+        K[st][0] = fma(k.a11, Y1, fma(k.a12, Y2, g[st]));
+        K[st][1] = fma(k.a21, Y1, k.a22 * Y2);
+    }
+}
+
+// ---------------------------------------------------------------------------------- homogeneous responses
+// Per subject, per chunk: M = d y(chunk end) / d y(chunk start); per observation: H = d y1(tau) / d y(start of
+// the chunk holding tau).  Depends only on (k0,k1,k2), the step grid and the tableau: computed once.
+__global__ __launch_bounds__(kBlock) void cpep2_homog_kernel(Cpep2Args a) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.base.N) return;
+    const int64_t N = a.base.N;
+    cptr_t obs_w = as_const(a.base.obs_w);
+    ciptr_t obs_step = as_const(a.base.obs_step);
+    ciptr_t cs = as_const(a.chunk_start);
+    const int T = a.base.T;
+    const double h = a.base.h;
+    const double k0 = a.base.k0[i], k1 = a.base.k1[i], k2 = a.base.k2[i];
+    const Kin kin{-(k0 + k2), k1, k2, -k1, 0.0};
+    const double g0[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < a.L; c++) {
+        const int n0 = cs[c], n1 = cs[c + 1];
+        for (int b = 0; b < 2; b++) {
+            double y1 = b == 0 ? 1.0 : 0.0, y2 = b == 0 ? 0.0 : 1.0;
+            double K[7][2];
+            K[0][0] = fma(kin.a11, y1, kin.a12 * y2);
+            K[0][1] = fma(kin.a21, y1, kin.a22 * y2);
+            int oi = 0;
+            while (oi < T && obs_step[oi] < n0) oi++;
+            for (int n = n0; n < n1; n++) {
+                double Y1, Y2;
+                rk_step(kin, h, y1, y2, g0, K, Y1, Y2);
+                while (oi < T && obs_step[oi] == n) {
+                    double o1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 7; j++) o1 = fma(obs_w[oi * 7 + j], K[j][0], o1);
+                    a.hom_obs[((int64_t)oi * 2 + b) * N + i] = fma(h, o1, y1);
+                    oi++;
+                }
+                y1 = Y1; y2 = Y2;
+                K[0][0] = K[6][0]; K[0][1] = K[6][1];
+            }
+            a.hom_M[((int64_t)c * 4 + 0 + b) * N + i] = y1;      // M[0][b]
+            a.hom_M[((int64_t)c * 4 + 2 + b) * N + i] = y2;      // M[1][b]
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- forward (forced, zero entry)
+template <int NIN, int W, int D, int NS>
+__global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
+    using Net = Mlp<NIN, W, D, 1>;
+    constexpr int NC = NIN - 1;
+    extern __shared__ double smem[];
+    double* s_q = smem;                         // [5][kBlock]
+    const CpepArgs& b = a.base;
+    const int lane = threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const bool active = gid < b.N;
+    const int64_t i = active ? gid : b.N - 1;
+    const int64_t N = b.N;
+    const int c_idx = blockIdx.y;
+    cptr_t p = as_const(b.nn);
+    cptr_t phi = as_const(b.phi);
+    cptr_t obs_w = as_const(b.obs_w);
+    ciptr_t seg = as_const(b.seg);
+    ciptr_t obs_step = as_const(b.obs_step);
+    ciptr_t cs = as_const(a.chunk_start);
+    const int T = b.T;
+    const double h = b.h;
+    const int n0 = cs[c_idx], n1 = cs[c_idx + 1];
+
+    const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
+    const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};
+    double cst[NC];
+    cst[0] = exp(b.cond[i]);
+    if (NC > 1) cst[1] = b.age[i];
+    double c[W];
+    Net::first_layer_offset(p, cst, c);
+    double chk = fma(cst[0], 0.0, Net::param_check(p));   // NaN iff a parameter / beta is non-finite
+    if (NC > 1) chk = fma(cst[1], 0.0, chk);
+
+    double y1 = 0.0, y2 = 0.0, y3 = 0.0;                  // forced response from a ZERO entry state
+    double qprev = 0.0, base = 0.0;
+    double K1a = 0.0, K1b = 0.0;
+    int cur_seg = -1;
+    double g_lo = 0.0, g_d = 0.0;
+    int oi = 0;
+    while (oi < T && obs_step[oi] < n0) oi++;
+    // evaluations: idx = -2 baseline NN([0; e^beta]); idx = -1 forcing at the chunk's first stage-1 time
+    // (= last stage time of the previous step; exactly 0 for the first chunk); idx >= 0 own stage times.
+    int n = n0, s = 0;
+    const int n_own = 5 * (n1 - n0);
+#pragma unroll 1
+    for (int idx = -2; idx < n_own; idx++) {
+        double xv = 0.0;
+        const int e = (idx >= 0) ? 5 * n0 + idx : 5 * n0 - 1;
+        if (idx >= 0 || (idx == -1 && n0 > 0)) {
+            const int sg = seg[e];
+            if (sg != cur_seg) {
+                cur_seg = sg;
+                g_lo = b.dG[(int64_t)sg * N + i];
+                g_d = b.dG[(int64_t)(sg + 1) * N + i] - g_lo;
+                chk = fma(g_d, 0.0, fma(g_lo, 0.0, chk));
+            }
+            xv = fma(phi[e], g_d, g_lo);
+        }
+        const double x[1] = {xv};
+        const double v = Net::eval(p, c, x);
+        if (idx == -2) { base = v; continue; }
+        if (idx == -1) {
+            qprev = v - base;
+            K1a = kin.f0 + qprev;                      // A*0 + [f0 + q; 0]
+            K1b = 0.0;
+            continue;
+        }
+        s_q[s * kBlock + lane] = v - base;
+        if (++s < 5) continue;
+        s = 0;
+        double q[7], g[7];
+        q[0] = qprev;
+#pragma unroll
+        for (int j = 0; j < 5; j++) q[j + 1] = s_q[j * kBlock + lane];
+        q[6] = q[5];
+#pragma unroll
+        for (int j = 0; j < 7; j++) g[j] = kin.f0 + q[j];
+        double K[7][2];
+        K[0][0] = K1a;
+        K[0][1] = K1b;
+        double Y1, Y2;
+        rk_step(kin, h, y1, y2, g, K, Y1, Y2);
+        double y3n = y3;
+        if (NS == 3) {
+            double t3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) t3 = fma(Tab::a(6, j), q[j], t3);
+            y3n = fma(h, t3, y3);
+        }
+        while (oi < T && obs_step[oi] == n) {
+            double o1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; j++) o1 = fma(obs_w[oi * 7 + j], K[j][0], o1);
+            if (active) a.fsum[((int64_t)c_idx * (3 + T) + 3 + oi) * N + i] = fma(h, o1, y1) + chk;
+            oi++;
+        }
+        y1 = Y1; y2 = Y2; y3 = y3n;
+        K1a = K[6][0]; K1b = K[6][1];
+        qprev = q[6];
+        n++;
+    }
+    if (active) {
+        double* f = a.fsum + (int64_t)c_idx * (3 + T) * N + i;
+        f[0] = y1 + chk;
+        f[N] = y2;
+        f[2 * N] = y3;
+    }
+}
+
+// ---------------------------------------------------------------------------------- scan + residuals
+template <int P>
+__global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
+    extern __shared__ double smem[];
+    const CpepArgs& b = a.base;
+    const int lane = threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const bool active = gid < b.N;
+    const int64_t i = active ? gid : b.N - 1;
+    const int64_t N = b.N;
+    ciptr_t obs_step = as_const(b.obs_step);
+    ciptr_t cs = as_const(a.chunk_start);
+    const int T = b.T;
+    const double k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
+    double y1 = c0, y2 = (k2 / k1) * c0, y3 = 0.0, sse = 0.0;
+    int oi = 0;
+    for (int c = 0; c < a.L; c++) {
+        const double* f = a.fsum + (int64_t)c * (3 + T) * N + i;
+        const int n1 = cs[c + 1];
+        while (oi < T && obs_step[oi] < n1) {
+            const double hy = fma(a.hom_obs[((int64_t)oi * 2) * N + i], y1, a.hom_obs[((int64_t)oi * 2 + 1) * N + i] * y2);
+            const double r = (f[(int64_t)(3 + oi) * N] + hy) - b.obs[(int64_t)oi * N + i];
+            sse = fma(r, r, sse);
+            if (active) a.res[(int64_t)oi * N + i] = r;
+            oi++;
+        }
+        const double* M = a.hom_M + (int64_t)c * 4 * N + i;
+        const double n1y = f[0] + fma(M[0], y1, M[N] * y2);
+        const double n2y = f[N] + fma(M[2 * N], y1, M[3 * N] * y2);
+        y1 = n1y; y2 = n2y;
+        y3 += f[2 * N];
+    }
+    const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);
+    if (active) {
+        if (b.sse != nullptr) b.sse[i] = sse;
+        if (b.auc != nullptr) b.auc[i] = y3;
+    }
+    const double v2[2] = {active ? sse : 0.0, (active && failed) ? 1.0 : 0.0};
+    block_reduce_store<2>(v2, smem, b.partials + (int64_t)blockIdx.x * (P + 2) + P, lane);
+}
+
+// ---------------------------------------------------------------------------------- reverse sweep
+// Stage-adjoint algebra of one step (J_f = A): consumes the adjoint (lam, kap) of (y_{n+1}, k_7), the
+// observation seeds of the step, and returns the adjoint of (y_n, k_1) plus the 5 network weights.
+__device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, cptr_t obs_w, ciptr_t obs_step,
+                                         const double* s_res, int lane, int n, int& oi, double& lam1, double& lam2,
+                                         double& kap1, double& kap2, double (&w)[5]) {
+    double kb[7][2];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { kb[j][0] = 0.0; kb[j][1] = 0.0; }
+    kb[6][0] = kap1;
+    kb[6][1] = kap2;
+    double yb1 = 0.0, yb2 = 0.0;
+    while (oi >= 0 && obs_step[oi] == n) {
+        const double g = gscale * s_res[oi * kBlock + lane];
+        yb1 += g;
+        const double hg = h * g;
+#pragma unroll
+        for (int j = 0; j < 7; j++) kb[j][0] = fma(obs_w[oi * 7 + j], hg, kb[j][0]);
+        oi--;
+    }
+    lam1 = fma(k.a11, kb[6][0], fma(k.a21, kb[6][1], lam1));
+    lam2 = fma(k.a12, kb[6][0], fma(k.a22, kb[6][1], lam2));
+    w[4] = kb[6][0];
+    yb1 += lam1;
+    yb2 += lam2;
+    {
+        const double hl1 = h * lam1, hl2 = h * lam2;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            kb[j][0] = fma(Tab::a(6, j), hl1, kb[j][0]);
+            kb[j][1] = fma(Tab::a(6, j), hl2, kb[j][1]);
+        }
+    }
+#pragma unroll
+    for (int st = 5; st >= 1; st--) {
+        const double Yb1 = fma(k.a11, kb[st][0], k.a21 * kb[st][1]);
+        const double Yb2 = fma(k.a12, kb[st][0], k.a22 * kb[st][1]);
+        if (st == 5) w[4] += kb[5][0];
+        else w[st - 1] = kb[st][0];
+        yb1 += Yb1;
+        yb2 += Yb2;
+        const double h1 = h * Yb1, h2 = h * Yb2;
+#pragma unroll
+        for (int j = 0; j < st; j++) {
+            kb[j][0] = fma(Tab::a(st, j), h1, kb[j][0]);
+            kb[j][1] = fma(Tab::a(st, j), h2, kb[j][1]);
+        }
+    }
+    lam1 = yb1;
+    lam2 = yb2;
+    kap1 = kb[0][0];
+    kap2 = kb[0][1];
+}
+
+template <int NIN, int W, int D>
+__global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
+    using Net = Mlp<NIN, W, D, 1>;
+    constexpr int P = Net::P;
+    constexpr int NC = NIN - 1;
+    extern __shared__ double smem[];
+    double* s_q = smem;                         // [5][kBlock] adjoint weights of the current step
+    double* s_red = smem + 5 * kBlock;          // [kRedRows][kBlock]
+    double* s_res = s_red + kRedRows * kBlock;  // [T][kBlock]
+    const CpepArgs& b = a.base;
+    const int lane = threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const bool active = gid < b.N;
+    const int64_t i = active ? gid : b.N - 1;
+    const int64_t N = b.N;
+    const int c_idx = blockIdx.y;
+    cptr_t p = as_const(b.nn);
+    cptr_t phi = as_const(b.phi);
+    cptr_t obs_w = as_const(b.obs_w);
+    ciptr_t seg = as_const(b.seg);
+    ciptr_t obs_step = as_const(b.obs_step);
+    ciptr_t cs = as_const(a.chunk_start);
+    const int S = b.S, T = b.T;
+    const double h = b.h;
+    const int n0 = cs[c_idx], n1 = cs[c_idx + 1];
+
+    const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
+    const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};
+    double cst[NC];
+    cst[0] = exp(b.cond[i]);
+    if (NC > 1) cst[1] = b.age[i];
+    double c[W];
+    Net::first_layer_offset(p, cst, c);
+    for (int t = 0; t < T; t++) s_res[t * kBlock + lane] = a.res[(int64_t)t * N + i];
+
+    double lam1 = 0.0, lam2 = 0.0, kap1 = 0.0, kap2 = 0.0;
+    const double gscale = 2.0 * b.inv_n;
+    int oi = T - 1;
+    double w[5];
+    // later chunks' steps: adjoint algebra only (their network sweeps belong to other lanes)
+#pragma unroll 1
+    for (int n = S - 1; n >= n1; n--) adj_step(kin, h, gscale, obs_w, obs_step, s_res, lane, n, oi, lam1, lam2, kap1, kap2, w);
+
+    double acc[Net::NACC];
+#pragma unroll
+    for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
+    double dxdummy[1] = {0.0};
+    double wtot = 0.0;
+    int cur_seg = -1;
+    double g_lo = 0.0, g_d = 0.0;
+    int n = n1 - 1, s = 4;
+    // own stage times in reverse order; e = 5 n0 - 1 stands for the baseline with weight -sum(own w)
+#pragma unroll 1
+    for (int e = 5 * n1 - 1; e >= 5 * n0 - 1; e--) {
+        const bool own = e >= 5 * n0;
+        if (own && s == 4) {
+            adj_step(kin, h, gscale, obs_w, obs_step, s_res, lane, n, oi, lam1, lam2, kap1, kap2, w);
+#pragma unroll
+            for (int j = 0; j < 5; j++) s_q[j * kBlock + lane] = w[j];
+            n--;
+        }
+        double xv = 0.0, wv;
+        if (own) {
+            const int sg = seg[e];
+            if (sg != cur_seg) {
+                cur_seg = sg;
+                g_lo = b.dG[(int64_t)sg * N + i];
+                g_d = b.dG[(int64_t)(sg + 1) * N + i] - g_lo;
+            }
+            xv = fma(phi[e], g_d, g_lo);
+            wv = s_q[s * kBlock + lane];
+            wtot += wv;
+            s = (s == 0) ? 4 : s - 1;
+        } else {
+            wv = -wtot;
+        }
+        const double x[1] = {xv};
+        Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy);
+    }
+    double g[P];
+    double dcond;
+    {
+        double gp[P];
+        Net::expand(p, acc, cst, gp, &dcond);
+        const double keep = active ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < P; q++) g[q] = gp[q] * keep;
+    }
+    if (active) a.g_cond_part[(int64_t)c_idx * N + i] = dcond;
+    double* out = a.partials2 + ((int64_t)c_idx * gridDim.x + blockIdx.x) * P;
+    block_reduce_store<P>(g, s_red, out, lane);
+}
+
+// g_cond[i] = sum_c part[c][i]
+__global__ void cpep2_sum_chunks_kernel(const double* __restrict__ part, int L, int64_t N, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double s = 0.0;
+    for (int c = 0; c < L; c++) s += part[(int64_t)c * N + i];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------- dispatch
+template <int NIN, int W, int D>
+static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStream_t s) {
+    using Net = Mlp<NIN, W, D, 1>;
+    const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
+    const dim3 grid2((unsigned)nblocks, (unsigned)a.L);
+    const size_t lds_f = sizeof(double) * 5 * kBlock;
+    if (n_state == 3) hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 3>), grid2, dim3(kBlock), lds_f, s, a);
+    else hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 2>), grid2, dim3(kBlock), lds_f, s, a);
+    hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks), dim3(kBlock), sizeof(double) * kRedRows * kBlock,
+                       s, a);
+    if (!grad) return hipGetLastError();
+    const size_t lds_r = sizeof(double) * (size_t)(5 + kRedRows + a.base.T) * kBlock;
+    hipLaunchKernelGGL((cpep2_rev_kernel<NIN, W, D>), grid2, dim3(kBlock), lds_r, s, a);
+    const int bs = 256;
+    hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N + bs - 1) / bs)), dim3(bs), 0, s,
+                       a.g_cond_part, a.L, a.base.N, a.base.g_cond);
+    return hipGetLastError();
+}
+
+#define CUDE_CPEP2_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3)
+
+bool cpep2_shape_supported(const NetShape& net, int n_state) {
+    if (n_state != 2 && n_state != 3) return false;
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return true;
+    CUDE_CPEP2_SHAPES(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s) {
+    const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(cpep2_homog_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_cpep2(const NetShape& net, int n_state, bool grad, const Cpep2Args& a, hipStream_t s) {
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return run_shape<NIN, W, D>(n_state, grad, a, s);
+    CUDE_CPEP2_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cude

@@ -131,8 +131,19 @@ struct Mlp {
     // convention (non-finite solve => loss = Inf).
     __device__ static __forceinline__ double param_check(cptr_t p) {
         double chk = 0.0;
+        constexpr int P8 = P / 8 * 8;
 #pragma unroll 1
-        for (int q = 0; q < P; q++) chk = fma(p[q], 0.0, chk);
+        for (int q0 = 0; q0 < P8; q0 += 8) {      // 8 doubles = one s_load_dwordx16 per trip
+            double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                c0 = fma(p[q0 + q], 0.0, c0);
+                c1 = fma(p[q0 + q + 1], 0.0, c1);
+            }
+            chk += c0 + c1;
+        }
+#pragma unroll
+        for (int q = P8; q < P; q++) chk = fma(p[q], 0.0, chk);
         return chk;
     }
 

@@ -43,6 +43,23 @@ struct CpepArgs {
     int64_t set_stride_nn, set_stride_cond;
 };
 
+// chunked loss+gradient path (cude_cpep2.hip): the S steps of every subject are split into L chunks
+struct Cpep2Args {
+    CpepArgs base;
+    int32_t L;
+    const int32_t* chunk_start;  // [L+1] step boundaries
+    double* hom_M;               // [L][4][N]   chunk transfer matrix d y_out / d y_in (static per population)
+    double* hom_obs;             // [T][2][N]   d y1(tau) / d y_in(chunk of tau)            (static)
+    double* fsum;                // [L][3+T][N] forced chunk response: v1, v2, quadrature, obs parts
+    double* res;                 // [T][N]      residuals
+    double* g_cond_part;         // [L][N]
+    double* partials2;           // [L][nblocks][P]
+};
+bool cpep2_shape_supported(const NetShape& net, int n_state);
+hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s);
+// forward (+ scan) only when !grad: per-subject SSE and the loss partials, no trajectory output
+hipError_t launch_cpep2(const NetShape& net, int n_state, bool grad, const Cpep2Args& a, hipStream_t s);
+
 // suppression cUDE (nonlinear: NN input is the state)
 struct SuppArgs {
     int64_t N;
