@@ -302,7 +302,10 @@ int32_t setup_chunks(cude_ctx* c) {
 }
 
 // launches the ensemble kernel + second-stage reduction (+ all-reduce, + L2 term)
-int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only = false) {
+// cond_ov / sse_ov: evaluate at other conditional parameters / write the per-subject SSE elsewhere and stop
+// after the ensemble kernels (used by the Metropolis E-step, which needs neither loss nor gradient).
+int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only = false,
+                     const double* cond_ov = nullptr, double* sse_ov = nullptr) {
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "parameters not set");
     const int S = c->cfg.n_steps;
@@ -325,10 +328,10 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.N = c->N;
         a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
         a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
-        a.cond = c->cond.p; a.nn = c->nn.p;
+        a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
         a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
         a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
-        a.sse = c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
+        a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         if (c->chunks > 1 && (grad || traj_dev == nullptr)) {
             cude::Cpep2Args a2 = chunk_args(c, a);
@@ -339,15 +342,16 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     } else {
         cude::SuppArgs a{};
         a.N = c->N;
-        a.data = c->data.p; a.cond = c->cond.p; a.nn = c->nn.p;
+        a.data = c->data.p; a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
         a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
         a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
         for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
-        a.ckpt = c->ckpt.p; a.sse = c->sse.p; a.traj = traj_dev;
+        a.ckpt = c->ckpt.p; a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         HIP_TRY(cude::launch_supp(c->net, grad, a, c->stream));
     }
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+    if (sse_ov) return CUDE_OK;
     const int P = c->P;
     if (grad && c->cfg.model == CUDE_MODEL_CPEP && c->chunks > 1) {
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream));
@@ -701,6 +705,41 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
                                                              : sum / c->n_global + c->cfg.lambda * reg;
         }
     }
+    return CUDE_OK;
+}
+
+int32_t cude_mh_estep(cude_ctx* c, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
+                      double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
+                      int64_t* accepted) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop || !c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "population / parameters not set");
+    if (n_mc < 1 || !normals || !uniforms) return fail(CUDE_ERR_ARG, "null/empty draws");
+    if (!(sigma > 0) || !(prior_sd > 0) || !(temperature > 0)) return fail(CUDE_ERR_ARG, "sigma, prior_sd, temperature must be > 0");
+    const int64_t N = c->N;
+    DevBuf<double> d_z, d_u, d_prop, d_sn, d_sc;
+    DevBuf<int64_t> d_acc;
+    HIP_TRY(d_z.resize((size_t)n_mc * N));
+    HIP_TRY(d_u.resize((size_t)n_mc * N));
+    HIP_TRY(d_prop.resize(N)); HIP_TRY(d_sn.resize(N)); HIP_TRY(d_sc.resize(N)); HIP_TRY(d_acc.resize(N));
+    HIP_TRY(hipMemcpyAsync(d_z.p, normals, (size_t)n_mc * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_u.p, uniforms, (size_t)n_mc * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_acc.p, 0, N * sizeof(int64_t), c->stream));
+    cude::MhArgs m{};
+    m.N = N; m.p = c->cond.p; m.prop = d_prop.p; m.sse_new = d_sn.p; m.sse_cur = d_sc.p; m.accepted = d_acc.p;
+    m.prior_mean = prior_mean; m.prior_sd = prior_sd;
+    m.ll_const = -(c->T / 2.0) * std::log(sigma * sigma);
+    m.inv_2s2 = 1.0 / (2.0 * sigma * sigma);
+    m.temperature = temperature; m.gamma = gamma;
+    for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
+        HIP_TRY(cude::launch_mh_propose(N, c->cond.p, d_z.p + (size_t)k * N, proposal_std, d_prop.p, c->stream));
+        if ((rc = run_ensemble(c, false, nullptr, true, d_prop.p, d_sn.p))) return rc;
+        if ((rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;   // re-evaluated as the reference does
+        m.u = d_u.p + (size_t)k * N;
+        HIP_TRY(cude::launch_mh_accept(m, c->stream));
+    }
+    if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return CUDE_OK;
 }
 

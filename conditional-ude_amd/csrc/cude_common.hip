@@ -105,6 +105,45 @@ hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_globa
     return hipGetLastError();
 }
 
+// ---- SAEM E-step (src/saem.jl:86-108): proposal and accept/reject of one Metropolis-Hastings step for
+// every subject.  The two likelihood evaluations in between are ordinary forward launches.
+__global__ void mh_propose_kernel(int64_t N, const double* __restrict__ p, const double* __restrict__ z,
+                                  double proposal_std, double* __restrict__ prop) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) prop[i] = fma(z[i], proposal_std, p[i]);
+}
+
+__global__ void mh_accept_kernel(MhArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const double p = a.p[i], q = a.prop[i];
+    // logpdf(Normal(mu, sd), x) differences: the normalisation cancels
+    const double zq = (q - a.prior_mean) / a.prior_sd, zp = (p - a.prior_mean) / a.prior_sd;
+    const double prior_ratio = -0.5 * zq * zq + 0.5 * zp * zp;
+    const double inf = __builtin_huge_val();
+    const double sn = a.sse_new[i], sc = a.sse_cur[i];
+    const bool okn = fabs(sn) <= 1.79769313486231570815e308, okc = fabs(sc) <= 1.79769313486231570815e308;
+    const double ll_new = okn ? a.ll_const - sn * a.inv_2s2 : -inf;     // -Inf on solver failure (:59-62)
+    const double ll_cur = okc ? a.ll_const - sc * a.inv_2s2 : -inf;
+    const double ratio = ll_new / a.temperature - ll_cur / a.temperature;
+    const bool acc = log(a.u[i]) < prior_ratio + ratio;                 // NaN compares false
+    a.p[i] = (1.0 - a.gamma) * p + a.gamma * (acc ? q : p);
+    if (acc) a.accepted[i] += 1;
+}
+
+hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, double proposal_std, double* prop,
+                             hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(mh_propose_kernel, dim3((unsigned)((N + bs - 1) / bs)), dim3(bs), 0, s, N, p, z, proposal_std, prop);
+    return hipGetLastError();
+}
+
+hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(mh_accept_kernel, dim3((unsigned)((a.N + bs - 1) / bs)), dim3(bs), 0, s, a);
+    return hipGetLastError();
+}
+
 // Adam exactly as Optimisers.jl: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 // x -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).  Skipped when any subject failed
 // (g_nn[P+1] > 0): the reference's optimiser would see an Inf objective there.

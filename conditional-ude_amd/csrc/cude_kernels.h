@@ -102,6 +102,19 @@ struct AdamArgs {
     double lr, b1, b2, eps, c1, c2;   // c1 = 1-b1^t, c2 = 1-b2^t
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
+// SAEM E-step (Metropolis-Hastings) helper kernels
+struct MhArgs {
+    int64_t N;
+    double* p;                 // chain state (conditional parameters), updated in place
+    const double* prop;        // proposals
+    const double* u;           // uniform draws of this step
+    const double* sse_new; const double* sse_cur;
+    int64_t* accepted;         // per-subject acceptance counter
+    double prior_mean, prior_sd, ll_const, inv_2s2, temperature, gamma;
+};
+hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, double proposal_std, double* prop,
+                             hipStream_t s);
+hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s);
 // population preparation
 hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const double* cpep_tn, const double* age,
                                const uint8_t* t2dm, double* k0, double* k1, double* k2, double* c0, double* dG,

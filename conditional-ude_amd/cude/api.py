@@ -437,6 +437,25 @@ def _log_normal(x, mu, sd):
     return -0.5 * ((x - mu) / sd) ** 2 - math.log(sd) - 0.5 * math.log(2 * math.pi)
 
 
+def mcmc_steps(sse_of, p_individual, n_obs, sigma, omega, proposal_std, prior_individual, temperature, gamma,
+               normals, uniforms):
+    """`mcmc_step` (src/saem.jl:86-108) applied `len(normals)` times to EVERY subject at once, with the
+    stochastic-approximation update of the chain state (:185).  `sse_of(beta[N]) -> SSE[N]` is one forward launch
+    over the population; normals / uniforms are (steps, N) draws (randn() / rand() of the reference).  As in the
+    reference the current state's likelihood is re-evaluated every step.  Returns (p_individual, accepted[N])."""
+    p = np.array(p_individual, dtype=np.float64)
+    acc_count = np.zeros(p.size, dtype=np.int64)
+    for z, u in zip(normals, uniforms):
+        prop = p + z * proposal_std
+        prior_ratio = _log_normal(prop, prior_individual, omega) - _log_normal(p, prior_individual, omega)
+        ll_new = individual_log_likelihood(sse_of(prop), n_obs, sigma)
+        ll_cur = individual_log_likelihood(sse_of(p), n_obs, sigma)
+        acc = np.log(u) < prior_ratio + (ll_new / temperature - ll_cur / temperature)
+        acc_count += acc
+        p = (1 - gamma) * p + gamma * np.where(acc, prop, p)
+    return p, acc_count
+
+
 def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0, prior_eta=0.0, prior_omega=1.0,
          iterations=500, n_burnin_iterations=100, proposal_std=0.1, proposal_std_bounds=(1e-3, 1.0), alpha=0.7,
          n_mcmc_steps=1, initial_mcmc_steps=None, target_acceptance_rate=0.25, initial_temperature=10.0,
@@ -464,14 +483,12 @@ def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0,
         steps = initial_mcmc_steps if it <= n_burnin_iterations else n_mcmc_steps
         temperature = max(1.0, initial_temperature * math.exp(-temperature_decay * it))
         accepted = 0
-        for _ in range(steps):                                     # E-step (:177-186)
-            prop = p_ind + rng.standard_normal(N) * proposal_std
-            prior_ratio = _log_normal(prop, prior_eta, omega) - _log_normal(p_ind, prior_eta, omega)
-            ll_new = individual_log_likelihood(sse_of(prop), T, sigma)
-            ll_cur = individual_log_likelihood(sse_of(p_ind), T, sigma)
-            acc = np.log(rng.random(N)) < prior_ratio + (ll_new - ll_cur) / temperature
-            accepted += int(acc.sum())
-            p_ind = (1 - gamma) * p_ind + gamma * np.where(acc, prop, p_ind)
+        # E-step (:177-186) fused on the device: all Metropolis steps queued on the stream, one synchronisation
+        eng.set_params(p_nn, p_ind)
+        n_acc = eng.mh_estep(rng.standard_normal((steps, N)), rng.random((steps, N)), sigma, prior_eta, omega,
+                             proposal_std, temperature, gamma)
+        _, p_ind = eng.get_params()
+        accepted = int(n_acc.sum())
         sse = sse_of(p_ind)
         loglik = float(individual_log_likelihood(sse, T, sigma).sum())
         # M-step (:118-131): 5 Adam iterations on (neural, sigma), random effects fixed

@@ -130,6 +130,19 @@ class Engine:
         check(self._lib.cude_multistart_forward(self._h, nn.shape[0], _ptr(nn), _ptr(cd), _ptr(losses)))
         return losses
 
+    def mh_estep(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0):
+        """n_mc Metropolis-Hastings steps for every subject on the device (chain state = the context's
+        conditional parameters, updated in place).  normals/uniforms: (n_mc, N).  Returns acceptance counts."""
+        z = _f64(normals)
+        u = _f64(uniforms)
+        if z.ndim != 2 or z.shape[1] != self.N or u.shape != z.shape:
+            raise ValueError(f"expected draws of shape (n_mc, {self.N})")
+        acc = np.zeros(self.N, dtype=np.int64)
+        check(self._lib.cude_mh_estep(self._h, z.shape[0], _ptr(z), _ptr(u), float(sigma), float(prior_mean),
+                                      float(prior_sd), float(proposal_std), float(temperature), float(gamma),
+                                      _ptr(acc)))
+        return acc
+
     def loss_grad(self, want_cond_grad=True):
         loss = C.c_double()
         g_nn = np.empty(self.P)

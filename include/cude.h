@@ -103,6 +103,19 @@ int32_t cude_forward(cude_ctx* ctx, double* loss, double* per_subject_sse, doubl
 int32_t cude_multistart_forward(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                                 double* losses);
 
+/* SAEM E-step on the device: n_mc Metropolis-Hastings steps of every subject's conditional parameter
+ * (`mcmc_step` src/saem.jl:86-108, applied n_mcmc_steps times with the stochastic-approximation update of the
+ * chain state :177-186).  The chain state is the context's conditional parameters (updated in place); the
+ * network is the context's current one.  normals / uniforms are the host's randn() / rand() draws, [n_mc][N]
+ * row-major.  log-likelihood = -(T/2) log sigma^2 - SSE/(2 sigma^2) (:55-66), -Inf on a failed solve; prior
+ * Normal(prior_mean, prior_sd); accept iff log u < prior ratio + (ll_new - ll_cur)/temperature; state <-
+ * (1-gamma) state + gamma (accepted ? proposal : state).  As in the reference the current state's likelihood is
+ * re-evaluated at every step.  accepted[N] (optional) receives per-subject acceptance counts.  All 5 n_mc
+ * launches are queued on the stream; the call synchronises once at the end. */
+int32_t cude_mh_estep(cude_ctx* ctx, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
+                      double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
+                      int64_t* accepted);
+
 /* Loss and gradient: replaces ForwardDiff.gradient(loss, theta) under AutoForwardDiff()
  * (parameter-estimation.jl:370; suppression_model.jl:155; saem.jl:120) by a discrete adjoint
  * of the same fixed-step map.  g_nn[P]; g_cond[N] may be NULL (stays on the device). */
