@@ -179,6 +179,11 @@ struct cude_ctx {
     double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-8;
     int64_t adam_t = 0;
     bool adam_ready = false;
+    DevBuf<double> adam_state, adam_trace;   // device-resident step state and per-iteration loss trace
+    int64_t trace_cap = 0;
+    hipGraph_t graph = nullptr;              // one captured optimiser iteration (cude_adam_run)
+    hipGraphExec_t graph_exec = nullptr;
+    bool capturing = false;
     int64_t last_failed = 0;
     // comm
     void* comm = nullptr;
@@ -205,8 +210,11 @@ int32_t allreduce_dev(cude_ctx* c, double* buf, size_t count) {
     return CUDE_OK;
 }
 
+void drop_graph(cude_ctx* c);
+
 int32_t alloc_common(cude_ctx* c) {
     const int64_t N = c->N;
+    drop_graph(c);
     c->nblocks = (N + cude::kBlock - 1) / cude::kBlock;
     HIP_TRY(c->cond.resize(N));
     HIP_TRY(c->g_cond.resize(N));
@@ -250,12 +258,38 @@ int32_t check_times(int32_t n_obs, const double* tp) {
     return CUDE_OK;
 }
 
+void drop_graph(cude_ctx* c) {
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+
+int32_t ensure_trace(cude_ctx* c, int64_t n) {
+    if (n <= c->trace_cap) return CUDE_OK;
+    drop_graph(c);                              // the captured kernels hold the old trace pointer
+    int64_t cap = std::max<int64_t>(n, 4096);
+    HIP_TRY(c->adam_trace.resize((size_t)cap * 2));
+    c->trace_cap = cap;
+    return CUDE_OK;
+}
+
+// queues the Adam update (+ state advance / loss trace) behind the gradient already on the stream
+int32_t enqueue_adam(cude_ctx* c) {
+    cude::AdamArgs a{};
+    a.N = c->N; a.P = c->P;
+    a.cond = c->cond.p; a.m_cond = c->m_cond.p; a.v_cond = c->v_cond.p; a.g_cond = c->g_cond.p;
+    a.nn = c->nn.p; a.m_nn = c->m_nn.p; a.v_nn = c->v_nn.p; a.g_nn = c->g_nn.p;
+    a.lr = c->lr; a.b1 = c->b1; a.b2 = c->b2; a.eps = c->eps;
+    a.state = c->adam_state.p; a.trace = c->adam_trace.p; a.trace_cap = c->trace_cap;
+    HIP_TRY(cude::launch_adam(a, c->stream));
+    return CUDE_OK;
+}
+
 cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base) {
     cude::Cpep2Args a2{};
     a2.base = base;
     a2.L = c->chunks;
     a2.chunk_start = c->chunk_start.p;
-    a2.hom_M = c->hom_M.p; a2.hom_obs = c->hom_obs.p; a2.fsum = c->fsum.p; a2.res = c->res.p;
+    a2.hom_M = c->hom_M.p; a2.hom_obs = c->hom_obs.p; a2.fsum = c->fsum.p; a2.wts = c->res.p;
     a2.g_cond_part = c->g_cond_part.p; a2.partials2 = c->partials2.p;
     return a2;
 }
@@ -285,7 +319,7 @@ int32_t setup_chunks(cude_ctx* c) {
     HIP_TRY(c->hom_M.resize((size_t)L * 4 * N));
     HIP_TRY(c->hom_obs.resize((size_t)T * 2 * N));
     HIP_TRY(c->fsum.resize((size_t)L * (3 + T) * N));
-    HIP_TRY(c->res.resize((size_t)T * N));
+    HIP_TRY(c->res.resize((size_t)5 * S * N));   // adjoint weights wts[5S][N]
     HIP_TRY(c->g_cond_part.resize((size_t)L * N));
     HIP_TRY(c->partials2.resize((size_t)L * c->nblocks * c->P));
     HIP_TRY(hipMemcpyAsync(c->chunk_start.p, cs.data(), (L + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -311,7 +345,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     const int S = c->cfg.n_steps;
     const double h = (c->tp.back() - c->tp.front()) / S;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing && grad) {
+    if (c->timing && grad && !c->capturing) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -453,6 +487,7 @@ int32_t cude_destroy(cude_ctx* c) {
     if (!c) return CUDE_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -613,6 +648,12 @@ int32_t cude_adam_init(cude_ctx* c, double lr, double beta1, double beta2, doubl
         return fail(CUDE_ERR_ARG, "bad Adam hyper-parameters");
     c->lr = lr; c->b1 = beta1; c->b2 = beta2; c->eps = eps;
     c->adam_t = 0;
+    drop_graph(c);                              // hyper-parameters are baked into the captured launches
+    HIP_TRY(c->adam_state.resize(4));
+    if ((rc = ensure_trace(c, 1))) return rc;
+    const double st0[4] = {1.0, 1.0, 0.0, 0.0};
+    HIP_TRY(hipMemcpyAsync(c->adam_state.p, st0, sizeof(st0), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // st0 is a stack buffer
     HIP_TRY(hipMemsetAsync(c->m_nn.p, 0, c->P * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->v_nn.p, 0, c->P * sizeof(double), c->stream));
     if (c->have_pop) {
@@ -629,18 +670,58 @@ int32_t cude_adam_step(cude_ctx* c, double* loss) {
     if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
     if ((rc = run_ensemble(c, true, nullptr))) return rc;
     c->adam_t += 1;
-    cude::AdamArgs a{};
-    a.N = c->N; a.P = c->P;
-    a.cond = c->cond.p; a.m_cond = c->m_cond.p; a.v_cond = c->v_cond.p; a.g_cond = c->g_cond.p;
-    a.nn = c->nn.p; a.m_nn = c->m_nn.p; a.v_nn = c->v_nn.p; a.g_nn = c->g_nn.p;
-    a.lr = c->lr; a.b1 = c->b1; a.b2 = c->b2; a.eps = c->eps;
-    a.c1 = 1.0 - std::pow(c->b1, (double)c->adam_t);
-    a.c2 = 1.0 - std::pow(c->b2, (double)c->adam_t);
     if (loss) {
         // read the loss of this iterate before the update kernel is queued behind it
         if ((rc = finish_loss(c, loss, nullptr))) return rc;
     }
-    HIP_TRY(cude::launch_adam(a, c->stream));
+    return enqueue_adam(c);
+}
+
+// n_iters optimiser iterations without any host round trip: one iteration (gradient kernels, reductions, L2
+// term, Adam, state advance) is captured once into a hipGraph and replayed; the per-iteration losses are
+// appended to a device trace and copied back after a single synchronisation.  With a communicator attached
+// the iterations are queued as plain launches (RCCL calls are not captured).
+int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
+    if (n_iters < 1) return fail(CUDE_ERR_ARG, "n_iters must be >= 1");
+    if (!c->have_pop || !c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "population / parameters not set");
+    if ((rc = ensure_trace(c, n_iters))) return rc;
+    HIP_TRY(hipMemsetAsync(c->adam_state.p + 3, 0, sizeof(double), c->stream));     // trace position = 0
+    const bool use_graph = (c->comm == nullptr) && !c->timing && getenv("CUDE_NO_GRAPH") == nullptr;
+    if (use_graph && !c->graph_exec) {
+        c->capturing = true;
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rc = run_ensemble(c, true, nullptr);
+            if (!rc) rc = enqueue_adam(c);
+            hipError_t e2 = hipStreamEndCapture(c->stream, &c->graph);
+            if (!rc && e2 == hipSuccess) e2 = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
+            if (rc || e2 != hipSuccess) { drop_graph(c); c->capturing = false; if (rc) return rc; return fail(CUDE_ERR_HIP, hipGetErrorString(e2)); }
+        } else {
+            c->capturing = false;
+            return fail(CUDE_ERR_HIP, hipGetErrorString(e));
+        }
+        c->capturing = false;
+    }
+    for (int k = 0; k < n_iters; k++) {
+        if (use_graph) {
+            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+        } else {
+            if ((rc = run_ensemble(c, true, nullptr))) return rc;
+            if ((rc = enqueue_adam(c))) return rc;
+        }
+    }
+    c->adam_t += n_iters;
+    std::vector<double> tr((size_t)n_iters * 2);
+    HIP_TRY(hipMemcpyAsync(tr.data(), c->adam_trace.p, tr.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_failed = (int64_t)std::llround(tr[(size_t)(n_iters - 1) * 2 + 1]);
+    if (losses)
+        for (int k = 0; k < n_iters; k++)
+            losses[k] = (tr[2 * k + 1] > 0.0 || !std::isfinite(tr[2 * k])) ? std::numeric_limits<double>::infinity()
+                                                                         : tr[2 * k] / c->n_global;
     return CUDE_OK;
 }
 
@@ -787,16 +868,8 @@ int32_t cude_adam_apply(cude_ctx* c, const double* reduced, double* loss) {
     if (c->cfg.lambda != 0.0)
         HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream));
     c->adam_t += 1;
-    cude::AdamArgs a{};
-    a.N = c->N; a.P = P;
-    a.cond = c->cond.p; a.m_cond = c->m_cond.p; a.v_cond = c->v_cond.p; a.g_cond = c->g_cond.p;
-    a.nn = c->nn.p; a.m_nn = c->m_nn.p; a.v_nn = c->v_nn.p; a.g_nn = c->g_nn.p;
-    a.lr = c->lr; a.b1 = c->b1; a.b2 = c->b2; a.eps = c->eps;
-    a.c1 = 1.0 - std::pow(c->b1, (double)c->adam_t);
-    a.c2 = 1.0 - std::pow(c->b2, (double)c->adam_t);
     if ((rc = finish_loss(c, loss, nullptr))) return rc;   // also synchronises: `reduced` may be freed after return
-    HIP_TRY(cude::launch_adam(a, c->stream));
-    return CUDE_OK;
+    return enqueue_adam(c);
 }
 
 int32_t cude_synchronize(cude_ctx* c) {

@@ -150,6 +150,10 @@ hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s) {
 __global__ void adam_kernel(AdamArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.g_nn[a.P + 1] > 0.0) return;
+    // bias corrections of step t = (steps done) + 1 from the device-resident running powers b^(t-1), so that a
+    // captured hipGraph of the iteration needs no per-iteration kernel arguments
+    a.c1 = 1.0 - a.state[0] * a.b1;
+    a.c2 = 1.0 - a.state[1] * a.b2;
     double *x, *m, *v;
     double g;
     if (idx < a.N) {
@@ -167,10 +171,30 @@ __global__ void adam_kernel(AdamArgs a) {
     *x -= a.lr * (mm / a.c1) / (sqrt(vv / a.c2) + a.eps);
 }
 
+// After the update: advance the running powers / step counter (unless the step was skipped because a subject
+// failed) and append [sum loss, n_failed] of this iterate to the loss trace.  state = {b1^t, b2^t, t, trace pos}.
+__global__ void adam_advance_kernel(double* state, double b1, double b2, const double* g_tail, double* trace,
+                                    int64_t cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!(g_tail[1] > 0.0)) {
+        state[0] *= b1;
+        state[1] *= b2;
+        state[2] += 1.0;
+    }
+    const int64_t pos = (int64_t)state[3];
+    if (pos < cap) {
+        trace[2 * pos] = g_tail[0];
+        trace[2 * pos + 1] = g_tail[1];
+    }
+    state[3] = (double)(pos + 1);
+}
+
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
     const int bs = 256;
     const int64_t n = a.N + a.P;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, a);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, s, a.state, a.b1, a.b2, a.g_nn + a.P, a.trace,
+                       a.trace_cap);
     return hipGetLastError();
 }
 

@@ -200,6 +200,13 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
 }
 
 // ---------------------------------------------------------------------------------- scan + residuals
+__device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, cptr_t obs_w, ciptr_t obs_step,
+                                         const double* s_res, int lane, int n, int& oi, double& lam1, double& lam2,
+                                         double& kap1, double& kap2, double (&w)[5]);
+
+// Stitches the chunks (affine maps), forms residuals / SSE, and -- for the gradient -- runs the network-free
+// stage-adjoint recursion ONCE per subject, storing the 5 network weights of every step (wts[5S][N]) so that
+// the reverse lanes of all chunks only have to read theirs.
 template <int P>
 __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     extern __shared__ double smem[];
@@ -212,7 +219,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     ciptr_t obs_step = as_const(b.obs_step);
     ciptr_t cs = as_const(a.chunk_start);
     const int T = b.T;
-    const double k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
+    double* s_res = smem + kRedRows * kBlock;   // [T][kBlock]
+    const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
     double y1 = c0, y2 = (k2 / k1) * c0, y3 = 0.0, sse = 0.0;
     int oi = 0;
     for (int c = 0; c < a.L; c++) {
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
             const double hy = fma(a.hom_obs[((int64_t)oi * 2) * N + i], y1, a.hom_obs[((int64_t)oi * 2 + 1) * N + i] * y2);
             const double r = (f[(int64_t)(3 + oi) * N] + hy) - b.obs[(int64_t)oi * N + i];
             sse = fma(r, r, sse);
-            if (active) a.res[(int64_t)oi * N + i] = r;
+            s_res[oi * kBlock + lane] = r;
             oi++;
         }
         const double* M = a.hom_M + (int64_t)c * 4 * N + i;
@@ -235,6 +243,21 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     if (active) {
         if (b.sse != nullptr) b.sse[i] = sse;
         if (b.auc != nullptr) b.auc[i] = y3;
+    }
+    if (a.wts != nullptr) {
+        const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};
+        cptr_t obs_w = as_const(b.obs_w);
+        double lam1 = 0.0, lam2 = 0.0, kap1 = 0.0, kap2 = 0.0, w[5];
+        const double gscale = 2.0 * b.inv_n;
+        oi = T - 1;
+#pragma unroll 1
+        for (int n = b.S - 1; n >= 0; n--) {
+            adj_step(kin, b.h, gscale, obs_w, obs_step, s_res, lane, n, oi, lam1, lam2, kap1, kap2, w);
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) a.wts[(int64_t)(5 * n + j) * N + i] = w[j];
+            }
+        }
     }
     const double v2[2] = {active ? sse : 0.0, (active && failed) ? 1.0 : 0.0};
     block_reduce_store<2>(v2, smem, b.partials + (int64_t)blockIdx.x * (P + 2) + P, lane);
@@ -300,9 +323,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     constexpr int P = Net::P;
     constexpr int NC = NIN - 1;
     extern __shared__ double smem[];
-    double* s_q = smem;                         // [5][kBlock] adjoint weights of the current step
-    double* s_red = smem + 5 * kBlock;          // [kRedRows][kBlock]
-    double* s_res = s_red + kRedRows * kBlock;  // [T][kBlock]
+    double* s_red = smem;                       // [kRedRows][kBlock]
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
@@ -312,31 +333,15 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     const int c_idx = blockIdx.y;
     cptr_t p = as_const(b.nn);
     cptr_t phi = as_const(b.phi);
-    cptr_t obs_w = as_const(b.obs_w);
     ciptr_t seg = as_const(b.seg);
-    ciptr_t obs_step = as_const(b.obs_step);
     ciptr_t cs = as_const(a.chunk_start);
-    const int S = b.S, T = b.T;
-    const double h = b.h;
     const int n0 = cs[c_idx], n1 = cs[c_idx + 1];
 
-    const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
-    const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};
     double cst[NC];
     cst[0] = exp(b.cond[i]);
     if (NC > 1) cst[1] = b.age[i];
     double c[W];
     Net::first_layer_offset(p, cst, c);
-    for (int t = 0; t < T; t++) s_res[t * kBlock + lane] = a.res[(int64_t)t * N + i];
-
-    double lam1 = 0.0, lam2 = 0.0, kap1 = 0.0, kap2 = 0.0;
-    const double gscale = 2.0 * b.inv_n;
-    int oi = T - 1;
-    double w[5];
-    // later chunks' steps: adjoint algebra only (their network sweeps belong to other lanes)
-#pragma unroll 1
-    for (int n = S - 1; n >= n1; n--) adj_step(kin, h, gscale, obs_w, obs_step, s_res, lane, n, oi, lam1, lam2, kap1, kap2, w);
-
     double acc[Net::NACC];
 #pragma unroll
     for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
@@ -344,17 +349,10 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     double wtot = 0.0;
     int cur_seg = -1;
     double g_lo = 0.0, g_d = 0.0;
-    int n = n1 - 1, s = 4;
     // own stage times in reverse order; e = 5 n0 - 1 stands for the baseline with weight -sum(own w)
 #pragma unroll 1
     for (int e = 5 * n1 - 1; e >= 5 * n0 - 1; e--) {
         const bool own = e >= 5 * n0;
-        if (own && s == 4) {
-            adj_step(kin, h, gscale, obs_w, obs_step, s_res, lane, n, oi, lam1, lam2, kap1, kap2, w);
-#pragma unroll
-            for (int j = 0; j < 5; j++) s_q[j * kBlock + lane] = w[j];
-            n--;
-        }
         double xv = 0.0, wv;
         if (own) {
             const int sg = seg[e];
@@ -364,9 +362,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
                 g_d = b.dG[(int64_t)(sg + 1) * N + i] - g_lo;
             }
             xv = fma(phi[e], g_d, g_lo);
-            wv = s_q[s * kBlock + lane];
+            wv = a.wts[(int64_t)e * N + i];
             wtot += wv;
-            s = (s == 0) ? 4 : s - 1;
         } else {
             wv = -wtot;
         }
@@ -405,10 +402,12 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     const size_t lds_f = sizeof(double) * 5 * kBlock;
     if (n_state == 3) hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 3>), grid2, dim3(kBlock), lds_f, s, a);
     else hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 2>), grid2, dim3(kBlock), lds_f, s, a);
-    hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks), dim3(kBlock), sizeof(double) * kRedRows * kBlock,
-                       s, a);
+    Cpep2Args as = a;
+    if (!grad) as.wts = nullptr;
+    hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks), dim3(kBlock),
+                       sizeof(double) * (size_t)(kRedRows + a.base.T) * kBlock, s, as);
     if (!grad) return hipGetLastError();
-    const size_t lds_r = sizeof(double) * (size_t)(5 + kRedRows + a.base.T) * kBlock;
+    const size_t lds_r = sizeof(double) * (size_t)kRedRows * kBlock;
     hipLaunchKernelGGL((cpep2_rev_kernel<NIN, W, D>), grid2, dim3(kBlock), lds_r, s, a);
     const int bs = 256;
     hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N + bs - 1) / bs)), dim3(bs), 0, s,

@@ -51,7 +51,7 @@ struct Cpep2Args {
     double* hom_M;               // [L][4][N]   chunk transfer matrix d y_out / d y_in (static per population)
     double* hom_obs;             // [T][2][N]   d y1(tau) / d y_in(chunk of tau)            (static)
     double* fsum;                // [L][3+T][N] forced chunk response: v1, v2, quadrature, obs parts
-    double* res;                 // [T][N]      residuals
+    double* wts;                 // [5S][N]     adjoint weight of every network evaluation (gradient only)
     double* g_cond_part;         // [L][N]
     double* partials2;           // [L][nblocks][P]
 };
@@ -99,7 +99,10 @@ struct AdamArgs {
     int64_t N; int P;
     double* cond; double* m_cond; double* v_cond; const double* g_cond;
     double* nn; double* m_nn; double* v_nn; const double* g_nn;   // g_nn[P+1] = n_failed
-    double lr, b1, b2, eps, c1, c2;   // c1 = 1-b1^t, c2 = 1-b2^t
+    double lr, b1, b2, eps, c1, c2;   // c1 = 1-b1^t, c2 = 1-b2^t (filled on the device from `state`)
+    double* state;                    // device: {b1^(t-1), b2^(t-1), steps done, trace position}
+    double* trace;                    // device: [trace_cap][2] = (sum loss, n_failed) per iteration
+    int64_t trace_cap;
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 // SAEM E-step (Metropolis-Hastings) helper kernels

@@ -234,13 +234,17 @@ def initial_parameters(*args, rng=None):
 def _adam_then_lbfgs(eng, nn0, cond0, adam_iters, lbfgs_iters, lr, callback=None):
     eng.set_params(nn0, cond0)
     eng.adam_init(lr)
-    last = np.inf
-    for _ in range(adam_iters):
-        last = eng.adam_step()
-        if callback is not None and callback(None, last):
-            break
-        if not np.isfinite(last):
+    if callback is None and adam_iters > 0:
+        trace = eng.adam_run(adam_iters)          # all iterations queued as one replayed hipGraph
+        if not np.all(np.isfinite(trace)):
             raise FloatingPointError("solver failure (non-finite loss) during Adam")
+    else:
+        for _ in range(adam_iters):
+            last = eng.adam_step()
+            if callback(None, last):
+                break
+            if not np.isfinite(last):
+                raise FloatingPointError("solver failure (non-finite loss) during Adam")
     nn, cond = eng.get_params()
     P = nn.size
 

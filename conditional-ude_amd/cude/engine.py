@@ -167,6 +167,13 @@ class Engine:
         check(self._lib.cude_adam_step(self._h, None))
         return None
 
+    def adam_run(self, n_iters):
+        """n_iters fused optimiser iterations with one synchronisation (hipGraph replay); returns the loss
+        before each update."""
+        losses = np.empty(int(n_iters))
+        check(self._lib.cude_adam_run(self._h, int(n_iters), _ptr(losses)))
+        return losses
+
     # -- bring-your-own collective
     def set_global_subjects(self, n_global, scale=None):
         sc = None if scale is None else _f64(scale)

@@ -131,6 +131,10 @@ int32_t cude_adam_init(cude_ctx* ctx, double lr, double beta1, double beta2, dou
  * synchronise (use cude_synchronize). The reported loss is the one BEFORE the update. */
 int32_t cude_adam_step(cude_ctx* ctx, double* loss);
 int32_t cude_synchronize(cude_ctx* ctx);
+/* n_iters optimiser iterations in one call (the `maxiters` loop of Optimization.solve(prob, Adam, maxiters),
+ * src/parameter-estimation.jl:176): one iteration is captured into a hipGraph and replayed without host round
+ * trips; losses[n_iters] (optional) receives the loss BEFORE each update, read back once at the end. */
+int32_t cude_adam_run(cude_ctx* ctx, int32_t n_iters, double* losses);
 
 /* --- bring-your-own collective (MPI.jl, gloo, ...) instead of the built-in RCCL path.
  * cude_loss_grad_partial returns this rank's un-reduced [g_nn(P); sum_i sse_i; n_failed] (gradient entries
