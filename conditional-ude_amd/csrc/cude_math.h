@@ -46,7 +46,18 @@ CUDE_HD double m_rcp(double d) {
 
 // exp(2 x) for x in [-354, 354]
 CUDE_HD double m_exp2x(double x) {
+#ifdef CUDE_MAGIC_ROUND
+    // round-to-nearest through the 1.5*2^52 trick: the integer lands in the low mantissa bits of t, so the
+    // fp64-rate v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64 become one subtraction and one 32-bit shift-add
+    const double t = fma(x, 2.88539008177792681472, 6755399441055744.0);
+    const double n = t - 6755399441055744.0;
+    long long tb;
+    __builtin_memcpy(&tb, &t, 8);
+    const int ni = (int)(unsigned)tb;
+#else
     const double n = rint(x * 2.88539008177792681472);                  // 2*log2(e)
+    const int ni = (int)n;
+#endif
     double s = fma(n, -3.46573590184561908245e-01, x);                   // ln2/2 hi
     s = fma(n, -9.54107464635293850010e-11, s);                          // ln2/2 lo ; |s| <= ln2/4
     double p = 2.82893898152419560454e-04;
@@ -60,7 +71,17 @@ CUDE_HD double m_exp2x(double x) {
     p = fma(p, s, 2.00000000000000222045e+00);
     p = fma(p, s, 2.00000000000001332268e+00);
     p = fma(p, s, 1.0);
-    return ldexp(p, (int)n);
+#ifdef CUDE_MAGIC_ROUND
+    // p in [0.70, 1.42] and |n| <= 1022 for the argument range used (|x| <= 354): adding n to the exponent
+    // field cannot leave the normal range
+    long long pb;
+    __builtin_memcpy(&pb, &p, 8);
+    pb += (long long)ni << 52;
+    __builtin_memcpy(&p, &pb, 8);
+    return p;
+#else
+    return ldexp(p, ni);
+#endif
 }
 
 CUDE_HD double m_exp(double y) { return m_exp2x(0.5 * y); }
