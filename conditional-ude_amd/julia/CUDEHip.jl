@@ -58,3 +58,33 @@ function adam!(c::Ctx, θ0, η, iters; callback = (l)->false)
     check(ccall((:cude_get_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond)); (nn, cond, l[])
 end
 end
+
+# --- additional entry points (same module; appended for readability) -----------------------------------------
+module CUDEHipExtras
+import ..CUDEHip: LIB, Ctx, check
+
+# screening loop of `train` (src/parameter-estimation.jl:362-366): K candidate parameter sets in one launch.
+# nn_sets is P×K, cond_sets is N×K (Julia column-major = the row-major [K][P] / [K][N] the ABI expects).
+function multistart_forward(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{Float64})
+    K = size(nn_sets, 2); losses = Vector{Float64}(undef, K)
+    GC.@preserve nn_sets cond_sets losses check(ccall((:cude_multistart_forward, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), c.h, K, nn_sets, cond_sets, losses))
+    losses
+end
+
+# `maxiters` Adam iterations in one call (hipGraph replay); returns the loss trace
+function adam_run!(c::Ctx, iters::Integer)
+    losses = Vector{Float64}(undef, iters)
+    check(ccall((:cude_adam_run, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}), c.h, iters, losses)); losses
+end
+
+# E-step of SAEM (src/saem.jl:177-186): n_mc Metropolis steps for every subject; draws are N×n_mc matrices
+function mh_estep!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, σ, prior_η, Ω, proposal_std;
+                   temperature = 1.0, γ = 1.0)
+    N, n_mc = size(normals); accepted = zeros(Int64, N)
+    GC.@preserve normals uniforms accepted check(ccall((:cude_mh_estep, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64, Float64, Float64, Ptr{Int64}),
+        c.h, n_mc, normals, uniforms, σ, prior_η, Ω, proposal_std, temperature, γ, accepted))
+    accepted
+end
+end
