@@ -571,7 +571,7 @@ int32_t cude_set_population_supp(cude_ctx* c, int64_t N, int32_t n_obs, const do
     c->n_global = ssum[3];
     for (int s = 0; s < 3; s++) c->scale[s] = ssum[s] / ssum[3];
     HIP_TRY(c->data.resize(d.size()));
-    HIP_TRY(c->ckpt.resize((size_t)c->cfg.n_steps * 3 * N));
+    HIP_TRY(c->ckpt.resize((size_t)(6 * c->cfg.n_steps + 1) * 3 * N));   // every stage input
     HIP_TRY(hipMemcpyAsync(c->data.p, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if ((rc = alloc_common(c))) return rc;
     if ((rc = upload_tables(c, false))) return rc;

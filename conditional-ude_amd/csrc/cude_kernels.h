@@ -71,7 +71,7 @@ struct SuppArgs {
     int32_t T, S;
     double h, inv_n;
     double iscale2[3];       // 1/scale_s^2
-    double* ckpt;            // [S][3][N] step-state checkpoints (grad)
+    double* ckpt;            // [6S+1][3][N] stage inputs (linearisation points of the reverse sweep)
     double* sse;             // [N] or nullptr (already divided by scale^2)
     double* traj;            // [3 x T x N] column-major or nullptr
     double* g_cond;          // [N]
