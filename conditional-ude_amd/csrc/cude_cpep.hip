@@ -32,15 +32,6 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     double* s_res = s_red + kRedRows * kBlock;  // [T][kBlock] residuals kept for the reverse sweep
 
     const int lane = threadIdx.x;
-#ifdef CUDE_STAGGER
-    // Two waves that share a SIMD run the same program; when they start together they hit the scalar-load
-    // waits and SALU stretches at the same time.  Delay the odd wave slots by a fraction of one evaluation so
-    // that the two instruction streams interleave (MI355X_MICROARCH.md "two waves per SIMD", item 9).
-    if (__builtin_amdgcn_s_getreg(0x1804) & 1) {      // HW_REG_HW_ID.wave_id bit 0
-#pragma unroll
-        for (int k = 0; k < CUDE_STAGGER; k++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
     const bool active = gid < a.N;
     const int64_t i = active ? gid : a.N - 1;
