@@ -34,7 +34,8 @@ def test_population_loss_and_gradient_on_ohashi_data():
     args = (models, g["timepoints"], g["cpeptide"])
     val = api.loss(theta, args)
     ref = co.cpep(g["timepoints"], g["glucose"], g["cpeptide"], g["ages"], g["t2dm"], (2, 4, 2), theta.neural,
-                  theta.conditional[:, 0], 30, 2)
+                  theta.conditional[:, 0], api.default_steps(g["timepoints"]), 2)
+    assert api.default_steps(g["timepoints"]) == 32          # 8 steps per 30-min interval: knots on step boundaries
     assert abs(val - ref["loss"]) < 1e-10 * ref["loss"]
     val2, grad = api.loss_and_gradient(theta, args)
     assert abs(val2 - ref["loss"]) < 1e-10 * ref["loss"]
