@@ -13,10 +13,11 @@
 //     M (and the response H_tau of every observation to y_in) depend only on the subject's kinetics and
 //     are precomputed once per population (cpep2_homog_kernel), and v / the forced observation parts
 //     come from running the chunk from a ZERO entry state with the network forcing (cpep2_fwd_kernel);
-//   * a tiny per-subject scan stitches the chunks and forms the residuals (cpep2_scan_kernel);
-//   * the adjoint recursion needs no network evaluation and no forward state (J_f = A), so the lane of
-//     chunk c replays the (cheap) stage-adjoint algebra from the last step down to its own chunk and
-//     evaluates the network reverse sweeps only for its own stage times (cpep2_rev_kernel).
+//   * a per-subject scan stitches the chunks, forms the residuals and -- because the adjoint recursion
+//     needs no network evaluation and no forward state (J_f = A) -- runs the whole stage-adjoint algebra
+//     once, storing the weight of every network evaluation (cpep2_scan_kernel);
+//   * the reverse lane of chunk c evaluates the network reverse sweeps of its own stage times with those
+//     weights and accumulates its share of the gradient (cpep2_rev_kernel).
 #include "cude_device.h"
 #include "cude_kernels.h"
 
