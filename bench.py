@@ -130,18 +130,29 @@ def main():
     eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
     transport = "rccl"          # all-reduce of the P+2 doubles inside libcude_hip.so (RCCL on the context's stream)
     if world > 1:
+        # Every rank issues the same sequence of collectives whatever fails locally: first agree that librccl
+        # is loadable everywhere (each rank draws an id; only rank 0's is used), then build the communicator.
         ok = torch.ones(1, device="cuda")
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.tensor(list(Engine.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            eng.comm_init(world, rank, bytes(uid.cpu().tolist()))
-        except Exception as exc:      # e.g. librccl not loadable: fall back to the host-collective transport
-            print(f"[rank {rank}] built-in RCCL communicator unavailable ({exc}); using torch.distributed",
-                  file=sys.stderr)
+        my_id = bytes(128)
+        if os.environ.get("CUDE_BENCH_TRANSPORT", "rccl") != "rccl":
             ok.zero_()
+        else:
+            try:
+                my_id = Engine.comm_unique_id()
+            except Exception as exc:  # e.g. librccl not loadable: fall back to the host-collective transport
+                print(f"[rank {rank}] built-in RCCL communicator unavailable ({exc}); using torch.distributed",
+                      file=sys.stderr)
+                ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() != 0:
+            uid = torch.tensor(list(my_id), dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            try:
+                eng.comm_init(world, rank, bytes(uid.cpu().tolist()))
+            except Exception as exc:
+                print(f"[rank {rank}] cude_comm_init failed ({exc}); using torch.distributed", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
             transport = "host"  # cude_loss_grad_partial -> dist.all_reduce (RCCL via PyTorch) -> cude_adam_apply
             eng.close()
