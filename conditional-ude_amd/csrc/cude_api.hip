@@ -198,6 +198,9 @@ struct cude_ctx {
 
 namespace {
 
+// both c-peptide models share the population layout, solver tables and the ensemble kernel
+bool is_cpep(const cude_ctx* c) { return c->cfg.model == CUDE_MODEL_CPEP || c->cfg.model == CUDE_MODEL_CPEP_SYM; }
+
 int32_t bind(cude_ctx* c) {
     if (!c) return fail(CUDE_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -357,8 +360,9 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         c->ev_used++;
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    if (c->cfg.model == CUDE_MODEL_CPEP) {
+    if (is_cpep(c)) {
         cude::CpepArgs a{};
+        a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
         a.N = c->N;
         a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
         a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
@@ -387,7 +391,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
     if (sse_ov) return CUDE_OK;
     const int P = c->P;
-    if (grad && c->cfg.model == CUDE_MODEL_CPEP && c->chunks > 1) {
+    if (grad && is_cpep(c) && c->chunks > 1) {
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream));
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
     } else if (grad) {
@@ -440,6 +444,7 @@ int32_t cude_device_count(int32_t* count) {
 }
 
 int32_t cude_n_params(int32_t nn_in, int32_t nn_width, int32_t nn_depth) {
+    if (nn_width == 0 && nn_depth == 0) return 1;   // analytic production model: [p0]
     if (nn_in < 1 || nn_width < 1 || nn_depth < 1) return fail(CUDE_ERR_ARG, "bad network shape");
     cude::NetShape n{nn_in, nn_width, nn_depth};
     return n.n_params();
@@ -449,13 +454,21 @@ int32_t cude_create(const cude_config* cfg, cude_ctx** out) {
     if (!cfg || !out) return fail(CUDE_ERR_ARG, "null argument");
     *out = nullptr;
     if (cfg->n_steps < 1 || cfg->n_steps > 100000) return fail(CUDE_ERR_ARG, "n_steps out of range");
-    if (cfg->nn_in < 1 || cfg->nn_width < 1 || cfg->nn_depth < 1) return fail(CUDE_ERR_ARG, "bad network shape");
     cude::NetShape net{cfg->nn_in, cfg->nn_width, cfg->nn_depth};
-    if (cfg->model == CUDE_MODEL_CPEP) {
-        if (!cude::cpep_shape_supported(net, cfg->n_state))
+    if (cfg->model == CUDE_MODEL_CPEP_SYM) {
+        if (cfg->nn_width != 0 || cfg->nn_depth != 0)
+            return fail(CUDE_ERR_ARG, "the symbolic model has no network: nn_width and nn_depth must be 0");
+        if (cfg->cond_space != CUDE_COND_LOG && cfg->cond_space != CUDE_COND_RAW)
+            return fail(CUDE_ERR_ARG, "cond_space must be CUDE_COND_LOG or CUDE_COND_RAW");
+        if (cfg->n_state != 2 && cfg->n_state != 3) return fail(CUDE_ERR_UNSUPPORTED, "n_state must be 2 or 3");
+        net = cude::NetShape{1, 0, 0};
+    } else if (cfg->model == CUDE_MODEL_CPEP || cfg->model == CUDE_MODEL_SUPP) {
+        if (cfg->nn_in < 1 || cfg->nn_width < 1 || cfg->nn_depth < 1) return fail(CUDE_ERR_ARG, "bad network shape");
+        if (cfg->cond_space != CUDE_COND_LOG)
+            return fail(CUDE_ERR_ARG, "cond_space must be CUDE_COND_LOG for the network models");
+        if (cfg->model == CUDE_MODEL_CPEP && !cude::cpep_shape_supported(net, cfg->n_state))
             return fail(CUDE_ERR_UNSUPPORTED, "c-peptide kernel not compiled for this (nn_in,width,depth,n_state)");
-    } else if (cfg->model == CUDE_MODEL_SUPP) {
-        if (cfg->n_state != 3 || !cude::supp_shape_supported(net))
+        if (cfg->model == CUDE_MODEL_SUPP && (cfg->n_state != 3 || !cude::supp_shape_supported(net)))
             return fail(CUDE_ERR_UNSUPPORTED, "suppression kernel not compiled for this (width,depth)");
     } else {
         return fail(CUDE_ERR_ARG, "unknown model id");
@@ -500,7 +513,7 @@ int32_t cude_set_population_cpep(cude_ctx* c, int64_t N, int32_t n_obs, const do
                                  const double* age, const uint8_t* t2dm) {
     int32_t rc = bind(c);
     if (rc) return rc;
-    if (c->cfg.model != CUDE_MODEL_CPEP) return fail(CUDE_ERR_STATE, "context is not a c-peptide model");
+    if (!is_cpep(c)) return fail(CUDE_ERR_STATE, "context is not a c-peptide model");
     if (N < 1 || !timepoints || !glucose || !cpeptide || !age || !t2dm) return fail(CUDE_ERR_ARG, "null/empty input");
     if ((rc = check_times(n_obs, timepoints))) return rc;
     const int T = n_obs;
@@ -749,8 +762,9 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
         const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
         HIP_TRY(hipMemcpyAsync(d_nn.p, nn_sets + k0 * P, kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_cond.p, cond_sets + k0 * N, kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (c->cfg.model == CUDE_MODEL_CPEP) {
+        if (is_cpep(c)) {
             cude::CpepArgs a{};
+            a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
             a.N = N;
             a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
             a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;

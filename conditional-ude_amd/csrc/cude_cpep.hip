@@ -21,11 +21,11 @@
 
 namespace cude {
 
-template <int NIN, int W, int D, int NS, bool GRAD>
+// Net: the production term -- Mlp<NIN, W, D, 1> (conditional UDE) or MmProd<RAW> (symbolic model).
+template <class Net, int NS, bool GRAD>
 __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
-    using Net = Mlp<NIN, W, D, 1>;
     constexpr int P = Net::P;
-    constexpr int NC = NIN - 1;
+    constexpr int NC = Net::NC;
     extern __shared__ double smem[];
     double* s_q = smem;                         // [5][kBlock] stage forcings (fwd) / adjoint weights (rev)
     double* s_red = smem + 5 * kBlock;          // [kRedRows][kBlock]
@@ -49,9 +49,9 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     const double k0 = a.k0[i], k1 = a.k1[i], k2 = a.k2[i], c0 = a.c0[i];
     const double a11 = -(k0 + k2), a12 = k1, a21 = k2, a22 = -k1, f0 = k0 * c0;
     double cst[NC];
-    cst[0] = exp(a.cond[set * a.set_stride_cond + i]);
+    cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
     if (NC > 1) cst[1] = a.age[i];
-    double c[W];
+    double c[Net::NCST];
     Net::first_layer_offset(p, cst, c);
 
     // ------------------------------------------------------------------ forward
@@ -271,19 +271,19 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ dispatch
-template <int NIN, int W, int D, int NS, bool GRAD>
+template <class Net, int NS, bool GRAD>
 static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(5 + kRedRows + (GRAD ? a.T : 0)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
-    hipLaunchKernelGGL((cpep_kernel<NIN, W, D, NS, GRAD>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((cpep_kernel<Net, NS, GRAD>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NIN, int W, int D>
+template <class Net>
 static hipError_t launch_shape(int n_state, bool grad, const CpepArgs& a, hipStream_t s) {
-    if (n_state == 2) return grad ? launch_one<NIN, W, D, 2, true>(a, s) : launch_one<NIN, W, D, 2, false>(a, s);
-    if (n_state == 3) return grad ? launch_one<NIN, W, D, 3, true>(a, s) : launch_one<NIN, W, D, 3, false>(a, s);
+    if (n_state == 2) return grad ? launch_one<Net, 2, true>(a, s) : launch_one<Net, 2, false>(a, s);
+    if (n_state == 3) return grad ? launch_one<Net, 3, true>(a, s) : launch_one<Net, 3, false>(a, s);
     return hipErrorInvalidValue;
 }
 
@@ -291,6 +291,7 @@ static hipError_t launch_shape(int n_state, bool grad, const CpepArgs& a, hipStr
 
 bool cpep_shape_supported(const NetShape& net, int n_state) {
     if (n_state != 2 && n_state != 3) return false;
+    if (net.symbolic()) return true;
 #define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return true;
     CUDE_CPEP_SHAPES(X)
 #undef X
@@ -298,7 +299,10 @@ bool cpep_shape_supported(const NetShape& net, int n_state) {
 }
 
 hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepArgs& a, hipStream_t s) {
-#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return launch_shape<NIN, W, D>(n_state, grad, a, s);
+    if (net.symbolic())
+        return a.cond_raw ? launch_shape<MmProd<true>>(n_state, grad, a, s) : launch_shape<MmProd<false>>(n_state, grad, a, s);
+#define X(NIN, W, D) \
+    if (net.nin == NIN && net.width == W && net.depth == D) return launch_shape<Mlp<NIN, W, D, 1>>(n_state, grad, a, s);
     CUDE_CPEP_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -104,6 +104,9 @@ __device__ __forceinline__ SCol<W> ld_col(cptr_t p, int off) {
 template <int NIN, int W, int D, int NV>
 struct Mlp {
     static constexpr int NC = NIN - NV;
+    static constexpr int NCST = W;                  // per-subject constants kept in registers (first-layer offsets)
+    // the conditional parameter enters the network as exp(beta) (src/c-peptide-models.jl:90)
+    __device__ static __forceinline__ double cond_input(double raw) { return exp(raw); }
     static constexpr int L1 = W * NIN + W;          // first layer params
     static constexpr int LH = W * W + W;            // each further hidden layer
     static constexpr int OUT = L1 + (D - 1) * LH;   // output layer offset
@@ -290,6 +293,44 @@ struct Mlp {
             s *= cst[0];
         }
         *dcond = s;
+    }
+};
+
+// ------------------------------------------------------------------------------------ analytic production
+// Drop-in for Mlp<2, W, D, 1> in the c-peptide kernel: the production term found by symbolic regression,
+//   production(dG, k) = dG >= 0 ? p0*dG/(dG + k) : 0,   p0 = 1.78 in the reference
+// (c-peptide/03-symreg.jl:37-40, evaluated through analytic_production src/c-peptide-models.jl:68-75; the same
+// term in src/saem-symreg.jl:23-29).  One shared parameter p0 and the per-subject k, which is the conditional
+// parameter itself (RAW, 03-symreg.jl:99-106) or its exponential (saem-symreg.jl:57-59 km_pop*exp(eta)).
+template <bool RAW>
+struct MmProd {
+    static constexpr int NC = 1, NCST = 1, P = 1;
+    static constexpr int NACC = 2;                  // [d/dp0, d/dk]
+    __device__ static __forceinline__ double cond_input(double raw) { return RAW ? raw : exp(raw); }
+    __device__ static __forceinline__ void first_layer_offset(cptr_t, const double (&cst)[1], double (&c)[1]) {
+        c[0] = cst[0];
+    }
+    __device__ static __forceinline__ double param_check(cptr_t p) { return fma(p[0], 0.0, 0.0); }
+    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[1], const double (&x)[1]) {
+        const double v = (p[0] * x[0]) / (x[0] + c[0]);
+        return x[0] >= 0.0 ? v : 0.0;
+    }
+    template <bool WANT_DX>
+    __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[1], const double (&x)[1],
+                                                       double wgt, double (&acc)[NACC], double (&dx)[1]) {
+        const double r = 1.0 / (x[0] + c[0]);
+        const double f = x[0] * r;                  // d/dp0
+        const bool pos = x[0] >= 0.0;
+        const double p0 = p[0];
+        acc[0] += pos ? wgt * f : 0.0;
+        acc[1] += pos ? -(wgt * p0) * f * r : 0.0;  // d/dk
+        if (WANT_DX) dx[0] += pos ? (wgt * p0) * c[0] * r * r : 0.0;
+        return pos ? p0 * f : 0.0;
+    }
+    __device__ static __forceinline__ void expand(cptr_t, const double (&acc)[NACC], const double (&cst)[1],
+                                                  double (&g)[P], double* dcond) {
+        g[0] = acc[0];
+        *dcond = RAW ? acc[1] : acc[1] * cst[0];
     }
 };
 

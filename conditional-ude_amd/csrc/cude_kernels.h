@@ -10,7 +10,9 @@ constexpr int kMaxObs = 32;
 
 struct NetShape {
     int nin, width, depth;
+    bool symbolic() const { return width == 0; }   // analytic production p0*dG/(dG+k): P = 1
     int n_params() const {
+        if (symbolic()) return 1;
         int p = 0, fan = nin;
         for (int l = 0; l < depth; l++) { p += width * fan + width; fan = width; }
         return p + fan + 1;
@@ -41,6 +43,7 @@ struct CpepArgs {
     // cond + k*set_stride_cond (and writes sse + k*set_stride_cond); 0/0/0 for the single-set path
     int32_t n_sets;
     int64_t set_stride_nn, set_stride_cond;
+    int32_t cond_raw;        // symbolic model only: 1 = k is the conditional itself, 0 = k = exp(conditional)
 };
 
 // chunked loss+gradient path (cude_cpep2.hip): the S steps of every subject are split into L chunks

@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcude_hip.so")
 
 MODEL_CPEP = 0
 MODEL_SUPP = 1
+MODEL_CPEP_SYM = 2
+COND_LOG = 0
+COND_RAW = 1
 UNIQUE_ID_BYTES = 128
 
 
@@ -24,7 +27,7 @@ class CudeError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("model", C.c_int32), ("n_state", C.c_int32), ("nn_in", C.c_int32),
                 ("nn_width", C.c_int32), ("nn_depth", C.c_int32), ("n_steps", C.c_int32),
-                ("device", C.c_int32), ("reserved", C.c_int32), ("lambda_", C.c_double)]
+                ("device", C.c_int32), ("cond_space", C.c_int32), ("lambda_", C.c_double)]
 
 
 _dp = C.POINTER(C.c_double)

@@ -16,6 +16,9 @@ Reference items mirrored (paths relative to the reference repo):
   individual_log_likelihood / mcmc_step / total_nll / update_population_parameters / SAEM
                                            src/saem.jl:55-66,86-131,134-237
   likelihood_profile                       src/likelihood-profiles.jl:4-17
+  CPeptideODEModel / production (symbolic) src/c-peptide-models.jl:68-75,118-142; c-peptide/03-symreg.jl:37-40
+  train_symbolic (per-subject k, sigma)    c-peptide/03-symreg.jl:94-106
+  SAEM_symbolic                            src/saem-symreg.jl:31-66,86-131,134-229
 Differences that are deliberate and documented in DESIGN.md: the ODE is solved with FIXED-step Tsit5
 (`n_steps`; default for the c-peptide model: 8 steps per observation interval, see default_steps; 30 for the
 suppression model) instead of the adaptive default; gradients are a discrete adjoint instead of
@@ -146,12 +149,50 @@ def CPeptideConditionalCovariateUDEModel(glucose_data, glucose_timepoints, age, 
                                        covariate=True)
 
 
+class MichaelisMentenProduction:
+    """production(dG, k) = dG >= 0 ? 1.78dG/(dG + k[1]) : 0.0 -- the analytic production term found by symbolic
+    regression (c-peptide/03-symreg.jl:37-40).  The reference passes an arbitrary Julia function to
+    CPeptideODEModel; this is the one form compiled into the HIP kernel (vmax generalises the literal 1.78)."""
+
+    def __init__(self, vmax=1.78):
+        self.vmax = float(vmax)
+
+    def __call__(self, dG, k):
+        dG = np.asarray(dG, dtype=np.float64)
+        k = np.asarray(k, dtype=np.float64)
+        pos = dG >= 0
+        return np.where(pos, self.vmax * dG / np.where(pos, dG + k, 1.0), 0.0)
+
+
+production = MichaelisMentenProduction()
+
+
+class CPeptideODEModel:
+    """CPeptideODEModel(glucose, timepoints, age, production, cpeptide, t2dm) (src/c-peptide-models.jl:118-142):
+    van Cauter kinetics + analytic production; the model parameter is the per-subject k."""
+
+    def __init__(self, glucose_data, glucose_timepoints, age, production_function, cpeptide_data, t2dm):
+        if not isinstance(production_function, MichaelisMentenProduction):
+            raise NotImplementedError("only MichaelisMentenProduction (vmax*dG/(dG+k)) is compiled for the GPU")
+        self.glucose = np.asarray(glucose_data, dtype=np.float64)
+        self.timepoints = np.asarray(glucose_timepoints, dtype=np.float64)
+        self.age = float(age)
+        self.production = production_function
+        self.cpeptide = np.asarray(cpeptide_data, dtype=np.float64)
+        self.t2dm = bool(t2dm)
+        if self.glucose.shape != self.timepoints.shape or self.cpeptide.shape != self.timepoints.shape:
+            raise ValueError("glucose, cpeptide and timepoints must have the same length")
+
+
 class _Pop:
     """Device-resident population built from a list of models (cached per list object)."""
 
-    def __init__(self, models, timepoints, cpeptide_data, n_steps, n_state, device):
-        net = models[0].chain
-        self.engine = Engine("cpep", net.arch, n_steps=n_steps, n_state=n_state, device=device)
+    def __init__(self, models, timepoints, cpeptide_data, n_steps, n_state, device, cond_space="log"):
+        if isinstance(models[0], CPeptideODEModel):
+            self.engine = Engine("cpep_sym", n_steps=n_steps, n_state=n_state, device=device, cond_space=cond_space)
+            self.shared = np.array([models[0].production.vmax])
+        else:
+            self.engine = Engine("cpep", models[0].chain.arch, n_steps=n_steps, n_state=n_state, device=device)
         G = np.stack([m.glucose for m in models])
         cp = np.asarray(cpeptide_data, dtype=np.float64).reshape(len(models), -1)
         self.engine.set_population_cpep(np.asarray(timepoints, dtype=np.float64), G, cp, [m.age for m in models],
@@ -175,19 +216,25 @@ def clear_cache():
     _CACHE.clear()
 
 
-def _population(models, timepoints, cpeptide_data, n_steps=None, n_state=2):
-    n_steps = default_steps(timepoints) if n_steps is None else n_steps
+def _population(models, timepoints, cpeptide_data, n_steps=None, n_state=2, cond_space="log"):
+    if n_steps is None:       # the analytic production has a kink at dG = 0: twice the steps of the smooth model
+        n_steps = default_steps(timepoints, 16 if isinstance(models[0], CPeptideODEModel) else 8)
     cp = np.asarray(cpeptide_data, dtype=np.float64)
-    key = (id(models), len(models), n_steps, n_state, cp.tobytes()[:256], cp.shape)
+    key = (id(models), len(models), n_steps, n_state, cp.tobytes()[:256], cp.shape, cond_space)
     pop = _CACHE.get(key)
     if pop is None:
-        pop = _Pop(models, timepoints, cp, n_steps, n_state, _DEVICE)
+        pop = _Pop(models, timepoints, cp, n_steps, n_state, _DEVICE, cond_space)
         _CACHE[key] = pop
     return pop
 
 
 def _is_model(x):
-    return isinstance(x, CPeptideConditionalUDEModel)
+    return isinstance(x, (CPeptideConditionalUDEModel, CPeptideODEModel))
+
+
+def _first(theta):
+    """theta[1] of a Julia ComponentArray(ode=[k], sigma=s) / vector / scalar."""
+    return float(np.ravel(getattr(theta, "ode", theta))[0])
 
 
 def loss(theta, args, *, n_steps=None):
@@ -202,6 +249,10 @@ def loss(theta, args, *, n_steps=None):
         out = pop.engine.forward(want_sse=True)
         return out["sse"][0] if np.isfinite(out["loss"]) else np.inf
     models, timepoints, data = args
+    if isinstance(models, CPeptideODEModel):        # p = theta, production(dG, p) reads p[1] (03-symreg.jl:38)
+        pop = _population([models], timepoints, np.asarray(data)[None, :], n_steps, cond_space="raw")
+        pop.engine.set_params(pop.shared, [_first(theta)])
+        return pop.engine.forward()["loss"]
     if _is_model(models):
         pop = _population([models], timepoints, np.asarray(data)[None, :], n_steps)
         pop.engine.set_params(theta.neural, np.atleast_1d(theta.conditional)[:1])
@@ -305,6 +356,26 @@ def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_00
     return [OptimizationSolution(u=np.array([b]), objective=s) for b, s in zip(beta, sse)]
 
 
+def _bracket_min(f, lo, hi, n_grid=61, iters=48):
+    """Vectorised 1-D minimisation of N independent functions: coarse grid, then golden section."""
+    grid = np.linspace(lo, hi, n_grid)
+    vals = np.stack([f(g) for g in grid])
+    vals = np.where(np.isfinite(vals), vals, np.inf)
+    k = np.clip(np.argmin(vals, axis=0), 1, n_grid - 2)
+    a, b = grid[k - 1], grid[k + 1]
+    gr = (math.sqrt(5) - 1) / 2
+    c, d = b - gr * (b - a), a + gr * (b - a)
+    fc, fd = f(c), f(d)
+    for _ in range(iters):
+        left = fc < fd
+        b = np.where(left, d, b)
+        a = np.where(left, a, c)
+        c, d = b - gr * (b - a), a + gr * (b - a)
+        fc, fd = f(c), f(d)
+    x = 0.5 * (a + b)
+    return x, f(x)
+
+
 def estimate_conditional(models, timepoints, cpeptide_data, nn, *, initial_beta=-2.0, lower=-4.0, upper=1.0,
                          n_steps=None, n_grid=41, iters=48):
     """All N independent 1-D problems min_beta SSE_i(beta) at once: every probe is ONE forward launch over
@@ -316,24 +387,9 @@ def estimate_conditional(models, timepoints, cpeptide_data, nn, *, initial_beta=
     eng.set_params(nn, np.full(N, lo))
 
     def sse(b):
-        eng.set_params(None, b)
+        eng.set_params(None, np.broadcast_to(b, (N,)))
         return eng.forward(want_sse=True)["sse"]
-    grid = np.linspace(lo, hi, n_grid)
-    vals = np.stack([sse(np.full(N, g)) for g in grid])
-    vals = np.where(np.isfinite(vals), vals, np.inf)
-    k = np.clip(np.argmin(vals, axis=0), 1, n_grid - 2)
-    a, b = grid[k - 1], grid[k + 1]
-    gr = (math.sqrt(5) - 1) / 2
-    c, d = b - gr * (b - a), a + gr * (b - a)
-    fc, fd = sse(c), sse(d)
-    for _ in range(iters):
-        left = fc < fd
-        b = np.where(left, d, b)
-        a = np.where(left, a, c)
-        c, d = b - gr * (b - a), a + gr * (b - a)
-        fc, fd = sse(c), sse(d)
-    x = 0.5 * (a + b)
-    return x, sse(x)
+    return _bracket_min(sse, lo, hi, n_grid, iters)
 
 
 def train_with_sigma(models, timepoints, cpeptide_data, nn, *, initial_beta=-2.0, lbfgs_lower_bound=-4.0,
@@ -532,3 +588,77 @@ def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0,
                                          proposal_std_bounds[0], proposal_std_bounds[1]))
     return SimpleNamespace(p_neural=p_nn, p_individuals=p_ind, Omega=omega, sigma=sigma, eta=prior_eta,
                            total_nll_values=nll_values, acceptance_rates=acc_rates)
+
+
+# ----------------------------------------------------------------------------- symbolic (Michaelis-Menten) model
+def train_symbolic(models, timepoints, cpeptide_data, *, lower=0.0, upper=1000.0, n_steps=None):
+    """The per-subject loop of c-peptide/03-symreg.jl:94-106: minimise loss_sigma over (k, sigma) with
+    0 <= k <= 1000 for every CPeptideODEModel.  For fixed k the optimum is sigma^2 = SSE/n, and k minimises the
+    SSE, so all N problems are solved together by a bracketing search on log k (one forward launch per probe).
+    Returns OptimizationSolution(u = ComponentArray(ode=[k], sigma), objective) per subject."""
+    pop = _population(models, timepoints, cpeptide_data, n_steps, cond_space="log")
+    eng, N = pop.engine, pop.N
+    eng.set_params(pop.shared, np.zeros(N))
+    lo = math.log(max(lower, 1e-6))
+    hi = math.log(upper)
+
+    def sse(logk):
+        eng.set_params(None, np.broadcast_to(logk, (N,)))
+        return eng.forward(want_sse=True)["sse"]
+    logk, val = _bracket_min(sse, lo, hi)
+    n = len(timepoints)
+    sigma = np.sqrt(np.maximum(val, 1e-300) / n)
+    obj = (n / 2) * np.log(sigma ** 2) + val / (2 * sigma ** 2)
+    return [OptimizationSolution(u=ComponentArray(ode=np.array([k]), sigma=s), objective=o)
+            for k, s, o in zip(np.exp(logk), sigma, obj)]
+
+
+def SAEM_symbolic(models, timepoints, cpeptide_data, initial_population_parameter, *, sigma=1.0, prior_eta=0.0,
+                  prior_omega=1.0, iterations=500, n_burnin_iterations=100, proposal_std=0.1,
+                  proposal_std_bounds=(1e-3, 1.0), alpha=0.7, n_mcmc_steps=1, initial_mcmc_steps=None,
+                  target_acceptance_rate=0.25, initial_temperature=10.0, temperature_decay=0.05,
+                  omega_learning_rate=0.04, rng=None, n_steps=None, m_step_iters=5):
+    """SAEM(individuals, initial_population_parameter; ...) of src/saem-symreg.jl:134-229: random effects eta_i
+    with k_i = km_pop * exp(eta_i) (:57-59), Metropolis E-step (:86-108) on the device through the log-space
+    conditional log k_i = log km_pop + eta_i (prior Normal(0, Omega) on eta), M-step = `m_step_iters` L-BFGS
+    iterations on (km, sigma) of total_nll (:110-131) with the device gradient."""
+    rng = np.random.default_rng() if rng is None else rng
+    initial_mcmc_steps = n_mcmc_steps if initial_mcmc_steps is None else initial_mcmc_steps
+    pop = _population(models, timepoints, cpeptide_data, n_steps, cond_space="log")
+    eng, N, T = pop.engine, pop.N, pop.T
+    eta = np.full(N, float(prior_eta))
+    km = float(initial_population_parameter)
+    omega = float(prior_omega)
+    nll_values, acc_rates = [], []
+    for it in range(1, iterations + 1):
+        gamma = 1.0 if it <= n_burnin_iterations else 1.0 / (it - n_burnin_iterations) ** alpha
+        steps = initial_mcmc_steps if it <= n_burnin_iterations else n_mcmc_steps
+        temperature = max(1.0, initial_temperature * math.exp(-temperature_decay * it))
+        # E-step: the chain state on the device is log k = log km + eta, so the prior is centred on log km
+        eng.set_params(pop.shared, math.log(km) + eta)
+        n_acc = eng.mh_estep(rng.standard_normal((steps, N)), rng.random((steps, N)), sigma, math.log(km), omega,
+                             proposal_std, temperature, gamma)
+        eta = eng.get_params()[1] - math.log(km)
+        sse = eng.forward(want_sse=True)["sse"]
+        loglik = float(individual_log_likelihood(sse, T, sigma).sum())
+
+        def fg(x):                                   # total_nll(km, eta, individuals, sigma) and its gradient
+            k_pop, s = x
+            if k_pop <= 0 or s <= 0:
+                return np.inf, np.zeros(2)
+            eng.set_params(None, math.log(k_pop) + eta)
+            mean_sse, _, g_log = eng.loss_grad()
+            val = N * T / 2 * math.log(s * s) + N * mean_sse / (2 * s * s)
+            return val, np.array([N * g_log.sum() / k_pop / (2 * s * s), N * T / s - N * mean_sse / s ** 3])
+        res = lbfgs(fg, np.array([km, sigma]), maxiters=m_step_iters)
+        km_new, sigma = float(res["x"][0]), float(res["x"][1])
+        km = (1 - gamma) * km + gamma * km_new
+        omega = (1 - omega_learning_rate) * omega + omega_learning_rate * float(np.var(eta, ddof=1))
+        rate = int(n_acc.sum()) / (N * steps)
+        nll_values.append(-loglik)
+        acc_rates.append(rate)
+        if it > n_burnin_iterations:
+            proposal_std = float(np.clip(math.exp(math.log(proposal_std) + gamma * (rate - target_acceptance_rate)),
+                                         proposal_std_bounds[0], proposal_std_bounds[1]))
+    return SimpleNamespace(km_pop=km, eta=eta, Omega=omega, sigma=sigma, total_nll_values=nll_values,
+                           acceptance_rates=acc_rates)

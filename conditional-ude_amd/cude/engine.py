@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MODEL_CPEP, MODEL_SUPP, CudeError, check
+from ._lib import COND_LOG, COND_RAW, MODEL_CPEP, MODEL_CPEP_SYM, MODEL_SUPP, CudeError, check
 
 
 def _f64(a):
@@ -29,16 +29,18 @@ def device_count():
 
 
 class Engine:
-    """model: 'cpep' | 'supp'.  arch = (nn_in, width, depth)."""
+    """model: 'cpep' | 'supp' | 'cpep_sym'.  arch = (nn_in, width, depth); (1, 0, 0) for 'cpep_sym' (the analytic
+    production p0*dG/(dG+k): parameters [p0], conditional k or log k according to cond_space = 'raw' | 'log')."""
 
-    def __init__(self, model, arch, n_steps=30, n_state=None, lam=0.0, device=0):
+    def __init__(self, model, arch=(1, 0, 0), n_steps=30, n_state=None, lam=0.0, device=0, cond_space="log"):
         self._lib = _lib.load()
-        self.model = {"cpep": MODEL_CPEP, "supp": MODEL_SUPP}[model]
+        self.model = {"cpep": MODEL_CPEP, "supp": MODEL_SUPP, "cpep_sym": MODEL_CPEP_SYM}[model]
         self.arch = tuple(int(v) for v in arch)
         if n_state is None:
-            n_state = 2 if self.model == MODEL_CPEP else 3
-        cfg = _lib.Config(self.model, n_state, self.arch[0], self.arch[1], self.arch[2], int(n_steps), int(device), 0,
-                          float(lam))
+            n_state = 3 if self.model == MODEL_SUPP else 2
+        space = {"log": COND_LOG, "raw": COND_RAW}[cond_space]
+        cfg = _lib.Config(self.model, n_state, self.arch[0], self.arch[1], self.arch[2], int(n_steps), int(device),
+                          space, float(lam))
         h = C.c_void_p()
         check(self._lib.cude_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -4,7 +4,7 @@ module CUDEHip
 const LIB = "libcude_hip.so"
 struct Config
     model::Int32; n_state::Int32; nn_in::Int32; nn_width::Int32; nn_depth::Int32
-    n_steps::Int32; device::Int32; reserved::Int32; lambda::Float64
+    n_steps::Int32; device::Int32; cond_space::Int32; lambda::Float64
 end
 check(st) = st < 0 ? error(unsafe_string(ccall((:cude_last_error, LIB), Cstring, ()))) : st
 

@@ -35,6 +35,17 @@ extern "C" {
 
 #define CUDE_MODEL_CPEP 0 /* c-peptide cUDE: src/c-peptide-models.jl:7-14,86-94,170-194 */
 #define CUDE_MODEL_SUPP 1 /* suppression cUDE: suppression/src/suppression_model.jl:88-95 */
+/* c-peptide model with the analytic (symbolic-regression) production term instead of the network:
+ * production(dG, k) = dG >= 0 ? p0*dG/(dG + k) : 0  with p0 = 1.78 in the reference
+ * (c-peptide/03-symreg.jl:37-40 via CPeptideODEModel / analytic_production, src/c-peptide-models.jl:68-75,
+ * 118-142; src/saem-symreg.jl:23-29 writes the same term).  The shared parameter vector is [p0] (P = 1,
+ * cude_n_params(.,0,0)); the per-subject conditional parameter is k.  Population data, loss, gradient,
+ * multi-start, Metropolis E-step, Adam and sharding are those of CUDE_MODEL_CPEP. */
+#define CUDE_MODEL_CPEP_SYM 2
+
+/* how the per-subject conditional parameter enters the symbolic model (cude_config.cond_space) */
+#define CUDE_COND_LOG 0 /* k = exp(conditional): the cUDE convention; km_pop*exp(eta) of saem-symreg.jl:57-59 */
+#define CUDE_COND_RAW 1 /* k = conditional: the box-constrained fit of 03-symreg.jl:99-106 (p.ode[1] in [0,1000]) */
 
 #define CUDE_UNIQUE_ID_BYTES 128
 
@@ -47,18 +58,19 @@ typedef struct cude_config {
     int32_t n_state;  /* CPEP: 2, or 3 = +cumulative-secretion quadrature state (zero loss weight); SUPP: 3 */
     int32_t nn_in;    /* CPEP: 2 = [dG, exp(beta)], 3 = [dG, exp(beta), age] (covariate model,
                          src/c-peptide-models.jl:96-104); SUPP: 4 = [u1,u2,u3,exp(theta)] */
-    int32_t nn_width; /* hidden width */
-    int32_t nn_depth; /* number of tanh hidden layers; output layer is softplus, 1 unit */
+    int32_t nn_width; /* hidden width (0 for CUDE_MODEL_CPEP_SYM) */
+    int32_t nn_depth; /* number of tanh hidden layers; output layer is softplus, 1 unit (0 for CPEP_SYM) */
     int32_t n_steps;  /* fixed Tsit5 steps over the time span */
     int32_t device;   /* HIP device ordinal */
-    int32_t reserved;
+    int32_t cond_space; /* CUDE_COND_*; must be CUDE_COND_LOG (0) for the network models */
     double lambda;    /* L2 weight on the network parameters (suppression_loss :128); 0 for CPEP */
 } cude_config;
 
 const char* cude_last_error(void);
 int32_t cude_device_count(int32_t* count);
 /* Number of network parameters for a shape: SimpleChains layout, per layer
- * [vec_colmajor(W out x in); b] (src/neural-network.jl:52-56). */
+ * [vec_colmajor(W out x in); b] (src/neural-network.jl:52-56).  width = depth = 0 names the analytic production
+ * model (CUDE_MODEL_CPEP_SYM): 1 shared parameter. */
 int32_t cude_n_params(int32_t nn_in, int32_t nn_width, int32_t nn_depth);
 
 int32_t cude_create(const cude_config* cfg, cude_ctx** out);

@@ -91,8 +91,13 @@ def locate_observations(timepoints, n_steps):
 
 
 # ----------------------------------------------------------------------------- MLP
+SYMBOLIC = (1, 0, 0)     # "architecture" of the analytic production model: one shared parameter p0
+
+
 def n_params(arch):
     nin, width, depth = arch
+    if width == 0:
+        return 1
     p, fan_in = 0, nin
     for _ in range(depth):
         p += width * fan_in + width
@@ -123,6 +128,15 @@ def mlp(xp, inputs, p, arch):
     for i in range(fan_in):
         z = z + p[off + i] * h[i]
     return softplus(xp, z)
+
+
+def symbolic_production(xp, dG, p0, k):
+    """production(dG, k) = dG >= 0 ? 1.78dG/(dG + k) : 0.0  (c-peptide/03-symreg.jl:37-40, called through
+    analytic_production src/c-peptide-models.jl:68-75; src/saem-symreg.jl:23-29 writes the same term with the
+    indicator glucose(t) > glucose(0)).  p0 generalises the literal 1.78."""
+    pos = dG >= 0
+    den = xp.where(pos, dG + k, 1.0 + 0.0 * dG)     # the untaken branch must not poison autograd
+    return xp.where(pos, (p0 * dG) / den, 0.0 * dG)
 
 
 # ----------------------------------------------------------------------------- models
@@ -172,7 +186,9 @@ def cpep_rhs(xp, pop, nn, eb, arch, t, u, n_state):
     """combined! = kinetics + conditional production, as written (baseline term re-evaluated)."""
     G = [_as(xp, pop.glucose[:, j]) for j in range(pop.T)]
     dG = linear_interp(pop.timepoints, G, t) - linear_interp(pop.timepoints, G, pop.timepoints[0])
-    if pop.covariate:
+    if arch[1] == 0:                       # CPeptideODEModel: no baseline term (c-peptide-models.jl:68-75)
+        prod = symbolic_production(xp, dG, nn[0], eb)
+    elif pop.covariate:
         age = _as(xp, pop.age)
         prod = mlp(xp, [dG, eb, age], nn, arch) - mlp(xp, [dG * 0.0, eb, age], nn, arch)
     else:
@@ -293,11 +309,12 @@ def solve_adaptive(rhs, u0, timepoints, abstol=1e-6, reltol=1e-3, max_steps=1000
 
 
 # ----------------------------------------------------------------------------- losses
-def cpep_forward(xp, nn, beta, pop, arch, n_steps, n_state=2):
-    """Returns (trajectory [T][state] of (N,) arrays)."""
+def cpep_forward(xp, nn, beta, pop, arch, n_steps, n_state=2, cond_space="log"):
+    """Returns (trajectory [T][state] of (N,) arrays).  cond_space = "raw" (symbolic model only): the
+    conditional parameter is k itself (03-symreg.jl:99-106) instead of its logarithm."""
     nn = _as(xp, nn)
     beta = _as(xp, beta)
-    eb = xp.exp(beta)
+    eb = xp.exp(beta) if cond_space == "log" else beta
     c0, k1, k2 = _as(xp, pop.c0), _as(xp, pop.k1), _as(xp, pop.k2)
     u0 = [c0, (k2 / k1) * c0]
     if n_state == 3:
@@ -306,10 +323,10 @@ def cpep_forward(xp, nn, beta, pop, arch, n_steps, n_state=2):
     return solve_fixed(rhs, u0, pop.timepoints, n_steps)
 
 
-def cpep_loss(xp, nn, beta, pop, arch, n_steps, n_state=2):
+def cpep_loss(xp, nn, beta, pop, arch, n_steps, n_state=2, cond_space="log"):
     """Population loss (src/parameter-estimation.jl:126-140): mean over subjects of the SSE on
     state 1.  Returns (loss, per-subject SSE).  Non-finite -> +Inf as the reference."""
-    traj = cpep_forward(xp, nn, beta, pop, arch, n_steps, n_state)
+    traj = cpep_forward(xp, nn, beta, pop, arch, n_steps, n_state, cond_space)
     sse = 0.0
     for ti in range(pop.T):
         r = traj[ti][0] - _as(xp, pop.cpeptide[:, ti])
@@ -358,12 +375,12 @@ def supp_loss(xp, nn, theta, data, timepoints, arch, n_steps, lam):
 
 
 # ----------------------------------------------------------------------------- gradients
-def cpep_loss_grad_torch(nn, beta, pop, arch, n_steps, n_state=2):
+def cpep_loss_grad_torch(nn, beta, pop, arch, n_steps, n_state=2, cond_space="log"):
     """Reverse-mode (torch float64 autograd) gradient of the same discretisation."""
     import torch
     nn_t = torch.tensor(np.asarray(nn, dtype=np.float64), requires_grad=True)
     be_t = torch.tensor(np.asarray(beta, dtype=np.float64), requires_grad=True)
-    loss, sse = cpep_loss(torch, nn_t, be_t, pop, arch, n_steps, n_state)
+    loss, sse = cpep_loss(torch, nn_t, be_t, pop, arch, n_steps, n_state, cond_space)
     loss.backward()
     return (float(loss.detach()), nn_t.grad.numpy().copy(), be_t.grad.numpy().copy(),
             sse.detach().numpy().copy())

@@ -31,6 +31,7 @@ def test_n_params_matches_simplechains_layout():
     assert n_params(2, 6, 2) == 67      # source_data/neural_network_parameters.jld2
     assert n_params(3, 4, 2) == 41      # c-peptide/07-covariate-inclusion.jl:32
     assert n_params(4, 3, 5) == 67      # suppression/suppression.jl:18
+    assert n_params(1, 0, 0) == 1       # symbolic model: the literal 1.78 of c-peptide/03-symreg.jl:38
 
 
 def test_no_silent_fallback_without_gpu():

@@ -49,6 +49,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "suppression_lambda0.npz"), nn_4x3x5x1=snn, group_data=group,
                         correlations=f64(sp, 40520, 25), losses=f64(sp, 40824, 25),
                         timepoints=np.linspace(0.0, 30.0, 8))
+    # dose-response table the reference's symbolic regression was run on (30 exp(beta) x 30 dG values)
+    prod = pd.read_csv(os.path.join(REF, "data/ohashi_production.csv"))
+    np.savez_compressed(os.path.join(OUT, "ohashi_production.npz"), beta=prod["Beta"].to_numpy(dtype=np.float64),
+                        glucose=prod["Glucose"].to_numpy(dtype=np.float64),
+                        production=prod["Production"].to_numpy(dtype=np.float64))
     print(glucose.shape, nn.shape, betas.shape, snn.shape, group.shape)
     print("losses", f64(sp, 40824, 25)[:4], "group_data[:,0,0]", group[:, 0, 0])
 
