@@ -662,3 +662,44 @@ def SAEM_symbolic(models, timepoints, cpeptide_data, initial_population_paramete
                                          proposal_std_bounds[0], proposal_std_bounds[1]))
     return SimpleNamespace(km_pop=km, eta=eta, Omega=omega, sigma=sigma, total_nll_values=nll_values,
                            acceptance_rates=acc_rates)
+
+
+# ----------------------------------------------------------------------------- checkpoints / data files (JLD2)
+def load_data(path):
+    """`jldopen("data/ohashi.jld2") do file; file["train"], file["test"]; end` (c-peptide/02-conditional.jl:15-17):
+    every top-level entry of a JLD2 file; NamedTuples become SimpleNamespaces with numpy fields."""
+    from . import jld2
+    out = {}
+    for k, v in jld2.load(path).items():
+        out[k] = SimpleNamespace(**v) if isinstance(v, dict) else v
+    return out
+
+
+def save_parameters(path, width, depth, parameters, betas=None, best_model_index=None, **extra):
+    """The checkpoint the training scripts write (c-peptide/02-conditional.jl:44-50, 07-covariate-inclusion.jl:59-65):
+    width, depth, parameters, betas, best_model_index (1-based, as in the reference).  Lists of vectors are stored
+    as matrices with one column per vector (`eachcol(file["parameters"])` in Julia)."""
+    from . import jld2
+    entries = {"width": int(width), "depth": int(depth), "parameters": parameters}
+    if betas is not None:
+        entries["betas"] = betas
+    if best_model_index is not None:
+        entries["best_model_index"] = int(best_model_index)
+    entries.update(extra)
+    jld2.save(path, entries)
+
+
+def load_parameters(path):
+    """Reads a checkpoint written by the reference (vectors of vectors) or by save_parameters (matrix columns):
+    namespace with width, depth, parameters (list of vectors, or one vector), betas, best_model_index."""
+    from . import jld2
+    d = jld2.load(path)
+
+    def as_list(v):
+        if isinstance(v, np.ndarray) and v.ndim == 2:
+            return [v[:, j].copy() for j in range(v.shape[1])]
+        return v
+    return SimpleNamespace(width=d.get("width"), depth=d.get("depth"), parameters=as_list(d.get("parameters")),
+                           betas=as_list(d.get("betas")), best_model_index=d.get("best_model_index"),
+                           extra={k: v for k, v in d.items()
+                                  if k not in ("width", "depth", "parameters", "betas", "best_model_index")})

@@ -111,6 +111,31 @@ def test_symbolic_multistart_and_estep_match_oracle():
     assert np.allclose(state, want_state, rtol=1e-12, atol=1e-13)
 
 
+def test_real_data_symbolic_fit_matches_the_network_model():
+    """Soft pin on the 117 complete Ohashi subjects: the symbolic production was regressed from the trained
+    network (03-symreg.jl), so (a) its per-subject fit must explain the data as well as the reference's stored
+    network does and (b) the fitted k must be a monotone function of that network's conditional parameter
+    (orientation arbitrary per training run).  Measured: mean SSE 0.320 vs 0.311, Spearman -0.977."""
+    import os
+    from scipy.stats import spearmanr
+    from cude import api
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ohashi_cude.npz")))
+    tp, N = g["timepoints"], len(g["ages"])
+    ode = [api.CPeptideODEModel(g["glucose"][i], tp, g["ages"][i], api.production, g["cpeptide"][i], g["t2dm"][i])
+           for i in range(N)]
+    sols = api.train_symbolic(ode, tp, g["cpeptide"])
+    k = np.array([s.u.ode[0] for s in sols])
+    sse = np.array([s.u.sigma for s in sols]) ** 2 * len(tp)
+    net = api.chain(4, 2, "tanh")
+    nnm = [api.CPeptideConditionalUDEModel(g["glucose"][i], tp, g["ages"][i], net, g["cpeptide"][i], g["t2dm"][i])
+           for i in range(N)]
+    beta, sse_nn = api.estimate_conditional(nnm, tp, g["cpeptide"], g["nn_2x4x4x1"][0], lower=-4.0, upper=3.0)
+    api.clear_cache()
+    assert np.all(np.isfinite(k)) and np.all(k > 0) and np.all(k <= 1000.0)
+    assert sse.mean() < 1.1 * sse_nn.mean() and np.median(sse) < 1.1 * np.median(sse_nn)
+    assert abs(spearmanr(k, beta)[0]) > 0.95
+
+
 def test_api_mirror_fit_recovers_k_and_saem_runs():
     import cude_oracle as o
     from cude import api

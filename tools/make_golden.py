@@ -1,29 +1,33 @@
 """Extracts small DATA fixtures (inputs + stored results, no source text) from the reference checkout
 into tests/golden/.  Run in the build container (needs /root/reference); the GPU box only sees the
-committed .npz files.
+committed files.
 
 Sources (paths relative to /root/reference):
   data/ohashi_csv/ohashi_OGTT.csv, ohashi_subjectinfo.csv   CC-BY-4.0, Ohashi et al. 2018 (see ATTRIBUTION.md)
       unit conversions as c-peptide/00-prepare-data.jl:30-31
+  data/ohashi.jld2                            the reference's own prepared train / test split of the same subjects
+      (written by c-peptide/00-prepare-data.jl): used to cross-check the unit conversions and for the split
   source_data/cude_neural_parameters.jld2     25 trained 2->4->4->1 weight vectors + their 57 training betas
       (written by c-peptide/02-conditional.jl:44-50)
   source_data/neural_network_parameters.jld2  legacy 2->6->6->1 weight vector (67 doubles)
+  source_data/ude_neural_parameters.jld2      copied as-is (1455 bytes): fixture of the JLD2 reader / writer
   suppression/results/lambda=0.0.jld2         25 x 67 weights (4->3x5->1), group_data 3x8x37, losses, correlations
       (written by suppression/suppression.jl:76-91)
-JLD2 stores these arrays uncompressed and contiguous; offsets were located by byte scan.
+  data/ohashi_production.csv                  dose-response table of the symbolic regression
+The .jld2 files are decoded with the build's own reader (conditional-ude_amd/cude/jld2.py).
 """
 import os
+import shutil
+import sys
+
 import numpy as np
 import pandas as pd
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-
-
-def f64(path, off, n):
-    with open(os.path.join(REF, path), "rb") as fh:
-        fh.seek(off)
-        return np.frombuffer(fh.read(8 * n), dtype="<f8").copy()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "conditional-ude_amd"))
+from cude import jld2  # noqa: E402
 
 
 def main():
@@ -36,26 +40,39 @@ def main():
     cpeptide = ogtt.iloc[:, 11:16].to_numpy(dtype=np.float64) * 0.3311
     ages = info["age"].to_numpy(dtype=np.float64)
     types = info["type"].to_numpy(dtype=str)
-    nn = np.stack([f64("source_data/cude_neural_parameters.jld2", 5688 + 400 * k, 37) for k in range(25)])
-    betas = np.stack([f64("source_data/cude_neural_parameters.jld2", 16024 + 560 * k, 57) for k in range(25)])
-    legacy = f64("source_data/neural_network_parameters.jld2", 816, 67)
-    np.savez_compressed(os.path.join(OUT, "ohashi_cude.npz"), subject_no=ogtt["No"].to_numpy(), glucose=glucose,
+    subject_no = ogtt["No"].to_numpy()
+    # the reference's prepared data set must be the same numbers (pins the unit conversions and the subject filter)
+    prepared = jld2.load(os.path.join(REF, "data/ohashi.jld2"))
+    for part in ("train", "test"):
+        p = prepared[part]
+        rows = np.array([np.flatnonzero(subject_no == s)[0] for s in p["subject_numbers"]])
+        assert np.allclose(p["glucose"], glucose[rows], rtol=1e-12) and np.allclose(p["cpeptide"], cpeptide[rows], rtol=1e-12)
+        assert np.array_equal(p["ages"], ages[rows]) and list(p["types"]) == list(types[rows])
+    cude = jld2.load(os.path.join(REF, "source_data/cude_neural_parameters.jld2"))
+    assert cude["width"] == 4 and cude["depth"] == 2
+    nn = np.stack(cude["parameters"])
+    betas = np.stack(cude["betas"])
+    legacy = jld2.load(os.path.join(REF, "source_data/neural_network_parameters.jld2"))["parameters"]
+    np.savez_compressed(os.path.join(OUT, "ohashi_cude.npz"), subject_no=subject_no, glucose=glucose,
                         cpeptide=cpeptide, ages=ages, t2dm=(types == "T2DM"), types=types,
                         timepoints=np.array([0.0, 30.0, 60.0, 90.0, 120.0]), nn_2x4x4x1=nn, betas_train=betas,
-                        nn_2x6x6x1_legacy=legacy)
-    sp = "suppression/results/lambda=0.0.jld2"
-    snn = np.stack([f64(sp, 5536 + 640 * k, 67) for k in range(25)])
-    group = f64(sp, 21552, 888).reshape(37, 8, 3).transpose(2, 1, 0)          # column-major 3 x 8 x 37
+                        nn_2x6x6x1_legacy=legacy, train_subject_numbers=prepared["train"]["subject_numbers"],
+                        test_subject_numbers=prepared["test"]["subject_numbers"],
+                        best_model_index=np.int64(cude["best_model_index"]))          # 1-based, as stored
+    supp = jld2.load(os.path.join(REF, "suppression/results/lambda=0.0.jld2"))
+    snn = np.stack(supp["neural_parameters"])
+    group = supp["group_data"]
     np.savez_compressed(os.path.join(OUT, "suppression_lambda0.npz"), nn_4x3x5x1=snn, group_data=group,
-                        correlations=f64(sp, 40520, 25), losses=f64(sp, 40824, 25),
-                        timepoints=np.linspace(0.0, 30.0, 8))
+                        correlations=supp["correlations"], losses=supp["losses"], timepoints=np.linspace(0.0, 30.0, 8))
     # dose-response table the reference's symbolic regression was run on (30 exp(beta) x 30 dG values)
     prod = pd.read_csv(os.path.join(REF, "data/ohashi_production.csv"))
     np.savez_compressed(os.path.join(OUT, "ohashi_production.npz"), beta=prod["Beta"].to_numpy(dtype=np.float64),
                         glucose=prod["Glucose"].to_numpy(dtype=np.float64),
                         production=prod["Production"].to_numpy(dtype=np.float64))
-    print(glucose.shape, nn.shape, betas.shape, snn.shape, group.shape)
-    print("losses", f64(sp, 40824, 25)[:4], "group_data[:,0,0]", group[:, 0, 0])
+    shutil.copyfile(os.path.join(REF, "source_data/ude_neural_parameters.jld2"),
+                    os.path.join(OUT, "ude_neural_parameters.jld2"))
+    print(glucose.shape, nn.shape, betas.shape, snn.shape, group.shape, "best model", cude["best_model_index"])
+    print("losses", supp["losses"][:4], "group_data[:,0,0]", group[:, 0, 0])
 
 
 if __name__ == "__main__":
