@@ -532,62 +532,21 @@ def mcmc_steps(sse_of, p_individual, n_obs, sigma, omega, proposal_std, prior_in
 def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0, prior_eta=0.0, prior_omega=1.0,
          iterations=500, n_burnin_iterations=100, proposal_std=0.1, proposal_std_bounds=(1e-3, 1.0), alpha=0.7,
          n_mcmc_steps=1, initial_mcmc_steps=None, target_acceptance_rate=0.25, initial_temperature=10.0,
-         temperature_decay=0.05, omega_learning_rate=0.04, rng=None, n_steps=None, m_step_iters=5, m_step_lr=1e-2):
+         temperature_decay=0.05, omega_learning_rate=0.04, rng=None, n_steps=None, m_step_iters=5, m_step_lr=1e-2,
+         collective=None):
     """SAEM(individuals, initial_neural_params, network; ...) (src/saem.jl:134-237) with the population on the
     GPU: every Metropolis step evaluates all subjects in one forward launch; the M-step's 5 Adam iterations on
-    (network, sigma) use the device gradient.  Quirks of the reference are preserved: the 'current' likelihood
-    is re-evaluated each step, the stochastic-approximation update is applied inside the chain (:185), Omega is
-    updated as a variance but used as a standard deviation (:91,:204)."""
-    rng = np.random.default_rng() if rng is None else rng
-    initial_mcmc_steps = n_mcmc_steps if initial_mcmc_steps is None else initial_mcmc_steps
+    (network, sigma) use the device gradient.  The loop itself is cude.parallel.saem_loop, shared with the
+    subject-sharded multi-GPU form (`collective`: this process holds one shard of `models`)."""
+    from .parallel import saem_loop
     pop = _population(models, timepoints, cpeptide_data, n_steps)
-    eng, N, T = pop.engine, pop.N, pop.T
-    p_ind = np.full(N, float(prior_eta))
-    p_nn = np.array(initial_neural_params, dtype=np.float64)
-    omega = float(prior_omega)
-    nll_values, acc_rates = [], []
-
-    def sse_of(beta):
-        eng.set_params(p_nn, beta)
-        return eng.forward(want_sse=True)["sse"]
-
-    for it in range(1, iterations + 1):
-        gamma = 1.0 if it <= n_burnin_iterations else 1.0 / (it - n_burnin_iterations) ** alpha
-        steps = initial_mcmc_steps if it <= n_burnin_iterations else n_mcmc_steps
-        temperature = max(1.0, initial_temperature * math.exp(-temperature_decay * it))
-        accepted = 0
-        # E-step (:177-186) fused on the device: all Metropolis steps queued on the stream, one synchronisation
-        eng.set_params(p_nn, p_ind)
-        n_acc = eng.mh_estep(rng.standard_normal((steps, N)), rng.random((steps, N)), sigma, prior_eta, omega,
-                             proposal_std, temperature, gamma)
-        _, p_ind = eng.get_params()
-        accepted = int(n_acc.sum())
-        sse = sse_of(p_ind)
-        loglik = float(individual_log_likelihood(sse, T, sigma).sum())
-        # M-step (:118-131): 5 Adam iterations on (neural, sigma), random effects fixed
-        x = np.concatenate([p_nn, [sigma]])
-        m, v = np.zeros_like(x), np.zeros_like(x)
-        for t in range(1, m_step_iters + 1):
-            eng.set_params(x[:-1], p_ind)
-            mean_sse, g_nn, _ = eng.loss_grad(want_cond_grad=False)   # mean SSE and its network gradient
-            sse_t = mean_sse * N
-            s = x[-1]
-            g = np.concatenate([g_nn * N / (2 * s * s), [N * T / s - sse_t / s ** 3]])
-            m = 0.9 * m + 0.1 * g
-            v = 0.999 * v + 0.001 * g * g
-            x = x - m_step_lr * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
-        sigma = float(x[-1])
-        p_nn = (1 - gamma) * p_nn + gamma * x[:-1]
-        omega = (1 - omega_learning_rate) * omega + omega_learning_rate * float(np.var(p_ind, ddof=1))
-        prior_eta = (1 - omega_learning_rate) * prior_eta + omega_learning_rate * float(np.mean(p_ind))
-        rate = accepted / (N * steps)
-        nll_values.append(-loglik)
-        acc_rates.append(rate)
-        if it > n_burnin_iterations:
-            proposal_std = float(np.clip(math.exp(math.log(proposal_std) + gamma * (rate - target_acceptance_rate)),
-                                         proposal_std_bounds[0], proposal_std_bounds[1]))
-    return SimpleNamespace(p_neural=p_nn, p_individuals=p_ind, Omega=omega, sigma=sigma, eta=prior_eta,
-                           total_nll_values=nll_values, acceptance_rates=acc_rates)
+    return saem_loop(pop.engine, pop.T, initial_neural_params, collective=collective, sigma=sigma,
+                     prior_eta=prior_eta, prior_omega=prior_omega, iterations=iterations,
+                     n_burnin_iterations=n_burnin_iterations, proposal_std=proposal_std,
+                     proposal_std_bounds=proposal_std_bounds, alpha=alpha, n_mcmc_steps=n_mcmc_steps,
+                     initial_mcmc_steps=initial_mcmc_steps, target_acceptance_rate=target_acceptance_rate,
+                     initial_temperature=initial_temperature, temperature_decay=temperature_decay,
+                     omega_learning_rate=omega_learning_rate, rng=rng, m_step_iters=m_step_iters, m_step_lr=m_step_lr)
 
 
 # ----------------------------------------------------------------------------- symbolic (Michaelis-Menten) model

@@ -107,3 +107,76 @@ class ShardedTrainer:
         lo, hi = shard_bounds(n_total, self.coll.world_size, self.coll.rank)
         out[lo:hi] = cond
         return self.coll.allreduce_sum(out)
+
+
+def saem_loop(engine, n_obs, initial_neural_params, *, collective=None, sigma=1.0, prior_eta=0.0, prior_omega=1.0,
+              iterations=500, n_burnin_iterations=100, proposal_std=0.1, proposal_std_bounds=(1e-3, 1.0), alpha=0.7,
+              n_mcmc_steps=1, initial_mcmc_steps=None, target_acceptance_rate=0.25, initial_temperature=10.0,
+              temperature_decay=0.05, omega_learning_rate=0.04, rng=None, draws=None, m_step_iters=5, m_step_lr=1e-2):
+    """`SAEM` of src/saem.jl:134-237 over the subjects resident in `engine` -- the whole population
+    (collective=None) or this rank's shard of it (BASELINE configs[4]: the E-step needs no communication).
+
+    Per iteration the ranks exchange, as sums of small host vectors: [accepted, log-likelihood, sum p, sum p^2]
+    after the E-step (acceptance rate, total NLL, Omega <- var(p), eta <- mean(p), :204-205) and the P+2 doubles
+    of the network gradient in each of the `m_step_iters` Adam iterations of the M-step (:118-131); every rank
+    then applies identical updates to its replica of (network, sigma, Omega, eta, proposal_std).
+    `draws(iteration, steps) -> (normals, uniforms)` of shape (steps, N_local) overrides the rank-local rng.
+    Quirks of the reference are preserved: the 'current' likelihood is re-evaluated each Metropolis step, the
+    stochastic-approximation update is applied inside the chain (:185), Omega is updated as a variance but used
+    as a standard deviation (:91,:204)."""
+    import math
+    from types import SimpleNamespace
+    rng = np.random.default_rng() if rng is None else rng
+    initial_mcmc_steps = n_mcmc_steps if initial_mcmc_steps is None else initial_mcmc_steps
+    reduce = (lambda v: np.asarray(v, dtype=np.float64)) if collective is None else collective.allreduce_sum
+    eng, N, T = engine, engine.N, int(n_obs)
+    n_glob = float(reduce([float(N)])[0])
+    if collective is not None:
+        eng.set_global_subjects(n_glob)
+    p_ind = np.full(N, float(prior_eta))
+    p_nn = np.array(initial_neural_params, dtype=np.float64)
+    P = p_nn.size
+    omega = float(prior_omega)
+    nll_values, acc_rates = [], []
+    for it in range(1, iterations + 1):
+        gamma = 1.0 if it <= n_burnin_iterations else 1.0 / (it - n_burnin_iterations) ** alpha
+        steps = initial_mcmc_steps if it <= n_burnin_iterations else n_mcmc_steps
+        temperature = max(1.0, initial_temperature * math.exp(-temperature_decay * it))
+        # E-step (:177-186) fused on the device: all Metropolis steps queued on the stream, one synchronisation
+        z, u = draws(it, steps) if draws is not None else (rng.standard_normal((steps, N)), rng.random((steps, N)))
+        eng.set_params(p_nn, p_ind)
+        n_acc = eng.mh_estep(z, u, sigma, prior_eta, omega, proposal_std, temperature, gamma)
+        _, p_ind = eng.get_params()
+        sse = eng.forward(want_sse=True)["sse"]
+        ll = np.where(np.isfinite(sse), -(T / 2) * math.log(sigma ** 2) - sse / (2 * sigma ** 2), -np.inf)
+        accepted, loglik, s1, s2 = reduce([float(np.sum(n_acc)), float(ll.sum()), float(p_ind.sum()),
+                                           float((p_ind * p_ind).sum())])
+        # M-step (:118-131): Adam iterations on (neural, sigma), random effects fixed
+        x = np.concatenate([p_nn, [sigma]])
+        m, v = np.zeros_like(x), np.zeros_like(x)
+        for t in range(1, m_step_iters + 1):
+            eng.set_params(x[:-1], p_ind)
+            if collective is None:
+                mean_sse, g_nn, _ = eng.loss_grad(want_cond_grad=False)      # mean SSE and its network gradient
+            else:
+                part = reduce(eng.loss_grad_partial()[0])
+                mean_sse, g_nn = (part[P] / n_glob if part[P + 1] == 0 else np.inf), part[:P]
+            s = x[-1]
+            g = np.concatenate([g_nn * n_glob / (2 * s * s), [n_glob * T / s - mean_sse * n_glob / s ** 3]])
+            m = 0.9 * m + 0.1 * g
+            v = 0.999 * v + 0.001 * g * g
+            x = x - m_step_lr * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
+        sigma = float(x[-1])
+        p_nn = (1 - gamma) * p_nn + gamma * x[:-1]
+        mean = s1 / n_glob
+        var = max(s2 - n_glob * mean * mean, 0.0) / (n_glob - 1) if n_glob > 1 else 0.0
+        omega = (1 - omega_learning_rate) * omega + omega_learning_rate * var
+        prior_eta = (1 - omega_learning_rate) * prior_eta + omega_learning_rate * mean
+        rate = accepted / (n_glob * steps)
+        nll_values.append(-loglik)
+        acc_rates.append(rate)
+        if it > n_burnin_iterations:
+            proposal_std = float(np.clip(math.exp(math.log(proposal_std) + gamma * (rate - target_acceptance_rate)),
+                                         proposal_std_bounds[0], proposal_std_bounds[1]))
+    return SimpleNamespace(p_neural=p_nn, p_individuals=p_ind, Omega=omega, sigma=sigma, eta=prior_eta,
+                           total_nll_values=nll_values, acceptance_rates=acc_rates)

@@ -207,3 +207,66 @@ def test_builtin_rccl_path_single_rank():
     a, b = run(False), run(True)
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     assert np.array_equal(b[4], [1.5, 2.5])
+
+
+# ------------------------------------------------------------------ sharded SAEM (BASELINE configs[4]), 2 ranks, 1 GPU
+_SAEM_KW = dict(sigma=0.4, prior_eta=-0.6, prior_omega=0.8, iterations=6, n_burnin_iterations=2, n_mcmc_steps=3,
+                initial_mcmc_steps=4, proposal_std=0.3)
+
+
+def _saem_draws(n_total, lo, hi):
+    def draws(it, steps):
+        rng = np.random.default_rng(1000 + it)             # one global stream, sliced per shard
+        return rng.standard_normal((steps, n_total))[:, lo:hi], rng.random((steps, n_total))[:, lo:hi]
+    return draws
+
+
+def _saem_engine(c, lo, hi):
+    from cude.engine import Engine
+    eng = Engine("cpep", (2, 4, 2), n_steps=30, n_state=2, device=0)
+    eng.set_population_cpep(c["tp"], c["G"][lo:hi], c["obs"][lo:hi], c["age"][lo:hi], c["t2dm"][lo:hi])
+    return eng
+
+
+def _gpu_saem_rank(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "conditional-ude_amd"), os.path.join(here, "..", "oracle"), here):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from cude.parallel import TorchCollective, saem_loop, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = make_cpep_case(n_total, (2, 4, 2))
+    lo, hi = shard_bounds(n_total, world, rank)
+    eng = _saem_engine(c, lo, hi)
+    coll = TorchCollective(dist)
+    res = saem_loop(eng, len(c["tp"]), c["nn"], collective=coll, draws=_saem_draws(n_total, lo, hi), **_SAEM_KW)
+    p_all = np.zeros(n_total)
+    p_all[lo:hi] = res.p_individuals
+    np.savez(os.path.join(out_dir, f"saem{rank}.npz"), nn=res.p_neural, p=coll.allreduce_sum(p_all), omega=res.Omega,
+             sigma=res.sigma, eta=res.eta, nll=res.total_nll_values, acc=res.acceptance_rates)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_saem_matches_single_engine(tmp_path):
+    """The E-step needs no communication; per iteration the ranks exchange 4 + 5 x (P+2) doubles.  With the same
+    global draws the sharded run must make the same accept / reject decisions and reach the same parameters."""
+    import torch.multiprocessing as mp
+    from cude.parallel import saem_loop
+    n_total, world = 201, 2
+    port = 30700 + (os.getpid() % 2000)
+    mp.spawn(_gpu_saem_rank, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "saem0.npz"), np.load(tmp_path / "saem1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    c = make_cpep_case(n_total, (2, 4, 2))
+    eng = _saem_engine(c, 0, n_total)
+    one = saem_loop(eng, len(c["tp"]), c["nn"], collective=None, draws=_saem_draws(n_total, 0, n_total), **_SAEM_KW)
+    eng.close()
+    assert np.array_equal(r0["acc"], one.acceptance_rates)
+    assert np.allclose(r0["p"], one.p_individuals, rtol=0, atol=1e-10)
+    assert np.allclose(r0["nn"], one.p_neural, rtol=0, atol=1e-9)
+    assert np.allclose(r0["nll"], one.total_nll_values, rtol=1e-10)
+    assert abs(r0["sigma"] - one.sigma) < 1e-10 and abs(r0["omega"] - one.Omega) < 1e-11

@@ -111,6 +111,34 @@ class OracleEngine:
     def get_params(self):
         return self.nn.copy(), self.cond.copy()
 
+    # -- the rest of the Engine interface used by cude.parallel.saem_loop
+    def set_params(self, nn=None, cond=None):
+        if nn is not None:
+            self.nn = np.array(nn, dtype=np.float64)
+        if cond is not None:
+            self.cond = np.array(cond, dtype=np.float64)
+
+    def _solve(self, grad):
+        c, s = self.c, slice(self.lo, self.hi)
+        return self.co.cpep(c["tp"], c["G"][s], c["obs"][s], c["age"][s], c["t2dm"][s], c["arch"], self.nn,
+                            self.cond, 30, 2, want_grad=grad)
+
+    def forward(self, want_sse=False, want_traj=False):
+        r = self._solve(False)
+        return {"loss": r["loss"], "sse": r["sse"]}
+
+    def loss_grad(self, want_cond_grad=True):
+        r = self._solve(True)
+        return r["loss"], r["g_nn"], r["g_beta"]
+
+    def mh_estep(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0):
+        import cude_oracle as o
+        c, s = self.c, slice(self.lo, self.hi)
+        pop = o.CPepPopulation(c["tp"], c["G"][s], c["obs"][s], c["age"][s], c["t2dm"][s])
+        self.cond, acc = o.mh_chain(self.nn, self.cond, pop, c["arch"], 30, sigma, prior_mean, prior_sd, proposal_std,
+                                    temperature, gamma, normals, uniforms)
+        return acc
+
 
 def _rank_main(rank, world, port, n_total, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -155,3 +183,56 @@ def test_two_rank_gloo_training_matches_single_process(tmp_path):
     assert np.allclose(r0["losses"], ref_losses, rtol=1e-12)
     assert np.allclose(r0["nn"], nn, rtol=0, atol=1e-12)
     assert np.allclose(r0["cond"], beta, rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ 2-rank gloo SAEM (BASELINE configs[4] sharding)
+_SAEM_KW = dict(sigma=0.4, prior_eta=-0.6, prior_omega=0.8, iterations=3, n_burnin_iterations=1, n_mcmc_steps=2,
+                initial_mcmc_steps=3, proposal_std=0.3, m_step_iters=2)
+
+
+def _saem_draws(n_total, lo, hi):
+    def draws(it, steps):
+        rng = np.random.default_rng(1000 + it)             # the same global stream on every rank, sliced per shard
+        return rng.standard_normal((steps, n_total))[:, lo:hi], rng.random((steps, n_total))[:, lo:hi]
+    return draws
+
+
+def _saem_rank_main(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "conditional-ude_amd"), os.path.join(here, "..", "oracle"), here):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from cude.parallel import TorchCollective, saem_loop, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = make_cpep_case(n_total, (2, 4, 2))
+    lo, hi = shard_bounds(n_total, world, rank)
+    coll = TorchCollective(dist)
+    res = saem_loop(OracleEngine(case, lo, hi), len(case["tp"]), case["nn"], collective=coll,
+                    draws=_saem_draws(n_total, lo, hi), **_SAEM_KW)
+    p_all = np.zeros(n_total)
+    p_all[lo:hi] = res.p_individuals
+    np.savez(os.path.join(out_dir, f"saem{rank}.npz"), nn=res.p_neural, p=coll.allreduce_sum(p_all), omega=res.Omega,
+             sigma=res.sigma, eta=res.eta, nll=res.total_nll_values, acc=res.acceptance_rates)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_saem_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from cude.parallel import saem_loop
+    n_total, world = 11, 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_saem_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "saem0.npz"), np.load(tmp_path / "saem1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k                  # replicas stay identical
+    case = make_cpep_case(n_total, (2, 4, 2))
+    one = saem_loop(OracleEngine(case, 0, n_total), len(case["tp"]), case["nn"], collective=None,
+                    draws=_saem_draws(n_total, 0, n_total), **_SAEM_KW)
+    assert np.array_equal(r0["acc"], one.acceptance_rates)       # identical accept / reject decisions
+    assert np.allclose(r0["p"], one.p_individuals, rtol=0, atol=1e-12)
+    assert np.allclose(r0["nn"], one.p_neural, rtol=0, atol=1e-10)
+    assert np.allclose(r0["nll"], one.total_nll_values, rtol=1e-11)
+    assert abs(r0["sigma"] - one.sigma) < 1e-11 and abs(r0["omega"] - one.Omega) < 1e-12
+    assert abs(r0["eta"] - one.eta) < 1e-13
