@@ -54,7 +54,29 @@ def executed_flops_per_trajectory(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS):
     stage_fwd = 2 * (2 * 21 + 2 * 6 + 7 * 4) + 2 * 6          # stage sums, Y, A*Y+g, quadrature
     stage_rev = 2 * (2 * 21 + 6 * 4 + 12) + 12
     obs_fl = n_obs * (2 * 3 * 7 + 8) * 2
-    return n_eval * fwd_eval + n_eval * (fwd_eval + bwd_eval) + n_steps * (stage_fwd + stage_rev) + obs_fl
+    total = n_eval * fwd_eval + n_eval * (fwd_eval + bwd_eval) + n_steps * (stage_fwd + stage_rev) + obs_fl
+    if 6 <= w <= 7:
+        # layer-1 exponent table (cude_device.h Mlp::HAS_TAB): inside a run of steps within one glucose piece the W
+        # layer-1 exponentials (7 + 13 FMA each) and the W first-layer FMAs are replaced by one multiply + min + add
+        # per neuron; per run and sweep: 6 W exponentials (table + anchor) and the range check; per step W multiplies
+        n_tab_steps, n_runs = table_steps(n_steps, n_obs)
+        saved_per_eval = w * (7 + 13 * 2) + 2 * w - 3 * w
+        exp_fl = 6 + 12 * 2
+        per_run = 6 * w * exp_fl + 10 * w
+        total += 2 * (-5 * n_tab_steps * saved_per_eval + n_runs * per_run + n_tab_steps * w)
+    return total
+
+
+def table_steps(n_steps, n_obs):
+    """(number of steps that lie inside one glucose piece, number of runs of such steps) for equidistant
+    observation times -- the classification of step_tables() in csrc/cude_api.hip."""
+    piece = []
+    for n in range(n_steps):
+        a, b = n * (n_obs - 1) / n_steps, (n + 1) * (n_obs - 1) / n_steps      # in units of one piece
+        j = min(int(a + 1e-9), n_obs - 2)
+        piece.append(j if b <= j + 1 + 1e-9 else -1)
+    runs = sum(1 for n in range(n_steps) if piece[n] >= 0 and (n == 0 or piece[n - 1] != piece[n]))
+    return sum(1 for p in piece if p >= 0), runs
 
 
 def synthetic_population(n, seed):

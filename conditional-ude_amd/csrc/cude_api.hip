@@ -87,6 +87,32 @@ void glucose_tables(const std::vector<double>& tp, int S, std::vector<int32_t>& 
     }
 }
 
+// Per-step tables of the layer-1 exponent recurrence (CpepArgs::stepk / stepd): a step is "inside" glucose piece j
+// when [t_n, t_n+h] lies within [tp[j], tp[j+1]]; consecutive inside steps of one piece form a run.
+void step_tables(const std::vector<double>& tp, int S, std::vector<int32_t>& k, std::vector<double>& d) {
+    const int T = (int)tp.size();
+    const double t0 = tp[0], h = (tp[T - 1] - tp[0]) / S, tol = 1e-9 * h;
+    k.assign((size_t)S * 3, 0);
+    d.assign((size_t)S * 3, 0.0);
+    std::vector<int> piece(S, -1);
+    for (int n = 0; n < S; n++) {
+        const double ta = t0 + n * h, tb = t0 + (n + 1) * h;
+        int j = 0;
+        while (j + 1 < T - 1 && tp[j + 1] <= ta + tol) j++;
+        const double len = tp[j + 1] - tp[j];
+        if (ta >= tp[j] - tol && tb <= tp[j + 1] + tol) piece[n] = j;
+        k[(size_t)n * 3 + 2] = j;
+        d[(size_t)n * 3 + 0] = (ta - tp[j]) / len;
+        d[(size_t)n * 3 + 1] = (tb - tp[j]) / len;
+        d[(size_t)n * 3 + 2] = h / len;
+    }
+    for (int n = 0; n < S; n++) {
+        if (piece[n] < 0) continue;
+        k[(size_t)n * 3 + 0] = (n > 0 && piece[n - 1] == piece[n]) ? 2 : 1;
+        k[(size_t)n * 3 + 1] = (n + 1 < S && piece[n + 1] == piece[n]) ? 2 : 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------- RCCL (dlopen)
 typedef struct { char internal[CUDE_UNIQUE_ID_BYTES]; } nccl_uid;
 struct Rccl {
@@ -166,8 +192,8 @@ struct cude_ctx {
     DevBuf<double> data, ckpt;
     double scale[3] = {1, 1, 1};
     // tables
-    DevBuf<int32_t> seg, obs_step;
-    DevBuf<double> phi, obs_w;
+    DevBuf<int32_t> seg, obs_step, stepk;
+    DevBuf<double> phi, obs_w, stepd;
     // parameters / gradients / optimiser
     DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;
     // chunked gradient path (cude_cpep2.hip)
@@ -194,6 +220,9 @@ struct cude_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double host_red[3];
+#ifdef CUDE_WAVE_TIMING
+    DevBuf<long long> dbg;
+#endif
 };
 
 namespace {
@@ -249,6 +278,16 @@ int32_t upload_tables(cude_ctx* c, bool glucose) {
         HIP_TRY(c->phi.resize(phi.size()));
         HIP_TRY(hipMemcpyAsync(c->seg.p, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->phi.p, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        std::vector<int32_t> sk;
+        std::vector<double> sd;
+        step_tables(c->tp, c->cfg.n_steps, sk, sd);
+        if (getenv("CUDE_NO_EXPTAB"))                      // development switch: direct exponentials everywhere
+            for (size_t q = 0; q < sk.size(); q += 3) sk[q] = sk[q + 1] = 0;
+        HIP_TRY(c->stepk.resize(sk.size()));
+        HIP_TRY(c->stepd.resize(sd.size()));
+        HIP_TRY(hipMemcpyAsync(c->stepk.p, sk.data(), sk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->stepd.p, sd.data(), sd.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));          // sk / sd die at the end of this block
     }
     HIP_TRY(hipStreamSynchronize(c->stream));   // host vectors die here
     return CUDE_OK;
@@ -363,11 +402,18 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     if (is_cpep(c)) {
         cude::CpepArgs a{};
         a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
+#ifdef CUDE_WAVE_TIMING
+        if (grad) {
+            HIP_TRY(c->dbg.resize((size_t)c->nblocks * 4));
+            a.dbg = c->dbg.p;
+        }
+#endif
         a.N = c->N;
         a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
         a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
         a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
         a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+        a.stepk = c->stepk.p; a.stepd = c->stepd.p;
         a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
         a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
@@ -770,6 +816,7 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
             a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
             a.cond = d_cond.p; a.nn = d_nn.p;
             a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+            a.stepk = c->stepk.p; a.stepd = c->stepd.p;
             a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
             a.partials = d_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
@@ -885,6 +932,18 @@ int32_t cude_adam_apply(cude_ctx* c, const double* reduced, double* loss) {
     if ((rc = finish_loss(c, loss, nullptr))) return rc;   // also synchronises: `reduced` may be freed after return
     return enqueue_adam(c);
 }
+
+#ifdef CUDE_WAVE_TIMING
+// development builds only: per-wave {start, end of forward sweep, end, hw id} of the last gradient launch
+int32_t cude_debug_wave_timing(cude_ctx* c, long long* out, int64_t n_waves) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->dbg.p, (size_t)std::min<int64_t>(n_waves, c->nblocks) * 4 * sizeof(long long),
+                      hipMemcpyDeviceToHost));
+    return CUDE_OK;
+}
+#endif
 
 int32_t cude_synchronize(cude_ctx* c) {
     int32_t rc = bind(c);

@@ -26,10 +26,13 @@ template <class Net, int NS, bool GRAD>
 __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     constexpr int P = Net::P;
     constexpr int NC = Net::NC;
+    constexpr int TABROWS = Net::HAS_TAB ? 5 * Net::NCST : 0;
+    constexpr int REDROWS = TABROWS > kRedRows ? TABROWS : kRedRows;
     extern __shared__ double smem[];
     double* s_q = smem;                         // [5][kBlock] stage forcings (fwd) / adjoint weights (rev)
-    double* s_red = smem + 5 * kBlock;          // [kRedRows][kBlock]
-    double* s_res = s_red + kRedRows * kBlock;  // [T][kBlock] residuals kept for the reverse sweep
+    double* s_red = smem + 5 * kBlock;          // [kRedRows][kBlock], only used after the time loops ...
+    double* s_tab = s_red;                      // ... which use the same rows as [5][W][kBlock] layer-1 factor table
+    double* s_res = s_red + REDROWS * kBlock;   // [T][kBlock] residuals kept for the reverse sweep
 
     const int lane = threadIdx.x;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     double c[Net::NCST];
     Net::first_layer_offset(p, cst, c);
 
+#ifdef CUDE_WAVE_TIMING
+    const long long dbg_t0 = wall_clock64();
+    long long dbg_t1 = 0;
+#endif
     // ------------------------------------------------------------------ forward
     double y1 = c0, y2 = (k2 / k1) * c0, y3 = 0.0;
     double qprev = 0.0;                          // q(t_0) = NN(0,.) - NN(0,.) == 0
@@ -69,9 +76,16 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     // s-th distinct stage time of step n.  After the 5th evaluation of a step the (state-only)
     // Runge-Kutta algebra of that step runs.
     int n = 0, s = -1;
+    // layer-1 exponent table (Mlp only): anchor A_j = exp(2 z_j(t_n)), factors in s_tab
+    ciptr_t stepk = as_const(a.stepk);
+    cptr_t stepd = as_const(a.stepd);
+    typename Net::Exps A, E1;
+    int kind = 0;
+    bool run_ok = false;                         // wave-uniform: the current run is inside the table's exact range
 #pragma unroll 1
     for (int e = -1; e < 5 * S; e++) {
         double xv = 0.0;
+        bool tab = false;
         if (e >= 0) {
             const int sg = seg[e];
             if (sg != cur_seg) {                 // wave-uniform: a handful of times per trajectory
@@ -81,9 +95,36 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
                 chk = fma(g_d, 0.0, fma(g_lo, 0.0, chk));
             }
             xv = fma(phi[e], g_d, g_lo);
+            if constexpr (Net::HAS_TAB) {
+                if (s == 0) {                    // first evaluation of step n
+                    kind = stepk[3 * n];
+                    if (kind == 2 && !run_ok) kind = 0;
+                    if (kind == 1) {             // a run of steps inside one glucose piece starts here
+                        const int s0 = stepk[3 * n + 2];
+                        const double lo = a.dG[(int64_t)s0 * N + i];
+                        const double d = a.dG[(int64_t)(s0 + 1) * N + i] - lo;
+                        run_ok = !__any(!Net::tab_safe(p, c, lo, d, stepd[3 * n + 2]));
+                        if (run_ok) {
+                            const double cf[5] = {Tab::c(1), Tab::c(2), Tab::c(3), Tab::c(4), 1.0};
+                            Net::tab_build(p, d * stepd[3 * n + 2], cf, s_tab, lane);
+                            Net::tab_anchor(p, c, fma(stepd[3 * n], d, lo), A);
+                        } else {
+                            kind = 0;
+                        }
+                    } else if (kind == 2) {
+#pragma unroll
+                        for (int j = 0; j < Net::NCST; j++) A.v[j] *= s_tab[(4 * Net::NCST + j) * kBlock + lane];
+                    }
+                }
+                tab = kind != 0;
+                if (tab) {
+#pragma unroll
+                    for (int j = 0; j < Net::NCST; j++) E1.v[j] = A.v[j] * s_tab[(s * Net::NCST + j) * kBlock + lane];
+                }
+            }
         }
         const double x[1] = {xv};
-        const double v = Net::eval(p, c, x);
+        const double v = Net::eval(p, c, x, tab, &E1);
         if (e < 0) { base = v; s = 0; continue; }
         s_q[s * kBlock + lane] = v - base;
         if (++s < 5) continue;
@@ -150,6 +191,9 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         n++;
     }
     sse += chk;
+#ifdef CUDE_WAVE_TIMING
+    dbg_t1 = wall_clock64();
+#endif
     const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);   // NaN or Inf
     if (active) {
         if (a.sse != nullptr) a.sse[set * a.set_stride_cond + i] = sse;
@@ -180,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         // evaluations in reverse order; e = -1 is the baseline with weight -sum(w)
 #pragma unroll 1
         for (int e = 5 * S - 1; e >= -1; e--) {
-            if (e >= 0 && s == 4) {
+                if (e >= 0 && s == 4) {
                 // ---- adjoint algebra of step n (J_f = A, no forward state needed)
                 double kb[7][2];
 #pragma unroll
@@ -233,9 +277,32 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
                 kap2 = kb[0][1];
 #pragma unroll
                 for (int j = 0; j < 5; j++) s_q[j * kBlock + lane] = w[j];
+                if constexpr (Net::HAS_TAB) {
+                    // reverse sweep: the anchor is exp(2 z_j) at the END of step n, factors reach back from there
+                    kind = stepk[3 * n + 1];
+                    if (kind == 2 && !run_ok) kind = 0;
+                    if (kind == 1) {
+                        const int s0 = stepk[3 * n + 2];
+                        const double lo = a.dG[(int64_t)s0 * N + i];
+                        const double d = a.dG[(int64_t)(s0 + 1) * N + i] - lo;
+                        run_ok = !__any(!Net::tab_safe(p, c, lo, d, stepd[3 * n + 2]));
+                        if (run_ok) {
+                            const double cr[5] = {Tab::c(1) - 1.0, Tab::c(2) - 1.0, Tab::c(3) - 1.0, Tab::c(4) - 1.0,
+                                                  -1.0};
+                            Net::tab_build(p, d * stepd[3 * n + 2], cr, s_tab, lane);
+                            Net::tab_anchor(p, c, fma(stepd[3 * n + 1], d, lo), A);
+                        } else {
+                            kind = 0;
+                        }
+                    } else if (kind == 2) {
+#pragma unroll
+                        for (int j = 0; j < Net::NCST; j++) A.v[j] *= s_tab[(4 * Net::NCST + j) * kBlock + lane];
+                    }
+                }
                 n--;
             }
             double xv = 0.0, wv;
+            bool tab = false;
             if (e >= 0) {
                 const int sg = seg[e];
                 if (sg != cur_seg) {
@@ -246,12 +313,23 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
                 xv = fma(phi[e], g_d, g_lo);
                 wv = s_q[s * kBlock + lane];
                 wtot += wv;
+                if constexpr (Net::HAS_TAB) {
+                    tab = kind != 0;
+                    if (tab) {
+                        const int sr = s < 4 ? s : 0;
+#pragma unroll
+                        for (int j = 0; j < Net::NCST; j++) {
+                            const double f = s_tab[(sr * Net::NCST + j) * kBlock + lane];
+                            E1.v[j] = s < 4 ? A.v[j] * f : A.v[j];      // stage 5 sits at the anchor time itself
+                        }
+                    }
+                }
                 s = (s == 0) ? 4 : s - 1;
             } else {
                 wv = -wtot;
             }
             const double x[1] = {xv};
-            Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy);
+            Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy, tab, &E1);
         }
 
         double g[P + 2];
@@ -267,6 +345,16 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         g[P + 1] = red_fail;
         if (active) a.g_cond[i] = dcond;
         block_reduce_store<P + 2>(g, s_red, out, lane);
+#ifdef CUDE_WAVE_TIMING
+        if (a.dbg != nullptr && lane == 0 && blockIdx.y == 0) {
+            long long* d = a.dbg + 4 * (long long)blockIdx.x;
+            d[0] = dbg_t0;
+            d[1] = dbg_t1;
+            d[2] = wall_clock64();
+            d[3] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |      // HW_ID
+                   ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // XCC_ID
+        }
+#endif
     }
 }
 
@@ -274,7 +362,9 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
 template <class Net, int NS, bool GRAD>
 static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
-    const size_t lds = sizeof(double) * (size_t)(5 + kRedRows + (GRAD ? a.T : 0)) * kBlock;
+    constexpr int TABROWS = Net::HAS_TAB ? 5 * Net::NCST : 0;
+    constexpr int REDROWS = TABROWS > kRedRows ? TABROWS : kRedRows;
+    const size_t lds = sizeof(double) * (size_t)(5 + REDROWS + (GRAD ? a.T : 0)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     hipLaunchKernelGGL((cpep_kernel<Net, NS, GRAD>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();

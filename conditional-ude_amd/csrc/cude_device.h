@@ -150,17 +150,69 @@ struct Mlp {
         return chk;
     }
 
-    // hidden activations of all layers: h[l][j]; returns the output pre-activation
-    __device__ static __forceinline__ double forward(cptr_t p, const double (&c)[W], const double (&x)[NV],
-                                                     double (&h)[D][W]) {
-        double z[W];
+    // ---- layer-1 exponent table (NV == 1: the only varying input is the forcing x(t)).
+    // Along a linear piece of x(t) the layer-1 exponentials exp(2 z_j), z_j = W1[j,0] x + c_j, form a geometric
+    // sequence in t, so inside a run of steps that stay within one piece they follow from an anchor value by ONE
+    // multiply with a tabulated factor instead of a 20-instruction exponential: E_j(e) = A_j * T[s][j].
+    // Measured on MI355X (tools/abl_bench.py): 2-6-6-1 gradient kernel -8.7 % at 125 000 subjects, -6 % at 1e6;
+    // forward kernel -9 % / -1.5 %.  For width 4 the 36 extra VGPRs drop the kernel from 3 to 2 waves per SIMD and
+    // the gain is lost (+2.7 % at 1e6); for width 8 (351 VGPRs, one wave per SIMD, 25 KB of LDS per wave) the
+    // exposed LDS latency makes it slower (+6 % / +18 %).  So the table is compiled in for widths 6 and 7 only.
+    static constexpr bool HAS_TAB = (NV == 1 && W >= 6 && W <= 7);
+    struct Exps {
+        double v[W];
+    };
+    // T[s][j] = exp(2 W1[j,0] * dx * coef[s]) -> s_tab[(s*W + j)*64 + lane]   (dx = change of x over one step)
+    __device__ static __forceinline__ void tab_build(cptr_t p, double dx, const double (&coef)[5], double* s_tab,
+                                                     int lane) {
+        const SCol<W> col = ld_col<W>(p, 0);
+#pragma unroll 1
+        for (int s = 0; s < 5; s++) {
+            const double cs = dx * coef[s];
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const SCol<W> col = ld_col<W>(p, W * i);
-#pragma unroll
-            for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
+            for (int j = 0; j < W; j++)
+                s_tab[(s * W + j) * 64 + lane] = m_exp2x(fmin(fmax(col.v[j] * cs, -300.0), 300.0));
         }
-        m_tanh_vec<W>(z, h[0]);
+    }
+    // A_j = exp(2 (W1[j,0] x + c_j))
+    __device__ static __forceinline__ void tab_anchor(cptr_t p, const double (&c)[W], double x, Exps& A) {
+        const SCol<W> col = ld_col<W>(p, 0);
+#pragma unroll
+        for (int j = 0; j < W; j++) A.v[j] = m_exp2x(fmin(fmax(fma(col.v[j], x, c[j]), -340.0), 340.0));
+    }
+    // The recurrence is exact (every anchor, factor and product representable, nothing clamped) iff the
+    // pre-activations stay within +-300 over the whole linear piece [x0, x0+dx] and move by at most 300 per step.
+    // Returns false for a lane where that does not hold (absurdly large first-layer weights); the kernel then runs
+    // the whole wave's run with direct exponentials, whose clamp at |z| = 20 is exact for any magnitude.
+    __device__ static __forceinline__ bool tab_safe(cptr_t p, const double (&c)[W], double x0, double dx, double hl) {
+        const SCol<W> col = ld_col<W>(p, 0);
+        double worst = 0.0;
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const double zs = fma(col.v[j], x0, c[j]);
+            worst = fmax(worst, fmax(fabs(zs), fabs(fma(col.v[j], dx, zs))));
+            worst = fmax(worst, fabs(col.v[j] * dx * hl));
+        }
+        return worst <= 300.0;                          // false for NaN as well
+    }
+
+    // hidden activations of all layers: h[l][j]; returns the output pre-activation.
+    // use_tab: the layer-1 activations come from the exponentials E1 instead of x.
+    __device__ static __forceinline__ double forward(cptr_t p, const double (&c)[W], const double (&x)[NV],
+                                                     double (&h)[D][W], bool use_tab = false,
+                                                     const Exps* E1 = nullptr) {
+        double z[W];
+        if (use_tab) {
+            m_tanh_from_exp<W>(E1->v, h[0]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const SCol<W> col = ld_col<W>(p, W * i);
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
+            }
+            m_tanh_vec<W>(z, h[0]);
+        }
 #pragma unroll
         for (int l = 1; l < D; l++) {
             const int o = L1 + (l - 1) * LH;
@@ -192,20 +244,22 @@ struct Mlp {
     }
 
     // value only
-    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[W], const double (&x)[NV]) {
+    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[W], const double (&x)[NV],
+                                                  bool use_tab = false, const Exps* E1 = nullptr) {
         p = launder(p);
         double h[D][W];
-        return act_softplus_val(forward(p, c, x, h));
+        return act_softplus_val(forward(p, c, x, h, use_tab, E1));
     }
 
     // value + weighted reverse sweep:  acc += wgt * d(out)/d(params);  if WANT_DX,
     // dx[i] += wgt * d(out)/dx_i.  Returns the network output.
     template <bool WANT_DX>
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[W], const double (&x)[NV],
-                                                       double wgt, double (&acc)[NACC], double (&dx)[NV]) {
+                                                       double wgt, double (&acc)[NACC], double (&dx)[NV],
+                                                       bool use_tab = false, const Exps* E1 = nullptr) {
         p = launder(p);
         double h[D][W];
-        const double zo = forward(p, c, x, h);
+        const double zo = forward(p, c, x, h, use_tab, E1);
         double sig;
         const double y = act_softplus(zo, &sig);
 
@@ -306,18 +360,24 @@ template <bool RAW>
 struct MmProd {
     static constexpr int NC = 1, NCST = 1, P = 1;
     static constexpr int NACC = 2;                  // [d/dp0, d/dk]
+    static constexpr bool HAS_TAB = false;          // one division per evaluation: nothing to tabulate
+    struct Exps {
+        double v[1];
+    };
     __device__ static __forceinline__ double cond_input(double raw) { return RAW ? raw : exp(raw); }
     __device__ static __forceinline__ void first_layer_offset(cptr_t, const double (&cst)[1], double (&c)[1]) {
         c[0] = cst[0];
     }
     __device__ static __forceinline__ double param_check(cptr_t p) { return fma(p[0], 0.0, 0.0); }
-    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[1], const double (&x)[1]) {
+    __device__ static __forceinline__ double eval(cptr_t p, const double (&c)[1], const double (&x)[1], bool = false,
+                                                  const Exps* = nullptr) {
         const double v = (p[0] * x[0]) / (x[0] + c[0]);
         return x[0] >= 0.0 ? v : 0.0;
     }
     template <bool WANT_DX>
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[1], const double (&x)[1],
-                                                       double wgt, double (&acc)[NACC], double (&dx)[1]) {
+                                                       double wgt, double (&acc)[NACC], double (&dx)[1], bool = false,
+                                                       const Exps* = nullptr) {
         const double r = 1.0 / (x[0] + c[0]);
         const double f = x[0] * r;                  // d/dp0
         const bool pos = x[0] >= 0.0;

@@ -32,6 +32,12 @@ struct CpepArgs {
     const double* phi;       // [S*5]  fraction inside the segment
     const int32_t* obs_step; // [T]
     const double* obs_w;     // [T][7] h-free dense-output weights b_i(theta)
+    // layer-1 exponent table of the network kernels: per step {kind in the forward sweep, kind in the reverse
+    // sweep, glucose piece of the step} with kind 0 = the step straddles a knot (direct exponentials), 1 = first
+    // step of a run inside one piece (build table + anchor), 2 = continues the run; and per step {fraction of
+    // t_n and of t_{n+1} inside the piece, h / piece length}
+    const int32_t* stepk;    // [S][3]
+    const double* stepd;     // [S][3]
     int32_t T, S;
     double h, inv_n;
     double* sse;             // [N] or nullptr
@@ -44,6 +50,9 @@ struct CpepArgs {
     int32_t n_sets;
     int64_t set_stride_nn, set_stride_cond;
     int32_t cond_raw;        // symbolic model only: 1 = k is the conditional itself, 0 = k = exp(conditional)
+#ifdef CUDE_WAVE_TIMING
+    long long* dbg;          // development builds only: [nblocks][4] = {start, end of forward, end, hw id} per wave
+#endif
 };
 
 // chunked loss+gradient path (cude_cpep2.hip): the S steps of every subject are split into L chunks

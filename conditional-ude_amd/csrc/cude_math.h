@@ -116,6 +116,27 @@ CUDE_HD void m_tanh_vec(const double (&z)[W], double (&t)[W]) {
     t[0] = copysign(fma(-2.0, r, 1.0), z[0]);
 }
 
+// t[j] = tanh(z[j]) given E[j] = exp(2 z[j]) (any sign of z): 1 - 2/(E+1), one shared reciprocal.
+// E is clamped to e^40 (tanh = 1 - 8.5e-18 there) so that the product of W <= 8 denominators stays finite.
+template <int W>
+CUDE_HD void m_tanh_from_exp(const double (&E)[W], double (&t)[W]) {
+    static_assert(W <= 8, "batched reciprocal: product of denominators must stay below 1e308");
+    double d[W], pre[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) d[j] = fmin(E[j], 2.35385266837019985408e17) + 1.0;
+    pre[0] = d[0];
+#pragma unroll
+    for (int j = 1; j < W; j++) pre[j] = pre[j - 1] * d[j];
+    double r = m_rcp(pre[W - 1]);
+#pragma unroll
+    for (int j = W - 1; j >= 1; j--) {
+        const double inv = r * pre[j - 1];
+        r = r * d[j];
+        t[j] = fma(-2.0, inv, 1.0);
+    }
+    t[0] = fma(-2.0, r, 1.0);
+}
+
 // softplus value and logistic derivative
 CUDE_HD double m_softplus(double x, double* sig) {
     const double e = m_exp2x(fmax(-0.5 * fabs(x), -350.0));     // exp(-|x|) in (0, 1]

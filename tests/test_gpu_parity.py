@@ -193,13 +193,15 @@ def test_full_size_properties_1e5_subjects():
 @pytest.mark.parametrize("n_steps,tp", [(30, [0.0, 30.0, 60.0, 90.0, 120.0]), (17, [0.0, 10.0, 45.0, 50.0, 120.0]),
                                          (60, [0.0, 15.0, 30.0, 45.0, 60.0, 75.0, 90.0, 120.0]), (5, [0.0, 120.0]),
                                          (1, [0.0, 60.0, 120.0])])
-def test_cpep_general_time_grids(n_steps, tp):
+@pytest.mark.parametrize("arch", [(2, 4, 2), (2, 6, 2)])
+def test_cpep_general_time_grids(n_steps, tp, arch):
     """Irregular observation times / step counts: observations inside, at the end of, and sharing a step; T=2;
-    a single step holding every observation."""
+    a single step holding every observation.  Width 6 runs the layer-1 exponent table: steps straddling glucose
+    knots, runs of one step, pieces shorter than a step."""
     import c_oracle as co
     import cude_oracle as o
     from cude.engine import Engine
-    arch, N = (2, 4, 2), 129
+    N = 129
     rng = np.random.default_rng(4)
     tp = np.array(tp)
     age, t2 = rng.uniform(20, 79, N), rng.random(N) < 0.4
@@ -217,6 +219,33 @@ def test_cpep_general_time_grids(n_steps, tp):
     assert np.max(np.abs(g_nn - ref["g_nn"])) < 1e-9 * np.max(np.abs(ref["g_nn"]))
     assert np.max(np.abs(g_cond - ref["g_beta"])) < 1e-9 * np.max(np.abs(ref["g_beta"]))
     eng.close()
+
+
+@pytest.mark.parametrize("scale", [1.0, 6.0, 40.0])
+def test_exponent_table_matches_direct_exponentials(scale, monkeypatch):
+    """The layer-1 exponent recurrence (anchor x tabulated factor) against the same kernel with the table switched
+    off, including saturated first-layer units (weights x40: |z| far beyond the tanh clamp) and n_state 2 / 3."""
+    from cude.engine import Engine
+    c = make_cpep_case(700, (2, 6, 2), nn_scale=1.0)
+    nn = c["nn"].copy()
+    nn[:18] *= scale                                   # first layer: W1 (12) and b1 (6)
+    out = {}
+    for mode in ("table", "direct"):
+        if mode == "direct":
+            monkeypatch.setenv("CUDE_NO_EXPTAB", "1")
+        monkeypatch.setenv("CUDE_CPEP_PATH", "1")      # the fused one-lane kernel at this small size
+        eng = Engine("cpep", (2, 6, 2), n_steps=30, n_state=3)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(nn, c["beta"])
+        f = eng.forward(want_sse=True, want_traj=True)
+        out[mode] = (f["traj"], f["sse"]) + eng.loss_grad()
+        eng.close()
+    t, d = out["table"], out["direct"]
+    assert np.max(np.abs(t[0] - d[0])) <= 1e-11 * np.max(np.abs(d[0]))
+    assert np.allclose(t[1], d[1], rtol=1e-10, atol=1e-14)
+    assert abs(t[2] - d[2]) <= 1e-11 * abs(d[2])
+    assert np.max(np.abs(t[3] - d[3])) <= 1e-9 * np.max(np.abs(d[3]))
+    assert np.max(np.abs(t[4] - d[4])) <= 1e-9 * np.max(np.abs(d[4]))
 
 
 def test_argument_errors_are_statuses():

@@ -17,7 +17,7 @@ _lib.LIB_PATH = os.path.join(ROOT, "tools", "abl_so", variant + ".so")
 from cude.engine import Engine  # noqa: E402
 
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 125000
-arch = (2, 6, 2)
+arch = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else (2, 6, 2)
 tp, G, cp, age, t2, bt, rng = o.synthetic_cpep_population(N)
 nn = o.glorot_params(arch, 1)
 eng = Engine("cpep", arch, n_steps=30, n_state=3)
@@ -30,4 +30,10 @@ eng.set_kernel_timing(True)
 for _ in range(30):
     eng.adam_step(want_loss=False)
 ms, n = eng.kernel_time_ms()
-print(f"{variant:10s} N={N} grad kernel {ms:.4f} ms  loss {eng.adam_step():.12f}")
+import time  # noqa: E402
+eng.forward()
+t0 = time.perf_counter()
+for _ in range(20):
+    eng.forward()
+fwd_ms = (time.perf_counter() - t0) / 20 * 1e3
+print(f"{variant:10s} arch={arch} N={N} grad kernel {ms:.4f} ms  forward call {fwd_ms:.4f} ms  loss {eng.adam_step():.12f}")
