@@ -71,6 +71,27 @@ def test_fixed_network_beta_estimation_recovers_stored_betas():
     api.clear_cache()
 
 
+def test_covariate_model_beta_estimation_recovers_stored_betas():
+    """CPeptideConditionalCovariateUDEModel (src/c-peptide-models.jl:196-220, network input [dG, exp(beta), age])
+    through the GPU path: with a stored covariate network of c-peptide/07-covariate-inclusion.jl the per-subject
+    refit reproduces that run's stored training betas (subjects of the reference's prepared train set)."""
+    from scipy.optimize import linear_sum_assignment
+    from cude import api
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    net = api.chain(4, 2, "tanh", input_dims=3)
+    models = [api.CPeptideConditionalCovariateUDEModel(g["glucose"][i], g["timepoints"], g["ages"][i], net,
+                                                       g["cpeptide"][i], g["t2dm"][i]) for i in range(len(g["ages"]))]
+    k = int(g["best_model_index_cov"]) - 1
+    beta_hat, sse = api.estimate_conditional(models, g["timepoints"], g["cpeptide"], g["nn_3x4x4x1_cov"][k],
+                                             lower=-4.0, upper=3.0, n_steps=30)
+    idx = np.flatnonzero(np.isin(g["subject_no"], g["train_subject_numbers"]))
+    cost = np.abs(g["betas_train_cov"][k][:, None] - beta_hat[None, idx])
+    r, c = linear_sum_assignment(cost)
+    assert np.median(cost[r, c]) < 5e-3 and np.quantile(cost[r, c], 0.9) < 0.1
+    assert np.mean(sse[idx[c]]) < 0.5
+    api.clear_cache()
+
+
 def test_population_training_decreases_loss():
     """train(models, timepoints, data, rng): screening -> Adam -> L-BFGS (parameter-estimation.jl:340-386)."""
     from cude import api

@@ -77,6 +77,50 @@ def test_cpeptide_stored_betas_are_recovered():
     assert np.mean(sse[idx[c2]]) < 0.4
 
 
+def _match_in_train(g, stored, beta_hat):
+    idx = np.flatnonzero(np.isin(g["subject_no"], g["train_subject_numbers"]))
+    cost = np.abs(stored[:, None] - beta_hat[None, idx])
+    r, c = linear_sum_assignment(cost)
+    return cost[r, c], idx[c]
+
+
+def test_covariate_model_stored_betas_are_recovered():
+    """Covariate cUDE (3 -> 4 -> 4 -> 1, network input [dG, exp(beta), age] with the age in years,
+    src/c-peptide-models.jl:96-104; stored run of c-peptide/07-covariate-inclusion.jl:59-65): refitting beta per
+    subject with a stored network reproduces the stored training betas.  Negative control: feeding the age and
+    exp(beta) in the other order does not."""
+    import c_oracle as co
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    k = int(g["best_model_index_cov"]) - 1
+    nn, stored = g["nn_3x4x4x1_cov"][k], g["betas_train_cov"][k]
+    N = g["glucose"].shape[0]
+
+    def refit(weights):
+        def sse(beta):
+            return co.cpep(g["timepoints"], g["glucose"], g["cpeptide"], g["ages"], g["t2dm"], (3, 4, 2), weights,
+                           beta, 30, 2, want_grad=False, covariate=True)["sse"]
+        return _argmin_1d(_Sse(sse, N), -4.0, 3.0)
+    beta_hat, sse = refit(nn)
+    d, who = _match_in_train(g, stored, beta_hat)
+    assert np.median(d) < 5e-3 and np.quantile(d, 0.9) < 0.1, (np.median(d), np.quantile(d, 0.9))
+    assert np.mean(sse[who]) < 0.5
+    swapped = nn.copy()                                  # columns 1 and 2 of W1 (4 x 3, column-major) exchanged
+    swapped[4:8], swapped[8:12] = nn[8:12], nn[4:8]
+    beta_bad, sse_bad = refit(swapped)
+    d_bad, who_bad = _match_in_train(g, stored, beta_bad)
+    assert np.median(d_bad) > 0.05 or np.mean(sse_bad[who_bad]) > 1.0
+
+
+def test_sigma_run_stored_betas_are_recovered():
+    """A second stored training run of the 2 -> 4 -> 4 -> 1 model (source_data/cude_neural_parameters_sigma.jld2)."""
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    k = int(g["best_model_index_sigma"]) - 1
+    beta_hat, sse = _cpep_refit(g["nn_2x4x4x1_sigma"][k], g)
+    d, who = _match_in_train(g, g["betas_train_sigma"][k], beta_hat)
+    assert np.median(d) < 5e-3 and np.quantile(d, 0.9) < 3e-2
+    assert np.mean(sse[who]) < 0.5
+
+
 def test_cpeptide_row_major_layout_is_rejected():
     """Negative control: reading the weight matrices row-major destroys the match (pins the layout)."""
     g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))

@@ -53,12 +53,21 @@ def main():
     nn = np.stack(cude["parameters"])
     betas = np.stack(cude["betas"])
     legacy = jld2.load(os.path.join(REF, "source_data/neural_network_parameters.jld2"))["parameters"]
+    # covariate model (3 -> 4 -> 4 -> 1, inputs [dG, exp(beta), age]; c-peptide/07-covariate-inclusion.jl:59-65) and
+    # the run of the 2 -> 4 -> 4 -> 1 model stored as cude_neural_parameters_sigma.jld2
+    cov = jld2.load(os.path.join(REF, "source_data/cude_covariate_neural_parameters_2.jld2"))
+    sig = jld2.load(os.path.join(REF, "source_data/cude_neural_parameters_sigma.jld2"))
+    assert cov["width"] == 4 and cov["depth"] == 2 and sig["width"] == 4 and sig["depth"] == 2
     np.savez_compressed(os.path.join(OUT, "ohashi_cude.npz"), subject_no=subject_no, glucose=glucose,
                         cpeptide=cpeptide, ages=ages, t2dm=(types == "T2DM"), types=types,
                         timepoints=np.array([0.0, 30.0, 60.0, 90.0, 120.0]), nn_2x4x4x1=nn, betas_train=betas,
                         nn_2x6x6x1_legacy=legacy, train_subject_numbers=prepared["train"]["subject_numbers"],
                         test_subject_numbers=prepared["test"]["subject_numbers"],
-                        best_model_index=np.int64(cude["best_model_index"]))          # 1-based, as stored
+                        best_model_index=np.int64(cude["best_model_index"]),          # 1-based, as stored
+                        nn_3x4x4x1_cov=np.stack(cov["parameters"]), betas_train_cov=np.stack(cov["betas"]),
+                        best_model_index_cov=np.int64(cov["best_model_index"]),
+                        nn_2x4x4x1_sigma=np.stack(sig["parameters"]), betas_train_sigma=np.stack(sig["betas"]),
+                        best_model_index_sigma=np.int64(sig["best_model_index"]))
     supp = jld2.load(os.path.join(REF, "suppression/results/lambda=0.0.jld2"))
     snn = np.stack(supp["neural_parameters"])
     group = supp["group_data"]
