@@ -136,6 +136,48 @@ def test_real_data_symbolic_fit_matches_the_network_model():
     assert abs(spearmanr(k, beta)[0]) > 0.95
 
 
+def test_external_data_set_of_the_reference():
+    """c-peptide/04-symreg-external.jl: the symbolic model on the 20 subjects of the Fujita data (14 irregularly
+    spaced observations from -10 to 240 min, glucose falling below its basal value at the end -> the dG < 0
+    branch).  Parity of loss / gradient / trajectory with the oracle on that grid, and the per-subject fit."""
+    import os
+    import cude_oracle as o
+    from cude import api
+    from cude.engine import Engine
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fujita.npz")))
+    tp, N = g["timepoints"], g["glucose"].shape[0]
+    assert tp[0] == -10.0 and tp.size == 14 and np.any(g["glucose"] < g["glucose"][:, :1])
+    t2 = np.zeros(N, bool)
+    pop = o.CPepPopulation(tp, g["glucose"], g["cpeptide"], g["ages"], t2)
+    k = np.linspace(15.0, 120.0, N)
+    n_steps = 100                                  # h = 2.5 min: every observation time is a step boundary
+    ref_loss, ref_gp, ref_gk, ref_sse = o.cpep_loss_grad_torch(np.array([1.78]), k, pop, o.SYMBOLIC, n_steps, 2, "raw")
+    ref_traj = o.cpep_forward(np, np.array([1.78]), k, pop, o.SYMBOLIC, n_steps, 2, "raw")
+    eng = Engine("cpep_sym", n_steps=n_steps, n_state=2, cond_space="raw")
+    eng.set_population_cpep(tp, g["glucose"], g["cpeptide"], g["ages"], t2)
+    eng.set_params([1.78], k)
+    out = eng.forward(want_sse=True, want_traj=True)
+    loss, g_p, g_k = eng.loss_grad()
+    eng.close()
+    assert abs(loss - ref_loss) <= 1e-10 * ref_loss and np.allclose(out["sse"], ref_sse, rtol=1e-10)
+    for t in range(tp.size):
+        assert np.allclose(out["traj"][0, t], ref_traj[t][0], rtol=1e-10, atol=1e-13)
+    assert np.max(np.abs(g_p - ref_gp)) <= 1e-9 * np.max(np.abs(ref_gp))
+    assert np.max(np.abs(g_k - ref_gk)) <= 1e-9 * np.max(np.abs(ref_gk))
+    # the script's fit: CPeptideODEModel(glucose, timepoints, 29.0, production, cpeptide, false), k in [0, 1000]
+    models = [api.CPeptideODEModel(g["glucose"][i], tp, 29.0, api.production, g["cpeptide"][i], False) for i in range(N)]
+    sols = api.train_symbolic(models, tp, g["cpeptide"], n_steps=n_steps)
+    k_fit = np.array([s.u.ode[0] for s in sols])
+    sse_fit = np.array([s.u.sigma for s in sols]) ** 2 * tp.size
+    assert np.all((k_fit > 0) & (k_fit <= 1000.0)) and np.all(np.isfinite(sse_fit))
+    # each fitted k is a (local) minimiser of that subject's SSE: the oracle's SSE is not lower 2 % to either side
+    for sign in (0.98, 1.02):
+        nearby = o.cpep_loss(np, np.array([1.78]), k_fit * sign, pop, o.SYMBOLIC, n_steps, 2, "raw")[1]
+        inside = (k_fit * sign < 1000.0) & (k_fit < 999.0)
+        assert np.all(nearby[inside] >= sse_fit[inside] * (1 - 1e-9))
+    api.clear_cache()
+
+
 def test_api_mirror_fit_recovers_k_and_saem_runs():
     import cude_oracle as o
     from cude import api

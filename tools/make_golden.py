@@ -78,6 +78,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ohashi_production.npz"), beta=prod["Beta"].to_numpy(dtype=np.float64),
                         glucose=prod["Glucose"].to_numpy(dtype=np.float64),
                         production=prod["Production"].to_numpy(dtype=np.float64))
+    # external data set of c-peptide/04-symreg-external.jl (20 subjects, 14 irregular time points from -10 min)
+    fuj = jld2.load(os.path.join(REF, "data/fujita.jld2"))
+    np.savez_compressed(os.path.join(OUT, "fujita.npz"), glucose=fuj["glucose"], cpeptide=fuj["cpeptide"],
+                        timepoints=fuj["timepoints"].astype(np.float64), ages=fuj["ages"].astype(np.float64))
     shutil.copyfile(os.path.join(REF, "source_data/ude_neural_parameters.jld2"),
                     os.path.join(OUT, "ude_neural_parameters.jld2"))
     print(glucose.shape, nn.shape, betas.shape, snn.shape, group.shape, "best model", cude["best_model_index"])
