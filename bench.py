@@ -140,9 +140,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # CUDE_BENCH_REHEARSAL=1 (development only): several ranks share the GPUs that exist and torch.distributed uses
+    # gloo, so that the multi-rank control flow of this script can be exercised on a 1-GPU box
+    rehearsal = os.environ.get("CUDE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
+    ctl = "cpu" if rehearsal else "cuda"          # device of the small control tensors handed to torch.distributed
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from cude.engine import Engine   # after torch: one shared HIP runtime
 
@@ -154,7 +163,7 @@ def main():
     if world > 1:
         # Every rank issues the same sequence of collectives whatever fails locally: first agree that librccl
         # is loadable everywhere (each rank draws an id; only rank 0's is used), then build the communicator.
-        ok = torch.ones(1, device="cuda")
+        ok = torch.ones(1, device=ctl)
         my_id = bytes(128)
         if os.environ.get("CUDE_BENCH_TRANSPORT", "rccl") != "rccl":
             ok.zero_()
@@ -167,7 +176,7 @@ def main():
                 ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() != 0:
-            uid = torch.tensor(list(my_id), dtype=torch.uint8, device="cuda")
+            uid = torch.tensor(list(my_id), dtype=torch.uint8, device=ctl)
             dist.broadcast(uid, 0)
             try:
                 eng.comm_init(world, rank, bytes(uid.cpu().tolist()))
@@ -198,7 +207,7 @@ def main():
         if transport == "rccl":
             return eng.adam_step(want_loss=want_loss)
         part, _ = eng.loss_grad_partial()
-        t = torch.from_numpy(part).cuda()
+        t = torch.from_numpy(part).to(ctl)
         dist.all_reduce(t)
         return eng.adam_apply(t.cpu().numpy())
 
@@ -230,7 +239,7 @@ def main():
     dt_async = time.perf_counter() - t1
 
     if world > 1:
-        t = torch.tensor([dt, dt_async, kern_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_async, kern_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_async, kern_ms = (float(v) for v in t.cpu())
 
