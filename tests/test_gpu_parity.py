@@ -248,6 +248,60 @@ def test_exponent_table_matches_direct_exponentials(scale, monkeypatch):
     assert np.max(np.abs(t[4] - d[4])) <= 1e-9 * np.max(np.abs(d[4]))
 
 
+def test_size_limits_and_missing_values():
+    """Edges of the domain: the maximum number of observation times (32) against the oracle, T = 33 and an empty
+    population rejected with a status, a one-subject population, and missing values (NaN in a subject's glucose /
+    c-peptide series -- the reference drops such subjects during data preparation, c-peptide/00-prepare-data.jl)
+    failing only that subject (loss = Inf, the others' SSE finite and unchanged)."""
+    import c_oracle as co
+    import cude_oracle as o
+    from cude.engine import Engine
+    from cude._lib import CudeError
+    rng = np.random.default_rng(12)
+    arch, N, T = (2, 6, 2), 70, 32
+    tp = np.cumsum(rng.uniform(1.0, 9.0, T))
+    tp -= tp[0]
+    age, t2 = rng.uniform(20, 79, N), rng.random(N) < 0.4
+    G = 5.0 + np.abs(rng.standard_normal((N, T))).cumsum(1) * 0.3
+    obs = 0.5 + rng.random((N, T))
+    nn, beta = o.glorot_params(arch, 3), rng.normal(-0.6, 0.5, N)
+    ref = co.cpep(tp, G, obs, age, t2, arch, nn, beta, 64, 2)
+    eng = Engine("cpep", arch, n_steps=64, n_state=2)
+    eng.set_population_cpep(tp, G, obs, age, t2)
+    eng.set_params(nn, beta)
+    loss, g_nn, g_cond = eng.loss_grad()
+    assert abs(loss - ref["loss"]) < 1e-10 * ref["loss"]
+    assert np.max(np.abs(g_nn - ref["g_nn"])) < 1e-9 * np.max(np.abs(ref["g_nn"]))
+    assert np.max(np.abs(g_cond - ref["g_beta"])) < 1e-9 * np.max(np.abs(ref["g_beta"]))
+    clean = eng.forward(want_sse=True)["sse"]
+    # missing values
+    G2, obs2 = G.copy(), obs.copy()
+    G2[7, 5] = np.nan
+    obs2[30, 31] = np.nan
+    eng.set_population_cpep(tp, G2, obs2, age, t2)
+    eng.set_params(nn, beta)
+    out = eng.forward(want_sse=True)
+    bad = np.zeros(N, bool)
+    bad[[7, 30]] = True
+    assert out["loss"] == np.inf and eng.n_failed() == 2
+    assert not np.any(np.isfinite(out["sse"][bad])) and np.array_equal(out["sse"][~bad], clean[~bad])
+    # one subject
+    eng.set_population_cpep(tp, G[:1], obs[:1], age[:1], t2[:1])
+    eng.set_params(nn, beta[:1])
+    one = eng.forward(want_sse=True)
+    assert abs(one["sse"][0] - clean[0]) <= 1e-12 * clean[0] and abs(one["loss"] - clean[0]) <= 1e-12 * clean[0]
+    # limits
+    with pytest.raises(CudeError):
+        eng.set_population_cpep(np.arange(33.0), np.ones((2, 33)), np.ones((2, 33)), np.ones(2) * 40, np.zeros(2))
+    with pytest.raises((CudeError, ValueError)):
+        eng.set_population_cpep(tp, G[:0], obs[:0], age[:0], t2[:0])
+    eng.close()
+    with pytest.raises(CudeError):
+        Engine("cpep_sym", (1, 4, 2))                  # the symbolic model has no network
+    with pytest.raises(CudeError):
+        Engine("cpep", (2, 6, 2), n_steps=0)
+
+
 def test_argument_errors_are_statuses():
     from cude.engine import Engine
     from cude._lib import CudeError
