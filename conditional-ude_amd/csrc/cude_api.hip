@@ -171,6 +171,8 @@ struct DevBuf {
         if (e == hipSuccess) n = count;
         return e;
     }
+    // grow-only variant for scratch that is reused across calls
+    hipError_t reserve(size_t count) { return count <= n ? hipSuccess : resize(count); }
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
@@ -220,6 +222,9 @@ struct cude_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double host_red[3];
+    // scratch of cude_multistart_loss_grad (kept between calls: it is called once per optimiser iteration)
+    DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt;
+    std::vector<double> ms_host;
 #ifdef CUDE_WAVE_TIMING
     DevBuf<long long> dbg;
 #endif
@@ -845,6 +850,89 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
             const double sum = h_out[2 * k], nf = h_out[2 * k + 1];
             losses[k0 + k] = (nf > 0.0 || !std::isfinite(sum)) ? std::numeric_limits<double>::infinity()
                                                              : sum / c->n_global + c->cfg.lambda * reg;
+        }
+    }
+    return CUDE_OK;
+}
+
+int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_sets, const double* cond_sets,
+                                  double* losses, double* g_nn_sets, double* g_cond_sets) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (n_sets < 1 || !nn_sets || !cond_sets || !losses || !g_nn_sets || !g_cond_sets)
+        return fail(CUDE_ERR_ARG, "null/empty input");
+    const int P = c->P, S = c->cfg.n_steps;
+    const int64_t N = c->N, nb = c->nblocks;
+    const double h = (c->tp.back() - c->tp.front()) / S;
+    const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
+    // sets per launch: bounded by the grid's y dimension and ~512 MB of scratch
+    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (supp ? (6.0 * S + 1) * 3 * N : 0.0));
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_sets, 32768), (int64_t)(512e6 / per_set)));
+    HIP_TRY(c->ms_nn.reserve((size_t)chunk * P));
+    HIP_TRY(c->ms_cond.reserve((size_t)chunk * N));
+    HIP_TRY(c->ms_gcond.reserve((size_t)chunk * N));
+    HIP_TRY(c->ms_part.reserve((size_t)chunk * nb * (P + 2)));
+    HIP_TRY(c->ms_out.reserve((size_t)chunk * (P + 2)));
+    if (supp) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * (6 * S + 1) * 3 * N));
+    c->ms_host.resize((size_t)chunk * (P + 2));
+    for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
+        const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
+        HIP_TRY(hipMemcpyAsync(c->ms_nn.p, nn_sets + k0 * P, kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->ms_cond.p, cond_sets + k0 * N, kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (!supp) {
+            cude::CpepArgs a{};
+            a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
+            a.N = N;
+            a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
+            a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+            a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
+            a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+            a.stepk = c->stepk.p; a.stepd = c->stepd.p;
+            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+            a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));     // one-lane kernel: the sets fill the chip
+        } else {
+            cude::SuppArgs a{};
+            a.N = N;
+            a.data = c->data.p; a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
+            a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+            for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+            a.ckpt = c->ms_ckpt.p; a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
+        }
+        HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, c->ms_out.p, c->stream, (int)kn));
+        if (c->comm && (rc = allreduce_dev(c, c->ms_out.p, (size_t)kn * (P + 2)))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->ms_host.data(), c->ms_out.p, kn * (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(g_cond_sets + k0 * N, c->ms_gcond.p, kn * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int64_t k = 0; k < kn; k++) {
+            const double* r = c->ms_host.data() + k * (P + 2);
+            const double* w = nn_sets + (k0 + k) * P;
+            double* g = g_nn_sets + (k0 + k) * P;
+            // L2 term in the arithmetic of l2_term_kernel (64 strided partial sums, xor-butterfly, fma), so that a
+            // set's loss and gradient are bit-identical to cude_loss_grad at the same parameters
+            double sum = r[P];
+            if (c->cfg.lambda != 0.0) {
+                double part[64], tmp[64];
+                for (int l = 0; l < 64; l++) {
+                    part[l] = 0.0;
+                    for (int q = l; q < P; q += 64) part[l] = std::fma(w[q], w[q], part[l]);
+                }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    for (int l = 0; l < 64; l++) tmp[l] = part[l] + part[l ^ off];
+                    std::memcpy(part, tmp, sizeof(part));
+                }
+                sum = std::fma(c->cfg.lambda * c->n_global, part[0], sum);
+                for (int q = 0; q < P; q++) g[q] = std::fma(2.0 * c->cfg.lambda, w[q], r[q]);
+            } else {
+                for (int q = 0; q < P; q++) g[q] = r[q];
+            }
+            losses[k0 + k] = (r[P + 1] > 0.0 || !std::isfinite(sum)) ? std::numeric_limits<double>::infinity()
+                                                                    : sum / c->n_global;
         }
     }
     return CUDE_OK;

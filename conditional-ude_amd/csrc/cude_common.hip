@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
                                                               int stride, int col0, double* __restrict__ out) {
     __shared__ double s[256];
     const int q = col0 + blockIdx.x;
+    partials += (int64_t)blockIdx.y * nblocks * stride;      // multi-start: one row of the grid per parameter set
+    out += (int64_t)blockIdx.y * stride;
     double v = 0.0;
     for (int64_t b = threadIdx.x; b < nblocks; b += 256) v += partials[b * stride + q];
     s[threadIdx.x] = v;
@@ -58,8 +60,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol), dim3(256), 0, s, partials, nblocks, stride, col0, out);
+                              hipStream_t s, int n_sets) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol, n_sets), dim3(256), 0, s, partials, nblocks, stride, col0,
+                       out);
     return hipGetLastError();
 }
 

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         }
         g[P] = red_loss;
         g[P + 1] = red_fail;
-        if (active) a.g_cond[i] = dcond;
+        if (active) a.g_cond[set * a.set_stride_cond + i] = dcond;
         block_reduce_store<P + 2>(g, s_red, out, lane);
 #ifdef CUDE_WAVE_TIMING
         if (a.dbg != nullptr && lane == 0 && blockIdx.y == 0) {

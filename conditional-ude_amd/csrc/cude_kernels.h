@@ -43,10 +43,10 @@ struct CpepArgs {
     double* sse;             // [N] or nullptr
     double* traj;            // [NS x T x N] column-major or nullptr
     double* auc;             // [N] or nullptr (NS == 3: cumulative secretion at t_end)
-    double* g_cond;          // [N] (grad)
+    double* g_cond;          // [n_sets][N] (grad)
     double* partials;        // [n_sets][nblocks][P+2]
-    // multi-start screening (forward only): n_sets parameter sets, set k reads nn + k*set_stride_nn and
-    // cond + k*set_stride_cond (and writes sse + k*set_stride_cond); 0/0/0 for the single-set path
+    // multi-start evaluation: n_sets parameter sets in the grid's y dimension, set k reads nn + k*set_stride_nn and
+    // cond + k*set_stride_cond (and writes sse / g_cond + k*set_stride_cond); 0/0/0 for the single-set path
     int32_t n_sets;
     int64_t set_stride_nn, set_stride_cond;
     int32_t cond_raw;        // symbolic model only: 1 = k is the conditional itself, 0 = k = exp(conditional)
@@ -83,12 +83,12 @@ struct SuppArgs {
     int32_t T, S;
     double h, inv_n;
     double iscale2[3];       // 1/scale_s^2
-    double* ckpt;            // [6S+1][3][N] stage inputs (linearisation points of the reverse sweep)
+    double* ckpt;            // [n_sets][6S+1][3][N] stage inputs (linearisation points of the reverse sweep)
     double* sse;             // [N] or nullptr (already divided by scale^2)
     double* traj;            // [3 x T x N] column-major or nullptr
-    double* g_cond;          // [N]
+    double* g_cond;          // [n_sets][N]
     double* partials;        // [n_sets][nblocks][P+2]
-    int32_t n_sets;          // multi-start screening (forward only), as CpepArgs
+    int32_t n_sets;          // multi-start evaluation, as CpepArgs
     int64_t set_stride_nn, set_stride_cond;
 };
 
@@ -99,9 +99,10 @@ bool cpep_shape_supported(const NetShape& net, int n_state);
 bool supp_shape_supported(const NetShape& net);
 
 // common kernels
-// out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol)
+// out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1
+// the same for every set k: partials + k*nblocks*stride -> out + k*stride
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s);
+                              hipStream_t s, int n_sets = 1);
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s);

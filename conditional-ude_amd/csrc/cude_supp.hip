@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     ciptr_t obs_step = as_const(a.obs_step);
     const int S = a.S, T = a.T;
     const double h = a.h;
+    double* ckpt = GRAD ? a.ckpt + set * ((int64_t)(6 * S + 1) * 3 * N) : nullptr;   // one scratch per parameter set
 #define KROW(j, s) s_K[((j) * 3 + (s)) * kBlock + lane]
 #define YROW(j, s) s_Y[((j) * 3 + (s)) * kBlock + lane]
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
         }
         if (GRAD) {      // linearisation point of evaluation e = 6n+st, reloaded by the reverse sweep
 #pragma unroll
-            for (int s = 0; s < 3; s++) a.ckpt[((int64_t)e * 3 + s) * N + i] = u[s];
+            for (int s = 0; s < 3; s++) ckpt[((int64_t)e * 3 + s) * N + i] = u[s];
         }
         double du[3];
         R::f(p, c, u, du);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
             double u[3], kb[3], ub[3];
             if (idx > 0) {
 #pragma unroll
-                for (int s = 0; s < 3; s++) { u[s] = a.ckpt[((int64_t)idx * 3 + s) * N + i]; kb[s] = KROW(st, s); }
+                for (int s = 0; s < 3; s++) { u[s] = ckpt[((int64_t)idx * 3 + s) * N + i]; kb[s] = KROW(st, s); }
             } else {
 #pragma unroll
                 for (int s = 0; s < 3; s++) { u[s] = y0[s]; kb[s] = kap[s]; }
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
         }
         g[P] = red_loss;
         g[P + 1] = red_fail;
-        if (active) a.g_cond[i] = dcond;
+        if (active) a.g_cond[set * a.set_stride_cond + i] = dcond;
         block_reduce_store<P + 2>(g, s_red, out, lane);
     }
 #undef KROW

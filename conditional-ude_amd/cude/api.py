@@ -30,7 +30,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from .engine import Engine
-from .lbfgs import lbfgs
+from .lbfgs import lbfgs, lbfgs_batched
 
 DEFAULT_STEPS = 30
 
@@ -321,13 +321,56 @@ def _adam_then_lbfgs(eng, nn0, cond0, adam_iters, lbfgs_iters, lr, callback=None
     return res["x"][:P], res["x"][P:], res["f"]
 
 
+def _batched_adam_then_lbfgs(eng, nn_inits, cond_inits, adam_iters, lbfgs_iters, lr, traces=None):
+    """The K selected restarts trained SIDE BY SIDE instead of one after the other (the reference's loop,
+    src/parameter-estimation.jl:372-383 / suppression_model.jl:140-170): every optimiser iteration evaluates the K
+    current points with one cude_multistart_loss_grad launch.  Adam (Optimisers.jl update rule) is vectorised over
+    the restarts; the K L-BFGS runs are the serial algorithm driven in lock step (cude.lbfgs.lbfgs_batched), so each
+    restart follows the path it would follow alone.  A restart whose loss becomes non-finite during Adam is
+    dropped, as the reference skips a failed optimisation.  Returns a list of (nn, cond, objective) or None."""
+    X = np.concatenate([np.asarray(nn_inits, dtype=np.float64), np.asarray(cond_inits, dtype=np.float64)], axis=1)
+    K, P = X.shape[0], eng.P
+    alive = np.ones(K, bool)
+    M, V = np.zeros_like(X), np.zeros_like(X)
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    for t in range(1, adam_iters + 1):
+        f, g_nn, g_cond = eng.multistart_loss_grad(X[:, :P], X[:, P:])
+        alive &= np.isfinite(f)
+        if traces is not None:
+            for k in range(K):
+                if alive[k]:
+                    traces[k].append(float(f[k]))
+        G = np.concatenate([g_nn, g_cond], axis=1)
+        G[~alive] = 0.0
+        M = b1 * M + (1 - b1) * G
+        V = b2 * V + (1 - b2) * G * G
+        step = lr * (M / (1 - b1 ** t)) / (np.sqrt(V / (1 - b2 ** t)) + eps)
+        X[alive] -= step[alive]
+    if not alive.any():
+        return [None] * K
+    idx = np.flatnonzero(alive)
+    Xa = X[idx]
+
+    def fg_batch(Xq):
+        f, g_nn, g_cond = eng.multistart_loss_grad(Xq[:, :P], Xq[:, P:])
+        return f, np.concatenate([g_nn, g_cond], axis=1)
+    cbs = None if traces is None else [(lambda _x, l, k=k: traces[k].append(float(l)) and False) for k in idx]
+    res = lbfgs_batched(fg_batch, Xa, maxiters=lbfgs_iters, callbacks=cbs)
+    out = [None] * K
+    for k, r in zip(idx, res):
+        out[k] = (r["x"][:P], r["x"][P:], r["f"])
+    return out
+
+
 def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_000, selected_initials=25,
           lhs_lower_bound=-2.0, lhs_upper_bound=0.0, n_conditional_parameters=1, number_of_iterations_adam=1000,
           number_of_iterations_lbfgs=1000, learning_rate_adam=1e-2, initial_beta=-2.0, lbfgs_lower_bound=-4.0,
-          lbfgs_upper_bound=1.0, lbfgs_iterations=1000, n_steps=None):
+          lbfgs_upper_bound=1.0, lbfgs_iterations=1000, n_steps=None, side_by_side=True):
     """Two methods of the reference, selected by the 4th argument as Julia's dispatch does:
     * rng (numpy Generator): population training, unknown network (:340-386): LHS + init screening of
-      `initial_guesses` candidates (forward-only), best `selected_initials` -> Adam -> L-BFGS.
+      `initial_guesses` candidates (forward-only), best `selected_initials` -> Adam -> L-BFGS; the selected
+      restarts are trained side by side (one launch per optimiser iteration for all of them) unless
+      side_by_side=False.
     * array of network parameters: per-subject estimation of the conditional parameter with the network
       frozen (:272-288)."""
     if isinstance(rng_or_nn, np.random.Generator):
@@ -340,6 +383,18 @@ def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_00
         losses = eng.multistart_forward(np.stack(nn_inits), np.ascontiguousarray(ode_inits.T))
         order = np.argsort(losses, kind="stable")[:selected_initials]
         sols = []
+        if side_by_side and len(order) > 1:
+            fits = _batched_adam_then_lbfgs(eng, np.stack([nn_inits[k] for k in order]), ode_inits[:, order].T,
+                                            number_of_iterations_adam, number_of_iterations_lbfgs, learning_rate_adam)
+            for fit in fits:
+                if fit is None:
+                    print("Optimization failed... Skipping")
+                    continue
+                nn, cond, obj = fit
+                sols.append(OptimizationSolution(
+                    u=ComponentArray(neural=nn, conditional=np.repeat(cond[:, None], n_conditional_parameters, 1)),
+                    objective=obj))
+            return sols
         for k in order:
             try:
                 nn, cond, obj = _adam_then_lbfgs(eng, nn_inits[k], ode_inits[:, k], number_of_iterations_adam,
@@ -480,13 +535,27 @@ def simul(p, prob, individual_data, timepoints, *, n_steps=None):
 
 
 def fit_suppression_model(p_init, prob, data, timepoints, lam, *, select_best_n=1, adam_iters=2000, lbfgs_iters=2000,
-                          n_steps=None):
-    """fit_suppression_model (:132-177): screen all initials, keep the best n, Adam() [eta = 1e-3] then L-BFGS."""
+                          n_steps=None, side_by_side=True):
+    """fit_suppression_model (:132-177): screen all initials, keep the best n, Adam() [eta = 1e-3] then L-BFGS.
+    The kept restarts are trained side by side (one launch per optimiser iteration for all of them) unless
+    side_by_side=False."""
     pop = _supp_population(prob, data, timepoints, lam, n_steps)
     eng = pop.engine
     init_losses = eng.multistart_forward(np.stack([p.neural for p in p_init]), np.stack([p.theta for p in p_init]))
     best = np.argsort(init_losses, kind="stable")[:max(1, select_best_n)]
     sols, traces = [], []
+    if side_by_side and len(best) > 1:
+        traces = [[] for _ in best]
+        fits = _batched_adam_then_lbfgs(eng, np.stack([p_init[k].neural for k in best]),
+                                        np.stack([p_init[k].theta for k in best]), adam_iters, lbfgs_iters, 1e-3,
+                                        traces=traces)
+        for fit in fits:
+            if fit is None:
+                print("Optimization failed")
+                continue
+            nn, th, obj = fit
+            sols.append(OptimizationSolution(u=ComponentArray(theta=th, neural=nn), objective=obj))
+        return sols, traces
     for k in best:
         trace = []
         try:

@@ -132,6 +132,19 @@ class Engine:
         check(self._lib.cude_multistart_forward(self._h, nn.shape[0], _ptr(nn), _ptr(cd), _ptr(losses)))
         return losses
 
+    def multistart_loss_grad(self, nn_sets, cond_sets):
+        """Loss and gradient of K parameter sets in one launch (restarts trained side by side).
+        nn_sets: (K, P); cond_sets: (K, N) -> losses (K,), g_nn (K, P), g_cond (K, N)."""
+        nn = _f64(nn_sets)
+        cd = _f64(cond_sets)
+        if nn.ndim != 2 or nn.shape[1] != self.P or cd.shape != (nn.shape[0], self.N):
+            raise ValueError(f"expected nn_sets (K, {self.P}) and cond_sets (K, {self.N})")
+        K = nn.shape[0]
+        losses, g_nn, g_cond = np.empty(K), np.empty((K, self.P)), np.empty((K, self.N))
+        check(self._lib.cude_multistart_loss_grad(self._h, K, _ptr(nn), _ptr(cd), _ptr(losses), _ptr(g_nn),
+                                                  _ptr(g_cond)))
+        return losses, g_nn, g_cond
+
     def mh_estep(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0):
         """n_mc Metropolis-Hastings steps for every subject on the device (chain state = the context's
         conditional parameters, updated in place).  normals/uniforms: (n_mc, N).  Returns acceptance counts."""

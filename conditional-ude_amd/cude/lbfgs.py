@@ -4,13 +4,19 @@ Second training stage of the reference: `Optimization.solve(prob, LBFGS(linesear
 (src/parameter-estimation.jl:179-180; suppression/src/suppression_model.jl:168).  Optim.jl defaults are
 restated: memory m = 10, BackTracking(c_1 = 1e-4, rho_hi = 0.5, rho_lo = 0.1, quadratic/cubic
 interpolation order 3, initial step 1), gradient-norm stop g_tol = 1e-8.  Only vector algebra happens
-here; every loss/gradient value comes from the HIP engine through `fg`.
+here; every loss/gradient value comes from the HIP engine.
+
+The algorithm is written once, as a generator that YIELDS the points it wants evaluated and is SENT (f, g):
+  * `lbfgs(fg, x0)` drives one such generator with a callback -- the reference's serial use;
+  * `lbfgs_batched(fg_batch, X0)` drives K of them in lock step, handing all pending points to ONE batched
+    evaluation per round (cude_multistart_loss_grad: the restarts of `train` side by side).  Every problem sees
+    exactly the sequence of values it would see alone, so the batched run reproduces K serial runs.
 """
 import numpy as np
 
 
-def _backtracking(fg, x, f0, g0, d, alpha0=1.0, c1=1e-4, rho_hi=0.5, rho_lo=0.1, max_iter=50):
-    """LineSearches.BackTracking (order 3).  Returns (alpha, f, g, n_eval) or None when no finite
+def _backtracking(x, f0, g0, d, alpha0=1.0, c1=1e-4, rho_hi=0.5, rho_lo=0.1, max_iter=50):
+    """LineSearches.BackTracking (order 3) as a generator.  Returns (alpha, f, g, n_eval) or None when no finite
     decrease is found."""
     dphi0 = float(g0 @ d)
     if not (dphi0 < 0):
@@ -18,13 +24,13 @@ def _backtracking(fg, x, f0, g0, d, alpha0=1.0, c1=1e-4, rho_hi=0.5, rho_lo=0.1,
     a1, a2 = alpha0, alpha0
     phi1 = phi2 = f0
     n_eval = 0
-    f, g = fg(x + a2 * d)
+    f, g = yield x + a2 * d
     n_eval += 1
     # shrink until finite (the reference's solver returns Inf on failure)
     it = 0
     while not np.isfinite(f) and it < max_iter:
         a1, a2 = a2, a2 * 0.5
-        f, g = fg(x + a2 * d)
+        f, g = yield x + a2 * d
         n_eval += 1
         it += 1
     phi1, phi2 = phi2, f
@@ -49,15 +55,16 @@ def _backtracking(fg, x, f0, g0, d, alpha0=1.0, c1=1e-4, rho_hi=0.5, rho_lo=0.1,
             a_tmp = a2 * rho_hi
         a2 = min(max(a_tmp, a2 * rho_lo), a2 * rho_hi)
         phi1 = f
-        f, g = fg(x + a2 * d)
+        f, g = yield x + a2 * d
         n_eval += 1
     return a2, f, g, n_eval
 
 
-def lbfgs(fg, x0, maxiters=1000, m=10, g_tol=1e-8, callback=None):
-    """Minimise with L-BFGS.  fg(x) -> (f, g).  Returns dict(x, f, g, iterations, f_calls, converged)."""
+def lbfgs_steps(x0, maxiters=1000, m=10, g_tol=1e-8, callback=None):
+    """The L-BFGS iteration as a generator: yields points x, expects (f, g) to be sent back, returns
+    dict(x, f, g, iterations, f_calls, converged)."""
     x = np.array(x0, dtype=np.float64)
-    f, g = fg(x)
+    f, g = yield x
     calls = 1
     S, Y, RHO = [], [], []
     it = 0
@@ -75,7 +82,8 @@ def lbfgs(fg, x0, maxiters=1000, m=10, g_tol=1e-8, callback=None):
             b = rho * (y @ q)
             q += (a - b) * s
         d = -q
-        res = _backtracking(fg, x, f, g, d, alpha0=1.0 if S else min(1.0, 1.0 / max(np.linalg.norm(g), 1e-300)))
+        res = yield from _backtracking(x, f, g, d,
+                                       alpha0=1.0 if S else min(1.0, 1.0 / max(np.linalg.norm(g), 1e-300)))
         if res is None:
             if not S:
                 break
@@ -98,3 +106,38 @@ def lbfgs(fg, x0, maxiters=1000, m=10, g_tol=1e-8, callback=None):
             break
         converged = bool(np.max(np.abs(g)) <= g_tol) or abs(f_prev - f) == 0.0
     return dict(x=x, f=f, g=g, iterations=it, f_calls=calls, converged=converged)
+
+
+def lbfgs(fg, x0, maxiters=1000, m=10, g_tol=1e-8, callback=None):
+    """Minimise with L-BFGS.  fg(x) -> (f, g).  Returns dict(x, f, g, iterations, f_calls, converged)."""
+    gen = lbfgs_steps(x0, maxiters, m, g_tol, callback)
+    x = next(gen)
+    try:
+        while True:
+            f, g = fg(x)
+            x = gen.send((float(f), np.array(g, dtype=np.float64)))
+    except StopIteration as done:
+        return done.value
+
+
+def lbfgs_batched(fg_batch, X0, maxiters=1000, m=10, g_tol=1e-8, callbacks=None):
+    """K independent L-BFGS runs in lock step.  fg_batch(X[K, n]) -> (f[K], g[K, n]) evaluates one point per
+    problem; a problem that has finished keeps re-submitting its final point (its values are ignored), so the
+    batch shape is fixed.  callbacks: optional list of K per-problem callbacks (x, f) -> stop.  Returns the list of
+    the K result dicts of `lbfgs`."""
+    X0 = np.asarray(X0, dtype=np.float64)
+    K = X0.shape[0]
+    gens = [lbfgs_steps(X0[k], maxiters, m, g_tol, None if callbacks is None else callbacks[k]) for k in range(K)]
+    pending = np.stack([next(gn) for gn in gens])
+    results = [None] * K
+    while any(r is None for r in results):
+        f, g = fg_batch(pending)
+        for k in range(K):
+            if results[k] is not None:
+                continue
+            try:
+                pending[k] = gens[k].send((float(f[k]), np.array(g[k], dtype=np.float64)))
+            except StopIteration as done:
+                results[k] = done.value
+                pending[k] = done.value["x"]
+    return results

@@ -115,6 +115,18 @@ int32_t cude_forward(cude_ctx* ctx, double* loss, double* per_subject_sse, doubl
 int32_t cude_multistart_forward(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                                 double* losses);
 
+/* Restarts trained side by side: loss AND gradient of n_sets independent parameter sets over the resident
+ * population in one launch (the grid's second dimension is the set).  The reference trains its selected
+ * initial guesses one after the other (`for p in initials[selected] ... _optimize(...)`,
+ * src/parameter-estimation.jl:372-383; suppression_model.jl:140-170), each a serial chain of thousands of
+ * loss+gradient evaluations over a few dozen subjects -- one wave of work per evaluation; evaluating all restarts'
+ * current points together turns that latency-bound loop into a throughput-bound one.
+ * nn_sets[n_sets][P], cond_sets[n_sets][N] row-major in; losses[n_sets] (+Inf for a set with a failed subject,
+ * L2 term included), g_nn_sets[n_sets][P], g_cond_sets[n_sets][N] out -- exactly what cude_loss_grad returns for
+ * each set.  Does not touch the context's current parameters. */
+int32_t cude_multistart_loss_grad(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
+                                  double* losses, double* g_nn_sets, double* g_cond_sets);
+
 /* SAEM E-step on the device: n_mc Metropolis-Hastings steps of every subject's conditional parameter
  * (`mcmc_step` src/saem.jl:86-108, applied n_mcmc_steps times with the stochastic-approximation update of the
  * chain state :177-186).  The chain state is the context's conditional parameters (updated in place); the

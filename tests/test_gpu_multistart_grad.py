@@ -1,0 +1,97 @@
+"""cude_multistart_loss_grad: loss and gradient of K parameter sets in one launch, and the restarts of `train` /
+`fit_suppression_model` trained side by side on top of it."""
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+from conftest import make_cpep_case, make_supp_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("model", ["cpep", "cpep4", "supp", "sym"])
+def test_every_set_equals_its_own_loss_grad_call(model):
+    """Bitwise: the per-set work is the same lanes, the same blocks and the same reduction tree as cude_loss_grad
+    of the one-lane kernel (CUDE_CPEP_PATH=1 pins that kernel for the single-set reference evaluation)."""
+    import os
+    from cude.engine import Engine
+    os.environ["CUDE_CPEP_PATH"] = "1"
+    try:
+        rng = np.random.default_rng(8)
+        K = 7
+        if model == "supp":
+            c = make_supp_case(150)
+            eng = Engine("supp", c["arch"], n_steps=30, lam=0.02)
+            eng.set_population_supp(c["tp"], c["data"])
+            nn0, cond0, N = c["nn"], c["theta"], 150
+        elif model == "sym":
+            c = make_cpep_case(150, (2, 6, 2))
+            eng = Engine("cpep_sym", n_steps=30, n_state=2, cond_space="log")
+            eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+            nn0, cond0, N = np.array([1.78]), np.log(40.0) + c["beta"], 150
+        else:
+            arch = (2, 6, 2) if model == "cpep" else (2, 4, 2)
+            c = make_cpep_case(150, arch)
+            eng = Engine("cpep", arch, n_steps=30, n_state=3)
+            eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+            nn0, cond0, N = c["nn"], c["beta"], 150
+        nn_sets = nn0[None, :] * (1.0 + 0.2 * rng.standard_normal((K, nn0.size)))
+        cond_sets = cond0[None, :] + 0.3 * rng.standard_normal((K, N))
+        cond_sets[3, 17] = np.nan                                   # one failing subject in set 3
+        eng.set_params(nn0, cond0)
+        losses, g_nn, g_cond = eng.multistart_loss_grad(nn_sets, cond_sets)
+        nn_now, cond_now = eng.get_params()                         # the context's own parameters are untouched
+        assert np.array_equal(nn_now, nn0) and np.array_equal(cond_now, cond0)
+        assert losses[3] == np.inf
+        for k in range(K):
+            eng.set_params(nn_sets[k], cond_sets[k])
+            l, gn, gc = eng.loss_grad()
+            assert (l == losses[k]) or (np.isinf(l) and np.isinf(losses[k]))
+            if k != 3:
+                assert np.array_equal(gn, g_nn[k]) and np.array_equal(gc, g_cond[k])
+        eng.close()
+    finally:
+        del os.environ["CUDE_CPEP_PATH"]
+
+
+def test_side_by_side_training_follows_the_serial_restarts():
+    """_batched_adam_then_lbfgs vs the one-after-the-other loop: the first Adam iterations agree to rounding (host
+    Adam vs the device Adam kernel), and a full short training ends at comparable objectives for every restart."""
+    from cude import api
+    from cude.engine import Engine
+    c = make_cpep_case(57, (2, 4, 2))
+    eng = Engine("cpep", (2, 4, 2), n_steps=32, n_state=2)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    rng = np.random.default_rng(2)
+    K = 6
+    nn_inits = np.stack([api.init_params(api.chain(4, 2, "tanh"), rng) for _ in range(K)])
+    cond_inits = rng.uniform(-2.0, 0.0, (K, 57))
+    few = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 5, 0, 1e-2)
+    for k in range(K):
+        nn, cond, _ = api._adam_then_lbfgs(eng, nn_inits[k], cond_inits[k], 5, 0, 1e-2)
+        assert np.allclose(few[k][0], nn, rtol=0, atol=1e-12) and np.allclose(few[k][1], cond, rtol=0, atol=1e-12)
+    full = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 150, 60, 1e-2)
+    start = eng.multistart_forward(nn_inits, cond_inits)
+    for k in range(K):
+        _, _, obj = api._adam_then_lbfgs(eng, nn_inits[k], cond_inits[k], 150, 60, 1e-2)
+        assert full[k][2] < 0.5 * start[k]
+        assert abs(full[k][2] - obj) < 0.05 * obj + 1e-3
+        eng.set_params(full[k][0], full[k][1])
+        assert abs(eng.forward()["loss"] - full[k][2]) <= 1e-12 * full[k][2]       # objective is the loss at the result
+    eng.close()
+
+
+def test_suppression_restarts_side_by_side():
+    from cude import api
+    c = make_supp_case(37)
+    rng = np.random.default_rng(5)
+    net = api.neural_network_model(5, 3, input_dims=4)
+    prob = api.SuppressionProblem(net)
+    p_init = [api.ComponentArray(theta=rng.uniform(-1, 1, 37), neural=api.init_params(net, rng)) for _ in range(40)]
+    sols, traces = api.fit_suppression_model(p_init, prob, c["data"], c["tp"], 0.0, select_best_n=5, adam_iters=60,
+                                             lbfgs_iters=25)
+    assert len(sols) == 5 and len(traces) == 5
+    for s, tr in zip(sols, traces):
+        assert len(tr) >= 60 and tr[-1] <= tr[0] and np.isfinite(s.objective)
+        assert abs(api.suppression_loss(s.u, (prob, c["data"], c["tp"], 0.0)) - s.objective) <= 1e-10 * s.objective
+    api.clear_cache()

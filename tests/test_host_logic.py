@@ -74,6 +74,35 @@ def test_lbfgs_and_backtracking():
     assert abs(r["x"][0] - 1.5) < 1e-6
 
 
+def test_batched_lbfgs_reproduces_serial_runs():
+    """lbfgs_batched drives K copies of the same generator in lock step: every problem must see exactly the values
+    it would see alone -- including problems that finish early or hit the Inf region -- whatever the others do."""
+    from cude.lbfgs import lbfgs, lbfgs_batched
+    rng = np.random.default_rng(0)
+    scales = [1.0, 3.0, 0.2, 10.0, 1.0]
+    starts = np.array([[-1.2, 1.0], [2.0, -1.0], [0.3, 0.3], [-0.5, 2.5], [1.0, 1.0]])     # the last one: converged at x0
+
+    def rosen(x, a):
+        if x[0] > 4.0:                                  # a solver-failure region
+            return np.inf, np.zeros(2)
+        f = a * (100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2)
+        g = a * np.array([-400 * x[0] * (x[1] - x[0] ** 2) - 2 * (1 - x[0]), 200 * (x[1] - x[0] ** 2)])
+        return f, g
+    n_batches = [0]
+
+    def fg_batch(X):
+        n_batches[0] += 1
+        vals = [rosen(X[k], scales[k]) for k in range(len(scales))]
+        return np.array([v[0] for v in vals]), np.stack([v[1] for v in vals])
+    batched = lbfgs_batched(fg_batch, starts, maxiters=60)
+    serial = [lbfgs(lambda x, a=a: rosen(x, a), starts[k], maxiters=60) for k, a in enumerate(scales)]
+    for b, s in zip(batched, serial):
+        assert np.array_equal(b["x"], s["x"]) and b["f"] == s["f"] and b["iterations"] == s["iterations"]
+        assert b["f_calls"] == s["f_calls"] and b["converged"] == s["converged"]
+    assert n_batches[0] == max(s["f_calls"] for s in serial)          # lock step: as many rounds as the longest run
+    assert batched[-1]["iterations"] == 0 and batched[0]["f"] < 1e-10
+
+
 # ------------------------------------------------------------------ 2-rank gloo data-parallel step
 class OracleEngine:
     """Test stand-in with the Engine interface used by ShardedTrainer (numerics from the CPU oracle)."""
