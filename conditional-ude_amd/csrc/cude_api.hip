@@ -106,10 +106,20 @@ void step_tables(const std::vector<double>& tp, int S, std::vector<int32_t>& k, 
         d[(size_t)n * 3 + 1] = (tb - tp[j]) / len;
         d[(size_t)n * 3 + 2] = h / len;
     }
-    for (int n = 0; n < S; n++) {
-        if (piece[n] < 0) continue;
-        k[(size_t)n * 3 + 0] = (n > 0 && piece[n - 1] == piece[n]) ? 2 : 1;
-        k[(size_t)n * 3 + 1] = (n + 1 < S && piece[n + 1] == piece[n]) ? 2 : 1;
+    // a run is re-anchored with fresh exponentials every kReanchor steps so that the rounding of the anchor
+    // recurrence (one multiply per step) stays below 256 ulp however many steps a piece holds
+    constexpr int kReanchor = 256;
+    for (int n = 0, pos = 0; n < S; n++) {
+        if (piece[n] < 0) { pos = 0; continue; }
+        const bool cont = n > 0 && piece[n - 1] == piece[n] && pos + 1 < kReanchor;
+        k[(size_t)n * 3 + 0] = cont ? 2 : 1;
+        pos = cont ? pos + 1 : 0;
+    }
+    for (int n = S - 1, pos = 0; n >= 0; n--) {
+        if (piece[n] < 0) { pos = 0; continue; }
+        const bool cont = n + 1 < S && piece[n + 1] == piece[n] && pos + 1 < kReanchor;
+        k[(size_t)n * 3 + 1] = cont ? 2 : 1;
+        pos = cont ? pos + 1 : 0;
     }
 }
 

@@ -192,7 +192,7 @@ def test_full_size_properties_1e5_subjects():
 
 @pytest.mark.parametrize("n_steps,tp", [(30, [0.0, 30.0, 60.0, 90.0, 120.0]), (17, [0.0, 10.0, 45.0, 50.0, 120.0]),
                                          (60, [0.0, 15.0, 30.0, 45.0, 60.0, 75.0, 90.0, 120.0]), (5, [0.0, 120.0]),
-                                         (1, [0.0, 60.0, 120.0])])
+                                         (1, [0.0, 60.0, 120.0]), (1200, [0.0, 60.0, 120.0])])
 @pytest.mark.parametrize("arch", [(2, 4, 2), (2, 6, 2)])
 def test_cpep_general_time_grids(n_steps, tp, arch):
     """Irregular observation times / step counts: observations inside, at the end of, and sharing a step; T=2;
