@@ -72,6 +72,17 @@ function multistart_forward(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{
     losses
 end
 
+# restart loop of `train` (src/parameter-estimation.jl:372-383) with all restarts evaluated per optimiser iteration:
+# losses (K), ∂/∂neural (P×K) and ∂/∂conditional (N×K) of the K current points in one launch.
+function multistart_loss_grad(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{Float64})
+    K = size(nn_sets, 2); N = size(cond_sets, 1)
+    losses = Vector{Float64}(undef, K); g_nn = similar(nn_sets); g_cond = similar(cond_sets)
+    GC.@preserve nn_sets cond_sets losses g_nn g_cond check(ccall((:cude_multistart_loss_grad, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, K, nn_sets, cond_sets, losses, g_nn, g_cond))
+    losses, g_nn, g_cond
+end
+
 # `maxiters` Adam iterations in one call (hipGraph replay); returns the loss trace
 function adam_run!(c::Ctx, iters::Integer)
     losses = Vector{Float64}(undef, iters)
