@@ -709,6 +709,61 @@ int32_t cude_loss_grad(cude_ctx* c, double* loss, double* g_nn, double* g_cond) 
     return finish_loss(c, loss, g_nn);
 }
 
+int32_t cude_simulate(cude_ctx* c, int32_t n_times, const double* times, double* traj) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!is_cpep(c)) return fail(CUDE_ERR_UNSUPPORTED, "cude_simulate: c-peptide models only");
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (!c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "parameters not set");
+    if (n_times < 1 || !times || !traj) return fail(CUDE_ERR_ARG, "null/empty input");
+    const int S = c->cfg.n_steps, NS = c->cfg.n_state;
+    const double t0 = c->tp.front(), t1 = c->tp.back(), h = (t1 - t0) / S;
+    for (int i = 0; i < n_times; i++) {
+        if (!(times[i] >= t0 - 1e-9 * h && times[i] <= t1 + 1e-9 * h))
+            return fail(CUDE_ERR_ARG, "output times must lie inside the time span of the population");
+        if (i > 0 && !(times[i] >= times[i - 1])) return fail(CUDE_ERR_ARG, "output times must be non-decreasing");
+    }
+    const int64_t N = c->N;
+    // output times per launch: ~1 GB of trajectory scratch at most (every launch integrates from t_0 again)
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_times, (int64_t)(1e9 / (8.0 * NS * (double)N))));
+    DevBuf<double> d_traj, d_w;
+    DevBuf<int32_t> d_step;
+    HIP_TRY(d_traj.resize((size_t)NS * chunk * N));
+    HIP_TRY(d_w.resize((size_t)chunk * 7));
+    HIP_TRY(d_step.resize((size_t)chunk));
+    std::vector<int32_t> step(chunk);
+    std::vector<double> w((size_t)chunk * 7);
+    for (int64_t k0 = 0; k0 < n_times; k0 += chunk) {
+        const int64_t kn = std::min<int64_t>(chunk, n_times - k0);
+        for (int64_t i = 0; i < kn; i++) {                  // as locate_obs: tau in (t_n, t_{n+1}]
+            const double x = (times[k0 + i] - t0) / h;
+            int n = (int)std::ceil(x - 1e-9) - 1;
+            n = std::min(std::max(n, 0), S - 1);
+            step[i] = n;
+            interp_weights((times[k0 + i] - (t0 + n * h)) / h, &w[(size_t)i * 7]);
+        }
+        HIP_TRY(hipMemcpyAsync(d_step.p, step.data(), kn * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_w.p, w.data(), kn * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        cude::CpepArgs a{};
+        a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
+        a.N = N;
+        a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
+        a.dG = c->dG.p; a.obs = nullptr; a.age = c->age.p;
+        a.cond = c->cond.p; a.nn = c->nn.p;
+        a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = d_step.p; a.obs_w = d_w.p;
+        a.stepk = c->stepk.p; a.stepd = c->stepd.p;
+        a.T = (int32_t)kn; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+        a.traj = d_traj.p; a.partials = c->partials.p;
+        HIP_TRY(cude::launch_cpep(c->net, NS, false, a, c->stream));
+        // device chunk [NS x kn x N] -> rows k0..k0+kn of the caller's [NS x n_times x N]
+        HIP_TRY(hipMemcpy2DAsync(traj + (size_t)NS * k0, (size_t)NS * n_times * sizeof(double), d_traj.p,
+                                 (size_t)NS * kn * sizeof(double), (size_t)NS * kn * sizeof(double), (size_t)N,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));           // step / w are reused by the next chunk
+    }
+    return CUDE_OK;
+}
+
 int32_t cude_n_failed(cude_ctx* c, int64_t* n_failed) {
     if (!c || !n_failed) return fail(CUDE_ERR_ARG, "null argument");
     *n_failed = c->last_failed;

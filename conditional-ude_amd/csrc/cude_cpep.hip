@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
             o1 = fma(h, o1, y1);
             o2 = fma(h, o2, y2);
             o3 = fma(h, o3, y3);
-            const double r = o1 - a.obs[(int64_t)oi * N + i];
+            const double r = a.obs != nullptr ? o1 - a.obs[(int64_t)oi * N + i] : 0.0;   // null: cude_simulate
             sse = fma(r, r, sse);
             if (GRAD) s_res[oi * kBlock + lane] = r;
             if (a.traj != nullptr && active) {

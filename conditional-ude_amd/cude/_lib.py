@@ -44,6 +44,7 @@ _SIGNATURES = {
     "cude_get_params": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cude_forward": (C.c_int32, [C.c_void_p, _dp, C.c_void_p, C.c_void_p]),
     "cude_loss_grad": (C.c_int32, [C.c_void_p, _dp, C.c_void_p, C.c_void_p]),
+    "cude_simulate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "cude_multistart_forward": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cude_multistart_loss_grad": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),

@@ -692,6 +692,19 @@ def SAEM_symbolic(models, timepoints, cpeptide_data, initial_population_paramete
                            acceptance_rates=acc_rates)
 
 
+def simulate(p_neural, p_individuals, models, timepoints, cpeptide_data, *, out_timepoints=None, n_steps=None,
+             save_idxs=1):
+    """`simulate(p_neural, p_individual, individual, network; timepoints)` of src/saem.jl:31-53 (and
+    src/saem-symreg.jl:31-53 for CPeptideODEModel lists, p_neural = None) for ALL individuals at once: plasma
+    c-peptide (state `save_idxs`, 1-based as in Julia) at `out_timepoints` -- any non-decreasing times inside the
+    span of `timepoints`, e.g. the dense grids t0:0.1:tend of the model-fit figures -- as an (N, n_times) array."""
+    sym = isinstance(models[0], CPeptideODEModel)
+    pop = _population(models, timepoints, cpeptide_data, n_steps, cond_space="raw" if sym else "log")
+    pop.engine.set_params(pop.shared if sym else p_neural, np.asarray(p_individuals, dtype=np.float64).reshape(-1))
+    times = np.asarray(timepoints if out_timepoints is None else out_timepoints, dtype=np.float64)
+    return pop.engine.simulate(times)[save_idxs - 1].T
+
+
 # ----------------------------------------------------------------------------- checkpoints / data files (JLD2)
 def load_data(path):
     """`jldopen("data/ohashi.jld2") do file; file["train"], file["test"]; end` (c-peptide/02-conditional.jl:15-17):

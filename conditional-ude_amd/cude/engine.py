@@ -121,6 +121,14 @@ class Engine:
             out["traj"] = traj.transpose(2, 1, 0)     # -> (n_state, T, N), the Julia Array(sol) shape
         return out
 
+    def simulate(self, times):
+        """States of every subject at arbitrary non-decreasing times inside the population's time span (dense
+        output of the same fixed-step solve) -> array (n_state, len(times), N).  c-peptide models only."""
+        t = _f64(times).reshape(-1)
+        out = np.empty((self.N, t.size, self.n_state))
+        check(self._lib.cude_simulate(self._h, t.size, _ptr(t), _ptr(out)))
+        return np.ascontiguousarray(out.transpose(2, 1, 0))
+
     def multistart_forward(self, nn_sets, cond_sets):
         """Losses of K candidate (network, conditional) parameter sets in one launch.
         nn_sets: (K, P); cond_sets: (K, N)."""

@@ -107,6 +107,14 @@ int32_t cude_get_params(cude_ctx* ctx, double* nn, double* cond);
  * (Julia Array(sol) layout of simul). */
 int32_t cude_forward(cude_ctx* ctx, double* loss, double* per_subject_sse, double* traj);
 
+/* Dense output: the states of every subject at n_times arbitrary, non-decreasing times inside [t[0], t[T-1]] (Tsit5
+ * interpolant of the same fixed-step solve), at the context's current parameters.  Replaces
+ * `simulate(p_neural, p_individual, individual, network; timepoints = t0:0.1:tend)` (src/saem.jl:31-53, called with
+ * dense grids at c-peptide/06-saem.jl:221-240) and `solve(model.problem, p=..., saveat=sol_timepoints)` of the
+ * model-fit figures (c-peptide/02-conditional.jl, 03-symreg.jl:113).  traj receives [n_state x n_times x N]
+ * column-major.  c-peptide models only (the reference simulates the suppression model at its data times: cude_forward). */
+int32_t cude_simulate(cude_ctx* ctx, int32_t n_times, const double* times, double* traj);
+
 /* Multi-start screening: forward-only loss of n_sets candidate parameter sets over the resident
  * population in one launch (first phase of `train`, src/parameter-estimation.jl:351-366;
  * fit_suppression_model suppression_model.jl:135; c-peptide/06-saem.jl:41-42).

@@ -248,6 +248,37 @@ def test_exponent_table_matches_direct_exponentials(scale, monkeypatch):
     assert np.max(np.abs(t[4] - d[4])) <= 1e-9 * np.max(np.abs(d[4]))
 
 
+@pytest.mark.parametrize("arch,n_state", [((2, 6, 2), 3), ((2, 4, 2), 2)])
+def test_dense_output_matches_the_oracle_interpolant(arch, n_state):
+    """cude_simulate: the reference's `simulate(...; timepoints = t0:0.1:tend)` (src/saem.jl:31-53).  1201 output
+    times on [0, 120] against the oracle's fixed-step solve with its Tsit5 interpolant at the same times; at the
+    observation times the dense output equals cude_forward's trajectory."""
+    import cude_oracle as o
+    from cude.engine import Engine
+    c = make_cpep_case(70, arch)
+    eng = Engine("cpep", arch, n_steps=30, n_state=n_state)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(c["nn"], c["beta"])
+    dense = np.round(np.arange(0.0, 120.0 + 1e-9, 0.1), 10)
+    got = eng.simulate(dense)
+    assert got.shape == (n_state, dense.size, 70)
+    at_obs = eng.simulate(c["tp"])
+    assert np.array_equal(at_obs, eng.forward(want_traj=True)["traj"])
+    pop = o.CPepPopulation(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eb = np.exp(c["beta"])
+    u0 = [pop.c0, (pop.k2 / pop.k1) * pop.c0] + ([pop.c0 * 0.0] if n_state == 3 else [])
+    rhs = lambda t, u: o.cpep_rhs(np, pop, c["nn"], eb, arch, t, u, n_state)
+    ref = o.solve_fixed(rhs, u0, list(dense), 30)
+    for k in range(dense.size):
+        for s in range(n_state):
+            assert np.allclose(got[s, k], ref[k][s], rtol=1e-10, atol=1e-12), (k, s)
+    with pytest.raises(Exception):
+        eng.simulate([0.0, 130.0])                      # outside the span
+    with pytest.raises(Exception):
+        eng.simulate([10.0, 5.0])                       # decreasing
+    eng.close()
+
+
 def test_size_limits_and_missing_values():
     """Edges of the domain: the maximum number of observation times (32) against the oracle, T = 33 and an empty
     population rejected with a status, a one-subject population, and missing values (NaN in a subject's glucose /
