@@ -1006,6 +1006,13 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
 int32_t cude_mh_estep(cude_ctx* c, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
                       double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
                       int64_t* accepted) {
+    return cude_mh_chain(c, n_mc, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature, gamma,
+                         accepted, nullptr);
+}
+
+int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
+                      double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
+                      int64_t* accepted, double* samples) {
     int32_t rc = bind(c);
     if (rc) return rc;
     if (!c->have_pop || !c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "population / parameters not set");
@@ -1032,7 +1039,12 @@ int32_t cude_mh_estep(cude_ctx* c, int32_t n_mc, const double* normals, const do
         if ((rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;   // re-evaluated as the reference does
         m.u = d_u.p + (size_t)k * N;
         HIP_TRY(cude::launch_mh_accept(m, c->stream));
+        if (samples)       // chain state after step k (the draws of this step are no longer needed: reuse their row)
+            HIP_TRY(hipMemcpyAsync(d_z.p + (size_t)k * N, c->cond.p, N * sizeof(double), hipMemcpyDeviceToDevice,
+                                   c->stream));
     }
+    if (samples)
+        HIP_TRY(hipMemcpyAsync(samples, d_z.p, (size_t)n_mc * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CUDE_OK;

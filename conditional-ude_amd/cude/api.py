@@ -618,6 +618,30 @@ def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0,
                      omega_learning_rate=omega_learning_rate, rng=rng, m_step_iters=m_step_iters, m_step_lr=m_step_lr)
 
 
+def individual_effects(models, timepoints, cpeptide_data, saem_result, *, n_samples=3000, proposal_std=0.3,
+                       rng=None, n_steps=None, lower=-6.0, upper=4.0):
+    """The per-individual loop that follows SAEM in c-peptide/06-saem.jl:97-135, for ALL individuals at once:
+    posterior samples of the conditional parameter (n_samples Metropolis steps from the population mean, every
+    state kept, :107-112), the MAP mode (minimiser of -(log-likelihood + log prior), :114-119), the MLE estimate
+    (:121-126) and `mse = -2 individual_log_likelihood(mode; sigma = 1)` = the SSE at the mode (:129).  The two 1-D
+    optimisations are bracketing searches over [lower, upper] with one forward launch per probe."""
+    rng = np.random.default_rng() if rng is None else rng
+    pop = _population(models, timepoints, cpeptide_data, n_steps)
+    eng, N, T = pop.engine, pop.N, pop.T
+    prior, omega, sigma = float(saem_result.eta), float(saem_result.Omega), float(saem_result.sigma)
+    eng.set_params(saem_result.p_neural, np.full(N, prior))
+    acc, samples = eng.mh_chain(rng.standard_normal((n_samples, N)), rng.random((n_samples, N)), sigma, prior, omega,
+                                proposal_std)
+
+    def sse(b):
+        eng.set_params(None, np.broadcast_to(b, (N,)))
+        return eng.forward(want_sse=True)["sse"]
+    modes, _ = _bracket_min(lambda b: sse(b) / (2 * sigma ** 2) + 0.5 * ((b - prior) / omega) ** 2, lower, upper, 81)
+    mle, _ = _bracket_min(sse, lower, upper, 81)
+    return SimpleNamespace(samples=samples, modes=modes, mle=mle, mse=sse(modes),
+                           acceptance_rate=float(acc.sum()) / (n_samples * N))
+
+
 # ----------------------------------------------------------------------------- symbolic (Michaelis-Menten) model
 def train_symbolic(models, timepoints, cpeptide_data, *, lower=0.0, upper=1000.0, n_steps=None):
     """The per-subject loop of c-peptide/03-symreg.jl:94-106: minimise loss_sigma over (k, sigma) with

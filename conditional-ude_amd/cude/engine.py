@@ -166,6 +166,19 @@ class Engine:
                                       _ptr(acc)))
         return acc
 
+    def mh_chain(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0):
+        """mh_estep that also returns every state of the chain: (accepted (N,), samples (n_mc, N))."""
+        z = _f64(normals)
+        u = _f64(uniforms)
+        if z.ndim != 2 or z.shape[1] != self.N or u.shape != z.shape:
+            raise ValueError(f"expected draws of shape (n_mc, {self.N})")
+        acc = np.zeros(self.N, dtype=np.int64)
+        samples = np.empty(z.shape)
+        check(self._lib.cude_mh_chain(self._h, z.shape[0], _ptr(z), _ptr(u), float(sigma), float(prior_mean),
+                                      float(prior_sd), float(proposal_std), float(temperature), float(gamma),
+                                      _ptr(acc), _ptr(samples)))
+        return acc, samples
+
     def loss_grad(self, want_cond_grad=True):
         loss = C.c_double()
         g_nn = np.empty(self.P)

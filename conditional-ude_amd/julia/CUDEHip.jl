@@ -98,4 +98,15 @@ function mh_estep!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, 
         c.h, n_mc, normals, uniforms, σ, prior_η, Ω, proposal_std, temperature, γ, accepted))
     accepted
 end
+
+# posterior sampling after SAEM (c-peptide/06-saem.jl:107-112) for all individuals at once: every chain state is kept;
+# returns (accepted, samples) with samples N×n_mc
+function mh_chain!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, σ, prior_η, Ω, proposal_std;
+                   temperature = 1.0, γ = 1.0)
+    N, n_mc = size(normals); accepted = zeros(Int64, N); samples = similar(normals)
+    GC.@preserve normals uniforms accepted samples check(ccall((:cude_mh_chain, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64, Float64, Float64, Ptr{Int64}, Ptr{Float64}),
+        c.h, n_mc, normals, uniforms, σ, prior_η, Ω, proposal_std, temperature, γ, accepted, samples))
+    accepted, samples
+end
 end

@@ -148,6 +148,14 @@ int32_t cude_mh_estep(cude_ctx* ctx, int32_t n_mc, const double* normals, const 
                       double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
                       int64_t* accepted);
 
+/* The same chain with every state kept: samples[n_mc][N] (row-major) receives each subject's conditional parameter
+ * after every step -- the per-individual posterior sampling loop that follows SAEM (`for _ in 1:3000; p_individual,
+ * accepted = mcmc_step(...); push!(individual_samples, p_individual)`, c-peptide/06-saem.jl:107-112) for all
+ * individuals at once.  samples may be NULL (then identical to cude_mh_estep). */
+int32_t cude_mh_chain(cude_ctx* ctx, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
+                      double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
+                      int64_t* accepted, double* samples);
+
 /* Loss and gradient: replaces ForwardDiff.gradient(loss, theta) under AutoForwardDiff()
  * (parameter-estimation.jl:370; suppression_model.jl:155; saem.jl:120) by a discrete adjoint
  * of the same fixed-step map.  g_nn[P]; g_cond[N] may be NULL (stays on the device). */

@@ -411,7 +411,7 @@ def log_normal_pdf(x, mu, sd):
 
 
 def mh_chain(nn, beta0, pop, arch, n_steps, sigma, prior_eta, omega, proposal_std,
-             temperature, gamma, normals, uniforms):
+             temperature, gamma, normals, uniforms, samples=None):
     """E-step of SAEM for every subject (src/saem.jl:86-108 and :177-186) with host-supplied
     draws: normals/uniforms are (n_mcmc, N).  Returns (beta, n_accepted per subject).
     The 'current' log-likelihood is recomputed every step as the reference does."""
@@ -431,6 +431,8 @@ def mh_chain(nn, beta0, pop, arch, n_steps, sigma, prior_eta, omega, proposal_st
         acc += accept
         newb = np.where(accept, prop, beta)
         beta = (1 - gamma) * beta + gamma * newb
+        if samples is not None:            # individual_samples of c-peptide/06-saem.jl:107-112
+            samples.append(beta.copy())
     return beta, acc
 
 

@@ -46,6 +46,47 @@ def test_mh_chain_matches_oracle_with_same_draws(gamma, temperature):
     assert np.max(np.abs(p_dev - p_ref)) < 1e-12
 
 
+def test_chain_samples_and_individual_effects():
+    """cude_mh_chain keeps every state of every subject's chain (c-peptide/06-saem.jl:107-112) -- equal to the
+    oracle chain step by step -- and api.individual_effects returns samples, MAP modes and MLE estimates whose
+    defining properties hold (the mode minimises the negative log-posterior, the MLE the SSE)."""
+    import cude_oracle as o
+    from cude import api
+    arch, N, steps = (2, 4, 2), 40, 25
+    c = make_cpep_case(N, arch)
+    rng = np.random.default_rng(11)
+    normals, uniforms = rng.standard_normal((steps, N)), rng.random((steps, N))
+    pop = o.CPepPopulation(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    want = []
+    start = np.full(N, -0.6)
+    _, acc_ref = o.mh_chain(c["nn"], start, pop, arch, 30, 0.4, -0.6, 0.9, 0.3, 1.0, 1.0, normals, uniforms,
+                            samples=want)
+    eng, _ = _engine(c, arch)
+    eng.set_params(c["nn"], start)
+    acc, samples = eng.mh_chain(normals, uniforms, 0.4, -0.6, 0.9, 0.3)
+    eng.close()
+    assert np.array_equal(acc, acc_ref) and samples.shape == (steps, N)
+    assert np.max(np.abs(samples - np.stack(want))) < 1e-12
+    # API mirror on the same subjects
+    net = api.chain(4, 2, "tanh")
+    models = [api.CPeptideConditionalUDEModel(c["G"][i], c["tp"], c["age"][i], net, c["obs"][i], bool(c["t2dm"][i]))
+              for i in range(N)]
+    saem = api.SimpleNamespace(p_neural=c["nn"], eta=-0.6, Omega=0.9, sigma=0.4)
+    eff = api.individual_effects(models, c["tp"], c["obs"], saem, n_samples=60, rng=np.random.default_rng(3), n_steps=30)
+    assert eff.samples.shape == (60, N) and 0.0 < eff.acceptance_rate < 1.0
+
+    def neg_log_post(b):
+        sse = o.cpep_loss(np, c["nn"], b, pop, arch, 30)[1]
+        return sse / (2 * 0.4 ** 2) + 0.5 * ((b - (-0.6)) / 0.9) ** 2
+    at = neg_log_post(eff.modes)
+    assert np.all(neg_log_post(eff.modes + 1e-3) >= at - 1e-9) and np.all(neg_log_post(eff.modes - 1e-3) >= at - 1e-9)
+    sse_at = o.cpep_loss(np, c["nn"], eff.mle, pop, arch, 30)[1]
+    for d in (1e-3, -1e-3):
+        assert np.all(o.cpep_loss(np, c["nn"], eff.mle + d, pop, arch, 30)[1] >= sse_at - 1e-9)
+    assert np.allclose(eff.mse, o.cpep_loss(np, c["nn"], eff.modes, pop, arch, 30)[1], rtol=1e-9)
+    api.clear_cache()
+
+
 def test_failed_solves_are_rejected():
     """A proposal whose solve is non-finite has log-likelihood -Inf and is never accepted (saem.jl:59-62)."""
     arch, N = (2, 4, 2), 70
