@@ -233,7 +233,8 @@ struct cude_ctx {
     size_t ev_used = 0;
     double host_red[3];
     // scratch of cude_multistart_loss_grad (kept between calls: it is called once per optimiser iteration)
-    DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt;
+    DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt, ms_act;
+    DevBuf<double> act;     // SUPP: kept network activations of the gradient launch (small populations only)
     std::vector<double> ms_host;
 #ifdef CUDE_WAVE_TIMING
     DevBuf<long long> dbg;
@@ -241,6 +242,19 @@ struct cude_ctx {
 };
 
 namespace {
+
+// SUPP gradient launches keep the network activations of the forward sweep (instead of recomputing them in the
+// reverse sweep) when that buffer is small: the launch is then latency-bound and 2/3 of the reverse sweep's
+// instructions are worth 8*(D*W+1) bytes per evaluation; at 1e5 subjects the 2.3 GB each way would cost more than the
+// recomputation.  CUDE_SUPP_STORE=0/1 overrides the size rule (A/B runs).
+size_t supp_act_doubles(const cude_ctx* c) {
+    return (size_t)(6 * c->cfg.n_steps + 1) * (size_t)(c->net.depth * c->net.width + 1) * (size_t)c->N;
+}
+bool supp_keep_activations(const cude_ctx* c, int64_t n_sets) {
+    const char* env = getenv("CUDE_SUPP_STORE");
+    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    return (double)n_sets * (double)supp_act_doubles(c) * 8.0 <= 256e6;
+}
 
 // both c-peptide models share the population layout, solver tables and the ensemble kernel
 bool is_cpep(const cude_ctx* c) { return c->cfg.model == CUDE_MODEL_CPEP || c->cfg.model == CUDE_MODEL_CPEP_SYM; }
@@ -446,6 +460,10 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
         for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
         a.ckpt = c->ckpt.p; a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev;
+        if (grad && supp_keep_activations(c, 1)) {
+            HIP_TRY(c->act.reserve(supp_act_doubles(c)));
+            a.act = c->act.p;
+        }
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         HIP_TRY(cude::launch_supp(c->net, grad, a, c->stream));
     }
@@ -966,6 +984,10 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
             a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
             for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
             a.ckpt = c->ms_ckpt.p; a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
+            if (supp_keep_activations(c, kn)) {
+                HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
+                a.act = c->ms_act.p;
+            }
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
         }

@@ -262,8 +262,23 @@ struct Mlp {
         const double zo = forward(p, c, x, h, use_tab, E1);
         double sig;
         const double y = act_softplus(zo, &sig);
+        backward<WANT_DX>(p, x, h, sig, wgt, acc, dx);
+        return y;
+    }
 
-        // reverse
+    // value with the activations kept for a later `backward`: h = tanh outputs of every layer, *sig = logistic
+    // derivative of the output unit
+    __device__ static __forceinline__ double eval_keep(cptr_t p, const double (&c)[W], const double (&x)[NV],
+                                                       double (&h)[D][W], double* sig) {
+        p = launder(p);
+        return act_softplus(forward(p, c, x, h), sig);
+    }
+
+    // weighted reverse sweep from kept activations:  acc += wgt * d(out)/d(params);  if WANT_DX,
+    // dx[i] += wgt * d(out)/dx_i
+    template <bool WANT_DX>
+    __device__ static __forceinline__ void backward(cptr_t p, const double (&x)[NV], const double (&h)[D][W], double sig,
+                                                    double wgt, double (&acc)[NACC], double (&dx)[NV]) {
         const double dz = wgt * sig;
         acc[G_OUT + W] += dz;
         double dh[W];
@@ -323,7 +338,6 @@ struct Mlp {
                 dx[i] += s0 + s1;
             }
         }
-        return y;
     }
 
     // Expand the accumulators into the SimpleChains parameter order; also d/d(conditional) through

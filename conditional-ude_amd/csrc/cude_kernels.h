@@ -84,6 +84,7 @@ struct SuppArgs {
     double h, inv_n;
     double iscale2[3];       // 1/scale_s^2
     double* ckpt;            // [n_sets][6S+1][3][N] stage inputs (linearisation points of the reverse sweep)
+    double* act;             // [n_sets][6S+1][D*W+1][N] kept network activations, or nullptr = recompute them
     double* sse;             // [N] or nullptr (already divided by scale^2)
     double* traj;            // [3 x T x N] column-major or nullptr
     double* g_cond;          // [n_sets][N]

@@ -35,6 +35,23 @@ struct SuppRhs {
         ub[1] += dx[1];
         ub[2] += fma(-0.3, kb[2], dx[2]);
     }
+    // the same pair with the network activations kept by the forward sweep instead of recomputed in the reverse one
+    __device__ static __forceinline__ void f_keep(cptr_t p, const double (&c)[W], const double (&u)[3], double (&du)[3],
+                                                  double (&h)[D][W], double* sig) {
+        const double uh = Net::eval_keep(p, c, u, h, sig);
+        du[0] = -0.4 * u[0];
+        du[1] = fma(0.4, u[0], -uh);
+        du[2] = fma(-0.3, u[2], uh);
+    }
+    __device__ static __forceinline__ void vjp_kept(cptr_t p, const double (&u)[3], const double (&h)[D][W], double sig,
+                                                    const double (&kb)[3], double (&ub)[3], double (&acc)[Net::NACC]) {
+        const double wgt = kb[2] - kb[1];
+        double dx[3] = {0.0, 0.0, 0.0};
+        Net::template backward<true>(launder(p), u, h, sig, wgt, acc, dx);
+        ub[0] += fma(-0.4, kb[0], fma(0.4, kb[1], dx[0]));
+        ub[1] += dx[1];
+        ub[2] += fma(-0.3, kb[2], dx[2]);
+    }
 };
 
 // LDS rows of kBlock doubles (one per lane):
@@ -43,7 +60,12 @@ struct SuppRhs {
 //   s_res[T][3] residuals kept for the reverse sweep
 constexpr int kSuppRowsFixed = 42;
 
-template <int W, int D, bool GRAD>
+// STORE (gradient only): the forward sweep also writes the D*W tanh outputs and the output unit's logistic derivative
+// of every evaluation to HBM ([evaluation][value][subject]) and the reverse sweep reads them back instead of
+// re-evaluating the network: 2/3 of the reverse sweep's instructions for 8*(D*W+1) bytes per evaluation and subject.
+// Pays when the launch is latency-bound (few waves, e.g. the reference's 37 subjects); the host enables it when the
+// buffer is small.
+template <int W, int D, bool GRAD, bool STORE>
 __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     using R = SuppRhs<W, D>;
     using Net = typename R::Net;
@@ -66,6 +88,8 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     const int S = a.S, T = a.T;
     const double h = a.h;
     double* ckpt = GRAD ? a.ckpt + set * ((int64_t)(6 * S + 1) * 3 * N) : nullptr;   // one scratch per parameter set
+    constexpr int NACT = D * W + 1;
+    double* act = STORE ? a.act + set * ((int64_t)(6 * S + 1) * NACT * N) : nullptr;
 #define KROW(j, s) s_K[((j) * 3 + (s)) * kBlock + lane]
 #define YROW(j, s) s_Y[((j) * 3 + (s)) * kBlock + lane]
 
@@ -105,7 +129,18 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
             for (int s = 0; s < 3; s++) ckpt[((int64_t)e * 3 + s) * N + i] = u[s];
         }
         double du[3];
-        R::f(p, c, u, du);
+        if (STORE) {
+            double hk[D][W], sg;
+            R::f_keep(p, c, u, du, hk, &sg);
+            double* dst = act + (int64_t)e * NACT * N + i;
+#pragma unroll
+            for (int l = 0; l < D; l++)
+#pragma unroll
+                for (int j = 0; j < W; j++) dst[(int64_t)(l * W + j) * N] = hk[l][j];
+            dst[(int64_t)(D * W) * N] = sg;
+        } else {
+            R::f(p, c, u, du);
+        }
 #pragma unroll
         for (int s = 0; s < 3; s++) KROW(st, s) = du[s];
         if (e == 0) { st = 1; continue; }
@@ -201,7 +236,17 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
 #pragma unroll
                 for (int s = 0; s < 3; s++) ub[s] = 0.0;
             }
-            R::vjp(p, c, u, kb, ub, acc);
+            if (STORE) {
+                double hk[D][W];
+                const double* src = act + (int64_t)idx * NACT * N + i;
+#pragma unroll
+                for (int l = 0; l < D; l++)
+#pragma unroll
+                    for (int j = 0; j < W; j++) hk[l][j] = src[(int64_t)(l * W + j) * N];
+                R::vjp_kept(p, u, hk, src[(int64_t)(D * W) * N], kb, ub, acc);
+            } else {
+                R::vjp(p, c, u, kb, ub, acc);
+            }
             if (idx == 0) break;
             // propagate ub through  Y_st = y_n + h sum_{j<st} a(st,j) k_j
 #pragma unroll
@@ -240,12 +285,12 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
 #undef YROW
 }
 
-template <int W, int D, bool GRAD>
+template <int W, int D, bool GRAD, bool STORE>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(kSuppRowsFixed + (GRAD ? 3 * a.T : 0)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
-    hipLaunchKernelGGL((supp_kernel<W, D, GRAD>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
 
@@ -261,7 +306,10 @@ bool supp_shape_supported(const NetShape& net) {
 
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
     if (net.nin != 4) return hipErrorInvalidValue;
-#define X(W, D) if (net.width == W && net.depth == D) return grad ? launch_one<W, D, true>(a, s) : launch_one<W, D, false>(a, s);
+#define X(W, D)                                                                                   \
+    if (net.width == W && net.depth == D)                                                         \
+        return !grad ? launch_one<W, D, false, false>(a, s)                                       \
+                     : (a.act != nullptr ? launch_one<W, D, true, true>(a, s) : launch_one<W, D, true, false>(a, s));
     CUDE_SUPP_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -73,3 +73,26 @@ def test_chunked_path_failure_convention():
     nn_after, _ = eng.get_params()
     assert np.array_equal(np.isnan(nn_after), np.isnan(nn_bad))
     eng.close()
+
+
+@pytest.mark.parametrize("arch", [(4, 3, 5), (4, 6, 2)])
+def test_suppression_kept_activations_equal_recomputation(arch, monkeypatch):
+    """The suppression gradient kernel either keeps the network activations of the forward sweep in HBM (small
+    populations: latency-bound) or recomputes them in the reverse sweep (large ones).  Same operations in the same
+    order on the same values: the two variants must agree bit for bit, for one set and for side-by-side sets."""
+    from conftest import make_supp_case
+    from cude.engine import Engine
+    c = make_supp_case(130, arch)
+    rng = np.random.default_rng(1)
+    nn_sets = c["nn"][None, :] * (1.0 + 0.1 * rng.standard_normal((3, c["nn"].size)))
+    th_sets = c["theta"][None, :] + 0.2 * rng.standard_normal((3, 130))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CUDE_SUPP_STORE", mode)
+        eng = Engine("supp", arch, n_steps=30, lam=0.01)
+        eng.set_population_supp(c["tp"], c["data"])
+        eng.set_params(c["nn"], c["theta"])
+        out[mode] = eng.loss_grad() + eng.multistart_loss_grad(nn_sets, th_sets)
+        eng.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
