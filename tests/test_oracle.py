@@ -100,6 +100,59 @@ def test_fixed_step_converges_and_brackets_adaptive():
     assert np.max(np.abs(ad - l480["traj"][0, :, 0])) < 5e-3 * np.max(np.abs(ad))
 
 
+def _mlp_matrix_form(x, p, arch):
+    """Independent restatement of the SimpleChains network for this test only: weight matrices rebuilt with
+    reshape(order="F") and applied with matmul (the oracle indexes the flat vector element by element)."""
+    nin, w, d = arch
+    off, h = 0, np.asarray(x, dtype=np.float64)
+    for layer in range(d):
+        fan = nin if layer == 0 else w
+        W = p[off:off + w * fan].reshape((w, fan), order="F")
+        b = p[off + w * fan:off + w * fan + w]
+        off += w * fan + w
+        h = np.tanh(W @ h + b)
+    return float(np.log1p(np.exp(p[off:off + w] @ h + p[off + w])))
+
+
+def test_against_scipy_integrators():
+    """The oracle's own Tsit5 (tableau, FSAL, dense output) against an integrator it shares no code with: scipy's
+    DOP853 at rtol 1e-12, restarted at the glucose knots, with the right-hand sides written independently here
+    (matrix-form MLP, np.interp glucose).  The fixed-step oracle at S = 960 must agree to ~1e-9."""
+    from scipy.integrate import solve_ivp
+    import cude_oracle as o
+    import c_oracle as co
+    arch = (2, 6, 2)
+    c = make_cpep_case(3, arch)
+    fixed = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], c["beta"], 960, 2, want_grad=False,
+                    want_traj=True)["traj"]
+    k0, k1, k2 = o.van_cauter_parameters(c["age"], c["t2dm"])
+    for i in range(3):
+        c0, eb = c["obs"][i, 0], np.exp(c["beta"][i])
+        base = _mlp_matrix_form([0.0, eb], c["nn"], arch)
+
+        def rhs(t, u):
+            dG = np.interp(t, c["tp"], c["G"][i]) - c["G"][i, 0]
+            prod = _mlp_matrix_form([dG, eb], c["nn"], arch) - base
+            return [-(k0[i] + k2[i]) * u[0] + k1[i] * u[1] + k0[i] * c0 + prod, -k1[i] * u[1] + k2[i] * u[0]]
+        u = np.array([c0, k2[i] / k1[i] * c0])
+        for j in range(1, len(c["tp"])):
+            sol = solve_ivp(rhs, (c["tp"][j - 1], c["tp"][j]), u, method="DOP853", rtol=1e-12, atol=1e-14)
+            u = sol.y[:, -1]
+            assert abs(u[0] - fixed[i, j, 0]) < 2e-9 * abs(u[0]) and abs(u[1] - fixed[i, j, 1]) < 2e-9 * abs(u[1])
+    # suppression model (state-dependent network input), smooth right-hand side: one integration over [0, 30]
+    s = make_supp_case(2)
+    fx = co.supp(s["tp"], s["data"], s["arch"], s["nn"], s["theta"], 0.0, 960, want_grad=False, want_traj=True)["traj"]
+    for i in range(2):
+        et = np.exp(s["theta"][i])
+
+        def rhs(t, u):
+            uh = _mlp_matrix_form([u[0], u[1], u[2], et], s["nn"], s["arch"])
+            return [-0.4 * u[0], 0.4 * u[0] - uh, uh - 0.3 * u[2]]
+        sol = solve_ivp(rhs, (s["tp"][0], s["tp"][-1]), s["data"][:, 0, i], method="DOP853", rtol=1e-12, atol=1e-14,
+                        t_eval=s["tp"])
+        assert np.max(np.abs(sol.y - fx[:, :, i])) < 2e-8 * np.max(np.abs(fx[:, :, i]))
+
+
 def test_failure_convention_and_adam():
     import cude_oracle as o
     import c_oracle as co
