@@ -72,7 +72,8 @@ def main():
     snn = np.stack(supp["neural_parameters"])
     group = supp["group_data"]
     np.savez_compressed(os.path.join(OUT, "suppression_lambda0.npz"), nn_4x3x5x1=snn, group_data=group,
-                        correlations=supp["correlations"], losses=supp["losses"], timepoints=np.linspace(0.0, 30.0, 8))
+                        correlations=supp["correlations"], losses=supp["losses"], timepoints=np.linspace(0.0, 30.0, 8),
+                        gt_sup_param=supp["gt_sup_param"])
     # dose-response table the reference's symbolic regression was run on (30 exp(beta) x 30 dG values)
     prod = pd.read_csv(os.path.join(REF, "data/ohashi_production.csv"))
     np.savez_compressed(os.path.join(OUT, "ohashi_production.npz"), beta=prod["Beta"].to_numpy(dtype=np.float64),
