@@ -73,7 +73,10 @@ def main():
     group = supp["group_data"]
     np.savez_compressed(os.path.join(OUT, "suppression_lambda0.npz"), nn_4x3x5x1=snn, group_data=group,
                         correlations=supp["correlations"], losses=supp["losses"], timepoints=np.linspace(0.0, 30.0, 8),
-                        gt_sup_param=supp["gt_sup_param"])
+                        gt_sup_param=supp["gt_sup_param"],
+                        **{k: supp[k] for k in ("validation_data", "validation_data_nonoise", "gt_validation_param",
+                                                "gt_validation_param_nonoise", "losses_valid", "losses_valid_nonoise",
+                                                "correlations_valid", "correlations_valid_nonoise")})
     # dose-response table the reference's symbolic regression was run on (30 exp(beta) x 30 dG values)
     prod = pd.read_csv(os.path.join(REF, "data/ohashi_production.csv"))
     np.savez_compressed(os.path.join(OUT, "ohashi_production.npz"), beta=prod["Beta"].to_numpy(dtype=np.float64),
