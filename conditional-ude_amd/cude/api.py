@@ -568,6 +568,27 @@ def fit_suppression_model(p_init, prob, data, timepoints, lam, *, select_best_n=
     return sols, traces
 
 
+def validate_suppression_model(p_init, prob, data, timepoints, network_params, *, n_steps=None, lower=-8.0,
+                               upper=5.0):
+    """validate_suppression_model(p_init, prob, data, timepoints, network_params) (:179-222): conditional parameters
+    of new subjects with the network frozen, returns (theta, objective).  With the network fixed the loss separates
+    per subject, so instead of one L-BFGS run from the best of `p_init` all subjects are solved together by a
+    bracketing search over [lower, upper] (one forward launch per probe) -- the global minimum per subject, hence an
+    objective <= the reference's.  p_init is accepted for signature compatibility and only widens the bracket."""
+    pop = _supp_population(prob, data, timepoints, 0.0, n_steps)
+    eng, N = pop.engine, np.asarray(data).shape[2]
+    if p_init is not None and len(p_init):
+        lower = min(lower, float(np.min(p_init)))
+        upper = max(upper, float(np.max(p_init)))
+    eng.set_params(network_params, np.zeros(N))
+
+    def sse(th):
+        eng.set_params(None, np.broadcast_to(th, (N,)))
+        return eng.forward(want_sse=True)["sse"]
+    theta, best = _bracket_min(sse, lower, upper, 161)
+    return theta, float(best.sum() / N)
+
+
 # ----------------------------------------------------------------------------- SAEM
 def individual_log_likelihood(sse, n_obs, sigma):
     """-(n/2) log sigma^2 - SSE/(2 sigma^2), -Inf on solver failure (src/saem.jl:55-66)."""

@@ -132,6 +132,23 @@ def test_suppression_api_matches_oracle_and_fits():
     api.clear_cache()
 
 
+@pytest.mark.parametrize("model,noise", [(0, ""), (7, ""), (0, "_nonoise"), (7, "_nonoise")])
+def test_validate_suppression_model_against_stored_results(model, noise):
+    """validate_suppression_model on the reference's stored validation sets with its stored networks: the stored
+    `losses_valid*` / `correlations_valid*` depend on stored quantities only (the network is frozen)."""
+    from scipy.stats import spearmanr
+    from cude import api
+    g = dict(np.load(os.path.join(GOLD, "suppression_lambda0.npz")))
+    prob = api.SuppressionProblem(api.neural_network_model(5, 3, input_dims=4))
+    theta, obj = api.validate_suppression_model(None, prob, g["validation_data" + noise], g["timepoints"],
+                                                g["nn_4x3x5x1"][model], n_steps=60)
+    stored = g["losses_valid" + noise][model]
+    assert 0.93 * stored <= obj <= 1.005 * stored
+    rho = spearmanr(theta, g["gt_validation_param" + noise])[0]
+    assert abs(rho - g["correlations_valid" + noise][model]) < 0.01
+    api.clear_cache()
+
+
 def test_saem_runs_and_improves_likelihood():
     from cude import api
     net = api.chain(4, 2, "tanh")
