@@ -77,6 +77,12 @@ def main():
                         **{k: supp[k] for k in ("validation_data", "validation_data_nonoise", "gt_validation_param",
                                                 "gt_validation_param_nonoise", "losses_valid", "losses_valid_nonoise",
                                                 "correlations_valid", "correlations_valid_nonoise")})
+    # the most regularised run (lambda = 1): the networks collapse to a constant output, the loss no longer depends on
+    # the (unsaved) conditional parameters and the stored final losses become known answers of suppression_loss
+    s1 = jld2.load(os.path.join(REF, "suppression/results/lambda=1.0.jld2"))
+    assert np.array_equal(s1["group_data"], group) and s1["λ"] == 1.0
+    np.savez_compressed(os.path.join(OUT, "suppression_lambda1.npz"), nn_4x3x5x1=np.stack(s1["neural_parameters"]),
+                        losses=s1["losses"])
     # dose-response table the reference's symbolic regression was run on (30 exp(beta) x 30 dG values)
     prod = pd.read_csv(os.path.join(REF, "data/ohashi_production.csv"))
     np.savez_compressed(os.path.join(OUT, "ohashi_production.npz"), beta=prod["Beta"].to_numpy(dtype=np.float64),
