@@ -190,14 +190,16 @@ def _rank_main(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_training_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_gloo_training_matches_single_process(tmp_path, world):
+    """world = 3 shards the 23 subjects unevenly (8 / 8 / 7)."""
     import torch.multiprocessing as mp
     import c_oracle as co
     import cude_oracle as o
-    n_total, world = 23, 2
-    port = 29500 + (os.getpid() % 2000)
+    n_total = 23
+    port = 29500 + (os.getpid() % 2000) + world
     mp.spawn(_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / f"rank{world - 1}.npz")
     assert np.array_equal(r0["losses"], r1["losses"]) and np.array_equal(r0["nn"], r1["nn"])
     # single-process reference: the same 4 Adam steps on the whole population
     c = make_cpep_case(n_total, (2, 6, 2))
