@@ -460,10 +460,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
         for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
         a.ckpt = c->ckpt.p; a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev;
-        if (grad && supp_keep_activations(c, 1)) {
-            HIP_TRY(c->act.reserve(supp_act_doubles(c)));
-            a.act = c->act.p;
-        }
+        // allocated by cude_set_population_supp (never here: this function also runs under stream capture)
+        if (grad && c->act.p && c->act.n >= supp_act_doubles(c)) a.act = c->act.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         HIP_TRY(cude::launch_supp(c->net, grad, a, c->stream));
     }
@@ -664,6 +662,7 @@ int32_t cude_set_population_supp(cude_ctx* c, int64_t N, int32_t n_obs, const do
     for (int s = 0; s < 3; s++) c->scale[s] = ssum[s] / ssum[3];
     HIP_TRY(c->data.resize(d.size()));
     HIP_TRY(c->ckpt.resize((size_t)(6 * c->cfg.n_steps + 1) * 3 * N));   // every stage input
+    HIP_TRY(c->act.resize(supp_keep_activations(c, 1) ? supp_act_doubles(c) : 0));   // kept activations (small N)
     HIP_TRY(hipMemcpyAsync(c->data.p, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if ((rc = alloc_common(c))) return rc;
     if ((rc = upload_tables(c, false))) return rc;

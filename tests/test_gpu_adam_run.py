@@ -63,6 +63,13 @@ def test_adam_run_suppression_and_failure():
     nn_after, _ = e1.get_params()
     assert np.array_equal(nn_after, c["nn"])
     e1.close()
+    # graph capture as the FIRST gradient evaluation of a fresh context (nothing may be allocated under capture)
+    e2 = Engine("supp", c["arch"], n_steps=30, lam=0.01)
+    e2.set_population_supp(c["tp"], c["data"])
+    e2.set_params(c["nn"], c["theta"])
+    e2.adam_init(1e-3)
+    assert np.array_equal(e2.adam_run(6), ref)
+    e2.close()
 
 
 def test_small_population_step_latency():
