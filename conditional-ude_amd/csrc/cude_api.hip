@@ -412,7 +412,7 @@ int32_t setup_chunks(cude_ctx* c) {
 int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only = false,
                      const double* cond_ov = nullptr, double* sse_ov = nullptr) {
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
-    if (!c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "parameters not set");
+    if (!c->have_nn || (!c->have_cond && !cond_ov)) return fail(CUDE_ERR_STATE, "parameters not set");
     const int S = c->cfg.n_steps;
     const double h = (c->tp.back() - c->tp.front()) / S;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1021,6 +1021,52 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
                                                                     : sum / c->n_global;
         }
     }
+    return CUDE_OK;
+}
+
+int32_t cude_fit_conditional(cude_ctx* c, double lower, double upper, int32_t n_grid, int32_t n_iters,
+                             double penalty_weight, double penalty_center, double* cond_out, double* objective_out,
+                             double* sse_out) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (!c->have_nn) return fail(CUDE_ERR_STATE, "shared parameters not set");
+    if (!(lower < upper) || !std::isfinite(lower) || !std::isfinite(upper)) return fail(CUDE_ERR_ARG, "need finite lower < upper");
+    if (n_grid < 3 || n_iters < 1 || !(penalty_weight >= 0) || !std::isfinite(penalty_center))
+        return fail(CUDE_ERR_ARG, "need n_grid >= 3, n_iters >= 1, penalty_weight >= 0");
+    if (!cond_out) return fail(CUDE_ERR_ARG, "null output");
+    const int64_t N = c->N;
+    DevBuf<double> buf;                                   // a, b, c, d, fc, best, sse_c, sse_d
+    HIP_TRY(buf.resize((size_t)8 * N));
+    cude::FitArgs f{};
+    f.N = N;
+    f.a = buf.p; f.b = buf.p + N; f.c = buf.p + 2 * N; f.d = buf.p + 3 * N;
+    f.fc = buf.p + 4 * N; f.best = buf.p + 5 * N;
+    double* sse_c = buf.p + 6 * N;
+    double* sse_d = buf.p + 7 * N;
+    f.sse_c = sse_c; f.sse_d = sse_d;
+    f.w = penalty_weight; f.mu = penalty_center;
+    f.lower = lower; f.step = (upper - lower) / (n_grid - 1); f.gr = (std::sqrt(5.0) - 1.0) / 2.0;
+    f.n_grid = n_grid;
+    // everything below is queued on the stream; the only synchronisation is the copy-back at the end
+    for (int k = 0; k < n_grid; k++) {                    // coarse scan of the box
+        const double x = (k == n_grid - 1) ? upper : std::fma((double)k, f.step, lower);
+        HIP_TRY(cude::launch_fill(N, x, f.c, c->stream));
+        if ((rc = run_ensemble(c, false, nullptr, true, f.c, sse_c))) return rc;
+        HIP_TRY(cude::launch_fit(0, f, k, x, c->stream));
+    }
+    HIP_TRY(cude::launch_fit(1, f, 0, 0.0, c->stream));
+    for (int it = 0; it < n_iters; it++) {                // golden section inside the bracket
+        if ((rc = run_ensemble(c, false, nullptr, true, f.c, sse_c))) return rc;
+        if ((rc = run_ensemble(c, false, nullptr, true, f.d, sse_d))) return rc;
+        HIP_TRY(cude::launch_fit(2, f, it == n_iters - 1 ? 1 : 0, 0.0, c->stream));
+    }
+    if ((rc = run_ensemble(c, false, nullptr, true, f.c, sse_c))) return rc;       // at the returned midpoint
+    HIP_TRY(cude::launch_fit(3, f, 0, 0.0, c->stream));
+    HIP_TRY(hipMemcpyAsync(cond_out, f.c, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (objective_out) HIP_TRY(hipMemcpyAsync(objective_out, f.fc, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (sse_out) HIP_TRY(hipMemcpyAsync(sse_out, sse_c, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return CUDE_OK;
 }
 

@@ -147,6 +147,86 @@ hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- per-subject 1-D fits with the shared parameters frozen (cude_fit_conditional): every subject minimises
+// f_i(x) = SSE_i(x) + w (x - mu)^2 over a box; all subjects advance together, one forward launch per probe.
+// Phase kernels between the forward launches keep the whole search on the device.
+__device__ __forceinline__ double fit_objective(double sse, double x, double w, double mu) {
+    const double f = fma(w * (x - mu), x - mu, sse);
+    return fabs(f) <= 1.79769313486231570815e308 ? f : __builtin_huge_val();     // failed solve = +Inf
+}
+
+// coarse scan: probe k of the grid was evaluated at x for everybody; keep the best index per subject
+__global__ void fit_grid_kernel(FitArgs a, int k, double x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const double f = fit_objective(a.sse_c[i], x, a.w, a.mu);
+    if (k == 0 || f < a.fc[i]) {       // strict <: first minimum wins, as numpy.argmin
+        a.fc[i] = f;
+        a.best[i] = k;
+    }
+}
+
+// bracket [grid[k-1], grid[k+1]] around the best grid point and the two golden-section probes inside it
+__global__ void fit_bracket_kernel(FitArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    int k = (int)a.best[i];
+    k = k < 1 ? 1 : (k > a.n_grid - 2 ? a.n_grid - 2 : k);
+    const double lo = fma((double)(k - 1), a.step, a.lower), hi = fma((double)(k + 1), a.step, a.lower);
+    a.a[i] = lo;
+    a.b[i] = hi;
+    a.c[i] = hi - a.gr * (hi - lo);
+    a.d[i] = lo + a.gr * (hi - lo);
+}
+
+// one golden-section step from the SSEs at c and d; final = 1 writes the midpoint to c instead of new probes
+__global__ void fit_golden_kernel(FitArgs a, int final) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    double lo = a.a[i], hi = a.b[i];
+    const double c = a.c[i], d = a.d[i];
+    const double fc = fit_objective(a.sse_c[i], c, a.w, a.mu), fd = fit_objective(a.sse_d[i], d, a.w, a.mu);
+    if (fc < fd) hi = d; else lo = c;
+    a.a[i] = lo;
+    a.b[i] = hi;
+    if (final) {
+        a.c[i] = 0.5 * (lo + hi);
+    } else {
+        a.c[i] = hi - a.gr * (hi - lo);
+        a.d[i] = lo + a.gr * (hi - lo);
+    }
+}
+
+// objective at the returned point
+__global__ void fit_finish_kernel(FitArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.N) a.fc[i] = fit_objective(a.sse_c[i], a.c[i], a.w, a.mu);
+}
+
+__global__ void fill_kernel(int64_t N, double v, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = v;
+}
+
+hipError_t launch_fit(int phase, const FitArgs& a, int k, double x, hipStream_t s) {
+    const int bs = 256;
+    const dim3 grid((unsigned)((a.N + bs - 1) / bs));
+    switch (phase) {
+        case 0: hipLaunchKernelGGL(fit_grid_kernel, grid, dim3(bs), 0, s, a, k, x); break;
+        case 1: hipLaunchKernelGGL(fit_bracket_kernel, grid, dim3(bs), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(fit_golden_kernel, grid, dim3(bs), 0, s, a, k); break;
+        case 3: hipLaunchKernelGGL(fit_finish_kernel, grid, dim3(bs), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(int64_t N, double v, double* out, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((N + bs - 1) / bs)), dim3(bs), 0, s, N, v, out);
+    return hipGetLastError();
+}
+
 // Adam exactly as Optimisers.jl: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 // x -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).  Skipped when any subject failed
 // (g_nn[P+1] > 0): the reference's optimiser would see an Inf objective there.

@@ -132,6 +132,20 @@ struct MhArgs {
 hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, double proposal_std, double* prop,
                              hipStream_t s);
 hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s);
+// per-subject 1-D fits (cude_fit_conditional): device-resident search state, all arrays [N]
+struct FitArgs {
+    int64_t N;
+    double* a; double* b; double* c; double* d;   // bracket and the two probes
+    double* fc; double* best;                     // best grid value / index (scan), objective at the result (finish)
+    const double* sse_c; const double* sse_d;     // per-subject SSE at the probes c and d
+    double w, mu;                                 // penalty w (x - mu)^2
+    double lower, step, gr;                       // grid = lower + k*step; golden ratio (sqrt(5)-1)/2
+    int32_t n_grid;
+};
+// phase 0: grid scan update (k = grid index, x = its value); 1: bracket; 2: golden step (k = 1 on the last one);
+// 3: objective at the result
+hipError_t launch_fit(int phase, const FitArgs& a, int k, double x, hipStream_t s);
+hipError_t launch_fill(int64_t N, double v, double* out, hipStream_t s);
 // population preparation
 hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const double* cpep_tn, const double* age,
                                const uint8_t* t2dm, double* k0, double* k1, double* k2, double* c0, double* dG,

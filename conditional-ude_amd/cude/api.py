@@ -411,40 +411,18 @@ def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_00
     return [OptimizationSolution(u=np.array([b]), objective=s) for b, s in zip(beta, sse)]
 
 
-def _bracket_min(f, lo, hi, n_grid=61, iters=48):
-    """Vectorised 1-D minimisation of N independent functions: coarse grid, then golden section."""
-    grid = np.linspace(lo, hi, n_grid)
-    vals = np.stack([f(g) for g in grid])
-    vals = np.where(np.isfinite(vals), vals, np.inf)
-    k = np.clip(np.argmin(vals, axis=0), 1, n_grid - 2)
-    a, b = grid[k - 1], grid[k + 1]
-    gr = (math.sqrt(5) - 1) / 2
-    c, d = b - gr * (b - a), a + gr * (b - a)
-    fc, fd = f(c), f(d)
-    for _ in range(iters):
-        left = fc < fd
-        b = np.where(left, d, b)
-        a = np.where(left, a, c)
-        c, d = b - gr * (b - a), a + gr * (b - a)
-        fc, fd = f(c), f(d)
-    x = 0.5 * (a + b)
-    return x, f(x)
-
-
 def estimate_conditional(models, timepoints, cpeptide_data, nn, *, initial_beta=-2.0, lower=-4.0, upper=1.0,
                          n_steps=None, n_grid=41, iters=48):
-    """All N independent 1-D problems min_beta SSE_i(beta) at once: every probe is ONE forward launch over
-    the population.  Box [lower, upper]; infinite bounds are replaced by initial_beta -/+ 6."""
+    """All N independent 1-D problems min_beta SSE_i(beta) at once (cude_fit_conditional: coarse scan + golden
+    section with the search state on the device, one forward launch over the population per probe).  Box
+    [lower, upper]; infinite bounds are replaced by initial_beta -/+ 6.  Returns (beta[N], SSE[N])."""
     pop = _population(models, timepoints, cpeptide_data, n_steps)
-    eng, N = pop.engine, pop.N
+    eng = pop.engine
     lo = lower if np.isfinite(lower) else np.min(initial_beta) - 6.0
     hi = upper if np.isfinite(upper) else np.max(initial_beta) + 6.0
-    eng.set_params(nn, np.full(N, lo))
-
-    def sse(b):
-        eng.set_params(None, np.broadcast_to(b, (N,)))
-        return eng.forward(want_sse=True)["sse"]
-    return _bracket_min(sse, lo, hi, n_grid, iters)
+    eng.set_params(nn, None)
+    x, _, sse = eng.fit_conditional(lo, hi, n_grid, iters)
+    return x, sse
 
 
 def train_with_sigma(models, timepoints, cpeptide_data, nn, *, initial_beta=-2.0, lbfgs_lower_bound=-4.0,
@@ -580,12 +558,8 @@ def validate_suppression_model(p_init, prob, data, timepoints, network_params, *
     if p_init is not None and len(p_init):
         lower = min(lower, float(np.min(p_init)))
         upper = max(upper, float(np.max(p_init)))
-    eng.set_params(network_params, np.zeros(N))
-
-    def sse(th):
-        eng.set_params(None, np.broadcast_to(th, (N,)))
-        return eng.forward(want_sse=True)["sse"]
-    theta, best = _bracket_min(sse, lower, upper, 161)
+    eng.set_params(network_params, None)
+    theta, _, best = eng.fit_conditional(lower, upper, 161, 48)
     return theta, float(best.sum() / N)
 
 
@@ -654,12 +628,10 @@ def individual_effects(models, timepoints, cpeptide_data, saem_result, *, n_samp
     acc, samples = eng.mh_chain(rng.standard_normal((n_samples, N)), rng.random((n_samples, N)), sigma, prior, omega,
                                 proposal_std)
 
-    def sse(b):
-        eng.set_params(None, np.broadcast_to(b, (N,)))
-        return eng.forward(want_sse=True)["sse"]
-    modes, _ = _bracket_min(lambda b: sse(b) / (2 * sigma ** 2) + 0.5 * ((b - prior) / omega) ** 2, lower, upper, 81)
-    mle, _ = _bracket_min(sse, lower, upper, 81)
-    return SimpleNamespace(samples=samples, modes=modes, mle=mle, mse=sse(modes),
+    # -(log-likelihood + log prior) = [SSE + (sigma/Omega)^2 (b - prior)^2] / (2 sigma^2) + const
+    modes, _, mse = eng.fit_conditional(lower, upper, 81, 48, (sigma / omega) ** 2, prior)
+    mle, _, _ = eng.fit_conditional(lower, upper, 81, 48)
+    return SimpleNamespace(samples=samples, modes=modes, mle=mle, mse=mse,
                            acceptance_rate=float(acc.sum()) / (n_samples * N))
 
 
@@ -675,10 +647,7 @@ def train_symbolic(models, timepoints, cpeptide_data, *, lower=0.0, upper=1000.0
     lo = math.log(max(lower, 1e-6))
     hi = math.log(upper)
 
-    def sse(logk):
-        eng.set_params(None, np.broadcast_to(logk, (N,)))
-        return eng.forward(want_sse=True)["sse"]
-    logk, val = _bracket_min(sse, lo, hi)
+    logk, _, val = eng.fit_conditional(lo, hi, 61, 48)
     n = len(timepoints)
     sigma = np.sqrt(np.maximum(val, 1e-300) / n)
     obj = (n / 2) * np.log(sigma ** 2) + val / (2 * sigma ** 2)

@@ -166,6 +166,15 @@ class Engine:
                                       _ptr(acc)))
         return acc
 
+    def fit_conditional(self, lower, upper, n_grid=41, n_iters=48, penalty_weight=0.0, penalty_center=0.0):
+        """All subjects' 1-D fits of the conditional parameter with the shared parameters frozen, on the device:
+        argmin_x SSE_i(x) + penalty_weight (x - penalty_center)^2 over [lower, upper] -> (x[N], objective[N], sse[N])."""
+        x, obj, sse = np.empty(self.N), np.empty(self.N), np.empty(self.N)
+        check(self._lib.cude_fit_conditional(self._h, float(lower), float(upper), int(n_grid), int(n_iters),
+                                             float(penalty_weight), float(penalty_center), _ptr(x), _ptr(obj),
+                                             _ptr(sse)))
+        return x, obj, sse
+
     def mh_chain(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0):
         """mh_estep that also returns every state of the chain: (accepted (N,), samples (n_mc, N))."""
         z = _f64(normals)

@@ -83,6 +83,16 @@ function multistart_loss_grad(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matri
     losses, g_nn, g_cond
 end
 
+# `train(models, timepoints, data, neural_network_parameters)` (src/parameter-estimation.jl:272-288) for all models at
+# once: per-subject minimisers of SSE_i(β) + w (β - μ)^2 over [lower, upper]; returns (β, objective, SSE)
+function fit_conditional(c::Ctx, lower, upper; n_grid = 41, n_iters = 48, penalty_weight = 0.0, penalty_center = 0.0)
+    β = Vector{Float64}(undef, c.N); obj = similar(β); sse = similar(β)
+    GC.@preserve β obj sse check(ccall((:cude_fit_conditional, LIB), Int32,
+        (Ptr{Cvoid}, Float64, Float64, Int32, Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, lower, upper, n_grid, n_iters, penalty_weight, penalty_center, β, obj, sse))
+    β, obj, sse
+end
+
 # `maxiters` Adam iterations in one call (hipGraph replay); returns the loss trace
 function adam_run!(c::Ctx, iters::Integer)
     losses = Vector{Float64}(undef, iters)

@@ -135,6 +135,23 @@ int32_t cude_multistart_forward(cude_ctx* ctx, int32_t n_sets, const double* nn_
 int32_t cude_multistart_loss_grad(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                                   double* losses, double* g_nn_sets, double* g_cond_sets);
 
+/* Per-subject fits of the conditional parameter with the shared parameters frozen, for all subjects at once:
+ * every subject i minimises  SSE_i(x) + penalty_weight * (x - penalty_center)^2  over [lower, upper] by a coarse scan
+ * of n_grid points followed by n_iters golden-section steps inside the best bracket; the whole search is queued on
+ * the stream (one forward launch per probe, search state on the device, one synchronisation at the end).
+ * Replaces the per-subject loops  `for (i, model) in enumerate(models) ... Optimization.solve(..., LBFGS, Fminbox)`:
+ *   train(models, timepoints, data, neural_network_parameters) / train_with_sigma   src/parameter-estimation.jl:272-307
+ *   evaluate_model                                                                   :406-433
+ *   validate_suppression_model (loss separates per subject for a frozen network)     suppression_model.jl:179-222
+ *   the (k, sigma) fits of the symbolic model                                        c-peptide/03-symreg.jl:94-106
+ *   MAP (penalty_weight = sigma^2/Omega^2, penalty_center = prior mean) and MLE      c-peptide/06-saem.jl:114-126
+ * (for fixed x the sigma of the reference's 2-parameter objectives has the closed form sigma^2 = SSE/n).
+ * cond_out[N]; objective_out[N] and sse_out[N] optional.  Uses the context's current shared parameters and leaves
+ * its conditional parameters untouched. */
+int32_t cude_fit_conditional(cude_ctx* ctx, double lower, double upper, int32_t n_grid, int32_t n_iters,
+                             double penalty_weight, double penalty_center, double* cond_out, double* objective_out,
+                             double* sse_out);
+
 /* SAEM E-step on the device: n_mc Metropolis-Hastings steps of every subject's conditional parameter
  * (`mcmc_step` src/saem.jl:86-108, applied n_mcmc_steps times with the stochastic-approximation update of the
  * chain state :177-186).  The chain state is the context's conditional parameters (updated in place); the
