@@ -321,13 +321,20 @@ def _adam_then_lbfgs(eng, nn0, cond0, adam_iters, lbfgs_iters, lr, callback=None
     return res["x"][:P], res["x"][P:], res["f"]
 
 
-def _batched_adam_then_lbfgs(eng, nn_inits, cond_inits, adam_iters, lbfgs_iters, lr, traces=None):
+def _batched_adam_then_lbfgs(eng, nn_inits, cond_inits, adam_iters, lbfgs_iters, lr, traces=None, native=True):
     """The K selected restarts trained SIDE BY SIDE instead of one after the other (the reference's loop,
     src/parameter-estimation.jl:372-383 / suppression_model.jl:140-170): every optimiser iteration evaluates the K
     current points with one cude_multistart_loss_grad launch.  Adam (Optimisers.jl update rule) is vectorised over
     the restarts; the K L-BFGS runs are the serial algorithm driven in lock step (cude.lbfgs.lbfgs_batched), so each
     restart follows the path it would follow alone.  A restart whose loss becomes non-finite during Adam is
     dropped, as the reference skips a failed optimisation.  Returns a list of (nn, cond, objective) or None."""
+    if native:                                # the same two stages inside the library (cude_train_restarts)
+        out = eng.train_restarts(nn_inits, cond_inits, adam_iters, lr, lbfgs_iters, want_trace=traces is not None)
+        nn, cond, obj = out[:3]
+        if traces is not None:
+            for k in range(len(obj)):
+                traces[k].extend(float(v) for v in out[3][k] if not np.isnan(v))
+        return [(nn[k], cond[k], float(obj[k])) if np.isfinite(obj[k]) else None for k in range(len(obj))]
     X = np.concatenate([np.asarray(nn_inits, dtype=np.float64), np.asarray(cond_inits, dtype=np.float64)], axis=1)
     K, P = X.shape[0], eng.P
     alive = np.ones(K, bool)

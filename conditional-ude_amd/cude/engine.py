@@ -22,6 +22,29 @@ def n_params(nn_in, width, depth):
     return check(_lib.load().cude_n_params(nn_in, width, depth))
 
 
+_OBJECTIVE = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                         C.c_void_p)
+
+
+def lbfgs_minimize(fg, x0, maxiters=1000):
+    """The library's host-side L-BFGS + BackTracking (cude_lbfgs_minimize; needs no GPU) on a Python objective
+    fg(x) -> (f, g).  Returns dict(x, f, iterations, f_calls, converged) like cude.lbfgs.lbfgs."""
+    x0 = _f64(x0).reshape(-1)
+    n = x0.size
+
+    def thunk(xp, nn, fp, gp, _user):
+        f, g = fg(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+        fp[0] = float(f)
+        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+        return 0
+    cb = _OBJECTIVE(thunk)
+    x = np.empty(n)
+    f, it, calls, conv = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(_lib.load().cude_lbfgs_minimize(n, _ptr(x0), int(maxiters), C.cast(cb, C.c_void_p), None, _ptr(x),
+                                          C.byref(f), C.byref(it), C.byref(calls), C.byref(conv)))
+    return dict(x=x, f=f.value, iterations=it.value, f_calls=calls.value, converged=bool(conv.value))
+
+
 def device_count():
     n = C.c_int32(0)
     check(_lib.load().cude_device_count(C.byref(n)))
@@ -165,6 +188,21 @@ class Engine:
                                       float(prior_sd), float(proposal_std), float(temperature), float(gamma),
                                       _ptr(acc)))
         return acc
+
+    def train_restarts(self, nn_sets, cond_sets, adam_iters, learning_rate, lbfgs_iters, want_trace=False):
+        """K restarts trained side by side inside the library (Adam, then L-BFGS + BackTracking in lock step):
+        nn_sets (K, P), cond_sets (K, N) -> trained (nn (K, P), cond (K, N), objective (K,); +Inf = dropped)
+        [, loss trace (K, adam_iters + lbfgs_iters), NaN after a run stopped]."""
+        nn = _f64(nn_sets)
+        cd = _f64(cond_sets)
+        if nn.ndim != 2 or nn.shape[1] != self.P or cd.shape != (nn.shape[0], self.N):
+            raise ValueError(f"expected nn_sets (K, {self.P}) and cond_sets (K, {self.N})")
+        K = nn.shape[0]
+        nn_out, cond_out, obj = np.empty_like(nn), np.empty_like(cd), np.empty(K)
+        trace = np.empty((K, int(adam_iters) + int(lbfgs_iters))) if want_trace else None
+        check(self._lib.cude_train_restarts(self._h, K, _ptr(nn), _ptr(cd), int(adam_iters), float(learning_rate),
+                                            int(lbfgs_iters), _ptr(nn_out), _ptr(cond_out), _ptr(obj), _ptr(trace)))
+        return (nn_out, cond_out, obj, trace) if want_trace else (nn_out, cond_out, obj)
 
     def fit_conditional(self, lower, upper, n_grid=41, n_iters=48, penalty_weight=0.0, penalty_center=0.0):
         """All subjects' 1-D fits of the conditional parameter with the shared parameters frozen, on the device:

@@ -83,6 +83,18 @@ function multistart_loss_grad(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matri
     losses, g_nn, g_cond
 end
 
+# second half of `train` (src/parameter-estimation.jl:368-383): the selected initial guesses (columns of nn_sets P×K and
+# cond_sets N×K) trained side by side with Adam(η) × adam_iters then LBFGS(BackTracking) × lbfgs_iters;
+# returns (neural P×K, conditional N×K, objectives K)
+function train_restarts(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{Float64}; adam_iters = 1000, η = 1e-2,
+                        lbfgs_iters = 1000)
+    K = size(nn_sets, 2); nn = similar(nn_sets); cond = similar(cond_sets); obj = Vector{Float64}(undef, K)
+    GC.@preserve nn_sets cond_sets nn cond obj check(ccall((:cude_train_restarts, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}), c.h, K, nn_sets, cond_sets, adam_iters, η, lbfgs_iters, nn, cond, obj, C_NULL))
+    nn, cond, obj
+end
+
 # `train(models, timepoints, data, neural_network_parameters)` (src/parameter-estimation.jl:272-288) for all models at
 # once: per-subject minimisers of SSE_i(β) + w (β - μ)^2 over [lower, upper]; returns (β, objective, SSE)
 function fit_conditional(c::Ctx, lower, upper; n_grid = 41, n_iters = 48, penalty_weight = 0.0, penalty_center = 0.0)

@@ -135,6 +135,28 @@ int32_t cude_multistart_forward(cude_ctx* ctx, int32_t n_sets, const double* nn_
 int32_t cude_multistart_loss_grad(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                                   double* losses, double* g_nn_sets, double* g_cond_sets);
 
+/* The second half of `train` (src/parameter-estimation.jl:368-383; fit_suppression_model suppression_model.jl:140-170)
+ * for n_sets selected initial guesses SIDE BY SIDE: `adam_iters` iterations of Optimisers.Adam(learning_rate), then
+ * up to `lbfgs_iters` iterations of Optim's L-BFGS (m = 10) with LineSearches.BackTracking -- every optimiser
+ * iteration evaluates all restarts' current points with one cude_multistart_loss_grad launch; each restart follows
+ * the path it would follow alone.  A restart whose loss becomes non-finite during Adam is dropped (objective +Inf),
+ * as the reference skips a failed optimisation.  In: nn_sets[n_sets][P], cond_sets[n_sets][N]; out: the trained
+ * nn_out / cond_out (same layout) and objective_out[n_sets] (`OptimizationSolution.objective`); loss_trace (optional,
+ * [n_sets][adam_iters + lbfgs_iters], NaN where a run had already stopped) receives what the reference's callbacks
+ * collect: the loss of every Adam iteration, then the loss after every successful L-BFGS iteration.  The optimiser
+ * bookkeeping runs on the host (vectors of P+N doubles); every loss and gradient comes from the device. */
+int32_t cude_train_restarts(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
+                            int32_t adam_iters, double learning_rate, int32_t lbfgs_iters, double* nn_out,
+                            double* cond_out, double* objective_out, double* loss_trace);
+
+/* The same L-BFGS + BackTracking for any objective (host only, needs no GPU): `Optimization.solve(prob,
+ * LBFGS(linesearch = BackTracking()), maxiters)` with Optim.jl's defaults (memory 10, g_tol 1e-8, c_1 1e-4,
+ * rho in [0.1, 0.5], cubic interpolation).  fn fills *f and g[n] at x and returns >= 0 (a non-finite f is a failed
+ * solve: the line search backs away from it).  iterations / f_calls / converged may be NULL. */
+typedef int32_t (*cude_objective_fn)(const double* x, int32_t n, double* f, double* g, void* user);
+int32_t cude_lbfgs_minimize(int32_t n, const double* x0, int32_t maxiters, cude_objective_fn fn, void* user,
+                            double* x_out, double* f_out, int32_t* iterations, int32_t* f_calls, int32_t* converged);
+
 /* Per-subject fits of the conditional parameter with the shared parameters frozen, for all subjects at once:
  * every subject i minimises  SSE_i(x) + penalty_weight * (x - penalty_center)^2  over [lower, upper] by a coarse scan
  * of n_grid points followed by n_iters golden-section steps inside the best bracket; the whole search is queued on

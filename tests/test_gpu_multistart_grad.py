@@ -66,10 +66,19 @@ def test_side_by_side_training_follows_the_serial_restarts():
     K = 6
     nn_inits = np.stack([api.init_params(api.chain(4, 2, "tanh"), rng) for _ in range(K)])
     cond_inits = rng.uniform(-2.0, 0.0, (K, 57))
-    few = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 5, 0, 1e-2)
+    few = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 5, 0, 1e-2, native=False)
+    few_native = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 5, 0, 1e-2)     # cude_train_restarts
     for k in range(K):
         nn, cond, _ = api._adam_then_lbfgs(eng, nn_inits[k], cond_inits[k], 5, 0, 1e-2)
         assert np.allclose(few[k][0], nn, rtol=0, atol=1e-12) and np.allclose(few[k][1], cond, rtol=0, atol=1e-12)
+        assert np.allclose(few_native[k][0], nn, rtol=0, atol=1e-12)
+        assert np.allclose(few_native[k][1], cond, rtol=0, atol=1e-12)
+        assert abs(few_native[k][2] - few[k][2]) <= 1e-12 * few[k][2]
+    # a short L-BFGS stage: the native state machines and the Python generators take the same steps
+    py = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 5, 6, 1e-2, native=False)
+    nat = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 5, 6, 1e-2)
+    for k in range(K):
+        assert abs(nat[k][2] - py[k][2]) <= 1e-9 * py[k][2] and np.allclose(nat[k][0], py[k][0], rtol=0, atol=1e-8)
     full = api._batched_adam_then_lbfgs(eng, nn_inits, cond_inits, 150, 60, 1e-2)
     start = eng.multistart_forward(nn_inits, cond_inits)
     for k in range(K):

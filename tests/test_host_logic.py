@@ -103,6 +103,39 @@ def test_batched_lbfgs_reproduces_serial_runs():
     assert batched[-1]["iterations"] == 0 and batched[0]["f"] < 1e-10
 
 
+def test_native_lbfgs_follows_the_python_statement():
+    """cude_lbfgs_minimize (csrc/cude_optim.h: the same algorithm as a resumable C++ state machine, the engine of
+    cude_train_restarts) against cude.lbfgs.lbfgs on host objectives.  The two differ only in the summation order
+    of their dot products, so iterates agree closely and the counters exactly on these problems."""
+    from cude.engine import lbfgs_minimize
+    from cude.lbfgs import lbfgs
+
+    def rosen(x):
+        f = 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2
+        g = np.array([-400 * x[0] * (x[1] - x[0] ** 2) - 2 * (1 - x[0]), 200 * (x[1] - x[0] ** 2)])
+        return f, g
+    a, b = lbfgs_minimize(rosen, [-1.2, 1.0], 200), lbfgs(rosen, np.array([-1.2, 1.0]), maxiters=200)
+    assert a["f"] < 1e-12 and np.allclose(a["x"], [1.0, 1.0], atol=1e-5) and a["converged"]
+    assert a["iterations"] == b["iterations"] and a["f_calls"] == b["f_calls"]
+    assert np.allclose(a["x"], b["x"], rtol=0, atol=1e-9)
+    A = np.diag(np.arange(1.0, 31.0))                     # more than m = 10 curvature pairs: the ring buffer wraps
+    quad = lambda x: (0.5 * x @ A @ x, A @ x)
+    a, b = lbfgs_minimize(quad, np.ones(30), 100), lbfgs(quad, np.ones(30), maxiters=100)
+    assert a["f"] < 1e-14 and a["iterations"] == b["iterations"] and a["f_calls"] == b["f_calls"]
+
+    def with_inf(x):                                      # solver-failure region: +Inf must be backed away from
+        if x[0] > 2.0:
+            return np.inf, np.zeros(1)
+        return (x[0] - 1.5) ** 2, np.array([2 * (x[0] - 1.5)])
+    a, b = lbfgs_minimize(with_inf, [-30.0], 50), lbfgs(with_inf, np.array([-30.0]), maxiters=50)
+    assert abs(a["x"][0] - 1.5) < 1e-6 and a["iterations"] == b["iterations"] and a["f_calls"] == b["f_calls"]
+    a = lbfgs_minimize(rosen, [1.0, 1.0], 50)             # already converged at x0
+    assert a["iterations"] == 0 and a["f_calls"] == 1 and a["converged"]
+    a, b = lbfgs_minimize(rosen, [-1.2, 1.0], 7), lbfgs(rosen, np.array([-1.2, 1.0]), maxiters=7)
+    assert a["iterations"] == 7 and not a["converged"] and np.allclose(a["x"], b["x"], atol=1e-12)
+    assert abs(a["f"] - b["f"]) < 1e-12
+
+
 # ------------------------------------------------------------------ 2-rank gloo data-parallel step
 class OracleEngine:
     """Test stand-in with the Engine interface used by ShardedTrainer (numerics from the CPU oracle)."""
