@@ -1054,6 +1054,10 @@ int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, 
     if (n_sets < 1 || !nn_sets || !cond_sets || !nn_out || !cond_out || !objective_out || adam_iters < 0 ||
         lbfgs_iters < 0 || !(learning_rate > 0))
         return fail(CUDE_ERR_ARG, "bad argument");
+    // Adam is element-wise and shards with the subjects; L-BFGS takes inner products over [neural; conditional], whose
+    // conditional part would have to be summed across ranks -- not done here
+    if (c->comm && lbfgs_iters > 0)
+        return fail(CUDE_ERR_UNSUPPORTED, "the L-BFGS stage is single-rank: pass lbfgs_iters = 0 on a sharded population");
     const int K = n_sets, P = c->P;
     const int64_t N = c->N, n = P + N;
     // working copies in the ABI's [K][P] / [K][N] layout

@@ -143,7 +143,9 @@ int32_t cude_multistart_loss_grad(cude_ctx* ctx, int32_t n_sets, const double* n
  * as the reference skips a failed optimisation.  In: nn_sets[n_sets][P], cond_sets[n_sets][N]; out: the trained
  * nn_out / cond_out (same layout) and objective_out[n_sets] (`OptimizationSolution.objective`); loss_trace (optional,
  * [n_sets][adam_iters + lbfgs_iters], NaN where a run had already stopped) receives what the reference's callbacks
- * collect: the loss of every Adam iteration, then the loss after every successful L-BFGS iteration.  The optimiser
+ * collect: the loss of every Adam iteration, then the loss after every successful L-BFGS iteration.  On a sharded
+ * population (cude_comm_init) only the Adam stage is available (lbfgs_iters must be 0: L-BFGS needs inner products
+ * over all subjects' conditional parameters).  The optimiser
  * bookkeeping runs on the host (vectors of P+N doubles); every loss and gradient comes from the device. */
 int32_t cude_train_restarts(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                             int32_t adam_iters, double learning_rate, int32_t lbfgs_iters, double* nn_out,
