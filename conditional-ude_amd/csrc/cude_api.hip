@@ -1025,6 +1025,57 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     return CUDE_OK;
 }
 
+int32_t cude_profile_conditional(cude_ctx* c, int32_t n_points, const double* values, double* sse_out) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (!c->have_nn) return fail(CUDE_ERR_STATE, "shared parameters not set");
+    if (n_points < 1 || !values || !sse_out) return fail(CUDE_ERR_ARG, "null/empty input");
+    const int P = c->P, S = c->cfg.n_steps;
+    const int64_t N = c->N, nb = c->nblocks;
+    const double h = (c->tp.back() - c->tp.front()) / S;
+    // grid points per launch: the grid's y dimension and ~512 MB of scratch (conditional sets, SSEs, partial rows)
+    const double per_point = 8.0 * (2.0 * N + (double)nb * (P + 2));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_points, 32768), (int64_t)(512e6 / per_point)));
+    DevBuf<double> d_val, d_cond, d_sse, d_part;
+    HIP_TRY(d_val.resize((size_t)chunk));
+    HIP_TRY(d_cond.resize((size_t)chunk * N));
+    HIP_TRY(d_sse.resize((size_t)chunk * N));
+    HIP_TRY(d_part.resize((size_t)chunk * nb * (P + 2)));
+    for (int64_t k0 = 0; k0 < n_points; k0 += chunk) {
+        const int64_t kn = std::min<int64_t>(chunk, n_points - k0);
+        HIP_TRY(hipMemcpyAsync(d_val.p, values + k0, kn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(cude::launch_fill_rows(N, (int)kn, d_val.p, d_cond.p, c->stream));
+        if (is_cpep(c)) {
+            cude::CpepArgs a{};
+            a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
+            a.N = N;
+            a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
+            a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+            a.cond = d_cond.p; a.nn = c->nn.p;
+            a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+            a.stepk = c->stepk.p; a.stepd = c->stepd.p;
+            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+            a.sse = d_sse.p; a.partials = d_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = 0; a.set_stride_cond = N;      // one network, kn grid values
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
+        } else {
+            cude::SuppArgs a{};
+            a.N = N;
+            a.data = c->data.p; a.cond = d_cond.p; a.nn = c->nn.p;
+            a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+            for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+            a.sse = d_sse.p; a.partials = d_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = 0; a.set_stride_cond = N;
+            HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(sse_out + k0 * N, d_sse.p, kn * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return CUDE_OK;
+}
+
 int32_t cude_lbfgs_minimize(int32_t n, const double* x0, int32_t maxiters, cude_objective_fn fn, void* user,
                             double* x_out, double* f_out, int32_t* iterations, int32_t* f_calls, int32_t* converged) {
     if (n < 1 || !x0 || !fn || !x_out || maxiters < 0) return fail(CUDE_ERR_ARG, "bad argument");

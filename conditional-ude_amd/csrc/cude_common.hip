@@ -221,6 +221,19 @@ hipError_t launch_fit(int phase, const FitArgs& a, int k, double x, hipStream_t 
     return hipGetLastError();
 }
 
+// out[k][i] = values[k]: the conditional-parameter sets of a likelihood-profile scan (every subject at the same value)
+__global__ void fill_rows_kernel(int64_t N, const double* __restrict__ values, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[(int64_t)blockIdx.y * N + i] = values[blockIdx.y];
+}
+
+hipError_t launch_fill_rows(int64_t N, int n_rows, const double* values, double* out, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((N + bs - 1) / bs), (unsigned)n_rows), dim3(bs), 0, s, N, values,
+                       out);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(int64_t N, double v, double* out, hipStream_t s) {
     const int bs = 256;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((N + bs - 1) / bs)), dim3(bs), 0, s, N, v, out);

@@ -146,6 +146,7 @@ struct FitArgs {
 // 3: objective at the result
 hipError_t launch_fit(int phase, const FitArgs& a, int k, double x, hipStream_t s);
 hipError_t launch_fill(int64_t N, double v, double* out, hipStream_t s);
+hipError_t launch_fill_rows(int64_t N, int n_rows, const double* values, double* out, hipStream_t s);
 // population preparation
 hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const double* cpep_tn, const double* age,
                                const uint8_t* t2dm, double* k0, double* k1, double* k2, double* c0, double* dG,

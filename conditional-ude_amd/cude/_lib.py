@@ -50,6 +50,7 @@ _SIGNATURES = {
                                               C.c_void_p]),
     "cude_mh_estep": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "cude_profile_conditional": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "cude_train_restarts": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cude_lbfgs_minimize": (C.c_int32, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -471,6 +471,20 @@ def likelihood_profile(beta, neural_network_parameters, model, timepoints, cpept
     return nll, nll_min, values
 
 
+def likelihood_profiles(betas, neural_network_parameters, models, timepoints, cpeptide_data, lower_bound, upper_bound,
+                        sigma, *, steps=1000, n_steps=None):
+    """The loop `[likelihood_profile(betas[i], nn, models[i], ...) for i in ...]` of c-peptide/02-conditional.jl:186-188
+    for ALL models with one launch (cude_profile_conditional: the scan value is the grid's second dimension).
+    Returns (nll (N, steps), nll_min (N,), values (steps,)) -- row i is likelihood_profile of subject i."""
+    pop = _population(models, timepoints, cpeptide_data, n_steps)
+    eng = pop.engine
+    values = np.linspace(lower_bound, upper_bound, steps)
+    eng.set_params(neural_network_parameters, np.asarray(betas, dtype=np.float64).reshape(-1))
+    nll_min = eng.forward(want_sse=True)["sse"] / (2 * sigma ** 2)
+    nll = eng.profile_conditional(values).T / (2 * sigma ** 2)
+    return nll, nll_min, values
+
+
 # ----------------------------------------------------------------------------- suppression model
 class _SuppPop:
     def __init__(self, data, timepoints, net, lam, n_steps, device):

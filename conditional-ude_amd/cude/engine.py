@@ -204,6 +204,14 @@ class Engine:
                                             int(lbfgs_iters), _ptr(nn_out), _ptr(cond_out), _ptr(obj), _ptr(trace)))
         return (nn_out, cond_out, obj, trace) if want_trace else (nn_out, cond_out, obj)
 
+    def profile_conditional(self, values):
+        """SSE of every subject at every scan value of the conditional parameter (shared parameters frozen), all in
+        one launch: values (K,) -> (K, N)."""
+        v = _f64(values).reshape(-1)
+        out = np.empty((v.size, self.N))
+        check(self._lib.cude_profile_conditional(self._h, v.size, _ptr(v), _ptr(out)))
+        return out
+
     def fit_conditional(self, lower, upper, n_grid=41, n_iters=48, penalty_weight=0.0, penalty_center=0.0):
         """All subjects' 1-D fits of the conditional parameter with the shared parameters frozen, on the device:
         argmin_x SSE_i(x) + penalty_weight (x - penalty_center)^2 over [lower, upper] -> (x[N], objective[N], sse[N])."""

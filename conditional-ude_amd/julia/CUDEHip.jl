@@ -105,6 +105,14 @@ function fit_conditional(c::Ctx, lower, upper; n_grid = 41, n_iters = 48, penalt
     β, obj, sse
 end
 
+# likelihood profiles (src/likelihood-profiles.jl:4-17) of all models at once: SSE_i(values[k]) as an N×K matrix
+function profile_conditional(c::Ctx, values::Vector{Float64})
+    sse = Matrix{Float64}(undef, c.N, length(values))
+    GC.@preserve values sse check(ccall((:cude_profile_conditional, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), c.h, length(values), values, sse))
+    sse
+end
+
 # `maxiters` Adam iterations in one call (hipGraph replay); returns the loss trace
 function adam_run!(c::Ctx, iters::Integer)
     losses = Vector{Float64}(undef, iters)

@@ -159,6 +159,13 @@ typedef int32_t (*cude_objective_fn)(const double* x, int32_t n, double* f, doub
 int32_t cude_lbfgs_minimize(int32_t n, const double* x0, int32_t maxiters, cude_objective_fn fn, void* user,
                             double* x_out, double* f_out, int32_t* iterations, int32_t* f_calls, int32_t* converged);
 
+/* Likelihood profiles of ALL subjects in one launch: sse_out[n_points][N] (row-major) = SSE_i(values[k]) with the
+ * shared parameters frozen -- the grid's second dimension is the scan value.  Replaces
+ * `likelihood_profile(beta, nn, model, timepoints, data, lower, upper, sigma; steps)` (src/likelihood-profiles.jl:4-17:
+ * `loss_values = [loss(b, (model, ...)) for b in range(lower, upper, length = steps)]`, called per subject with
+ * 1000-10000 points at c-peptide/02-conditional.jl:186-188); the profile is sse / (2 sigma^2). */
+int32_t cude_profile_conditional(cude_ctx* ctx, int32_t n_points, const double* values, double* sse_out);
+
 /* Per-subject fits of the conditional parameter with the shared parameters frozen, for all subjects at once:
  * every subject i minimises  SSE_i(x) + penalty_weight * (x - penalty_center)^2  over [lower, upper] by a coarse scan
  * of n_grid points followed by n_iters golden-section steps inside the best bracket; the whole search is queued on

@@ -174,6 +174,35 @@ def test_likelihood_profile_shape_and_minimum():
     api.clear_cache()
 
 
+def test_likelihood_profiles_of_all_subjects_in_one_launch():
+    """cude_profile_conditional: the scan value is the grid's second dimension.  Every row must equal the
+    single-subject likelihood_profile (same kernel, same lanes: bit-identical SSEs), for the network model and for the
+    suppression model (profile_conditional through the engine)."""
+    from cude import api
+    net = api.chain(4, 2, "tanh")
+    g, models = _ohashi_models(api, net, n=9)
+    nn = g["nn_2x4x4x1"][0]
+    betas = np.linspace(-1.5, 0.5, 9)
+    nll, nll_min, values = api.likelihood_profiles(betas, nn, models, g["timepoints"], g["cpeptide"][:9], -4.0, 3.0,
+                                                   0.3, steps=200)
+    assert nll.shape == (9, 200) and values.shape == (200,)
+    for i in (0, 4, 8):
+        one, one_min, _ = api.likelihood_profile(betas[i], nn, models[i], g["timepoints"], g["cpeptide"][i], -4.0, 3.0,
+                                                 0.3, steps=200)
+        assert np.allclose(nll[i], one, rtol=1e-12, atol=0) and abs(nll_min[i] - one_min) <= 1e-12 * one_min
+    api.clear_cache()
+    from cude.engine import Engine
+    c = make_supp_case(40)
+    eng = Engine("supp", c["arch"], n_steps=30)
+    eng.set_population_supp(c["tp"], c["data"])
+    eng.set_params(c["nn"], c["theta"])
+    scan = eng.profile_conditional([-1.0, 0.0, 0.7])
+    for k, v in enumerate([-1.0, 0.0, 0.7]):
+        eng.set_params(None, np.full(40, v))
+        assert np.array_equal(scan[k], eng.forward(want_sse=True)["sse"])
+    eng.close()
+
+
 # ------------------------------------------------------------------ two ranks sharing the one GPU of the test box
 def _gpu_rank(rank, world, port, n_total, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
