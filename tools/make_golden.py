@@ -10,14 +10,13 @@ Sources (paths relative to /root/reference):
   source_data/cude_neural_parameters.jld2     25 trained 2->4->4->1 weight vectors + their 57 training betas
       (written by c-peptide/02-conditional.jl:44-50)
   source_data/neural_network_parameters.jld2  legacy 2->6->6->1 weight vector (67 doubles)
-  source_data/ude_neural_parameters.jld2      copied as-is (1455 bytes): fixture of the JLD2 reader / writer
+  source_data/ude_neural_parameters.jld2      decoded content + SHA-256 of its 1455 bytes: target of the JLD2 writer test
   suppression/results/lambda=0.0.jld2         25 x 67 weights (4->3x5->1), group_data 3x8x37, losses, correlations
       (written by suppression/suppression.jl:76-91)
   data/ohashi_production.csv                  dose-response table of the symbolic regression
 The .jld2 files are decoded with the build's own reader (conditional-ude_amd/cude/jld2.py).
 """
 import os
-import shutil
 import sys
 
 import numpy as np
@@ -92,8 +91,15 @@ def main():
     fuj = jld2.load(os.path.join(REF, "data/fujita.jld2"))
     np.savez_compressed(os.path.join(OUT, "fujita.npz"), glucose=fuj["glucose"], cpeptide=fuj["cpeptide"],
                         timepoints=fuj["timepoints"].astype(np.float64), ages=fuj["ages"].astype(np.float64))
-    shutil.copyfile(os.path.join(REF, "source_data/ude_neural_parameters.jld2"),
-                    os.path.join(OUT, "ude_neural_parameters.jld2"))
+    # a file JLD2.jl itself wrote, as decoded content + the digest of its bytes (the file itself is not copied): the
+    # writer test regenerates the bytes from the content and must hit the digest
+    import hashlib
+    src = os.path.join(REF, "source_data/ude_neural_parameters.jld2")
+    raw = open(src, "rb").read()
+    f = jld2.JLD2File(src)
+    np.savez_compressed(os.path.join(OUT, "jld2_known_file.npz"), width=np.int64(f["width"]),
+                        depth=np.int64(f["depth"]), parameters=f["parameters"], julia_version=f.julia_version,
+                        n_bytes=np.int64(len(raw)), sha256=hashlib.sha256(raw).hexdigest())
     print(glucose.shape, nn.shape, betas.shape, snn.shape, group.shape, "best model", cude["best_model_index"])
     print("losses", supp["losses"][:4], "group_data[:,0,0]", group[:, 0, 0])
 
