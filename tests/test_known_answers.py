@@ -69,6 +69,76 @@ def test_adaptive_restatement_reproduces_the_reference_to_1e_minus_10():
         assert abs(loss - stored[n]) < 2e-9, (n, loss, stored[n])
 
 
+def _load_validation():
+    g1 = np.load(os.path.join(GOLD, "suppression_lambda1.npz"))
+    g0 = np.load(os.path.join(GOLD, "suppression_lambda0.npz"))
+    sets = [(g0["validation_data"], g1["losses_valid"]), (g0["validation_data_nonoise"], g1["losses_valid_nonoise"])]
+    return g1["nn_4x3x5x1"], sets, g0["timepoints"]
+
+
+def test_oracle_reproduces_the_reference_validation_objectives():
+    """The same file stores, per network, the objective `validate_suppression_model` returned on the two validation
+    sets (suppression/suppression.jl:59-65): `suppression_loss` with lambda = 0 and the network held fixed
+    (suppression_model.jl:179-187).  With the collapsed networks it is again independent of the fitted conditional
+    parameters: 2 x 25 further known answers on two further data sets (30 subjects each, their own `scale`)."""
+    import c_oracle as co
+    nns, sets, tp = _load_validation()
+    rng = np.random.default_rng(2)
+    offsets = []
+    for data, stored in sets:
+        assert data.shape == (3, 8, 30) and stored.shape == (25,)
+        for n in range(25):
+            theta = rng.uniform(-3.0, 3.0, data.shape[2])
+            got = co.supp(tp, data, ARCH, nns[n], theta, 0.0, 240, want_grad=False)["loss"]
+            assert abs(got - stored[n]) < 2e-6, (n, got, stored[n])
+            offsets.append(got - stored[n])
+    # the offsets are the reference solver's own discretisation error: one value per data set, not per network
+    offsets = np.array(offsets).reshape(2, 25)
+    assert np.all(np.ptp(offsets, axis=1) < 5e-9) and np.all(offsets > 5e-7)
+
+
+def test_adaptive_restatement_reproduces_the_validation_objectives():
+    import cude_oracle as o
+    nns, sets, tp = _load_validation()
+    for data, stored in sets:
+        scale = o.supp_scale(data)
+        N = data.shape[2]
+        for n in (3, 21):
+            nn = nns[n]
+            total = 0.0
+            for i in range(N):
+                rhs = lambda t, u: [float(v) for v in o.supp_rhs(np, nn, 1.0, ARCH, t, [np.float64(x) for x in u])]
+                sol = o.solve_adaptive(rhs, list(data[:, 0, i]), list(tp), abstol=1e-6, reltol=1e-3)
+                for ti in range(len(tp)):
+                    for s in range(3):
+                        r = (sol[ti][s] - data[s, ti, i]) / scale[s]
+                        total += r * r
+            assert abs(total / N - stored[n]) < 2e-9, (n, total / N, stored[n])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_reference_validation_objectives():
+    """... and through the product path: the loss itself, and `validate_suppression_model` end to end (the objective
+    is flat in the conditional parameters -- the reference's stored validation correlations are accordingly one and
+    the same number for all 25 networks -- so whatever the per-subject search returns, its objective is the known
+    answer)."""
+    import torch  # noqa: F401
+    from cude import api
+    nns, sets, tp = _load_validation()
+    prob = api.SuppressionProblem(api.neural_network_model(5, 3, input_dims=4))
+    rng = np.random.default_rng(3)
+    for data, stored in sets:
+        for n in (0, 12):
+            p = api.ComponentArray(theta=rng.uniform(-3.0, 3.0, 30), neural=nns[n])
+            got = api.suppression_loss(p, (prob, data, tp, 0.0), n_steps=240)
+            assert abs(got - stored[n]) < 2e-6, (n, got, stored[n])
+        p_init = [rng.random(30) for _ in range(4)]
+        res, objective = api.validate_suppression_model(p_init, prob, data, tp, nns[5], n_steps=240)
+        assert abs(objective - stored[5]) < 2e-6
+        assert res.shape == (30,) and np.all(np.isfinite(res))
+    api.clear_cache()
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_the_reference_objectives():
     import torch  # noqa: F401

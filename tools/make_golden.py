@@ -29,6 +29,19 @@ sys.path.insert(0, os.path.join(ROOT, "conditional-ude_amd"))
 from cude import jld2  # noqa: E402
 
 
+def _save(name, **arrays):
+    """np.savez_compressed, skipped when the committed file already holds exactly this content (zip members carry a
+    time stamp, so a rewrite would change the bytes of an unchanged fixture)."""
+    path = os.path.join(OUT, name)
+    if os.path.exists(path):
+        old = np.load(path)
+        if set(old.files) == set(arrays) and all(
+                np.asarray(arrays[k]).shape == old[k].shape and np.array_equal(np.asarray(arrays[k]), old[k], equal_nan=(
+                    old[k].dtype.kind == "f")) for k in arrays):
+            return
+    np.savez_compressed(path, **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ogtt = pd.read_csv(os.path.join(REF, "data/ohashi_csv/ohashi_OGTT.csv"), sep=";").dropna()
@@ -57,7 +70,7 @@ def main():
     cov = jld2.load(os.path.join(REF, "source_data/cude_covariate_neural_parameters_2.jld2"))
     sig = jld2.load(os.path.join(REF, "source_data/cude_neural_parameters_sigma.jld2"))
     assert cov["width"] == 4 and cov["depth"] == 2 and sig["width"] == 4 and sig["depth"] == 2
-    np.savez_compressed(os.path.join(OUT, "ohashi_cude.npz"), subject_no=subject_no, glucose=glucose,
+    _save("ohashi_cude.npz", subject_no=subject_no, glucose=glucose,
                         cpeptide=cpeptide, ages=ages, t2dm=(types == "T2DM"), types=types,
                         timepoints=np.array([0.0, 30.0, 60.0, 90.0, 120.0]), nn_2x4x4x1=nn, betas_train=betas,
                         nn_2x6x6x1_legacy=legacy, train_subject_numbers=prepared["train"]["subject_numbers"],
@@ -70,7 +83,7 @@ def main():
     supp = jld2.load(os.path.join(REF, "suppression/results/lambda=0.0.jld2"))
     snn = np.stack(supp["neural_parameters"])
     group = supp["group_data"]
-    np.savez_compressed(os.path.join(OUT, "suppression_lambda0.npz"), nn_4x3x5x1=snn, group_data=group,
+    _save("suppression_lambda0.npz", nn_4x3x5x1=snn, group_data=group,
                         correlations=supp["correlations"], losses=supp["losses"], timepoints=np.linspace(0.0, 30.0, 8),
                         gt_sup_param=supp["gt_sup_param"],
                         **{k: supp[k] for k in ("validation_data", "validation_data_nonoise", "gt_validation_param",
@@ -80,16 +93,20 @@ def main():
     # the (unsaved) conditional parameters and the stored final losses become known answers of suppression_loss
     s1 = jld2.load(os.path.join(REF, "suppression/results/lambda=1.0.jld2"))
     assert np.array_equal(s1["group_data"], group) and s1["λ"] == 1.0
-    np.savez_compressed(os.path.join(OUT, "suppression_lambda1.npz"), nn_4x3x5x1=np.stack(s1["neural_parameters"]),
-                        losses=s1["losses"])
+    # ... and so do the stored validation objectives (suppression_loss with lambda = 0 on the two validation sets,
+    # suppression_model.jl:179-187), whose data sets are those of the lambda = 0 fixture
+    assert all(np.array_equal(s1[k], supp[k]) for k in ("validation_data", "validation_data_nonoise"))
+    _save("suppression_lambda1.npz", nn_4x3x5x1=np.stack(s1["neural_parameters"]),
+                        losses=s1["losses"], losses_valid=s1["losses_valid"],
+                        losses_valid_nonoise=s1["losses_valid_nonoise"])
     # dose-response table the reference's symbolic regression was run on (30 exp(beta) x 30 dG values)
     prod = pd.read_csv(os.path.join(REF, "data/ohashi_production.csv"))
-    np.savez_compressed(os.path.join(OUT, "ohashi_production.npz"), beta=prod["Beta"].to_numpy(dtype=np.float64),
+    _save("ohashi_production.npz", beta=prod["Beta"].to_numpy(dtype=np.float64),
                         glucose=prod["Glucose"].to_numpy(dtype=np.float64),
                         production=prod["Production"].to_numpy(dtype=np.float64))
     # external data set of c-peptide/04-symreg-external.jl (20 subjects, 14 irregular time points from -10 min)
     fuj = jld2.load(os.path.join(REF, "data/fujita.jld2"))
-    np.savez_compressed(os.path.join(OUT, "fujita.npz"), glucose=fuj["glucose"], cpeptide=fuj["cpeptide"],
+    _save("fujita.npz", glucose=fuj["glucose"], cpeptide=fuj["cpeptide"],
                         timepoints=fuj["timepoints"].astype(np.float64), ages=fuj["ages"].astype(np.float64))
     # a file JLD2.jl itself wrote, as decoded content + the digest of its bytes (the file itself is not copied): the
     # writer test regenerates the bytes from the content and must hit the digest
@@ -97,7 +114,7 @@ def main():
     src = os.path.join(REF, "source_data/ude_neural_parameters.jld2")
     raw = open(src, "rb").read()
     f = jld2.JLD2File(src)
-    np.savez_compressed(os.path.join(OUT, "jld2_known_file.npz"), width=np.int64(f["width"]),
+    _save("jld2_known_file.npz", width=np.int64(f["width"]),
                         depth=np.int64(f["depth"]), parameters=f["parameters"], julia_version=f.julia_version,
                         n_bytes=np.int64(len(raw)), sha256=hashlib.sha256(raw).hexdigest())
     print(glucose.shape, nn.shape, betas.shape, snn.shape, group.shape, "best model", cude["best_model_index"])
