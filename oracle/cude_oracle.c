@@ -7,7 +7,9 @@
  *
  * PARITY STATUS: the reference is Julia with no tests and cannot run in the build image.  Suppression path: pinned
  * by the reference's stored lambda = 1 objectives (known answers, tests/test_known_answers.py: this file reproduces
- * them to 1.26e-6, the reference solver's own tolerance); c-peptide path: PARITY UNPINNED, soft-pinned by stored
+ * them to 1.26e-6, the reference solver's own tolerance); c-peptide path: pinned at FIGURE RESOLUTION (~1e-4) by
+ * the trajectories and objectives plotted in the reference's vector figures (tests/test_figure_pins.py, through
+ * oracle/cude_oracle.py, with which this file agrees to 1e-12), not at fp64 tolerance; soft-pinned by stored
  * training results.  See oracle/cude_oracle.py for the full statement.
  *
  * This file restates the reference's OWN differentiation method: ForwardDiff dual numbers

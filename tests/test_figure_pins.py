@@ -1,0 +1,232 @@
+"""Known answers of the c-peptide path, read off the reference's own vector figures.
+
+The reference stores no c-peptide objective, but its committed CairoMakie figures are vector graphics: the plotted
+paths ARE the numbers its scripts computed, quantised by Cairo to 1/256 px (tests/golden/figure_traces.npz, decoded
+by tools/extract_figure_traces.py; pixel coordinates only).  Every model-fit panel also draws the subject's five
+measurements, which are stored data -- so each panel calibrates its own axes (no tick label is read) and identifies
+its subject.  What the panels then pin, at the figures' resolution (1/256 px = 1.2e-4 nmol/L resp. 1.6e-4 of SSE):
+
+  * `model_fit_train_median.svg` a-c (02-conditional.jl:444-489): plasma c-peptide of three training-data subjects
+    on 0:0.1:120 min simulated with the STORED best network, at the fitted beta and at two confidence-bound betas:
+    9 trajectories x ~1000 points, each a function of stored quantities and ONE unknown scalar (beta);
+  * panel d (:495-503): the fitted objective of all 82 training-data subjects -- `min_beta SSE_i(beta)` with the
+    stored network, in subject order: 82 known answers of the per-subject loss up to one affine axis map;
+  * `model_fit_test_all.svg` (:532-588): the same three curves for each of the 35 test subjects;
+  * `model_fit_test_covariate_median.svg` (07-covariate-inclusion.jl): three test subjects and the 35 test objectives
+    of the covariate model (3 -> 4 -> 4 -> 1, inputs [dG, exp(beta), age]).
+
+The reference integrates with adaptive Tsit5 at OrdinaryDiffEq's default tolerances (reltol 1e-3), unaware of the
+kinks of the glucose forcing, so its own curves carry a discretisation error of ~5e-3 nmol/L; the oracle's adaptive
+mode (`cude_oracle.solve_adaptive`, the restatement pinned to 4e-10 on the suppression objectives) reproduces them
+to the quantisation of the figure -- when, and only when, it takes the reference's sequence of accepted steps: as a
+function of beta the mismatch is piecewise smooth with a narrow window (~1e-4 wide) at the figure's resolution around
+the beta the reference used, and ~1e-3 outside it.  The converged fixed-step mode (the product's discretisation)
+agrees to the reference solver's own error.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize_scalar
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TYPES = ("NGT", "IGT", "T2DM")
+TOL = 4e-4          # nmol/L: ~3 quantisation steps of the y coordinate
+
+
+class _Data:
+    """The reference's prepared data set (data/ohashi.jld2 split) from the committed fixture."""
+
+    def __init__(self):
+        g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+        self.tp = g["timepoints"]
+        self.g = g
+        self.part = {}
+        for part in ("train", "test"):
+            rows = np.array([np.flatnonzero(g["subject_no"] == s)[0] for s in g[part + "_subject_numbers"]])
+            self.part[part] = dict(types=g["types"][rows], G=g["glucose"][rows], C=g["cpeptide"][rows],
+                                   age=g["ages"][rows], t2dm=g["t2dm"][rows])
+        self.fig = np.load(os.path.join(GOLD, "figure_traces.npz"))
+
+    def network(self, covariate):
+        """(stored best network, arch, box of the reference's per-subject fits).  The box is a function of stored
+        quantities too: lb / ub = min / max of the best model's training betas -+ 10 % (02-conditional.jl:88-89,
+        07-covariate-inclusion.jl:77-78); subjects whose loss keeps falling as beta -> -inf end AT lb."""
+        sfx = "_cov" if covariate else ""
+        k = int(self.g["best_model_index" + sfx]) - 1
+        b = self.g["betas_train" + sfx][k]
+        box = (b.min() - 0.1 * abs(b.min()), b.max() + 0.1 * abs(b.max()))
+        return (self.g["nn_3x4x4x1_cov"][k], (3, 4, 2), box) if covariate else (self.g["nn_2x4x4x1"][k], (2, 4, 2), box)
+
+
+@pytest.fixture(scope="module")
+def data():
+    return _Data()
+
+
+class _Subject:
+    """One subject of the reference's data with the oracle's two integrators."""
+
+    def __init__(self, d, part, i, covariate):
+        import cude_oracle as o
+        p = d.part[part]
+        self.o, self.tp, self.obs, self.covariate = o, d.tp, p["C"][i], covariate
+        self.nn, self.arch, self.box = d.network(covariate)
+        self.row = tuple(p[k][i:i + 1] for k in ("G", "C", "age", "t2dm"))
+        self.pop = o.CPepPopulation(d.tp, *self.row, covariate=covariate)
+
+    def adaptive(self, beta, times):
+        """plasma c-peptide at `times` (first 0, last 120), integrated as the reference did: adaptive Tsit5 with
+        OrdinaryDiffEq's default tolerances."""
+        o = self.o
+        c0 = float(self.pop.c0[0])
+        u0 = [c0, float(self.pop.k2[0] / self.pop.k1[0]) * c0]
+        sol = o.solve_adaptive(o.cpep_rhs_scalar(self.pop, 0, self.nn, np.exp(beta), self.arch), u0,
+                               [float(t) for t in times], abstol=1e-6, reltol=1e-3)
+        return np.array([s[0] for s in sol])
+
+    def fixed(self, betas, times, n_steps=240):
+        """the same on a fixed grid for a whole vector of betas at once -> (len(betas), len(times))."""
+        o = self.o
+        betas = np.atleast_1d(np.asarray(betas, dtype=np.float64))
+        pop = o.CPepPopulation(self.tp, *(np.repeat(a, betas.size, axis=0) for a in self.row), covariate=self.covariate)
+        eb = np.exp(betas)
+        u0 = [pop.c0, (pop.k2 / pop.k1) * pop.c0]
+        sol = o.solve_fixed(lambda t, u: o.cpep_rhs(np, pop, self.nn, eb, self.arch, t, u, 2), u0,
+                            [float(t) for t in times], n_steps)
+        return np.array([s[0] for s in sol]).T
+
+    def sse_adaptive(self, beta):
+        return float(np.sum((self.adaptive(beta, self.tp) - self.obs) ** 2))
+
+    def argmin_sse(self):
+        """min over the reference's box of the SSE: bracket on a fixed-step scan, refine on the adaptive SSE (the
+        reference's objective); returns (beta, SSE)."""
+        grid = np.linspace(self.box[0], self.box[1], 400)
+        sse = np.sum((self.fixed(grid, self.tp, 60) - self.obs[None, :]) ** 2, axis=1)
+        j = int(np.argmin(sse))
+        r = minimize_scalar(self.sse_adaptive, bounds=(grid[max(j - 3, 0)], grid[min(j + 3, grid.size - 1)]),
+                            method="bounded", options=dict(xatol=1e-8))
+        return r.x, r.fun
+
+
+def _calibrate(markers, tp, obs):
+    """pixel -> data maps of one panel from its five measurement markers: (t_of_x, y_of_px, worst residual in px)."""
+    ax = np.polyfit(tp, markers[:, 0], 1)
+    ay = np.polyfit(obs, markers[:, 1], 1)
+    res = max(np.max(np.abs(np.polyval(ax, tp) - markers[:, 0])), np.max(np.abs(np.polyval(ay, obs) - markers[:, 1])))
+    return (lambda x: (x - ax[1]) / ax[0]), (lambda y: (y - ay[1]) / ay[0]), res
+
+
+def _identify(markers, tp, C, candidates):
+    """the candidate subject whose measurements the markers are (must be unambiguous)."""
+    res = sorted((_calibrate(markers, tp, C[i])[2], i) for i in candidates)
+    assert res[0][0] < 0.01 and res[1][0] > 0.3, res[:2]        # px: quantisation vs the next-best subject
+    return res[0][1]
+
+
+def _curve(fig, key, t_of_x, y_of_px):
+    """(times, values) of one plotted simulation.  The vertices were computed on the grid 0:0.1:120, so the time of
+    a vertex is snapped to that grid: this removes the quantisation of the x coordinate altogether."""
+    c = fig[key] / 256.0
+    t = np.round(t_of_x(c[:, 0]) * 10.0) / 10.0
+    assert np.max(np.abs(t - t_of_x(c[:, 0]))) < 0.01 and t[0] == 0.0 and t[-1] == 120.0 and np.all(np.diff(t) > 0)
+    return t, y_of_px(c[:, 1])
+
+
+def _beta_of_curve(subject, t, y, lo, hi):
+    """The one unknown of a plotted simulation: the beta it was run at.  The mismatch is a smooth function of beta
+    for the fixed-step integrator but only piecewise smooth for the adaptive one, so: locate beta with the former
+    (all candidates in one vectorised solve), then scan a neighbourhood finely with the latter."""
+    sel = np.unique(np.r_[np.arange(0, t.size, 8), t.size - 1])            # always integrate over the full [0, 120]
+    lo0, hi0 = lo, hi
+    for n in (81, 81, 41):
+        scan = np.linspace(lo, hi, n)
+        err = np.max(np.abs(subject.fixed(scan, t[sel], 60) - y[None, sel]), axis=1)
+        j = int(np.argmin(err))
+        lo, hi = scan[max(j - 1, 0)], scan[min(j + 1, n - 1)]
+    centre = min(max(scan[j], lo0 + 6e-3), hi0 - 6e-3)
+    near = centre + np.linspace(-6e-3, 6e-3, 121)
+    errs = [float(np.max(np.abs(subject.adaptive(b, t[sel]) - y[sel]))) for b in near]
+    k = int(np.argmin(errs))
+    r = minimize_scalar(lambda b: float(np.max(np.abs(subject.adaptive(b, t[sel]) - y[sel]))), method="bounded",
+                        bounds=(near[max(k - 1, 0)], near[min(k + 1, 120)]), options=dict(xatol=1e-7))
+    beta = r.x if r.fun < errs[k] else near[k]
+    return beta, float(np.max(np.abs(subject.adaptive(beta, t) - y)))
+
+
+def _check_panel(subject, fig, prefix, names=("fit", "bound0", "bound1"), profile=(10.0, 15.0)):
+    """fit, lower and upper curve of one panel -> {name: (beta, error)} and the panel's pixel -> data maps."""
+    tx, ty, res = _calibrate(fig[prefix + "_markers"], subject.tp, subject.obs)
+    assert res < 0.01
+    beta_star, sse_star = subject.argmin_sse()
+    out = {}
+    for name in names:
+        if prefix + "_" + name not in fig.files:
+            continue
+        t, y = _curve(fig, prefix + "_" + name, tx, ty)
+        # the fit was run at a beta inside the optimiser's box; the confidence-bound betas lie anywhere in the
+        # profiled range (likelihood_profile: beta - 10 ... beta + 15 in 02-conditional.jl, - 3 ... + 5 in 07-*.jl)
+        lo, hi = subject.box if name == "fit" else (out["fit"][0] - profile[0], out["fit"][0] + profile[1])
+        beta, err = _beta_of_curve(subject, t, y, lo, hi)
+        assert err < TOL, (prefix, name, beta, err)
+        out[name] = (beta, err)
+    # the plotted fit was run at the minimiser of the subject's loss over the box (to the reference optimiser's
+    # stopping accuracy); where the loss is still falling at the lower edge, AT that edge
+    beta_fit = out["fit"][0]
+    if beta_star > subject.box[0] + 0.05:
+        assert abs(beta_fit - beta_star) < 5e-2, (prefix, beta_fit, beta_star)    # shallow minima: see the SSE check
+    else:
+        assert beta_fit < subject.box[0] + 0.02, (prefix, beta_fit, subject.box)
+    # (the adaptive-step SSE is a jagged function of beta -- its step sequence changes with beta -- with ripples of
+    # ~1 %, and the reference's L-BFGS stopped in one of them)
+    assert subject.sse_adaptive(beta_fit) - sse_star < 2e-2 * max(sse_star, 0.05)
+    return out, (tx, ty)
+
+
+def _check_objectives(data, part, tag, covariate):
+    """fitted objectives in subject order vs the scatter panel, one affine axis map for all of them."""
+    p = data.part[part]
+    order = np.concatenate([np.flatnonzero(p["types"] == t) for t in TYPES])
+    px = np.concatenate([data.fig[f"{tag}_{t}_objectives"][:, 1] for t in TYPES])
+    assert order.size == px.size == p["types"].size
+    sse = np.array([_Subject(data, part, i, covariate).argmin_sse()[1] for i in order])
+    a, b = np.polyfit(sse, px, 1)
+    res = np.abs((np.polyval([a, b], sse) - px) / a)                  # in SSE units; quantisation 1.6e-4
+    assert abs(0.5 / 256 / a) < 3e-4 and np.ptp(sse) > 3.0
+    assert np.median(res) < 3e-4 and np.quantile(res, 0.9) < 1.5e-3 and res.max() < 4e-3, (np.median(res), res.max())
+
+
+def test_train_median_panels_reproduce_the_reference_trajectories(data):
+    p = data.part["train"]
+    for t in TYPES:
+        i = _identify(data.fig[f"train_{t}_markers"], data.tp, p["C"], np.flatnonzero(p["types"] == t))
+        sub = _Subject(data, "train", i, covariate=False)
+        out, (tx, ty) = _check_panel(sub, data.fig, f"train_{t}")
+        assert len(out) == 3
+        # the converged fixed-step solution (the product's discretisation) differs by the reference solver's own error
+        tt, yy = _curve(data.fig, f"train_{t}_fit", tx, ty)
+        assert np.max(np.abs(sub.fixed(out["fit"][0], tt, 1200)[0] - yy)) < 1.5e-2
+
+
+def test_train_objectives_reproduce_panel_d(data):
+    _check_objectives(data, "train", "train", covariate=False)
+
+
+def test_all_test_subject_panels_reproduce_the_reference_trajectories(data):
+    p = data.part["test"]
+    n_curves = 0
+    for i in range(35):
+        assert _calibrate(data.fig[f"testall_{i}_markers"], data.tp, p["C"][i])[2] < 0.01    # panels in subject order
+        out, _ = _check_panel(_Subject(data, "test", i, covariate=False), data.fig, f"testall_{i}")
+        n_curves += len(out)
+    assert n_curves == 100          # 35 fits + 65 confidence-bound simulations (five bounds are infinite: not drawn)
+
+
+def test_covariate_panels_and_objectives(data):
+    p = data.part["test"]
+    for t in TYPES:
+        i = _identify(data.fig[f"covariate_{t}_markers"], data.tp, p["C"], np.flatnonzero(p["types"] == t))
+        out, _ = _check_panel(_Subject(data, "test", i, covariate=True), data.fig, f"covariate_{t}", profile=(3.0, 5.0))
+        assert len(out) == 3
+    _check_objectives(data, "test", "covariate", covariate=True)

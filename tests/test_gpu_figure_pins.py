@@ -1,0 +1,82 @@
+"""The product path against the reference's published model-fit figures (see tests/test_figure_pins.py for what the
+figure traces are and how each panel calibrates itself).
+
+The reference's curves carry its adaptive solver's own error (reltol 1e-3: ~5e-3 ... 2e-2 nmol/L, ~1 % of an SSE);
+the oracle's adaptive restatement removes that error and matches to the figures' quantisation (CPU test).  The HIP
+path integrates on a fixed grid, so it can agree with the figures only to that solver error -- which is what is
+asserted here, end to end through the reference's own call sequence (`train_with_sigma` -> `simulate`,
+c-peptide/02-conditional.jl:88-106, :447, :535): 35 + 35 + 82 fitted objectives and 38 trajectories.
+"""
+import numpy as np
+import pytest
+
+import test_figure_pins as F
+
+pytestmark = pytest.mark.gpu
+FINE = np.round(np.arange(1201) * 0.1, 10)          # sol_timepoints = 0:0.1:120
+
+
+def _models(api, d, part, covariate):
+    p = d.part[part]
+    net = api.chain(4, 2, "tanh", input_dims=3 if covariate else 2)
+    make = api.CPeptideConditionalCovariateUDEModel if covariate else api.CPeptideConditionalUDEModel
+    return [make(p["G"][i], d.tp, p["age"][i], net, p["C"][i], p["t2dm"][i]) for i in range(p["C"].shape[0])]
+
+
+def _fit(api, d, part, covariate):
+    """the reference's per-subject fit: box from the stored training betas, SSE recovered from the NLL objective."""
+    nn, _, (lb, ub) = d.network(covariate)
+    models = _models(api, d, part, covariate)
+    C = d.part[part]["C"]
+    sols = api.train_with_sigma(models, d.tp, C, nn, lbfgs_lower_bound=lb, lbfgs_upper_bound=ub, initial_beta=-1.0)
+    beta = np.array([s.u.ode[0] for s in sols])
+    sigma = np.array([s.u.sigma for s in sols])
+    sse = (np.array([s.objective for s in sols]) - (len(d.tp) / 2) * np.log(sigma ** 2)) * (2 * sigma ** 2)
+    return models, nn, beta, sse
+
+
+def _objectives_vs_scatter(d, part, tag, sse):
+    p = d.part[part]
+    order = np.concatenate([np.flatnonzero(p["types"] == t) for t in F.TYPES])
+    px = np.concatenate([d.fig[f"{tag}_{t}_objectives"][:, 1] for t in F.TYPES])
+    a, b = np.polyfit(sse[order], px, 1)
+    return np.abs((np.polyval([a, b], sse[order]) - px) / a)
+
+
+def test_gpu_fitted_objectives_match_the_figures():
+    import torch  # noqa: F401
+    from cude import api
+    d = F._Data()
+    for part, tag, covariate in (("train", "train", False), ("test", "covariate", True)):
+        _, _, _, sse = _fit(api, d, part, covariate)
+        res = _objectives_vs_scatter(d, part, tag, sse)
+        # SSE units; objectives span 0.002 ... 6.  The residual is the reference solver's error in its own objective.
+        assert np.median(res) < 3e-3 and res.max() < 5e-2, (tag, np.median(res), res.max())
+    api.clear_cache()
+
+
+def test_gpu_trajectories_match_the_figures():
+    import torch  # noqa: F401
+    from cude import api
+    d = F._Data()
+    # all 35 test subjects (model_fit_test_all.svg), panels in subject order
+    models, nn, beta, _ = _fit(api, d, "test", False)
+    sim = api.simulate(nn, beta, models, d.tp, d.part["test"]["C"], out_timepoints=FINE)
+    assert sim.shape == (35, 1201)
+    errs = []
+    for i in range(35):
+        tx, ty, res = F._calibrate(d.fig[f"testall_{i}_markers"], d.tp, d.part["test"]["C"][i])
+        t, y = F._curve(d.fig, f"testall_{i}_fit", tx, ty)
+        errs.append(np.max(np.abs(sim[i, np.rint(t * 10).astype(int)] - y)))
+    errs = np.array(errs)
+    assert np.median(errs) < 1e-2 and errs.max() < 4e-2, (np.median(errs), errs.max())      # nmol/L; curves span 0.3 ... 6
+    # the three median training-data subjects (model_fit_train_median.svg)
+    models, nn, beta, _ = _fit(api, d, "train", False)
+    sim = api.simulate(nn, beta, models, d.tp, d.part["train"]["C"], out_timepoints=FINE)
+    p = d.part["train"]
+    for typ in F.TYPES:
+        i = F._identify(d.fig[f"train_{typ}_markers"], d.tp, p["C"], np.flatnonzero(p["types"] == typ))
+        tx, ty, _ = F._calibrate(d.fig[f"train_{typ}_markers"], d.tp, p["C"][i])
+        t, y = F._curve(d.fig, f"train_{typ}_fit", tx, ty)
+        assert np.max(np.abs(sim[i, np.rint(t * 10).astype(int)] - y)) < 4e-2
+    api.clear_cache()

@@ -153,6 +153,23 @@ def test_against_scipy_integrators():
         assert np.max(np.abs(sol.y - fx[:, :, i])) < 2e-8 * np.max(np.abs(fx[:, :, i]))
 
 
+def test_scalar_rhs_is_the_array_rhs():
+    """cpep_rhs_scalar (plain floats, fed to solve_adaptive) against cpep_rhs, all three production terms."""
+    import cude_oracle as o
+    rng = np.random.default_rng(4)
+    for arch, covariate in (((2, 4, 2), False), ((3, 4, 2), True), (o.SYMBOLIC, False)):
+        c = make_cpep_case(6, arch if arch[1] else (2, 4, 2))
+        pop = o.CPepPopulation(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], covariate=covariate)
+        nn = o.glorot_params(arch, 3) if arch[1] else np.array([1.78])
+        cond = np.exp(rng.normal(0.0, 1.0, pop.N))
+        for t in (0.0, 7.3, 30.0, 61.9, 120.0):
+            u = [rng.random(pop.N) + 0.5, rng.random(pop.N) + 0.5]
+            ref = o.cpep_rhs(np, pop, nn, cond, arch, t, u, 2)
+            for i in range(pop.N):
+                got = o.cpep_rhs_scalar(pop, i, nn, cond[i], arch)(t, [float(u[0][i]), float(u[1][i])])
+                assert abs(got[0] - ref[0][i]) < 1e-14 and abs(got[1] - ref[1][i]) < 1e-14
+
+
 def test_failure_convention_and_adam():
     import cude_oracle as o
     import c_oracle as co

@@ -1,0 +1,135 @@
+"""Decodes the plotted DATA of the reference's vector figures into tests/golden/figure_traces.npz.
+
+The reference has no tests and stores no c-peptide objective, but its committed figures are CairoMakie vector
+graphics whose paths are the numbers its scripts computed, quantised by Cairo to 1/256 px:
+
+  figures/revision/supplementary/model_fit_train_median.svg   (c-peptide/02-conditional.jl:444-524)
+      panels a-c: for the median-error training subject of each glucose-tolerance type, the simulated plasma
+      c-peptide on 0:0.1:120 min (solid line), its five measurements (markers) and two dotted simulations at the
+      confidence bounds of beta; panel d: the fitted objective (sum of squared errors) of all 82 training-data
+      subjects, drawn type by type in subject order
+  figures/revision/supplementary/model_fit_test_all.svg       (c-peptide/02-conditional.jl:532-588)
+      one panel per test subject (35, in subject order): model fit, confidence-bound simulations, measurements
+  figures/revision/supplementary/model_fit_test_covariate_median.svg   (c-peptide/07-covariate-inclusion.jl)
+      the train-median panels of the covariate model (3 -> 4 -> 4 -> 1 network)
+
+Only pixel coordinates are stored, as integers in units of 1/256 px (exactly what Cairo wrote): poly-line vertices
+and marker centres in drawing order.  Mapping them to data units is the test's job (tests/test_figure_pins.py: the
+markers are the subject's own measurements, which calibrates every axis without reading a tick label).  Runs only
+where /root/reference exists.
+"""
+import os
+import re
+import sys
+
+import numpy as np
+
+REF = "/root/reference/figures/revision"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden", "figure_traces.npz")
+# stroke / fill colours of the three glucose-tolerance types (COLORS in c-peptide/02-conditional.jl:67-71)
+TYPES = {"NGT": "rgb(0.392157%, 39.607844%, 61.56863%)", "IGT": "rgb(78.823531%, 30.588236%, 0%)",
+         "T2DM": "rgb(0.392157%, 47.058824%, 31.37255%)"}
+BLACK = "rgb(0%, 0%, 0%)"
+
+PATH = re.compile(r'<path ([^>]*?)d="([^"]*)"([^>]*)/>')
+NUM = re.compile(r"-?\d+\.?\d*")
+
+
+def _q(v):
+    """pixel coordinates -> integer multiples of 1/256 px (asserting that they are)."""
+    k = np.rint(np.asarray(v) * 256.0)
+    assert np.max(np.abs(k - np.asarray(v) * 256.0)) < 2e-3
+    return k.astype(np.int32)
+
+
+def primitives(svg_file):
+    """Drawing-order list of ("line", attrs, (n,2)) and ("marker", attrs, centre(2,), radius) of one Cairo SVG."""
+    text = open(svg_file).read()
+    body = text[text.index("</defs>"):]
+    out = []
+    for before, d, after in PATH.findall(body):
+        attrs = before + " " + after
+        v = np.array([float(x) for x in NUM.findall(d)]).reshape(-1, 2)
+        if 'fill="none"' in attrs and d.count("L") >= 10 and "C" not in d:
+            out.append(("line", attrs, v))
+        elif d.count("C") in (2, 4) and "L" not in d:
+            # a Makie circle marker: one closed path of two or four Bezier arcs; centre = middle of the control-point box
+            out.append(("marker", attrs, 0.5 * (v.min(axis=0) + v.max(axis=0)), 0.5 * float(np.ptp(v[:, 0]))))
+    return out
+
+
+def decode_type_panels(svg_file):
+    """{type: fit, bounds[], markers(5,2), objectives(m,2)} of a figure with one coloured panel per type."""
+    out = {t: dict(fit=None, bounds=[], markers=[], objectives=[]) for t in TYPES}
+    for prim in primitives(svg_file):
+        for t, colour in TYPES.items():
+            if colour not in prim[1]:
+                continue
+            rec = out[t]
+            if prim[0] == "line":
+                if "stroke-dasharray" in prim[1]:
+                    rec["bounds"].append(prim[2])
+                elif rec["fit"] is None:                                 # solid, linewidth 2 or 1.5
+                    rec["fit"] = prim[2]
+            elif 'fill-opacity="1"' in prim[1] and prim[3] > 1.5:      # markersize 5 / 7: the measurements (+ legend)
+                rec["markers"].append(prim[2])
+            elif 'fill-opacity="0.8"' in prim[1]:                       # markersize 3: objective scatter
+                rec["objectives"].append(prim[2])
+    for t in TYPES:
+        out[t]["markers"] = np.array(out[t]["markers"][:5])             # the legend's marker is drawn last
+        out[t]["objectives"] = np.array(out[t]["objectives"]).reshape(-1, 2)
+    return out
+
+
+def decode_subject_panels(svg_file):
+    """[dict(fit, bounds[], markers(5,2))] of a figure with one black panel per subject, in drawing order: per panel
+    the dotted bound lines, then the solid fit, then five markers."""
+    panels, cur = [], dict(fit=None, bounds=[], markers=[])
+    for prim in primitives(svg_file):
+        if BLACK not in prim[1]:
+            continue
+        if prim[0] == "line":
+            if len(cur["markers"]) == 5:                                 # first line of the next panel
+                panels.append(cur)
+                cur = dict(fit=None, bounds=[], markers=[])
+            if "stroke-dasharray" in prim[1]:
+                cur["bounds"].append(prim[2])
+            elif 'stroke-width="2"' in prim[1]:
+                cur["fit"] = prim[2]
+        elif prim[3] > 2.0 and cur["fit"] is not None and len(cur["markers"]) < 5:
+            cur["markers"].append(prim[2])
+    if cur["fit"] is not None and len(cur["markers"]) == 5:
+        panels.append(cur)
+    for p in panels:
+        p["markers"] = np.array(p["markers"])
+    return panels
+
+
+def main():
+    arrays = {}
+    for tag, rel in (("train", "supplementary/model_fit_train_median.svg"),
+                     ("covariate", "supplementary/model_fit_test_covariate_median.svg")):
+        for t, rec in decode_type_panels(os.path.join(REF, rel)).items():
+            arrays[f"{tag}_{t}_fit"] = _q(rec["fit"])
+            arrays[f"{tag}_{t}_markers"] = rec["markers"]              # centres: half-units, kept as float64
+            arrays[f"{tag}_{t}_objectives"] = rec["objectives"]
+            for k, b in enumerate(rec["bounds"]):
+                arrays[f"{tag}_{t}_bound{k}"] = _q(b)
+            print(tag, t, "fit", rec["fit"].shape, "markers", rec["markers"].shape, "objectives",
+                  rec["objectives"].shape, "bounds", [b.shape for b in rec["bounds"]])
+    panels = decode_subject_panels(os.path.join(REF, "supplementary/model_fit_test_all.svg"))
+    print("test_all panels", len(panels), "fit points", [p["fit"].shape[0] for p in panels][:8], "bounds",
+          [len(p["bounds"]) for p in panels])
+    for i, p in enumerate(panels):
+        arrays[f"testall_{i}_fit"] = _q(p["fit"])
+        arrays[f"testall_{i}_markers"] = p["markers"]
+        for k, b in enumerate(p["bounds"]):
+            arrays[f"testall_{i}_bound{k}"] = _q(b)
+    if "--dry" not in sys.argv:
+        np.savez_compressed(OUT, **arrays)
+        print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
