@@ -63,6 +63,32 @@ def cpep(timepoints, glucose, cpeptide, age, t2dm, arch, nn, beta, n_steps, n_st
     return dict(loss=loss.value, sse=sse, g_nn=g_nn, g_beta=g_beta, traj=traj, n_failed=rc)
 
 
+def cpep_adaptive(timepoints, glucose, cpeptide, age, t2dm, arch, nn, cond, out_times, covariate=False,
+                  abstol=1e-6, reltol=1e-3, nthreads=0):
+    """Plasma c-peptide of N subjects at `out_times` (N x n_out) integrated with the adaptive restatement
+    (cude_oracle.solve_adaptive in C).  cond = exp(beta), or k for the symbolic model (arch width 0).  Failed
+    subjects give NaN rows."""
+    glucose = np.ascontiguousarray(glucose, dtype=np.float64)
+    cpeptide = np.ascontiguousarray(cpeptide, dtype=np.float64)
+    N, T = glucose.shape
+    tp = np.ascontiguousarray(timepoints, dtype=np.float64)
+    age = np.ascontiguousarray(age, dtype=np.float64)
+    t2 = np.ascontiguousarray(t2dm, dtype=np.uint8)
+    nn = np.ascontiguousarray(nn, dtype=np.float64)
+    cond = np.ascontiguousarray(cond, dtype=np.float64)
+    tout = np.ascontiguousarray(out_times, dtype=np.float64)
+    nin, width, depth = arch
+    assert cond.size == N and age.size == N and nn.size == (1 if width == 0 else _n_params(*arch))
+    out = np.zeros((N, tout.size))
+    rc = lib().cude_oracle_cpep_adaptive(C.c_int(N), C.c_int(T), _p(tp), _p(glucose), _p(cpeptide), _p(age), _p(t2),
+                                         C.c_int(int(covariate)), C.c_int(nin), C.c_int(width), C.c_int(depth),
+                                         _p(nn), _p(cond), C.c_int(tout.size), _p(tout), C.c_double(abstol),
+                                         C.c_double(reltol), C.c_int(nthreads), _p(out))
+    if rc < 0:
+        raise ValueError("cude_oracle_cpep_adaptive: unsupported size")
+    return out
+
+
 def supp(timepoints, data, arch, nn, theta, lam, n_steps, want_grad=True, want_traj=False, nthreads=0):
     """data: 3 x T x N numpy array (any layout; converted to Julia column-major)."""
     data = np.asarray(data, dtype=np.float64)

@@ -367,3 +367,159 @@ int cude_oracle_supp(int N, int T, const double* tp, const double* data,
     *loss = nfail ? INFINITY : tot / N + lambda * reg;
     return nfail;
 }
+
+/* ---------------------------------------------------------------- adaptive mode (plain doubles)
+ * cude_oracle.solve_adaptive + cpep_rhs_scalar restated operation for operation in C, for N independent subjects at
+ * once: OrdinaryDiffEq's Tsit5 with its default controller (PI, beta1 = 7/50, beta2 = 2/25, gamma = 0.9, qmin = 0.2,
+ * qmax = 10), Hairer's initial-step heuristic and `saveat` through the free interpolant.  It exists so that the tests
+ * which compare with what the reference RAN (tests/test_figure_pins.py) can scan a parameter finely; the Python
+ * function stays the restatement that the known answers pin, and tests/test_oracle.py holds the two together.
+ * cond[i] = exp(beta_i), or k_i for the symbolic production (width == 0: nn[0] dG / (dG + k) for dG >= 0, else 0).
+ * out is N x n_out (state 1 at out_times; integration runs from out_times[0] to out_times[n_out-1]); a failed
+ * subject's row is NaN.  Returns the number of failed subjects. */
+/* No multiply-add contraction in this section, so that it rounds like the Python statement of the same formulas. */
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
+
+static void interp_weights_nc(double th, double* w) {
+    if (fabs(th - 1.0) < 1e-12) { for (int j = 0; j < 6; j++) w[j] = TA[6][j]; w[6] = 0.0; return; }
+    for (int i = 0; i < 7; i++)
+        w[i] = ((TR[i][3] * th + TR[i][2]) * th + TR[i][1]) * th * th + TR[i][0] * th;
+}
+
+static double lin_interp_nc(const double* tk, const double* u, int T, double t) {
+    int j = 0;
+    while (j + 1 < T && tk[j + 1] <= t) j++;
+    if (j > T - 2) j = T - 2;
+    double slope = (u[j + 1] - u[j]) / (tk[j + 1] - tk[j]);
+    return u[j] + (t - tk[j]) * slope;
+}
+
+static const double TBT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+                              -0.1447110071732629, 0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+
+static double mlp_plain(const double* in, int nin, int width, int depth, const double* nn) {
+    double h[MAXW], nx[MAXW];
+    int fan = nin, off = 0;
+    for (int i = 0; i < nin; i++) h[i] = in[i];
+    for (int l = 0; l < depth; l++) {
+        for (int j = 0; j < width; j++) {
+            double z = nn[off + fan * width + j];
+            for (int i = 0; i < fan; i++) z = z + nn[off + j + width * i] * h[i];
+            nx[j] = tanh(z);
+        }
+        off += fan * width + width;
+        fan = width;
+        for (int j = 0; j < width; j++) h[j] = nx[j];
+    }
+    double z = nn[off + fan];
+    for (int i = 0; i < fan; i++) z = z + nn[off + i] * h[i];
+    return log(1.0 + exp(z));
+}
+
+typedef struct {
+    int nin, width, depth, covariate, T;
+    const double *nn, *tp, *G;
+    double k0, k1, k2, c0, age, cond;
+} plain_ctx;
+
+static void rhs_plain(const plain_ctx* c, double t, const double* u, double* du) {
+    double dG = lin_interp_nc(c->tp, c->G, c->T, t) - c->G[0], prod;
+    if (c->width == 0) {
+        prod = dG >= 0 ? (c->nn[0] * dG) / (dG + c->cond) : 0.0;
+    } else {
+        double in[3] = {dG, c->cond, c->age}, in0[3] = {0.0, c->cond, c->age};
+        prod = mlp_plain(in, c->nin, c->width, c->depth, c->nn) - mlp_plain(in0, c->nin, c->width, c->depth, c->nn);
+    }
+    du[0] = -(c->k0 + c->k2) * u[0] + c->k1 * u[1] + c->k0 * c->c0 + prod;
+    du[1] = -c->k1 * u[1] + c->k2 * u[0];
+}
+
+static double rms2(double a, double b) { return sqrt((a * a + b * b) / 2); }
+
+static int solve_adaptive_plain(const plain_ctx* c, const double* u0, int n_out, const double* tout,
+                                double abstol, double reltol, double* out) {
+    const double beta1 = 7.0 / 50, beta2 = 2.0 / 25, gamma = 0.9, qmin = 0.2, qmax = 10.0;
+    double t0 = tout[0], t1 = tout[n_out - 1];
+    double y[2] = {u0[0], u0[1]}, ynew[2], Y[2], k[7][2], f1[2], y1[2];
+    int nxt = 1;
+    out[0] = y[0];
+    rhs_plain(c, t0, y, k[0]);
+    double sk0 = abstol + reltol * fabs(y[0]), sk1 = abstol + reltol * fabs(y[1]);
+    double d0 = rms2(y[0] / sk0, y[1] / sk1), d1 = rms2(k[0][0] / sk0, k[0][1] / sk1);
+    double dt = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    for (int s = 0; s < 2; s++) y1[s] = y[s] + dt * k[0][s];
+    rhs_plain(c, t0 + dt, y1, f1);
+    double d2 = rms2((f1[0] - k[0][0]) / sk0, (f1[1] - k[0][1]) / sk1) / dt;
+    double dm = d1 > d2 ? d1 : d2;
+    double dt1 = dm <= 1e-15 ? fmax(1e-6, dt * 1e-3) : pow(0.01 / dm, 1.0 / 5);
+    dt = fmin(fmin(100 * dt, dt1), t1 - t0);
+    double t = t0, qold = 1e-4;
+    for (int it = 0; it < 100000; it++) {
+        if (t >= t1 - 1e-14 * fmax(1.0, fabs(t1))) break;
+        dt = fmin(dt, t1 - t);
+        for (int i = 1; i < 7; i++) {
+            for (int s = 0; s < 2; s++) {
+                double acc = 0.0;
+                for (int j = 0; j < i; j++) acc = acc + TA[i][j] * k[j][s];
+                Y[s] = y[s] + dt * acc;
+            }
+            if (i < 6) rhs_plain(c, t + TC[i] * dt, Y, k[i]);
+            else { ynew[0] = Y[0]; ynew[1] = Y[1]; rhs_plain(c, t + dt, ynew, k[6]); }
+        }
+        double e[2];
+        for (int s = 0; s < 2; s++) {
+            double acc = 0.0;
+            for (int j = 0; j < 7; j++) acc = acc + TBT[j] * k[j][s];
+            e[s] = dt * acc / (abstol + reltol * fmax(fabs(y[s]), fabs(ynew[s])));
+        }
+        double est = rms2(e[0], e[1]);
+        if (!isfinite(est)) return 1;
+        double q11 = est > 0 ? pow(est, beta1) : 1e-12;
+        if (est <= 1.0) {
+            while (nxt < n_out && tout[nxt] <= t + dt + 1e-12) {
+                double th = fmin(1.0, (tout[nxt] - t) / dt), w[7], acc = 0.0;
+                interp_weights_nc(th, w);
+                for (int j = 0; j < 7; j++) acc = acc + w[j] * k[j][0];
+                out[nxt++] = y[0] + dt * acc;
+            }
+            double q = q11 / pow(qold, beta2);
+            q = fmax(1 / qmax, fmin(1 / qmin, q / gamma));
+            t = t + dt; y[0] = ynew[0]; y[1] = ynew[1]; k[0][0] = k[6][0]; k[0][1] = k[6][1];
+            qold = fmax(est, 1e-4);
+            dt = dt / q;
+        } else {
+            dt = dt / fmin(1 / qmin, q11 / gamma);
+        }
+    }
+    return nxt < n_out;
+}
+
+int cude_oracle_cpep_adaptive(int N, int T, const double* tp, const double* glucose, const double* cpeptide,
+                              const double* age, const uint8_t* t2dm, int covariate,
+                              int nin, int width, int depth, const double* nn, const double* cond,
+                              int n_out, const double* out_times, double abstol, double reltol, int nthreads,
+                              double* out) {
+    if (T > MAXT || width > MAXW || n_out < 2) return -1;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    int nfail = 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) reduction(+ : nfail)
+    for (int i = 0; i < N; i++) {
+        plain_ctx c;
+        c.nin = nin; c.width = width; c.depth = depth; c.covariate = covariate; c.T = T;
+        c.nn = nn; c.tp = tp; c.G = glucose + (size_t)i * T;
+        van_cauter(age[i], t2dm[i], &c.k0, &c.k1, &c.k2);
+        c.c0 = cpeptide[(size_t)i * T]; c.age = age[i]; c.cond = cond[i];
+        double u0[2] = {c.c0, (c.k2 / c.k1) * c.c0};
+        if (solve_adaptive_plain(&c, u0, n_out, out_times, abstol, reltol, out + (size_t)i * n_out)) {
+            for (int j = 0; j < n_out; j++) out[(size_t)i * n_out + j] = NAN;
+            nfail += 1;
+        }
+    }
+    return nfail;
+}
+#pragma GCC pop_options

@@ -15,11 +15,12 @@ against a RUN of the reference.  It is checked against the reference's STORED ou
     (tests/test_known_answers.py).
     Likewise the 2 x 25 stored validation objectives of that run (7.6e-7 / 9.4e-7).
   * c-peptide path -- PINNED AT FIGURE RESOLUTION by the reference's own vector figures
-    (tests/test_figure_pins.py, tests/golden/figure_traces.npz): 118 simulated c-peptide
-    trajectories (stored network, conditional and covariate model; each a function of stored
-    quantities and one scalar) are reproduced by the adaptive mode to 1.2e-4 ... 2.3e-4 nmol/L --
-    the 1/256 px quantisation of the figures, ~1e-4 of the plotted range -- and 117 fitted
-    per-subject objectives to a median 1.1e-4 of SSE.  No finer c-peptide output of the reference
+    (tests/test_figure_pins.py, tests/golden/figure_traces.npz): 127 simulated c-peptide
+    trajectories (stored networks of the conditional and the covariate model, and the symbolic
+    model on the external data set; each a function of stored quantities and one scalar) are
+    reproduced by the adaptive mode to 0.9e-4 ... 2.3e-4 nmol/L -- the 1/256 px quantisation of
+    the figures, ~1e-4 of the plotted range -- and 117 fitted per-subject objectives to a median
+    1.1e-4 of SSE (20 more, symbolic model, to ~1 %).  No finer c-peptide output of the reference
     exists (it stores no objective), so the fp64 tolerance 1e-6 is NOT pinned against the
     reference on this path; it is additionally soft-pinned by the stored training results of four
     runs (tests/test_soft_pins.py): conditional parameters recovered to ~1e-3, layout /

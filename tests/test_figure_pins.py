@@ -13,14 +13,18 @@ its subject.  What the panels then pin, at the figures' resolution (1/256 px = 1
     stored network, in subject order: 82 known answers of the per-subject loss up to one affine axis map;
   * `model_fit_test_all.svg` (:532-588): the same three curves for each of the 35 test subjects;
   * `model_fit_test_covariate_median.svg` (07-covariate-inclusion.jl): three test subjects and the 35 test objectives
-    of the covariate model (3 -> 4 -> 4 -> 1, inputs [dG, exp(beta), age]).
+    of the covariate model (3 -> 4 -> 4 -> 1, inputs [dG, exp(beta), age]);
+  * `figure_6.svg` (04-symreg-external.jl:72-170): the symbolic model (production 1.78 dG / (dG + k), no network) on
+    the external data set -- 14 irregular time points from -10 min, simulations on -10:0.1:240 -- three subjects x
+    (fit, two confidence bounds) and the 20 fitted objectives.
 
 The reference integrates with adaptive Tsit5 at OrdinaryDiffEq's default tolerances (reltol 1e-3), unaware of the
 kinks of the glucose forcing, so its own curves carry a discretisation error of ~5e-3 nmol/L; the oracle's adaptive
 mode (`cude_oracle.solve_adaptive`, the restatement pinned to 4e-10 on the suppression objectives) reproduces them
 to the quantisation of the figure -- when, and only when, it takes the reference's sequence of accepted steps: as a
-function of beta the mismatch is piecewise smooth with a narrow window (~1e-4 wide) at the figure's resolution around
-the beta the reference used, and ~1e-3 outside it.  The converged fixed-step mode (the product's discretisation)
+function of beta the mismatch is piecewise smooth with a narrow window (~1e-4 wide on the 120-minute grid, down to
+~2e-6 on the 250-minute one) at the figure's resolution around the beta the reference used, and ~1e-3 ... 3e-2 outside
+it -- hence the fine scans, done with the C copy of the adaptive mode and confirmed with the Python one.  The converged fixed-step mode (the product's discretisation)
 agrees to the reference solver's own error.
 """
 import os
@@ -68,12 +72,24 @@ class _Subject:
     """One subject of the reference's data with the oracle's two integrators."""
 
     def __init__(self, d, part, i, covariate):
-        import cude_oracle as o
         p = d.part[part]
-        self.o, self.tp, self.obs, self.covariate = o, d.tp, p["C"][i], covariate
-        self.nn, self.arch, self.box = d.network(covariate)
-        self.row = tuple(p[k][i:i + 1] for k in ("G", "C", "age", "t2dm"))
-        self.pop = o.CPepPopulation(d.tp, *self.row, covariate=covariate)
+        self._setup(d.tp, tuple(p[k][i:i + 1] for k in ("G", "C", "age", "t2dm")), *d.network(covariate), covariate)
+
+    @classmethod
+    def external(cls, tp, glucose, cpeptide):
+        """A subject of the external data set under the symbolic model, as c-peptide/04-symreg-external.jl:44-46
+        builds it: age 29, not diabetic, production 1.78 dG / (dG + k); "beta" is log k here (k in (0, 1000])."""
+        import cude_oracle as o
+        self = cls.__new__(cls)
+        self._setup(tp, (glucose[None, :], cpeptide[None, :], np.array([29.0]), np.array([False])), np.array([1.78]),
+                    o.SYMBOLIC, (np.log(1e-2), np.log(1000.0)), False)
+        return self
+
+    def _setup(self, tp, row, nn, arch, box, covariate):
+        import cude_oracle as o
+        self.o, self.tp, self.row, self.obs, self.covariate = o, tp, row, row[1][0], covariate
+        self.nn, self.arch, self.box = nn, arch, box
+        self.pop = o.CPepPopulation(tp, *row, covariate=covariate)
 
     def adaptive(self, beta, times):
         """plasma c-peptide at `times` (first 0, last 120), integrated as the reference did: adaptive Tsit5 with
@@ -96,17 +112,27 @@ class _Subject:
                             [float(t) for t in times], n_steps)
         return np.array([s[0] for s in sol]).T
 
+    def adaptive_many(self, betas, times):
+        """`adaptive` for a whole vector of betas at once (the same restatement in C, tests/test_oracle.py holds the
+        two together to 1e-11): what makes fine parameter scans affordable."""
+        import c_oracle as co
+        betas = np.atleast_1d(np.asarray(betas, dtype=np.float64))
+        rows = [np.repeat(a, betas.size, axis=0) for a in self.row]
+        return co.cpep_adaptive(self.tp, *rows, self.arch, self.nn, np.exp(betas), times, covariate=self.covariate)
+
     def sse_adaptive(self, beta):
         return float(np.sum((self.adaptive(beta, self.tp) - self.obs) ** 2))
 
     def argmin_sse(self):
-        """min over the reference's box of the SSE: bracket on a fixed-step scan, refine on the adaptive SSE (the
-        reference's objective); returns (beta, SSE)."""
+        """min over the reference's box of the SSE, found the way an optimiser finds it: bracket on the smooth
+        fixed-step SSE, then a line search on the adaptive-step SSE (the reference's objective -- a jagged function of
+        beta whose global minimum is a downward spike no optimiser lands in); returns (beta, SSE)."""
         grid = np.linspace(self.box[0], self.box[1], 400)
         sse = np.sum((self.fixed(grid, self.tp, 60) - self.obs[None, :]) ** 2, axis=1)
         j = int(np.argmin(sse))
-        r = minimize_scalar(self.sse_adaptive, bounds=(grid[max(j - 3, 0)], grid[min(j + 3, grid.size - 1)]),
-                            method="bounded", options=dict(xatol=1e-8))
+        f = lambda b: float(np.sum((self.adaptive_many(b, self.tp)[0] - self.obs) ** 2))
+        r = minimize_scalar(f, bounds=(grid[max(j - 3, 0)], grid[min(j + 3, grid.size - 1)]), method="bounded",
+                            options=dict(xatol=1e-8))
         return r.x, r.fun
 
 
@@ -125,12 +151,12 @@ def _identify(markers, tp, C, candidates):
     return res[0][1]
 
 
-def _curve(fig, key, t_of_x, y_of_px):
-    """(times, values) of one plotted simulation.  The vertices were computed on the grid 0:0.1:120, so the time of
-    a vertex is snapped to that grid: this removes the quantisation of the x coordinate altogether."""
+def _curve(fig, key, t_of_x, y_of_px, span=(0.0, 120.0)):
+    """(times, values) of one plotted simulation.  The vertices were computed on the grid t0:0.1:tend, so the time
+    of a vertex is snapped to that grid: this removes the quantisation of the x coordinate altogether."""
     c = fig[key] / 256.0
-    t = np.round(t_of_x(c[:, 0]) * 10.0) / 10.0
-    assert np.max(np.abs(t - t_of_x(c[:, 0]))) < 0.01 and t[0] == 0.0 and t[-1] == 120.0 and np.all(np.diff(t) > 0)
+    t = np.round((t_of_x(c[:, 0]) - span[0]) * 10.0) / 10.0 + span[0]
+    assert np.max(np.abs(t - t_of_x(c[:, 0]))) < 0.02 and t[0] == span[0] and t[-1] == span[1] and np.all(np.diff(t) > 0)
     return t, y_of_px(c[:, 1])
 
 
@@ -145,14 +171,17 @@ def _beta_of_curve(subject, t, y, lo, hi):
         err = np.max(np.abs(subject.fixed(scan, t[sel], 60) - y[None, sel]), axis=1)
         j = int(np.argmin(err))
         lo, hi = scan[max(j - 1, 0)], scan[min(j + 1, n - 1)]
-    centre = min(max(scan[j], lo0 + 6e-3), hi0 - 6e-3)
-    near = centre + np.linspace(-6e-3, 6e-3, 121)
-    errs = [float(np.max(np.abs(subject.adaptive(b, t[sel]) - y[sel]))) for b in near]
-    k = int(np.argmin(errs))
-    r = minimize_scalar(lambda b: float(np.max(np.abs(subject.adaptive(b, t[sel]) - y[sel]))), method="bounded",
-                        bounds=(near[max(k - 1, 0)], near[min(k + 1, 120)]), options=dict(xatol=1e-7))
-    beta = r.x if r.fun < errs[k] else near[k]
-    return beta, float(np.max(np.abs(subject.adaptive(beta, t) - y)))
+    # The window in which the adaptive restatement takes the reference's accepted-step sequence is ~1e-4 wide in beta
+    # on the 120-minute Ohashi grid and down to ~2e-6 on the 250-minute external grid: scan at 2e-5, then at 1e-6.
+    centre = min(max(scan[j], lo0 + 8e-3), hi0 - 8e-3)
+    for n in (801, 16001):
+        near = centre + np.linspace(-8e-3, 8e-3, n)
+        errs = np.max(np.abs(subject.adaptive_many(near, t[sel]) - y[None, sel]), axis=1)
+        k = int(np.nanargmin(errs))
+        if errs[k] < TOL:
+            break
+    # the verdict is the Python restatement's, on every vertex
+    return near[k], float(np.max(np.abs(subject.adaptive(near[k], t) - y)))
 
 
 def _check_panel(subject, fig, prefix, names=("fit", "bound0", "bound1"), profile=(10.0, 15.0)):
@@ -164,10 +193,16 @@ def _check_panel(subject, fig, prefix, names=("fit", "bound0", "bound1"), profil
     for name in names:
         if prefix + "_" + name not in fig.files:
             continue
-        t, y = _curve(fig, prefix + "_" + name, tx, ty)
+        t, y = _curve(fig, prefix + "_" + name, tx, ty, (subject.tp[0], subject.tp[-1]))
         # the fit was run at a beta inside the optimiser's box; the confidence-bound betas lie anywhere in the
-        # profiled range (likelihood_profile: beta - 10 ... beta + 15 in 02-conditional.jl, - 3 ... + 5 in 07-*.jl)
-        lo, hi = subject.box if name == "fit" else (out["fit"][0] - profile[0], out["fit"][0] + profile[1])
+        # profiled range (likelihood_profile: beta - 10 ... beta + 15 in 02-conditional.jl, - 3 ... + 5 in 07-*.jl,
+        # k - 25 ... k + 1000 in 04-symreg-external.jl)
+        if name == "fit":
+            lo, hi = subject.box
+        elif callable(profile):
+            lo, hi = profile(out["fit"][0])
+        else:
+            lo, hi = out["fit"][0] - profile[0], out["fit"][0] + profile[1]
         beta, err = _beta_of_curve(subject, t, y, lo, hi)
         assert err < TOL, (prefix, name, beta, err)
         out[name] = (beta, err)
@@ -190,11 +225,17 @@ def _check_objectives(data, part, tag, covariate):
     order = np.concatenate([np.flatnonzero(p["types"] == t) for t in TYPES])
     px = np.concatenate([data.fig[f"{tag}_{t}_objectives"][:, 1] for t in TYPES])
     assert order.size == px.size == p["types"].size
-    sse = np.array([_Subject(data, part, i, covariate).argmin_sse()[1] for i in order])
-    a, b = np.polyfit(sse, px, 1)
-    res = np.abs((np.polyval([a, b], sse) - px) / a)                  # in SSE units; quantisation 1.6e-4
-    assert abs(0.5 / 256 / a) < 3e-4 and np.ptp(sse) > 3.0
+    res, sse = _objective_residuals([_Subject(data, part, i, covariate) for i in order], px)
+    assert np.ptp(sse) > 3.0
     assert np.median(res) < 3e-4 and np.quantile(res, 0.9) < 1.5e-3 and res.max() < 4e-3, (np.median(res), res.max())
+
+
+def _objective_residuals(subjects, px):
+    """|fitted objective - plotted objective| in SSE units after the one affine map of the scatter's y axis."""
+    sse = np.array([s.argmin_sse()[1] for s in subjects])
+    a, b = np.polyfit(sse, px, 1)
+    assert abs(0.5 / 256 / a) < 3e-4                                   # quantisation of the plotted value
+    return np.abs((np.polyval([a, b], sse) - px) / a), sse
 
 
 def test_train_median_panels_reproduce_the_reference_trajectories(data):
@@ -230,3 +271,26 @@ def test_covariate_panels_and_objectives(data):
         out, _ = _check_panel(_Subject(data, "test", i, covariate=True), data.fig, f"covariate_{t}", profile=(3.0, 5.0))
         assert len(out) == 3
     _check_objectives(data, "test", "covariate", covariate=True)
+
+
+def test_external_symbolic_model_panels_and_objectives(data):
+    """figure_6 (c-peptide/04-symreg-external.jl:72-170): the symbolic model -- no network, every constant in the
+    source -- on the external data set: 14 irregular time points starting at -10 min, simulations on -10:0.1:240.
+    Three quartile subjects x (fit, two confidence bounds) and the 20 fitted objectives."""
+    fj = np.load(os.path.join(GOLD, "fujita.npz"))
+    tp, G, C = fj["timepoints"], fj["glucose"], fj["cpeptide"]
+    assert tp[0] == -10.0 and tp[-1] == 240.0 and G.shape == (20, 14)
+    subjects = [_Subject.external(tp, G[i], C[i]) for i in range(20)]
+    # confidence bounds were searched on k - 25 ... k + 1000 (raw k); "beta" is log k
+    profile = lambda b: (np.log(max(np.exp(b) - 25.0, 1e-2)), np.log(np.exp(b) + 1000.0))
+    seen = set()
+    for panel in range(3):
+        i = _identify(data.fig[f"external_{panel}_markers"], tp, C, range(20))
+        out, _ = _check_panel(subjects[i], data.fig, f"external_{panel}", profile=profile)
+        assert len(out) == 3
+        seen.add(i)
+    assert len(seen) == 3
+    # The objectives (0.14 ... 5.2) agree only to the ripple of the adaptive-step SSE, which on this 250-minute grid is
+    # ~1 % (the trajectories above needed their k to 1e-6 to be matched; the 17 other subjects' k are not known)
+    res, sse = _objective_residuals(subjects, data.fig["external_objectives"][:, 1])
+    assert np.median(res) < 1e-2 and res.max() < 5e-2 and np.median(res / sse) < 1e-2, (np.median(res), res.max())

@@ -55,6 +55,35 @@ def test_gpu_fitted_objectives_match_the_figures():
     api.clear_cache()
 
 
+def test_gpu_symbolic_model_matches_the_external_figure():
+    """figure_6 end to end (c-peptide/04-symreg-external.jl:44-60, :76-77): symbolic model on the external data set
+    (14 irregular time points from -10 min), `train_symbolic` -> `simulate` on -10:0.1:240; agreement to the
+    reference solver's own error on this 250-minute grid (~1e-2 nmol/L on the curves, ~1 % on the objectives)."""
+    import os
+    import torch  # noqa: F401
+    from cude import api
+    d = F._Data()
+    fj = np.load(os.path.join(F.GOLD, "fujita.npz"))
+    tp, G, C = fj["timepoints"], fj["glucose"], fj["cpeptide"]
+    models = [api.CPeptideODEModel(G[i], tp, 29.0, api.production, C[i], False) for i in range(20)]
+    sols = api.train_symbolic(models, tp, C, lower=0.0, upper=1000.0)
+    k = np.array([s.u.ode[0] for s in sols])
+    sigma = np.array([s.u.sigma for s in sols])
+    sse = (np.array([s.objective for s in sols]) - (len(tp) / 2) * np.log(sigma ** 2)) * (2 * sigma ** 2)
+    px = d.fig["external_objectives"][:, 1]
+    a, b = np.polyfit(sse, px, 1)
+    res = np.abs((np.polyval([a, b], sse) - px) / a)
+    assert np.median(res) < 2e-2 and res.max() < 1e-1, (np.median(res), res.max())       # objectives 0.14 ... 5.2
+    fine = np.round(np.arange(2501) * 0.1 - 10.0, 10)
+    sim = api.simulate(None, k, models, tp, C, out_timepoints=fine)
+    for panel in range(3):
+        i = F._identify(d.fig[f"external_{panel}_markers"], tp, C, range(20))
+        tx, ty, _ = F._calibrate(d.fig[f"external_{panel}_markers"], tp, C[i])
+        t, y = F._curve(d.fig, f"external_{panel}_fit", tx, ty, (tp[0], tp[-1]))
+        assert np.max(np.abs(sim[i, np.rint((t + 10.0) * 10).astype(int)] - y)) < 3e-2     # curves span 0.5 ... 5
+    api.clear_cache()
+
+
 def test_gpu_trajectories_match_the_figures():
     import torch  # noqa: F401
     from cude import api

@@ -170,6 +170,27 @@ def test_scalar_rhs_is_the_array_rhs():
                 assert abs(got[0] - ref[0][i]) < 1e-14 and abs(got[1] - ref[1][i]) < 1e-14
 
 
+def test_c_adaptive_mode_is_the_python_adaptive_mode():
+    """cude_oracle_cpep_adaptive (C, used to scan parameters finely) takes the same accepted steps as
+    cude_oracle.solve_adaptive (the restatement the known answers pin): all three production terms, dense output."""
+    import cude_oracle as o
+    import c_oracle as co
+    rng = np.random.default_rng(5)
+    times = np.round(np.arange(0.0, 120.01, 2.5), 10)
+    for arch, covariate in (((2, 4, 2), False), ((3, 4, 2), True), (o.SYMBOLIC, False)):
+        c = make_cpep_case(5, arch if arch[1] else (2, 4, 2))
+        pop = o.CPepPopulation(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], covariate=covariate)
+        nn = o.glorot_params(arch, 3) if arch[1] else np.array([1.78])
+        cond = np.exp(rng.normal(0.0, 1.0, pop.N)) * (30.0 if arch[1] == 0 else 1.0)
+        got = co.cpep_adaptive(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, nn, cond, times,
+                               covariate=covariate)
+        for i in range(pop.N):
+            c0 = float(pop.c0[i])
+            ref = o.solve_adaptive(o.cpep_rhs_scalar(pop, i, nn, cond[i], arch), [c0, float(pop.k2[i] / pop.k1[i]) * c0],
+                                   list(times))
+            assert np.max(np.abs(got[i] - np.array([r[0] for r in ref]))) < 1e-11
+
+
 def test_failure_convention_and_adam():
     import cude_oracle as o
     import c_oracle as co

@@ -11,7 +11,10 @@ graphics whose paths are the numbers its scripts computed, quantised by Cairo to
   figures/revision/supplementary/model_fit_test_all.svg       (c-peptide/02-conditional.jl:532-588)
       one panel per test subject (35, in subject order): model fit, confidence-bound simulations, measurements
   figures/revision/supplementary/model_fit_test_covariate_median.svg   (c-peptide/07-covariate-inclusion.jl)
-      the train-median panels of the covariate model (3 -> 4 -> 4 -> 1 network)
+      the test-median panels and the 35 test objectives of the covariate model (3 -> 4 -> 4 -> 1 network)
+  figures/revision/figure_6/figure_6.svg                      (c-peptide/04-symreg-external.jl:72-170)
+      the symbolic model (production 1.78 dG / (dG + k)) on the external data set (14 irregular time points from
+      -10 min): quartile subjects' simulations on -10:0.1:240 min, their measurements, the 20 fitted objectives
 
 Only pixel coordinates are stored, as integers in units of 1/256 px (exactly what Cairo wrote): poly-line vertices
 and marker centres in drawing order.  Mapping them to data units is the test's job (tests/test_figure_pins.py: the
@@ -106,8 +109,36 @@ def decode_subject_panels(svg_file):
     return panels
 
 
+def decode_quartile_panels(svg_file, n_obs=14):
+    """figure_6 (c-peptide/04-symreg-external.jl:72-170): three panels, each a solid model line in the NGT colour,
+    the subject's n_obs measurements as black markers and up to two dotted bound lines; then the objective scatter."""
+    panels, objectives = [], []
+    for prim in primitives(svg_file):
+        if prim[0] == "line" and TYPES["NGT"] in prim[1]:
+            if "stroke-dasharray" in prim[1]:
+                panels[-1]["bounds"].append(prim[2])
+            else:
+                panels.append(dict(fit=prim[2], bounds=[], markers=[]))
+        elif prim[0] == "marker" and BLACK in prim[1] and prim[3] > 1.5 and panels and len(panels[-1]["markers"]) < n_obs:
+            panels[-1]["markers"].append(prim[2])
+        elif prim[0] == "marker" and TYPES["NGT"] in prim[1] and prim[3] < 1.5:
+            objectives.append(prim[2])
+    for p in panels:
+        p["markers"] = np.array(p["markers"])
+    return panels, np.array(objectives)
+
+
 def main():
     arrays = {}
+    panels, objectives = decode_quartile_panels(os.path.join(REF, "figure_6/figure_6.svg"))
+    print("figure_6 panels", [(p["fit"].shape[0], p["markers"].shape, [b.shape[0] for b in p["bounds"]]) for p in panels],
+          "objectives", objectives.shape)
+    arrays["external_objectives"] = objectives
+    for i, p in enumerate(panels):
+        arrays[f"external_{i}_fit"] = _q(p["fit"])
+        arrays[f"external_{i}_markers"] = p["markers"]
+        for k, b in enumerate(p["bounds"]):
+            arrays[f"external_{i}_bound{k}"] = _q(b)
     for tag, rel in (("train", "supplementary/model_fit_train_median.svg"),
                      ("covariate", "supplementary/model_fit_test_covariate_median.svg")):
         for t, rec in decode_type_panels(os.path.join(REF, rel)).items():
