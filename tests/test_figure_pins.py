@@ -16,7 +16,9 @@ its subject.  What the panels then pin, at the figures' resolution (1/256 px = 1
     of the covariate model (3 -> 4 -> 4 -> 1, inputs [dG, exp(beta), age]);
   * `figure_6.svg` (04-symreg-external.jl:72-170): the symbolic model (production 1.78 dG / (dG + k), no network) on
     the external data set -- 14 irregular time points from -10 min, simulations on -10:0.1:240 -- three subjects x
-    (fit, two confidence bounds) and the 20 fitted objectives.
+    (fit, two confidence bounds) and the 20 fitted objectives;
+  * `figure_5.svg` panel d (03-symreg.jl:100-112): the fitted objective of the symbolic model for all 117 subjects of
+    the main data set.
 
 The reference integrates with adaptive Tsit5 at OrdinaryDiffEq's default tolerances (reltol 1e-3), unaware of the
 kinks of the glucose forcing, so its own curves carry a discretisation error of ~5e-3 nmol/L; the oracle's adaptive
@@ -271,6 +273,26 @@ def test_covariate_panels_and_objectives(data):
         out, _ = _check_panel(_Subject(data, "test", i, covariate=True), data.fig, f"covariate_{t}", profile=(3.0, 5.0))
         assert len(out) == 3
     _check_objectives(data, "test", "covariate", covariate=True)
+
+
+def test_symbolic_model_objectives_of_all_ohashi_subjects(data):
+    """figure_5 panel d (c-peptide/03-symreg.jl:100-112): the fitted objective of the symbolic model for all 117
+    subjects, [train; test] order within each type -- 117 known answers of that model's loss on the main data set."""
+    import cude_oracle as o
+    p = {k: np.concatenate([data.part["train"][k], data.part["test"][k]]) for k in ("types", "G", "C", "age", "t2dm")}
+    subjects = []
+    for t in TYPES:
+        for i in np.flatnonzero(p["types"] == t):
+            s = _Subject.__new__(_Subject)
+            s._setup(data.tp, tuple(p[k][i:i + 1] for k in ("G", "C", "age", "t2dm")), np.array([1.78]), o.SYMBOLIC,
+                     (np.log(1e-2), np.log(1000.0)), False)             # 0 <= k <= 1000 (:103-104); "beta" = log k
+            subjects.append(s)
+    px = np.concatenate([data.fig[f"symbolic_{t}_objectives"][:, 1] for t in TYPES])
+    assert px.size == len(subjects) == 117
+    res, sse = _objective_residuals(subjects, px)
+    assert np.ptp(sse) > 5.0
+    # one subject (1.8e-2) is where the reference's L-BFGS stopped short; the rest is the plot's quantisation
+    assert np.median(res) < 4e-4 and np.quantile(res, 0.9) < 1.5e-3 and res.max() < 3e-2, (np.median(res), res.max())
 
 
 def test_external_symbolic_model_panels_and_objectives(data):

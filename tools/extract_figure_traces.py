@@ -128,8 +128,24 @@ def decode_quartile_panels(svg_file, n_obs=14):
     return panels, np.array(objectives)
 
 
+def decode_small_markers_by_type(svg_file):
+    """{type: (m,2)} centres of the markersize-3 scatter of a figure, per type colour, in drawing order."""
+    out = {t: [] for t in TYPES}
+    for prim in primitives(svg_file):
+        if prim[0] == "marker" and prim[3] < 1.5:
+            for t, colour in TYPES.items():
+                if colour in prim[1]:
+                    out[t].append(prim[2])
+    return {t: np.array(v) for t, v in out.items()}
+
+
 def main():
     arrays = {}
+    # figure_5 panel d (c-peptide/03-symreg.jl:100-112, :190-200): fitted objectives of the symbolic model for all 117
+    # subjects ([train; test] order within each type)
+    for t, v in decode_small_markers_by_type(os.path.join(REF, "figure_5/figure_5.svg")).items():
+        arrays[f"symbolic_{t}_objectives"] = v
+        print("figure_5 objectives", t, v.shape)
     panels, objectives = decode_quartile_panels(os.path.join(REF, "figure_6/figure_6.svg"))
     print("figure_6 panels", [(p["fit"].shape[0], p["markers"].shape, [b.shape[0] for b in p["bounds"]]) for p in panels],
           "objectives", objectives.shape)
