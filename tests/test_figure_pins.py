@@ -186,7 +186,7 @@ def _beta_of_curve(subject, t, y, lo, hi):
     return near[k], float(np.max(np.abs(subject.adaptive(near[k], t) - y)))
 
 
-def _check_panel(subject, fig, prefix, names=("fit", "bound0", "bound1"), profile=(10.0, 15.0)):
+def _check_panel(subject, fig, prefix, names=("fit", "bound0", "bound1"), profile=(10.0, 15.0), threshold=7.16):
     """fit, lower and upper curve of one panel -> {name: (beta, error)} and the panel's pixel -> data maps."""
     tx, ty, res = _calibrate(fig[prefix + "_markers"], subject.tp, subject.obs)
     assert res < 0.01
@@ -217,7 +217,15 @@ def _check_panel(subject, fig, prefix, names=("fit", "bound0", "bound1"), profil
         assert beta_fit < subject.box[0] + 0.02, (prefix, beta_fit, subject.box)
     # (the adaptive-step SSE is a jagged function of beta -- its step sequence changes with beta -- with ripples of
     # ~1 %, and the reference's L-BFGS stopped in one of them)
-    assert subject.sse_adaptive(beta_fit) - sse_star < 2e-2 * max(sse_star, 0.05)
+    sse_fit = subject.sse_adaptive(beta_fit)
+    assert sse_fit - sse_star < 2e-2 * max(sse_star, 0.05)
+    # ... and the two dotted simulations at the ends of the 95 % Cantelli interval of the likelihood profile
+    # (src/likelihood-profiles.jl:4-17, :34-37): the outermost profile points with NLL - NLL_min <= 7.16, where
+    # NLL = SSE / (2 sigma^2) and the fitted sigma^2 = SSE_min / n
+    for name in ("bound0", "bound1"):
+        if name in out:
+            d_nll = (subject.sse_adaptive(out[name][0]) - sse_fit) / (2.0 * sse_fit / len(subject.tp))
+            assert 0.88 * threshold < d_nll < 1.05 * threshold, (prefix, name, d_nll)
     return out, (tx, ty)
 
 
@@ -270,7 +278,9 @@ def test_covariate_panels_and_objectives(data):
     p = data.part["test"]
     for t in TYPES:
         i = _identify(data.fig[f"covariate_{t}_markers"], data.tp, p["C"], np.flatnonzero(p["types"] == t))
-        out, _ = _check_panel(_Subject(data, "test", i, covariate=True), data.fig, f"covariate_{t}", profile=(3.0, 5.0))
+        # this script profiles beta - 3 ... beta + 5 and cuts at the chi-square threshold (target = :raue95, :160-167)
+        out, _ = _check_panel(_Subject(data, "test", i, covariate=True), data.fig, f"covariate_{t}", profile=(3.0, 5.0),
+                              threshold=3.8415)
         assert len(out) == 3
     _check_objectives(data, "test", "covariate", covariate=True)
 
