@@ -471,6 +471,23 @@ def likelihood_profile(beta, neural_network_parameters, model, timepoints, cpept
     return nll, nll_min, values
 
 
+_CI_THRESHOLDS = {"cantelli95": 7.16, "cantelli90": 5.24, "raue95": 3.841458820694124}   # last: quantile(Chisq(1), 0.95)
+
+
+def find_confidence_intervals(loss_values, loss_minimum, parameter_values, *, target="cantelli95"):
+    """src/likelihood-profiles.jl:34-59: the outermost profile points whose value is within the target's threshold of
+    the minimum; an end of the interval that coincides with an end of the profiled range is reported as -/+Inf.
+    An unknown target falls back to raue95, as the reference does."""
+    loss_values = np.asarray(loss_values, dtype=np.float64)
+    threshold = loss_minimum + _CI_THRESHOLDS.get(target, _CI_THRESHOLDS["raue95"])
+    idx = np.flatnonzero(loss_values <= threshold)
+    if idx.size == 0:
+        raise ValueError("no profile point lies within the threshold of the minimum")     # Julia: minimum of empty
+    lo = -np.inf if idx[0] == 0 else float(parameter_values[idx[0]])
+    hi = np.inf if idx[-1] == len(loss_values) - 1 else float(parameter_values[idx[-1]])
+    return lo, hi
+
+
 def likelihood_profiles(betas, neural_network_parameters, models, timepoints, cpeptide_data, lower_bound, upper_bound,
                         sigma, *, steps=1000, n_steps=None):
     """The loop `[likelihood_profile(betas[i], nn, models[i], ...) for i in ...]` of c-peptide/02-conditional.jl:186-188

@@ -84,6 +84,27 @@ def test_gpu_symbolic_model_matches_the_external_figure():
     api.clear_cache()
 
 
+def test_gpu_confidence_intervals_match_the_plotted_bounds():
+    """`likelihood_profile` -> `find_confidence_intervals` (c-peptide/02-conditional.jl:549-559) through the product
+    path for test subjects 2 ... 7, against the betas at which the reference ran the dotted curves of
+    model_fit_test_all.svg (recovered from those curves by the CPU machinery of tests/test_figure_pins.py)."""
+    import torch  # noqa: F401
+    from cude import api
+    d = F._Data()
+    models, nn, beta, sse = _fit(api, d, "test", False)
+    for i in range(2, 8):
+        sub = F._Subject(d, "test", i, covariate=False)
+        out, _ = F._check_panel(sub, d.fig, f"testall_{i}")
+        sigma = np.sqrt(sse[i] / len(d.tp))
+        nll, nll_min, values = api.likelihood_profile(beta[i], nn, models[i], d.tp, d.part["test"]["C"][i],
+                                                      beta[i] - 10.0, beta[i] + 15.0, sigma, steps=10_000)
+        lo, hi = api.find_confidence_intervals(nll, nll_min, values)
+        # profile grid spacing 2.5e-3; the reference's profile carries its adaptive solver's ~1 % ripple
+        assert abs(lo - out["bound0"][0]) < 0.01 * max(1.0, beta[i] - lo), (i, lo, out["bound0"][0])
+        assert abs(hi - out["bound1"][0]) < 0.01 * max(1.0, hi - beta[i]), (i, hi, out["bound1"][0])
+    api.clear_cache()
+
+
 def test_gpu_trajectories_match_the_figures():
     import torch  # noqa: F401
     from cude import api

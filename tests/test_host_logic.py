@@ -43,6 +43,24 @@ def test_init_params_and_latin_hypercube():
         assert sorted(np.floor((row + 2.0) / 2.0 * 50).astype(int)) == list(range(50))
 
 
+def test_find_confidence_intervals_semantics():
+    """src/likelihood-profiles.jl:34-59: thresholds per target, outermost points, infinite ends, fallback target."""
+    from cude import api
+    values = np.linspace(-2.0, 2.0, 401)
+    nll = 10.0 * values ** 2                                            # minimum 0 at 0
+    lo, hi = api.find_confidence_intervals(nll, 0.0, values, target="cantelli95")
+    assert abs(hi - np.sqrt(0.716)) < 0.011 and hi <= np.sqrt(0.716) and abs(lo + hi) < 1e-12
+    lo90, hi90 = api.find_confidence_intervals(nll, 0.0, values, target="cantelli90")
+    lo_r, hi_r = api.find_confidence_intervals(nll, 0.0, values, target="raue95")
+    assert hi_r < hi90 < hi and abs(hi_r - np.sqrt(0.3841458820694124)) < 0.011
+    assert api.find_confidence_intervals(nll, 0.0, values, target="nonsense") == (lo_r, hi_r)
+    flat_right = np.where(values > 0, 0.0, nll)                         # unidentifiable upwards
+    assert api.find_confidence_intervals(flat_right, 0.0, values) == (lo, np.inf)
+    assert api.find_confidence_intervals(np.zeros(401), 0.0, values) == (-np.inf, np.inf)
+    with pytest.raises(ValueError):
+        api.find_confidence_intervals(nll + 100.0, 0.0, values)
+
+
 def test_shard_bounds_cover_and_balance():
     from cude.parallel import shard_bounds
     for n, w in [(10, 3), (1000000, 8), (5, 8), (64, 2)]:
