@@ -1,8 +1,8 @@
 """Soft pins of the CPU oracle against the reference's STORED results (tests/golden/*.npz).
 
-The reference has no tests and cannot run here (Julia); apart from the known answers of tests/test_known_answers.py
-(suppression path) parity is formally unpinned; these checks
-tie the restated equations, unit conversions, van Cauter constants, MLP parameter layout and loss
+The reference has no tests and cannot run here (Julia).  Next to the known answers of tests/test_known_answers.py
+(suppression path, stored objectives) and tests/test_figure_pins.py (c-peptide path, the reference's vector figures),
+these checks tie the restated equations, unit conversions, van Cauter constants, MLP parameter layout and loss
 definitions to numbers the reference itself produced.  Tolerances are the adaptive-solver level
 (reference: reltol 1e-3), not the 1e-6 kernel-parity level.
 """
