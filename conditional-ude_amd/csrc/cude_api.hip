@@ -133,6 +133,9 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -156,6 +159,9 @@ int32_t load_rccl() {
         (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
+    g_rccl.GetVersion = (int (*)(int*))dlsym(h, "ncclGetVersion");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(CUDE_ERR_COMM, "librccl lacks a required symbol");
     g_rccl.handle = h;
@@ -236,6 +242,7 @@ struct cude_ctx {
     // scratch of cude_multistart_loss_grad (kept between calls: it is called once per optimiser iteration)
     DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt, ms_act;
     DevBuf<double> act;     // SUPP: kept network activations of the gradient launch (small populations only)
+    DevBuf<double> red_tmp; // staging of small host vectors reduced through the communicator
     std::vector<double> ms_host;
 #ifdef CUDE_WAVE_TIMING
     DevBuf<long long> dbg;
@@ -266,10 +273,29 @@ int32_t bind(cude_ctx* c) {
     return CUDE_OK;
 }
 
-int32_t allreduce_dev(cude_ctx* c, double* buf, size_t count) {
+// op: 0 = sum, 1 = max (ncclSum = 0, ncclMax = 2)
+int32_t allreduce_dev(cude_ctx* c, double* buf, size_t count, int op = 0) {
     if (!c->comm) return CUDE_OK;
-    RCCL_TRY(g_rccl.AllReduce(buf, buf, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
+    RCCL_TRY(g_rccl.AllReduce(buf, buf, count, /*ncclFloat64*/ 8, op == 1 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, c->comm,
+                              c->stream));
     return CUDE_OK;
+}
+
+// sum / max of a small host vector over all ranks through the context's communicator (identity without one)
+int32_t comm_reduce_host(cude_ctx* c, double* values, int32_t count, int op) {
+    if (!c->comm) return CUDE_OK;
+    HIP_TRY(c->red_tmp.reserve((size_t)count));
+    HIP_TRY(hipMemcpyAsync(c->red_tmp.p, values, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int32_t rc = allreduce_dev(c, c->red_tmp.p, (size_t)count, op);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(values, c->red_tmp.p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
+// cude::ReduceFn over the context's communicator (the L-BFGS stage of cude_train_restarts on a sharded population)
+int32_t lbfgs_comm_reduce(double* values, int32_t count, int32_t op, void* user) {
+    return comm_reduce_host(static_cast<cude_ctx*>(user), values, count, op);
 }
 
 void drop_graph(cude_ctx* c);
@@ -1096,6 +1122,29 @@ int32_t cude_lbfgs_minimize(int32_t n, const double* x0, int32_t maxiters, cude_
     return CUDE_OK;
 }
 
+int32_t cude_lbfgs_minimize_sharded(int32_t n, int32_t n_shared, const double* x0, int32_t maxiters, cude_objective_fn fn,
+                                    cude_reduce_fn reduce, void* user, double* x_out, double* f_out,
+                                    int32_t* iterations, int32_t* f_calls, int32_t* converged) {
+    if (n < 1 || n_shared < 0 || n_shared > n || !x0 || !fn || !reduce || !x_out || maxiters < 0)
+        return fail(CUDE_ERR_ARG, "bad argument");
+    cude::Lbfgs opt(x0, n, maxiters, 10, 1e-8, n_shared, reduce, user);
+    std::vector<double> g(n);
+    while (const double* x = opt.pending()) {
+        double f = std::numeric_limits<double>::quiet_NaN();
+        const int32_t rc = fn(x, n, &f, g.data(), user);
+        if (rc < 0) return fail(CUDE_ERR_ARG, "objective callback reported an error");
+        opt.feed(f, g.data());
+        if (opt.comm_failed()) return fail(CUDE_ERR_COMM, "reduce callback reported an error");
+    }
+    const cude::Lbfgs::Result r = opt.result();
+    std::copy(opt.x().begin(), opt.x().end(), x_out);
+    if (f_out) *f_out = r.f;
+    if (iterations) *iterations = r.iterations;
+    if (f_calls) *f_calls = r.f_calls;
+    if (converged) *converged = r.converged ? 1 : 0;
+    return CUDE_OK;
+}
+
 int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                             int32_t adam_iters, double learning_rate, int32_t lbfgs_iters, double* nn_out,
                             double* cond_out, double* objective_out, double* loss_trace) {
@@ -1105,10 +1154,9 @@ int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, 
     if (n_sets < 1 || !nn_sets || !cond_sets || !nn_out || !cond_out || !objective_out || adam_iters < 0 ||
         lbfgs_iters < 0 || !(learning_rate > 0))
         return fail(CUDE_ERR_ARG, "bad argument");
-    // Adam is element-wise and shards with the subjects; L-BFGS takes inner products over [neural; conditional], whose
-    // conditional part would have to be summed across ranks -- not done here
-    if (c->comm && lbfgs_iters > 0)
-        return fail(CUDE_ERR_UNSUPPORTED, "the L-BFGS stage is single-rank: pass lbfgs_iters = 0 on a sharded population");
+    // Adam is element-wise and shards with the subjects; L-BFGS takes inner products over [neural; conditional]: on a
+    // sharded population the conditional part of every inner product / max-norm is reduced over the ranks (a few
+    // doubles per iteration, cude::Lbfgs reducer), so every rank follows the same iterates
     const int K = n_sets, P = c->P;
     const int64_t N = c->N, n = P + N;
     // working copies in the ABI's [K][P] / [K][N] layout
@@ -1142,7 +1190,8 @@ int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, 
         if (!alive[k]) continue;
         std::copy(nn.begin() + (size_t)k * P, nn.begin() + (size_t)(k + 1) * P, x0.begin());
         std::copy(cond.begin() + (size_t)k * N, cond.begin() + (size_t)(k + 1) * N, x0.begin() + P);
-        opt.emplace_back(x0.data(), (int)n, lbfgs_iters);
+        if (c->comm) opt.emplace_back(x0.data(), (int)n, lbfgs_iters, 10, 1e-8, P, lbfgs_comm_reduce, c);
+        else opt.emplace_back(x0.data(), (int)n, lbfgs_iters);
         owner.push_back(k);
     }
     std::vector<double> b_nn, b_cond, b_f, b_gnn, b_gcond, gfull(n);
@@ -1169,6 +1218,7 @@ int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, 
             o.feed(b_f[a], gfull.data());
             if (loss_trace && o.accepted_steps() > before && before < lbfgs_iters)     // where Optim's callback fires
                 loss_trace[(int64_t)owner[active[a]] * trace_len + adam_iters + before] = o.current_f();
+            if (o.comm_failed()) return CUDE_ERR_COMM;     // message already set by the reducer
         }
     }
     for (int k = 0; k < K; k++) objective_out[k] = std::numeric_limits<double>::infinity();
@@ -1282,6 +1332,7 @@ int32_t cude_set_global_subjects(cude_ctx* c, double n_global, const double* sca
     if (rc) return rc;
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!(n_global >= (double)c->N)) return fail(CUDE_ERR_ARG, "global subject count smaller than the local one");
+    drop_graph(c);                              // 1/n_global and the scale are baked into the captured launches
     c->n_global = n_global;
     if (scale3) {
         for (int s = 0; s < 3; s++) {
@@ -1383,6 +1434,15 @@ int32_t cude_comm_init(cude_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t
     if (rc) return rc;
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !id) return fail(CUDE_ERR_ARG, "bad communicator arguments");
     if (c->comm) return fail(CUDE_ERR_STATE, "communicator already attached");
+    // Multi-process RCCL needs dmabuf IPC on hosts whose driver has no legacy IPC: without
+    // HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the first HIP call, ncclCommInitRank dies much later
+    // with "hipIpcGetMemHandle: invalid argument".  Too late to set it here, so say so now.
+    if (n_ranks > 1) {
+        const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+        if ((!ipc || std::strcmp(ipc, "0") != 0) && !getenv("CUDE_ALLOW_LEGACY_IPC"))
+            return fail(CUDE_ERR_COMM, "export HSA_ENABLE_IPC_MODE_LEGACY=0 before the process touches the GPU "
+                                       "(dmabuf IPC for RCCL); set CUDE_ALLOW_LEGACY_IPC=1 to skip this check");
+    }
     if ((rc = load_rccl())) return rc;
     nccl_uid u;
     std::memcpy(u.internal, id, CUDE_UNIQUE_ID_BYTES);
@@ -1396,13 +1456,21 @@ int32_t cude_comm_allreduce_host(cude_ctx* c, double* values, int32_t count) {
     int32_t rc = bind(c);
     if (rc) return rc;
     if (!values || count < 1) return fail(CUDE_ERR_ARG, "bad buffer");
-    if (!c->comm) return CUDE_OK;   // single rank: identity
-    DevBuf<double> tmp;
-    HIP_TRY(tmp.resize(count));
-    HIP_TRY(hipMemcpyAsync(tmp.p, values, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if ((rc = allreduce_dev(c, tmp.p, count))) return rc;
-    HIP_TRY(hipMemcpyAsync(values, tmp.p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    return comm_reduce_host(c, values, count, 0);   // single rank: identity
+}
+
+int32_t cude_comm_info(cude_ctx* c, int32_t* n_ranks, int32_t* rank, int32_t* version) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!n_ranks || !rank || !version) return fail(CUDE_ERR_ARG, "null output");
+    *n_ranks = 1; *rank = 0; *version = 0;
+    if (!c->comm) return CUDE_OK;
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(CUDE_ERR_COMM, "librccl lacks ncclCommCount/ncclCommUserRank");
+    int n = 0, r = 0, v = 0;
+    RCCL_TRY(g_rccl.CommCount(c->comm, &n));
+    RCCL_TRY(g_rccl.CommUserRank(c->comm, &r));
+    if (g_rccl.GetVersion) RCCL_TRY(g_rccl.GetVersion(&v));
+    *n_ranks = n; *rank = r; *version = v;
     return CUDE_OK;
 }
 

@@ -55,6 +55,8 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cude_lbfgs_minimize": (C.c_int32, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cude_lbfgs_minimize_sharded": (C.c_int32, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cude_fit_conditional": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cude_mh_chain": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
@@ -73,6 +75,7 @@ _SIGNATURES = {
     "cude_comm_unique_id": (C.c_int32, [C.c_void_p]),
     "cude_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "cude_comm_allreduce_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "cude_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -45,6 +45,34 @@ def lbfgs_minimize(fg, x0, maxiters=1000):
     return dict(x=x, f=f.value, iterations=it.value, f_calls=calls.value, converged=bool(conv.value))
 
 
+_REDUCE = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p)
+
+
+def lbfgs_minimize_sharded(fg, x0, n_shared, reduce, maxiters=1000):
+    """cude_lbfgs_minimize_sharded: x = [shared (n_shared, replicated); local]; fg(x) -> (global f, local g);
+    reduce(values: ndarray, op) -> ndarray sums (op 0) / maximises (op 1) over the ranks."""
+    x0 = _f64(x0).reshape(-1)
+    n = x0.size
+
+    def thunk(xp, nn, fp, gp, _user):
+        f, g = fg(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+        fp[0] = float(f)
+        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+        return 0
+
+    def red(vp, count, op, _user):
+        v = np.ctypeslib.as_array(vp, shape=(count,))
+        v[:] = reduce(v.copy(), int(op))
+        return 0
+    cb, rcb = _OBJECTIVE(thunk), _REDUCE(red)
+    x = np.empty(n)
+    f, it, calls, conv = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(_lib.load().cude_lbfgs_minimize_sharded(n, int(n_shared), _ptr(x0), int(maxiters), C.cast(cb, C.c_void_p),
+                                                  C.cast(rcb, C.c_void_p), None, _ptr(x), C.byref(f), C.byref(it),
+                                                  C.byref(calls), C.byref(conv)))
+    return dict(x=x, f=f.value, iterations=it.value, f_calls=calls.value, converged=bool(conv.value))
+
+
 def device_count():
     n = C.c_int32(0)
     check(_lib.load().cude_device_count(C.byref(n)))
@@ -311,6 +339,12 @@ class Engine:
     def comm_init(self, n_ranks, rank, unique_id):
         buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         check(self._lib.cude_comm_init(self._h, n_ranks, rank, buf))
+
+    def comm_info(self):
+        """(ranks, rank, rccl version) as the attached communicator reports them; (1, 0, 0) without one."""
+        n, r, v = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self._lib.cude_comm_info(self._h, C.byref(n), C.byref(r), C.byref(v)))
+        return n.value, r.value, v.value
 
     def allreduce_host(self, values):
         v = _f64(values).copy()

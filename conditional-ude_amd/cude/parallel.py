@@ -45,6 +45,15 @@ class TorchCollective:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
+    def allreduce(self, vec, op=0):
+        """op 0 = sum, 1 = max (the cude_reduce_fn convention)."""
+        import torch
+        t = torch.as_tensor(np.asarray(vec, dtype=np.float64).copy())
+        if self.device is not None:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
     def broadcast_bytes(self, payload, src=0):
         import torch
         n = len(payload) if payload is not None else 0
@@ -86,9 +95,40 @@ class ShardedTrainer:
         if scale_sums is None:
             tot = self.coll.allreduce_sum([float(self.engine.N)])
             self.engine.set_global_subjects(tot[0])
+            self.n_global = float(tot[0])
         else:
             tot = self.coll.allreduce_sum(list(scale_sums) + [float(self.engine.N)])
             self.engine.set_global_subjects(tot[3], tot[:3] / tot[3])
+            self.n_global = float(tot[3])
+
+    def lbfgs(self, maxiters, lam=0.0):
+        """Second stage of `_optimize` (src/parameter-estimation.jl:179-180: L-BFGS + BackTracking after Adam) on the
+        sharded population, starting from the engine's current parameters; leaves the result in the engine and
+        returns dict(f, iterations, f_calls, converged) -- identical on every rank.
+
+        rccl: cude_train_restarts (one restart) reduces losses, network gradients and the conditional part of every
+        inner product over its communicator.  host: the library's L-BFGS state machine
+        (cude_lbfgs_minimize_sharded) with this trainer's collective as the reducer; every evaluation is
+        cude_loss_grad_partial + one sum of P+2 doubles.  `lam` is the context's L2 weight (host transport adds the
+        term here, as cude_adam_apply does on the device)."""
+        nn, cond = self.engine.get_params()
+        P = nn.size
+        if self.transport == "rccl":
+            nn_o, cond_o, obj = self.engine.train_restarts(nn[None, :], cond[None, :], 0, 1e-3, int(maxiters))
+            self.engine.set_params(nn_o[0], cond_o[0])
+            return dict(f=float(obj[0]))
+        from .engine import lbfgs_minimize_sharded
+        n_glob = self.n_global
+
+        def fg(x):
+            self.engine.set_params(x[:P], x[P:])
+            part, g_cond = self.engine.loss_grad_partial(want_cond_grad=True)
+            red = self.coll.allreduce_sum(part)
+            f = red[P] / n_glob + lam * float(x[:P] @ x[:P]) if red[P + 1] == 0 and np.isfinite(red[P]) else np.inf
+            return f, np.concatenate([red[:P] + 2.0 * lam * x[:P], g_cond])
+        r = lbfgs_minimize_sharded(fg, np.concatenate([nn, cond]), P, self.coll.allreduce, maxiters)
+        self.engine.set_params(r["x"][:P], r["x"][P:])
+        return {k: r[k] for k in ("f", "iterations", "f_calls", "converged")}
 
     def adam_init(self, lr, **kw):
         self.engine.adam_init(lr, **kw)

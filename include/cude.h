@@ -144,8 +144,9 @@ int32_t cude_multistart_loss_grad(cude_ctx* ctx, int32_t n_sets, const double* n
  * nn_out / cond_out (same layout) and objective_out[n_sets] (`OptimizationSolution.objective`); loss_trace (optional,
  * [n_sets][adam_iters + lbfgs_iters], NaN where a run had already stopped) receives what the reference's callbacks
  * collect: the loss of every Adam iteration, then the loss after every successful L-BFGS iteration.  On a sharded
- * population (cude_comm_init) only the Adam stage is available (lbfgs_iters must be 0: L-BFGS needs inner products
- * over all subjects' conditional parameters).  The optimiser
+ * population (cude_comm_init) cond_sets / cond_out hold this rank's subjects; losses and network gradients are
+ * all-reduced inside the launch sequence and the conditional part of every L-BFGS inner product is summed over the
+ * ranks, so all ranks return the same networks and objectives.  The optimiser
  * bookkeeping runs on the host (vectors of P+N doubles); every loss and gradient comes from the device. */
 int32_t cude_train_restarts(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                             int32_t adam_iters, double learning_rate, int32_t lbfgs_iters, double* nn_out,
@@ -158,6 +159,18 @@ int32_t cude_train_restarts(cude_ctx* ctx, int32_t n_sets, const double* nn_sets
 typedef int32_t (*cude_objective_fn)(const double* x, int32_t n, double* f, double* g, void* user);
 int32_t cude_lbfgs_minimize(int32_t n, const double* x0, int32_t maxiters, cude_objective_fn fn, void* user,
                             double* x_out, double* f_out, int32_t* iterations, int32_t* f_calls, int32_t* converged);
+
+/* The same optimiser for a SHARDED vector: x = [shared (n_shared entries, replicated on every rank); local (this
+ * rank's n - n_shared conditional parameters)].  fn returns the GLOBAL f and this rank's gradient entries; `reduce`
+ * sums (op 0) or takes the maximum (op 1) of `count` doubles over all ranks in place (MPI.Allreduce!, gloo, ...) and
+ * returns >= 0.  Every inner product / max-norm of the L-BFGS recursion takes its local part through `reduce`, so all
+ * ranks walk the same iterates as one process holding the whole vector would (up to the summation order of the inner
+ * products).  This is the second stage of `_optimize` (src/parameter-estimation.jl:179-180) on a population sharded
+ * over GPUs; cude_train_restarts does the same internally over its RCCL communicator. */
+typedef int32_t (*cude_reduce_fn)(double* values, int32_t count, int32_t op, void* user);
+int32_t cude_lbfgs_minimize_sharded(int32_t n, int32_t n_shared, const double* x0, int32_t maxiters,
+                                    cude_objective_fn fn, cude_reduce_fn reduce, void* user, double* x_out,
+                                    double* f_out, int32_t* iterations, int32_t* f_calls, int32_t* converged);
 
 /* Likelihood profiles of ALL subjects in one launch: sse_out[n_points][N] (row-major) = SSE_i(values[k]) with the
  * shared parameters frozen -- the grid's second dimension is the scan value.  Replaces
@@ -244,12 +257,17 @@ int32_t cude_set_kernel_timing(cude_ctx* ctx, int32_t enabled);
 /* --- multi-GPU: subjects are sharded, one context (process) per GPU; the only exchange is one
  * sum all-reduce of P+2 doubles per optimiser step (the reference has no distributed path; this
  * is the data-parallel form of EnsembleThreads, suppression_model.jl:113,123).
- * rank 0 creates the id, the host distributes its bytes, every rank calls cude_comm_init. */
+ * rank 0 creates the id, the host distributes its bytes, every rank calls cude_comm_init.
+ * Multi-process RCCL on hosts without legacy IPC needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment before the
+ * process first touches the GPU; cude_comm_init with n_ranks > 1 returns CUDE_ERR_COMM if it is not set. */
 int32_t cude_comm_unique_id(uint8_t id[CUDE_UNIQUE_ID_BYTES]);
 int32_t cude_comm_init(cude_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[CUDE_UNIQUE_ID_BYTES]);
 /* Sum all-reduce of a host vector through the communicator (used for population statistics
  * such as SAEM's mean/var of the random effects, saem.jl:204-205). */
 int32_t cude_comm_allreduce_host(cude_ctx* ctx, double* values, int32_t count);
+/* What the attached communicator itself reports: ncclCommCount, ncclCommUserRank, ncclGetVersion (1, 0, 0 without a
+ * communicator) -- lets a launcher prove which transport and how many ranks a multi-GPU run really used. */
+int32_t cude_comm_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* version);
 
 #ifdef __cplusplus
 }

@@ -36,8 +36,9 @@ def num_threads():
 
 
 def cpep(timepoints, glucose, cpeptide, age, t2dm, arch, nn, beta, n_steps, n_state=2,
-         want_grad=True, want_traj=False, covariate=False, nthreads=0):
-    """Returns dict(loss, sse, g_nn, g_beta, traj, n_failed)."""
+         want_grad=True, want_traj=False, covariate=False, nthreads=0, method="forward"):
+    """Returns dict(loss, sse, g_nn, g_beta, traj, n_failed).  method: "forward" = the reference's own AD
+    (forward-mode duals, cude_oracle.c) or "reverse" = per-subject discrete adjoint (cude_oracle_rev.c, no traj)."""
     glucose = np.ascontiguousarray(glucose, dtype=np.float64)
     cpeptide = np.ascontiguousarray(cpeptide, dtype=np.float64)
     N, T = glucose.shape
@@ -54,6 +55,15 @@ def cpep(timepoints, glucose, cpeptide, age, t2dm, arch, nn, beta, n_steps, n_st
     g_nn = np.zeros(P) if want_grad else None
     g_beta = np.zeros(N) if want_grad else None
     traj = np.zeros((N, T, n_state)) if want_traj else None
+    if method == "reverse":
+        assert not want_traj
+        rc = lib().cude_oracle_cpep_rev(C.c_int(N), C.c_int(T), _p(tp), _p(glucose), _p(cpeptide), _p(age), _p(t2),
+                                        C.c_int(int(covariate)), C.c_int(nin), C.c_int(width), C.c_int(depth),
+                                        _p(nn), _p(beta), C.c_int(n_steps), C.c_int(n_state), C.c_int(int(want_grad)),
+                                        C.c_int(nthreads), C.byref(loss), _p(sse), _p(g_nn), _p(g_beta))
+        if rc < 0:
+            raise ValueError("cude_oracle_cpep_rev: unsupported size")
+        return dict(loss=loss.value, sse=sse, g_nn=g_nn, g_beta=g_beta, traj=None, n_failed=rc)
     rc = lib().cude_oracle_cpep(C.c_int(N), C.c_int(T), _p(tp), _p(glucose), _p(cpeptide), _p(age), _p(t2),
                                 C.c_int(int(covariate)), C.c_int(nin), C.c_int(width), C.c_int(depth),
                                 _p(nn), _p(beta), C.c_int(n_steps), C.c_int(n_state), C.c_int(int(want_grad)),
@@ -89,8 +99,9 @@ def cpep_adaptive(timepoints, glucose, cpeptide, age, t2dm, arch, nn, cond, out_
     return out
 
 
-def supp(timepoints, data, arch, nn, theta, lam, n_steps, want_grad=True, want_traj=False, nthreads=0):
-    """data: 3 x T x N numpy array (any layout; converted to Julia column-major)."""
+def supp(timepoints, data, arch, nn, theta, lam, n_steps, want_grad=True, want_traj=False, nthreads=0,
+         method="forward"):
+    """data: 3 x T x N numpy array (any layout; converted to Julia column-major).  method as in cpep."""
     data = np.asarray(data, dtype=np.float64)
     _, T, N = data.shape
     dcol = np.ascontiguousarray(data.transpose(2, 1, 0))      # memory: i slowest, s fastest
@@ -106,6 +117,14 @@ def supp(timepoints, data, arch, nn, theta, lam, n_steps, want_grad=True, want_t
     g_nn = np.zeros(P) if want_grad else None
     g_th = np.zeros(N) if want_grad else None
     traj = np.zeros((N, T, 3)) if want_traj else None
+    if method == "reverse":
+        assert not want_traj
+        rc = lib().cude_oracle_supp_rev(C.c_int(N), C.c_int(T), _p(tp), _p(dcol), C.c_int(width), C.c_int(depth),
+                                        _p(nn), _p(theta), C.c_double(lam), C.c_int(n_steps), C.c_int(int(want_grad)),
+                                        C.c_int(nthreads), C.byref(loss), _p(sse), _p(g_nn), _p(g_th))
+        if rc < 0:
+            raise ValueError("cude_oracle_supp_rev: unsupported size")
+        return dict(loss=loss.value, sse=sse, g_nn=g_nn, g_theta=g_th, traj=None, n_failed=rc)
     rc = lib().cude_oracle_supp(C.c_int(N), C.c_int(T), _p(tp), _p(dcol), C.c_int(width), C.c_int(depth),
                                 _p(nn), _p(theta), C.c_double(lam), C.c_int(n_steps), C.c_int(int(want_grad)),
                                 C.c_int(nthreads), C.byref(loss), _p(sse), _p(g_nn), _p(g_th), _p(traj))

@@ -267,6 +267,66 @@ def test_two_rank_gloo_training_matches_single_process(tmp_path, world):
     assert np.allclose(r0["cond"], beta, rtol=0, atol=1e-12)
 
 
+# ------------------------------------------------------------------ sharded L-BFGS (second stage of _optimize)
+def _lbfgs_rank_main(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "conditional-ude_amd"), os.path.join(here, "..", "oracle"), here):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from cude.parallel import ShardedTrainer, TorchCollective, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = make_cpep_case(n_total, (2, 4, 2))
+    lo, hi = shard_bounds(n_total, world, rank)
+    tr = ShardedTrainer(OracleEngine(case, lo, hi), TorchCollective(dist), transport="host")
+    tr.sync_population_statistics()
+    tr.adam_init(1e-2)
+    for _ in range(2):
+        tr.adam_step()
+    res = tr.lbfgs(6)
+    cond = tr.gather_conditional(n_total)
+    nn, _ = tr.engine.get_params()
+    np.savez(os.path.join(out_dir, f"lbfgs{rank}.npz"), f=res["f"], it=res["iterations"], calls=res["f_calls"],
+             cond=cond, nn=nn)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lbfgs_follows_the_single_process_iterates(tmp_path, world):
+    """Adam x2 then L-BFGS x6 (`_optimize`, src/parameter-estimation.jl:170-183) with the subjects sharded over
+    2 / 3 gloo ranks: every inner product of the L-BFGS recursion takes its conditional part through the collective
+    (cude_lbfgs_minimize_sharded).  Must reproduce the run of one process holding all subjects -- same iteration and
+    evaluation counts, iterates equal up to the summation order of the inner products."""
+    import torch.multiprocessing as mp
+    import c_oracle as co
+    import cude_oracle as o
+    from cude.engine import lbfgs_minimize
+    n_total = 17
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_lbfgs_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "lbfgs0.npz"), np.load(tmp_path / f"lbfgs{world - 1}.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k                  # every rank walked the same path
+    c = make_cpep_case(n_total, (2, 4, 2))
+    nn, beta = c["nn"].copy(), c["beta"].copy()
+    P = nn.size
+    m_n, v_n, m_b, v_b = np.zeros_like(nn), np.zeros_like(nn), np.zeros_like(beta), np.zeros_like(beta)
+    for t in range(1, 3):
+        r = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], c["arch"], nn, beta, 30, 3)
+        nn, m_n, v_n = o.adam_update(nn, r["g_nn"], m_n, v_n, t, 1e-2)
+        beta, m_b, v_b = o.adam_update(beta, r["g_beta"], m_b, v_b, t, 1e-2)
+
+    def fg(x):
+        r = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], c["arch"], x[:P], x[P:], 30, 3)
+        return r["loss"], np.concatenate([r["g_nn"], r["g_beta"]])
+    one = lbfgs_minimize(fg, np.concatenate([nn, beta]), 6)
+    assert int(r0["it"]) == one["iterations"] == 6 and int(r0["calls"]) == one["f_calls"]
+    assert abs(float(r0["f"]) - one["f"]) <= 1e-10 * abs(one["f"])
+    assert np.allclose(r0["nn"], one["x"][:P], rtol=0, atol=1e-9)
+    assert np.allclose(r0["cond"], one["x"][P:], rtol=0, atol=1e-9)
+
+
 # ------------------------------------------------------------------ 2-rank gloo SAEM (BASELINE configs[4] sharding)
 _SAEM_KW = dict(sigma=0.4, prior_eta=-0.6, prior_omega=0.8, iterations=3, n_burnin_iterations=1, n_mcmc_steps=2,
                 initial_mcmc_steps=3, proposal_std=0.3, m_step_iters=2)

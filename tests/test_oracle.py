@@ -201,3 +201,34 @@ def test_failure_convention_and_adam():
     assert r["loss"] == np.inf and r["n_failed"] == 1
     x, m, v = o.adam_update(np.array([1.0]), np.array([0.5]), np.zeros(1), np.zeros(1), 1, 1e-2)
     assert abs(x[0] - (1.0 - 1e-2 * 0.5 / (0.5 + 1e-8))) < 1e-15
+
+
+@pytest.mark.parametrize("arch,n_state", [((2, 6, 2), 3), ((2, 4, 2), 2), ((3, 4, 2), 2), ((2, 4, 3), 3), ((2, 8, 2), 2)])
+def test_reverse_mode_oracle_agrees_with_forward_mode_cpep(arch, n_state):
+    """oracle/cude_oracle_rev.c (per-subject discrete adjoint, the CPU baseline of bench.py) against the
+    forward-mode duals of oracle/cude_oracle.c (the reference's own AD method): two algorithms, one answer."""
+    import c_oracle as co
+    from conftest import make_cpep_case
+    c = make_cpep_case(37, arch)
+    kw = dict(covariate=(arch[0] == 3))
+    a = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], c["beta"], 30, n_state, **kw)
+    for nthreads in (1, 3):
+        b = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], c["beta"], 30, n_state,
+                    method="reverse", nthreads=nthreads, **kw)
+        assert abs(a["loss"] - b["loss"]) <= 1e-13 * abs(a["loss"])
+        assert np.max(np.abs(a["sse"] - b["sse"])) <= 1e-13 * np.max(a["sse"])
+        assert np.max(np.abs(a["g_nn"] - b["g_nn"])) <= 1e-12 * np.max(np.abs(a["g_nn"]))
+        assert np.max(np.abs(a["g_beta"] - b["g_beta"])) <= 1e-12 * np.max(np.abs(a["g_beta"]))
+
+
+@pytest.mark.parametrize("arch", [(4, 3, 5), (4, 3, 2), (4, 6, 2)])
+def test_reverse_mode_oracle_agrees_with_forward_mode_supp(arch):
+    import c_oracle as co
+    from conftest import make_supp_case
+    s = make_supp_case(29, arch)
+    for lam in (0.0, 0.01):
+        a = co.supp(s["tp"], s["data"], arch, s["nn"], s["theta"], lam, 30)
+        b = co.supp(s["tp"], s["data"], arch, s["nn"], s["theta"], lam, 30, method="reverse")
+        assert abs(a["loss"] - b["loss"]) <= 1e-13 * abs(a["loss"])
+        assert np.max(np.abs(a["g_nn"] - b["g_nn"])) <= 1e-12 * np.max(np.abs(a["g_nn"]))
+        assert np.max(np.abs(a["g_theta"] - b["g_theta"])) <= 1e-12 * np.max(np.abs(a["g_theta"]))
