@@ -13,17 +13,28 @@ T=5 observations on [0,120] min, seeded synthetic population.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the contract fields: `roofline` (HBM, the contract's object),
+`roofline_valu` (the binding one), `cpu_baseline` (reverse-mode CPU port; `cpu_baseline_forward_mode` = the
+reference's own AD method), `extra` (the other BASELINE configs a single GPU can run: forward-only 1e4, the
+reference-faithful 2->4->4->1 and suppression instances at 1e5, the SAEM E-step 1e4 x 100), and for N>1 the proof of
+the transport: `rccl_ranks` / `rccl_version` as the communicator reports them, `allreduce_check` (one optimiser step
+through RCCL inside the library vs through torch.distributed on a twin context), per-rank kernel times.
 """
-import argparse
-import json
 import os
-import sys
-import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# dmabuf IPC for multi-process RCCL on this pool: must be in the environment before the first HIP call
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import argparse  # noqa: E402
+import glob  # noqa: E402
+import hashlib  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "conditional-ude_amd"))
@@ -34,37 +45,32 @@ N_STEPS = 30
 T_OBS = 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
-# algorithmic bytes per subject-trajectory of the dominant (forward+adjoint) kernel, SURVEY.md 8(d):
-# reads k0,k1,k2,c0 (32) + beta (8) + glucose increments (40) + observations (40); writes dL/dbeta (8) + sse (8)
-# + cumulative secretion (8, the CPEP3 quadrature output)
-ALGO_BYTES_PER_SUBJECT = 32 + 8 + 8 * T_OBS + 8 * T_OBS + 8 + 8 + 8
+PREWARM_STEPS = 64             # untimed launches before the W warm-up steps: the GPU needs ~30 launches (20 ms) to
+                               # reach its steady clock after an idle period (profiles/r02/clock_ramp.txt)
 
 
-def executed_flops_per_trajectory(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS):
-    """fp64 flops the forward+adjoint kernel actually executes per subject (FMA = 2), counted from
-    the kernel's structure (DESIGN.md "flop accounting"): evaluations x per-evaluation counts."""
-    nin, w, d = arch
+# ------------------------------------------------------------------------------------------ counted work
+def cpep_algo_bytes(n_obs, n_state, grad):
+    """Algorithmic bytes per subject-trajectory of the c-peptide kernels: reads k0,k1,k2,c0 (32) +
+    beta (8) + glucose increments + observations (8 T each); writes sse (8) [+ dL/dbeta (8)] [+ cumulative secretion
+    (8), the CPEP3 quadrature output]."""
+    return 32 + 8 + 8 * n_obs + 8 * n_obs + 8 + (8 if grad else 0) + (8 if n_state == 3 else 0)
+
+
+def supp_algo_bytes(n_obs, grad):
+    """u0 is data[:, 0, :] (part of the observations): reads theta (8) + data (3 x 8 T); writes sse (8) [+ dL/dtheta]."""
+    return 8 + 3 * 8 * n_obs + 8 + (8 if grad else 0)
+
+
+def mlp_flops(nv, w, d, want_dx=False):
+    """(forward, backward) fp64 flops of one network evaluation as the kernels execute it (FMA = 2; cude_math.h)."""
     # m_tanh_vec per neuron: min, mul, rndne, cvt, ldexp, add, bfi (7 x 1 flop) + 13 FMA (2 reduction, 10 Horner,
-    # 1 final) ; per layer: one reciprocal (rcp + 3 FMA) + 3(W-1) multiplies
-    tanh_layer_fl = w * (7 + 13 * 2) + (1 + 3 * 2) + 3 * (w - 1)
-    softplus_fl = 26 * 2 + 22      # exp (12 FMA) + shared reciprocal (3 FMA) + atanh series (11 FMA) + 22 other ops
-    fwd_eval = 2 * (w * 1 + (d - 1) * w * w + w) + d * tanh_layer_fl + softplus_fl
-    bwd_eval = (2 * w + w + 2) + (d - 1) * w * (4 + 4 * w) + w * 6
-    n_eval = 5 * n_steps + 1
-    stage_fwd = 2 * (2 * 21 + 2 * 6 + 7 * 4) + 2 * 6          # stage sums, Y, A*Y+g, quadrature
-    stage_rev = 2 * (2 * 21 + 6 * 4 + 12) + 12
-    obs_fl = n_obs * (2 * 3 * 7 + 8) * 2
-    total = n_eval * fwd_eval + n_eval * (fwd_eval + bwd_eval) + n_steps * (stage_fwd + stage_rev) + obs_fl
-    if 6 <= w <= 7:
-        # layer-1 exponent table (cude_device.h Mlp::HAS_TAB): inside a run of steps within one glucose piece the W
-        # layer-1 exponentials (7 + 13 FMA each) and the W first-layer FMAs are replaced by one multiply + min + add
-        # per neuron; per run and sweep: 6 W exponentials (table + anchor) and the range check; per step W multiplies
-        n_tab_steps, n_runs = table_steps(n_steps, n_obs)
-        saved_per_eval = w * (7 + 13 * 2) + 2 * w - 3 * w
-        exp_fl = 6 + 12 * 2
-        per_run = 6 * w * exp_fl + 10 * w
-        total += 2 * (-5 * n_tab_steps * saved_per_eval + n_runs * per_run + n_tab_steps * w)
-    return total
+    # 1 final); per layer: one reciprocal (rcp + 3 FMA) + 3(W-1) multiplies
+    tanh_layer = w * (7 + 13 * 2) + (1 + 3 * 2) + 3 * (w - 1)
+    softplus = 26 * 2 + 22      # exp (12 FMA) + shared reciprocal (3 FMA) + atanh series (11 FMA) + 22 other ops
+    fwd = 2 * (w * nv + (d - 1) * w * w + w) + d * tanh_layer + softplus
+    bwd = (2 * w + w + 2) + (d - 1) * w * (4 + 4 * w) + w * (4 + 2 * nv) + (2 * nv * w if want_dx else 0)
+    return fwd, bwd
 
 
 def table_steps(n_steps, n_obs):
@@ -79,6 +85,84 @@ def table_steps(n_steps, n_obs):
     return sum(1 for p in piece if p >= 0), runs
 
 
+def cpep_flops(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS, n_state=N_STATE, grad=True):
+    """fp64 flops the one-lane-per-subject c-peptide kernel executes per subject (FMA = 2), counted from the kernel's
+    structure (cude_cpep.hip): 5 S + 1 network evaluations per sweep, the Runge-Kutta algebra per step."""
+    nin, w, d = arch
+    fwd_eval, bwd_eval = mlp_flops(1, w, d)
+    n_eval = 5 * n_steps + 1
+    stage_fwd = 2 * (2 * 21 + 2 * 6 + 7 * 4) + (2 * 6 if n_state == 3 else 0)   # stage sums, Y, A*Y+g [, quadrature]
+    stage_rev = 2 * (2 * 21 + 6 * 4 + 12) + 12
+    obs_fl = n_obs * (2 * (3 if n_state == 3 else 2) * 7 + 8)
+    total = n_eval * fwd_eval + n_steps * stage_fwd + obs_fl
+    if grad:
+        total += n_eval * (fwd_eval + bwd_eval) + n_steps * stage_rev + obs_fl
+    if 6 <= w <= 7:
+        # layer-1 exponent table (cude_device.h Mlp::HAS_TAB): inside a run of steps within one glucose piece the W
+        # layer-1 exponentials (7 + 13 FMA each) and the W first-layer FMAs are replaced by one multiply + min + add
+        # per neuron; per run and sweep: 6 W exponentials (table + anchor) and the range check; per step W multiplies
+        n_tab_steps, n_runs = table_steps(n_steps, n_obs)
+        saved_per_eval = w * (7 + 13 * 2) + 2 * w - 3 * w
+        per_run = 6 * w * (6 + 12 * 2) + 10 * w
+        total += (2 if grad else 1) * (-5 * n_tab_steps * saved_per_eval + n_runs * per_run + n_tab_steps * w)
+    return total
+
+
+def supp_flops(arch, n_steps, n_obs, grad=True):
+    """The same count for supp_kernel (cude_supp.hip): 6 S + 1 evaluations per sweep, all three inputs varying; the
+    reverse sweep re-evaluates the network at the stored stage inputs (no kept activations at this size)."""
+    nin, w, d = arch
+    fwd_eval, bwd_eval = mlp_flops(3, w, d, want_dx=True)
+    n_eval = 6 * n_steps + 1
+    stage = 2 * 3 * 21 + 6 * 3 * 2 + 6 * 4            # stage sums + Y per stage + RHS algebra
+    obs_fl = n_obs * (2 * 3 * 7 + 3 * 5)
+    total = n_eval * fwd_eval + n_steps * stage + obs_fl
+    if grad:
+        total += n_eval * (fwd_eval + bwd_eval + 10) + n_steps * (2 * 3 * 21 + 6 * 3 * 2) + obs_fl
+    return total
+
+
+def kernel_source_sha():
+    """Digest of the kernel sources: a PMC traffic record (profiles/pmc_traffic.json) is only quoted for the code it
+    was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "conditional-ude_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "conditional-ude_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_key, n_local):
+    """HBM bytes per launch from the committed PMC passes, or (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    rec = rec.get("kernels", {}).get(kernel_key) if "kernels" in rec else (rec if kernel_key == "headline" else None)
+    if not rec:
+        return None, f"no PMC record for {kernel_key}"
+    if rec.get("source_sha") != kernel_source_sha():
+        return None, f"stale PMC record (kernel sources changed since {rec.get('source_sha')})"
+    if rec.get("subjects_per_gpu") != n_local:
+        return None, f"PMC record is for {rec.get('subjects_per_gpu')} subjects"
+    return rec.get("hbm_bytes_per_launch"), None
+
+
+def rooflines(kernel, kern_ms, launches, n_subjects, bytes_per_subject, flops_per_subject, traffic=None, note=None):
+    gbs = bytes_per_subject * n_subjects / (kern_ms * 1e-3) / 1e9
+    tfs = flops_per_subject * n_subjects / (kern_ms * 1e-3) / 1e12
+    hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "traffic": traffic, "kernel": kernel, "kernel_ms": kern_ms, "launches": launches,
+           "algorithmic_bytes_per_launch": bytes_per_subject * n_subjects,
+           "note": note or "path is fp64-VALU bound (SURVEY.md 8d), see roofline_valu"}
+    valu = {"bound": "valu_fp64", "achieved": tfs, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+            "frac": tfs / FP64_VALU_PEAK_TF, "flops_per_trajectory": flops_per_subject}
+    return hbm, valu
+
+
+# ------------------------------------------------------------------------------------------ synthetic data
 def synthetic_population(n, seed):
     """Seeded synthetic population of the c-peptide shape; numpy only."""
     rng = np.random.default_rng(seed)
@@ -94,6 +178,24 @@ def synthetic_population(n, seed):
     return tp, G, c0, age, t2dm, beta, rng
 
 
+def synthetic_suppression(n, seed):
+    """Suppression-model data of the reference's shape (3 x 8 x N on [0, 30], u0 = (10, 0, 0) + noise; smooth
+    closed-form curves + 10 % multiplicative noise stand in for `generate_data`, suppression_model.jl:39-63)."""
+    rng = np.random.default_rng(seed)
+    T = 8
+    tp = np.linspace(0.0, 30.0, T)
+    t = tp[None, :, None]
+    k = 0.3 + 0.2 * rng.random((1, 1, n))
+    data = np.empty((3, T, n))
+    data[0] = (10.0 * np.exp(-0.4 * t))[0]
+    data[1] = (6.0 * t * np.exp(-k * t) / 3.0)[0] + 0.2
+    data[2] = (4.0 * (1 - np.exp(-0.15 * t)) * np.exp(-0.02 * t))[0] + 0.1
+    data *= 1.0 + 0.1 * rng.standard_normal(data.shape)
+    data = np.maximum(data, 0.0)
+    data[0, 0] = 10.0 * (1 + 0.05 * rng.standard_normal(n))
+    return tp, data, 0.5 * rng.standard_normal(n)
+
+
 def glorot(arch, seed):
     rng = np.random.default_rng(seed)
     nin, w, d = arch
@@ -105,22 +207,151 @@ def glorot(arch, seed):
     return np.concatenate(parts)
 
 
-def cpu_baseline(tp, G, obs, age, t2dm, nn, beta, sample):
-    """Times the CPU oracle ("port": forward-mode duals + OpenMP, oracle/cude_oracle.c) on a bounded
-    sample of the same population.  Baseline only."""
+def cpep_engine(Engine, arch, n_state, n, seed, device, nn):
+    """Engine with a resident synthetic c-peptide population whose observations are the device's own forward solve at
+    the true betas + 5 % multiplicative noise; parameters set to a perturbed start."""
+    tp, G, c0, age, t2dm, beta_true, rng = synthetic_population(n, seed)
+    eng = Engine("cpep", arch, n_steps=N_STEPS, n_state=n_state, device=device)
+    T = len(tp)
+    eng.set_population_cpep(tp, G, np.repeat(c0[:, None], T, axis=1), age, t2dm)
+    eng.set_params(nn, beta_true)
+    traj = eng.forward(want_traj=True)["traj"]
+    obs = traj[0].T * (1.0 + 0.05 * rng.standard_normal((n, T)))
+    obs[:, 0] = c0
+    beta0 = beta_true + 0.3 * rng.standard_normal(n)
+    return eng, dict(tp=tp, G=G, obs=obs, age=age, t2dm=t2dm, beta0=beta0, rng=rng)
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(pop, nn, sample):
+    """Times the CPU port on a bounded sample of the same population: the per-subject reverse-mode gradient with OpenMP
+    static scheduling over subjects (oracle/cude_oracle_rev.c), and -- for the record -- the
+    reference's own AD method, forward-mode duals with P+1 partials per subject (oracle/cude_oracle.c).  Baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle as co
-    n = min(sample, G.shape[0])
+    n = min(sample, pop["G"].shape[0])
     threads = co.num_threads()
-    co.cpep(tp, G[:64], obs[:64], age[:64], t2dm[:64], ARCH, nn, beta[:64], N_STEPS, N_STATE)   # warm-up
+    a = (pop["tp"], pop["G"][:n], pop["obs"][:n], pop["age"][:n], pop["t2dm"][:n], ARCH, nn, pop["beta0"][:n], N_STEPS,
+         N_STATE)
+    co.cpep(pop["tp"], pop["G"][:256], pop["obs"][:256], pop["age"][:256], pop["t2dm"][:256], ARCH, nn,
+            pop["beta0"][:256], N_STEPS, N_STATE, method="reverse")                   # warm-up (thread pool)
+    reps = 3
     t0 = time.perf_counter()
-    r = co.cpep(tp, G[:n], obs[:n], age[:n], t2dm[:n], ARCH, nn, beta[:n], N_STEPS, N_STATE, want_grad=True)
+    for _ in range(reps):
+        co.cpep(*a, method="reverse")
+    dt = (time.perf_counter() - t0) / reps
+    rev = {"value": n / dt, "unit": "subject-trajectories/s", "cores": threads, "kind": "port",
+           "sample": f"{n} subjects of the same population, {reps} loss+gradient evaluations (per-subject reverse-mode "
+                     f"discrete adjoint, OpenMP static over subjects), {dt:.2f} s each"}
+    t0 = time.perf_counter()
+    co.cpep(*a)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "subject-trajectories/s", "cores": threads, "kind": "port",
-            "sample": f"{n} subjects of the same population, 1 loss+gradient evaluation "
-                      f"(forward-mode duals, P+1 partials per subject, OpenMP static over subjects), {dt:.2f} s"}, r
+    fwd = {"value": n / dt, "unit": "subject-trajectories/s", "cores": threads, "kind": "port",
+           "sample": f"{n} subjects, 1 loss+gradient evaluation by the reference's AD method (forward-mode duals, P+1 "
+                     f"partials per subject; the reference itself carries N+P), {dt:.2f} s"}
+    return rev, fwd
 
 
+# ------------------------------------------------------------------------------------------ extra configurations
+def timed_adam(eng, n, steps, warm):
+    for _ in range(warm):
+        eng.adam_step(want_loss=False)
+    eng.set_kernel_timing(True)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.adam_step()                              # loss returned every step, as in the headline
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ms, launches = eng.kernel_time_ms()
+    eng.set_kernel_timing(False)
+    return dt, ms, launches
+
+
+def extras(Engine, device, steps=20, warm=40):
+    """The other BASELINE configs one GPU can run, each with its own kernel time, counted bytes / flops and both
+    roofline fractions (SURVEY.md 8(d) "always also report")."""
+    out = {}
+    # ---- configs[1]: forward-only ensemble, 1e4 subjects, headline model
+    n = 10000
+    eng, pop = cpep_engine(Engine, ARCH, N_STATE, n, 777, device, glorot(ARCH, 1234))
+    eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+    eng.set_params(glorot(ARCH, 1234), pop["beta0"])
+    for _ in range(warm):
+        eng.forward()
+    eng.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward()
+    dt = (time.perf_counter() - t0) / steps
+    ms, launches = eng.kernel_time_ms()
+    eng.set_kernel_timing(False)
+    hbm, valu = rooflines("cpep2_fwd_kernel<2,6,2,3> + cpep2_scan_kernel (time-split forward)", ms, launches, n,
+                          cpep_algo_bytes(T_OBS, N_STATE, False), cpep_flops(grad=False))
+    out["forward_only_1e4"] = {"config": "BASELINE configs[1]: CPEP3 2x6x6x1, 1e4 subjects, forward-only loss",
+                               "value": n / dt, "unit": "subject-trajectories/s", "ms_per_call": dt * 1e3,
+                               "roofline": hbm, "roofline_valu": valu}
+    eng.close()
+    # ---- reference-faithful c-peptide instance: 2->4->4->1, 2 states, 1e5 subjects, fwd + adjoint + Adam
+    n, arch = 100000, (2, 4, 2)
+    nn4 = glorot(arch, 1234)
+    eng, pop = cpep_engine(Engine, arch, 2, n, 778, device, nn4)
+    eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+    eng.set_params(nn4, pop["beta0"])
+    eng.adam_init(1e-2)
+    dt, ms, launches = timed_adam(eng, n, steps, warm)
+    hbm, valu = rooflines("cpep gradient launch <2,4,2,2> (library's path selector)", ms, launches, n,
+                          cpep_algo_bytes(T_OBS, 2, True), cpep_flops(arch, N_STEPS, T_OBS, 2, True))
+    out["cpep2_4_1e5"] = {"config": "reference c-peptide cUDE (02-conditional.jl:22): 2x4x4x1, 2 states, 1e5 subjects, "
+                                    "fwd + adjoint + Adam",
+                          "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
+                          "roofline": hbm, "roofline_valu": valu}
+    eng.close()
+    # ---- suppression instance: 4->3x5->1, 3 states, T = 8, 1e5 subjects, fwd + adjoint + Adam
+    n, arch = 100000, (4, 3, 5)
+    tp, data, theta = synthetic_suppression(n, 779)
+    eng = Engine("supp", arch, n_steps=N_STEPS, lam=0.01, device=device)
+    eng.set_population_supp(tp, data)
+    eng.set_params(glorot(arch, 1234), theta)
+    eng.adam_init(1e-3)
+    dt, ms, launches = timed_adam(eng, n, steps, 10)
+    scratch = 2 * (6 * N_STEPS + 1) * 3 * 8          # stage inputs written by the forward and read by the reverse sweep
+    hbm, valu = rooflines("supp_kernel<3,5,grad>", ms, launches, n, supp_algo_bytes(8, True),
+                          supp_flops(arch, N_STEPS, 8, True),
+                          note=f"+ {scratch} B/subject of stage-input scratch (stored linearisation points instead of "
+                               f"a recomputed forward sweep; profiles/r02/supp_scratch_tradeoff.txt)")
+    out["supp_1e5"] = {"config": "suppression cUDE (suppression.jl:18): 4x3x3x3x3x3x1, 3 states, T=8, 1e5 subjects, "
+                                 "fwd + adjoint + Adam, lambda=0.01",
+                       "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
+                       "roofline": hbm, "roofline_valu": valu}
+    eng.close()
+    # ---- configs[4] on one GPU: SAEM E-step, 1e4 subjects x 100 Metropolis steps (2 forward solves per step)
+    n, n_mc, arch = 10000, 100, (2, 4, 2)
+    eng, pop = cpep_engine(Engine, arch, 2, n, 780, device, nn4)
+    eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+    eng.set_params(nn4, pop["beta0"])
+    rng = np.random.default_rng(5)
+    z, u = rng.standard_normal((n_mc, n)), rng.random((n_mc, n))
+    eng.mh_estep(z[:10], u[:10], 0.5, -0.6, 0.8, 0.3)
+    eng.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    acc = eng.mh_estep(z, u, 0.5, -0.6, 0.8, 0.3)
+    dt = time.perf_counter() - t0
+    ms, launches = eng.kernel_time_ms()
+    eng.set_kernel_timing(False)
+    hbm, valu = rooflines("time-split forward launches <2,4,2,2> inside cude_mh_estep", ms, launches, n,
+                          cpep_algo_bytes(T_OBS, 2, False), cpep_flops(arch, N_STEPS, T_OBS, 2, False))
+    out["saem_estep_1e4x100"] = {"config": "BASELINE configs[4] on one GPU: SAEM E-step (saem.jl:86-108,177-186), 1e4 "
+                                           "subjects x 100 Metropolis steps, 2x4x4x1, host-supplied draws uploaded "
+                                           "inside the timed call",
+                                 "value": 2 * n * n_mc / dt, "unit": "forward solves/s", "ms_per_estep": dt * 1e3,
+                                 "acceptance_rate": float(acc.sum()) / (n * n_mc),
+                                 "roofline": hbm, "roofline_valu": valu}
+    eng.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +362,7 @@ def main():
                          "configs[2] training step at that shard size")
     ap.add_argument("--cpu-sample", type=int, default=125000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other single-GPU configurations")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +372,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        raise SystemExit("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for multi-process RCCL on this pool")
     # CUDE_BENCH_REHEARSAL=1 (development only): several ranks share the GPUs that exist and torch.distributed uses
     # gloo, so that the multi-rank control flow of this script can be exercised on a 1-GPU box
     rehearsal = os.environ.get("CUDE_BENCH_REHEARSAL") == "1"
@@ -156,10 +390,10 @@ def main():
     from cude.engine import Engine   # after torch: one shared HIP runtime
 
     n_local = args.subjects_per_gpu
-    tp, G, c0, age, t2dm, beta_true, rng = synthetic_population(n_local, 20250905 + rank)
     nn = glorot(ARCH, 1234)
-    eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
+    eng, pop = cpep_engine(Engine, ARCH, N_STATE, n_local, 20250905 + rank, local_rank, nn)
     transport = "rccl"          # all-reduce of the P+2 doubles inside libcude_hip.so (RCCL on the context's stream)
+    rccl_info = None
     if world > 1:
         # Every rank issues the same sequence of collectives whatever fails locally: first agree that librccl
         # is loadable everywhere (each rank draws an id; only rank 0's is used), then build the communicator.
@@ -180,36 +414,35 @@ def main():
             dist.broadcast(uid, 0)
             try:
                 eng.comm_init(world, rank, bytes(uid.cpu().tolist()))
+                rccl_info = eng.comm_info()          # (ranks, rank, version) as RCCL itself reports them
+                if rccl_info[0] != world or rccl_info[1] != rank:
+                    raise RuntimeError(f"communicator reports {rccl_info}, expected ({world}, {rank})")
             except Exception as exc:
                 print(f"[rank {rank}] cude_comm_init failed ({exc}); using torch.distributed", file=sys.stderr)
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
             transport = "host"  # cude_loss_grad_partial -> dist.all_reduce (RCCL via PyTorch) -> cude_adam_apply
+            rccl_info = None
             eng.close()
             eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
-    # observations = the device's own forward solve at the true betas + 5 % multiplicative noise
-    cp0 = np.repeat(c0[:, None], T_OBS, axis=1)
-    eng.set_population_cpep(tp, G, cp0, age, t2dm)
-    eng.set_params(nn, beta_true)
-    traj = eng.forward(want_traj=True)["traj"]
-    obs = traj[0].T * (1.0 + 0.05 * rng.standard_normal((n_local, T_OBS)))
-    obs[:, 0] = c0
-    eng.set_population_cpep(tp, G, obs, age, t2dm)
+    eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])   # global count all-reduced here
     if transport == "host":
         eng.set_global_subjects(n_local * world)
-    beta0 = beta_true + 0.3 * rng.standard_normal(n_local)
-    eng.set_params(nn, beta0)
+    eng.set_params(nn, pop["beta0"])
     eng.adam_init(1e-2)
+
+    def host_step(e):
+        part, _ = e.loss_grad_partial()
+        t = torch.from_numpy(part).to(ctl)
+        dist.all_reduce(t)
+        return e.adam_apply(t.cpu().numpy())
 
     def train_step(want_loss=True):
         """One optimiser iteration over ALL ranks' subjects; returns the global loss."""
         if transport == "rccl":
             return eng.adam_step(want_loss=want_loss)
-        part, _ = eng.loss_grad_partial()
-        t = torch.from_numpy(part).to(ctl)
-        dist.all_reduce(t)
-        return eng.adam_apply(t.cpu().numpy())
+        return host_step(eng)
 
     def barrier():
         eng.synchronize()
@@ -217,6 +450,28 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # ---- N > 1: the same optimiser step through both transports, from the same state (fresh Adam moments)
+    allreduce_check = None
+    if world > 1 and transport == "rccl":
+        twin = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
+        twin.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+        twin.set_global_subjects(n_local * world)
+        twin.set_params(nn, pop["beta0"])
+        twin.adam_init(1e-2)
+        loss_a = eng.adam_step()
+        loss_b = host_step(twin)
+        (nn_a, cond_a), (nn_b, cond_b) = eng.get_params(), twin.get_params()
+        twin.close()
+        diff = max(abs(loss_a - loss_b) / abs(loss_b), float(np.max(np.abs(nn_a - nn_b)) / np.max(np.abs(nn_b))),
+                   float(np.max(np.abs(cond_a - cond_b)) / np.max(np.abs(cond_b))))
+        t = torch.tensor([diff], dtype=torch.float64, device=ctl)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_check = float(t.item())
+
+    # ---- untimed: bring the GPU to its steady clock (same count on every rank: the collectives must pair up), then
+    # the W warm-up steps of the contract
+    for _ in range(PREWARM_STEPS):
+        train_step(want_loss=False)
     for _ in range(args.warmup):
         train_step()
     eng.set_kernel_timing(True)
@@ -238,26 +493,21 @@ def main():
     barrier()
     dt_async = time.perf_counter() - t1
 
+    kern_min = kern_max = kern_ms
     if world > 1:
-        t = torch.tensor([dt, dt_async, kern_ms], dtype=torch.float64, device=ctl)
+        t = torch.tensor([dt, dt_async, kern_ms, -kern_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_async, kern_ms = (float(v) for v in t.cpu())
+        dt, dt_async, kern_max, kern_min = float(t[0]), float(t[1]), float(t[2]), -float(t[3])
+        kern_ms = kern_max
 
     if rank == 0:
         n_total = n_local * world
         value = n_total * args.steps / dt
-        flops = executed_flops_per_trajectory()
-        algo_bytes = ALGO_BYTES_PER_SUBJECT * n_local
-        achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("subjects_per_gpu") == n_local:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = pmc_traffic("headline", n_local)
+        hbm, valu = rooflines("cpep_kernel<Mlp<2,6,2,1>,3,grad>", kern_ms, n_launch, n_local,
+                              cpep_algo_bytes(T_OBS, N_STATE, True), cpep_flops(), traffic)
+        if traffic is None:
+            hbm["traffic_note"] = traffic_note
         out = {
             "metric": "subject-trajectories/sec (fwd+adjoint, 3-state ODE, 30 steps)",
             "value": value, "unit": "subject-trajectories/s", "n_gpus": world, "steps": args.steps,
@@ -266,24 +516,28 @@ def main():
             "config": {"workload": f"CPEP3 cUDE training step (fwd Tsit5 x{N_STEPS} + discrete adjoint + Adam), "
                                    f"2x6x6x1 MLP, T={T_OBS}, {n_local} subjects/GPU "
                                    f"({n_total} total; BASELINE configs[2]/[3] shape)",
-                       "subjects_per_gpu": n_local, "parallelism": f"subject-shard x{world}", "allreduce": transport if world > 1 else None},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "cpep_kernel<2,6,2,3,grad>", "kernel_ms": kern_ms, "launches": n_launch,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "path is fp64-VALU bound (SURVEY.md 8d), see roofline_valu"},
-            "roofline_valu": {"bound": "valu_fp64", "achieved": flops * n_local / (kern_ms * 1e-3) / 1e12,
-                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": flops * n_local / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                              "flops_per_trajectory": flops},
+                       "subjects_per_gpu": n_local, "parallelism": f"subject-shard x{world}",
+                       "allreduce": transport if world > 1 else None},
+            "roofline": hbm, "roofline_valu": valu,
             "async_value": n_total * args.steps / dt_async,
-            "final_loss": loss,
+            "final_loss": loss, "prewarm_steps": PREWARM_STEPS, "kernel_source_sha": kernel_source_sha(),
         }
-        if not args.no_cpu_baseline and world == 1:
-            cb, _ = cpu_baseline(tp, G, obs, age, t2dm, nn, beta0, args.cpu_sample)
-            out["cpu_baseline"] = cb
+        if world > 1:
+            out["rccl_ranks"] = rccl_info[0] if rccl_info else None
+            out["rccl_version"] = rccl_info[2] if rccl_info else None
+            out["allreduce_check"] = allreduce_check
+            out["kernel_ms_per_rank"] = {"min": kern_min, "max": kern_max}
+            out["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        if world == 1:
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"], out["cpu_baseline_forward_mode"] = cpu_baseline(pop, nn, args.cpu_sample)
+            if not args.no_extra:
+                eng.close()
+                eng = None
+                out["extra"] = extras(Engine, local_rank)
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

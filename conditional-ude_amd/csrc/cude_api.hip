@@ -392,20 +392,43 @@ cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base) {
     return a2;
 }
 
-// Chunking of the step range for the time-split gradient path: L = min(3, S) contiguous chunks (0 <-> disabled
-// by CUDE_CPEP_PATH=1 or an unsupported shape).  Precomputes the kinetics-only chunk transfer matrices.
+// Relative cost of one gradient launch when `waves` workgroups of `evals` network evaluations each run on `slots`
+// resident-wave slots: full rounds cost one wave length each; a last partial round that leaves at least half of the
+// SIMDs with a single wave runs at single-wave speed (measured on MI355X: a wave alone on its SIMD takes 0.69 of the
+// time it takes next to a second one; profiles/r02/sweep_chunks.txt).
+double launch_cost(double waves, double slots, double evals) {
+    const double x = waves / slots;
+    const double full = std::floor(x + 1e-9), frac = x - full;
+    const double rounds = full + (frac < 1e-9 ? 0.0 : (frac <= 0.5 ? 0.69 : 1.0));
+    return rounds * evals;
+}
+
+// Chunking of the step range for the time-split gradient path (1 <-> the one-lane-per-subject kernel; forced by
+// CUDE_CPEP_PATH=1 / =2:L or an unsupported shape).  Precomputes the kinetics-only chunk transfer matrices.
+//
+// Choice of L (divisors of S): the launch that minimises launch_cost().  One lane per subject gives nblocks waves of
+// 5S+1 evaluations; L chunks give nblocks*L waves of 5S/L+3 (two extra forward and one extra reverse evaluation per
+// chunk).  Splitting pays when the one-shot grid would end in a mostly idle round -- 1e5 subjects = 1563 waves on
+// 2048 slots took as long as 125 000 -- or leave the chip empty (57 subjects = one wave).  Measured (round 2, 2x6x6x1,
+// S = 30): 1e5 subjects 0.644 -> 0.571 ms (L = 5), 8e4 0.637 -> 0.477 (L = 3), 2e5 1.222 -> 1.135 (L = 3), 125 000
+// stays at L = 1 (0.654 vs 0.683 for L = 2).
 int32_t setup_chunks(cude_ctx* c) {
     c->chunks = 1;
     const char* env = getenv("CUDE_CPEP_PATH");
     if (env && env[0] == '1') return CUDE_OK;
     if (!cude::cpep2_shape_supported(c->net, c->cfg.n_state)) return CUDE_OK;
     const int S = c->cfg.n_steps;
-    // Largest divisor L of S that keeps nblocks*L within ~2.5 waves per SIMD (1024 SIMDs): measured optimum on
-    // MI355X (tools/quick_bench.py): 57 subjects L=30 (0.43 -> 0.08 ms per step), 1e4 subjects L=6..15
-    // (0.43 -> 0.12 ms), >= 1e5 subjects L=1 (the one-lane-per-subject kernel already fills the chip).
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device);
+    const int occ_rev = std::max(1, cude::cpep2_rev_waves_per_cu(c->net));
+    const int occ_one = std::max(1, cude::cpep_grad_waves_per_cu(c->net, c->cfg.n_state, c->T));
     int L = 1;
-    for (int d = 1; d <= S; d++)
-        if (S % d == 0 && c->nblocks * d <= 2560) L = d;
+    double best = launch_cost((double)c->nblocks, (double)n_cu * occ_one, 5.0 * S + 1.0);
+    for (int d = 2; d <= S; d++) {
+        if (S % d) continue;
+        const double cost = launch_cost((double)c->nblocks * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
+        if (cost < best * (1.0 - 1e-3)) { best = cost; L = d; }
+    }
     if (env && env[0] == '2' && env[1] == ':') L = atoi(env + 2);
     if (L > S) L = S;
     if (L < 2) return CUDE_OK;
@@ -443,7 +466,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     const int S = c->cfg.n_steps;
     const double h = (c->tp.back() - c->tp.front()) / S;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing && grad && !c->capturing) {
+    if (c->timing && !c->capturing) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));

@@ -359,6 +359,8 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ dispatch
+#define CUDE_CPEP_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3)
+
 template <class Net, int NS, bool GRAD>
 static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
@@ -377,7 +379,24 @@ static hipError_t launch_shape(int n_state, bool grad, const CpepArgs& a, hipStr
     return hipErrorInvalidValue;
 }
 
-#define CUDE_CPEP_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3)
+template <class Net>
+static int grad_occupancy(int n_state, int T) {
+    constexpr int TABROWS = Net::HAS_TAB ? 5 * Net::NCST : 0;
+    constexpr int REDROWS = TABROWS > kRedRows ? TABROWS : kRedRows;
+    const size_t lds = sizeof(double) * (size_t)(5 + REDROWS + T) * kBlock;
+    int n = 0;
+    hipError_t e = n_state == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpep_kernel<Net, 3, true>, kBlock, lds)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpep_kernel<Net, 2, true>, kBlock, lds);
+    return e == hipSuccess ? n : 0;
+}
+// resident waves per CU of the one-lane-per-subject gradient kernel (0 = unknown)
+int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T) {
+    if (net.symbolic()) return grad_occupancy<MmProd<false>>(n_state, T);
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return grad_occupancy<Mlp<NIN, W, D, 1>>(n_state, T);
+    CUDE_CPEP_SHAPES(X)
+#undef X
+    return 0;
+}
 
 bool cpep_shape_supported(const NetShape& net, int n_state) {
     if (n_state != 2 && n_state != 3) return false;

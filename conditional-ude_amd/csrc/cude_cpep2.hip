@@ -426,6 +426,21 @@ bool cpep2_shape_supported(const NetShape& net, int n_state) {
     return false;
 }
 
+// resident waves per CU of the reverse kernel (register / LDS limited): the slot count of the chunk-count selector
+template <int NIN, int W, int D>
+static int rev_occupancy() {
+    int n = 0;
+    const size_t lds_r = sizeof(double) * (size_t)kRedRows * kBlock;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpep2_rev_kernel<NIN, W, D>, kBlock, lds_r) != hipSuccess) return 0;
+    return n;
+}
+int cpep2_rev_waves_per_cu(const NetShape& net) {
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return rev_occupancy<NIN, W, D>();
+    CUDE_CPEP2_SHAPES(X)
+#undef X
+    return 0;
+}
+
 hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s) {
     const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(cpep2_homog_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, a);

@@ -68,6 +68,8 @@ struct Cpep2Args {
     double* partials2;           // [L][nblocks][P]
 };
 bool cpep2_shape_supported(const NetShape& net, int n_state);
+int cpep2_rev_waves_per_cu(const NetShape& net);
+int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T);
 hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s);
 // forward (+ scan) only when !grad: per-subject SSE and the loss partials, no trajectory output
 hipError_t launch_cpep2(const NetShape& net, int n_state, bool grad, const Cpep2Args& a, hipStream_t s);

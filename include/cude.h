@@ -248,8 +248,8 @@ int32_t cude_get_scale(cude_ctx* ctx, double* scale3, double* n_global);
 int32_t cude_loss_grad_partial(cude_ctx* ctx, double* partial /* P+2 */, double* g_cond /* N or NULL */);
 int32_t cude_adam_apply(cude_ctx* ctx, const double* reduced /* P+2 */, double* loss);
 
-/* Average device time (ms) of the dominant kernel (forward+adjoint) over the launches since the
- * last call, measured with HIP events on the context's stream; resets the accumulator. */
+/* Average device time (ms) of the ensemble launches (forward, or forward+adjoint: whatever the calls since the last
+ * query ran) measured with HIP events on the context's stream; resets the accumulator. */
 int32_t cude_kernel_time_ms(cude_ctx* ctx, double* avg_ms, int64_t* launches);
 /* Enable(1)/disable(0) the per-launch event timing used by cude_kernel_time_ms. */
 int32_t cude_set_kernel_timing(cude_ctx* ctx, int32_t enabled);

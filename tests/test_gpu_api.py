@@ -276,6 +276,82 @@ def test_builtin_rccl_path_single_rank():
     assert np.array_equal(b[4], [1.5, 2.5])
 
 
+def test_builtin_rccl_path_reports_itself_and_runs_the_lbfgs_stage():
+    """cude_comm_info returns what RCCL itself says about the communicator; cude_train_restarts with an L-BFGS stage
+    on a context WITH a communicator (every inner product's conditional part goes through ncclAllReduce, sum and
+    max) must reproduce the no-communicator run exactly when there is one rank."""
+    from cude.engine import Engine
+    c = make_cpep_case(150, (2, 4, 2))
+
+    def run(with_comm):
+        eng = Engine("cpep", (2, 4, 2), n_steps=30, n_state=2)
+        info = eng.comm_info()
+        assert info == (1, 0, 0)
+        if with_comm:
+            eng.comm_init(1, 0, Engine.comm_unique_id())
+            n, r, v = eng.comm_info()
+            assert (n, r) == (1, 0) and v > 20000          # RCCL tracks NCCL's version numbering (2.x.y -> 2xxyy)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        out = eng.train_restarts(c["nn"][None, :], c["beta"][None, :], 3, 1e-2, 8, want_trace=True)
+        eng.close()
+        return out
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert np.isfinite(a[2][0]) and a[2][0] < a[3][0, 0]      # the objective went down
+
+
+def _gpu_lbfgs_rank(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "conditional-ude_amd"), os.path.join(here, "..", "oracle"), here):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from cude.engine import Engine
+    from cude.parallel import ShardedTrainer, TorchCollective, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = make_cpep_case(n_total, (2, 4, 2))
+    lo, hi = shard_bounds(n_total, world, rank)
+    eng = Engine("cpep", (2, 4, 2), n_steps=30, n_state=2, device=0)
+    eng.set_population_cpep(c["tp"], c["G"][lo:hi], c["obs"][lo:hi], c["age"][lo:hi], c["t2dm"][lo:hi])
+    eng.set_params(c["nn"], c["beta"][lo:hi])
+    tr = ShardedTrainer(eng, TorchCollective(dist), transport="host")
+    tr.sync_population_statistics()
+    tr.adam_init(1e-2)
+    for _ in range(3):
+        tr.adam_step()
+    res = tr.lbfgs(10)
+    cond = tr.gather_conditional(n_total)
+    nn, _ = eng.get_params()
+    np.savez(os.path.join(out_dir, f"lb{rank}.npz"), f=res["f"], it=res["iterations"], calls=res["f_calls"], cond=cond,
+             nn=nn)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_lbfgs_matches_single_engine(tmp_path):
+    """`_optimize` (src/parameter-estimation.jl:170-183: Adam, then L-BFGS + BackTracking) with the subjects sharded over
+    two processes on one GPU: Adam x3 + L-BFGS x10 must follow the single-engine run (cude_train_restarts) -- same
+    iteration / evaluation counts, parameters equal up to the summation order of the inner products."""
+    import torch.multiprocessing as mp
+    from cude.engine import Engine
+    n_total, world = 157, 2
+    port = 32700 + (os.getpid() % 2000)
+    mp.spawn(_gpu_lbfgs_rank, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "lb0.npz"), np.load(tmp_path / "lb1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    c = make_cpep_case(n_total, (2, 4, 2))
+    eng = Engine("cpep", (2, 4, 2), n_steps=30, n_state=2)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    nn, cond, obj, trace = eng.train_restarts(c["nn"][None, :], c["beta"][None, :], 3, 1e-2, 10, want_trace=True)
+    eng.close()
+    assert int(r0["it"]) == int(np.sum(np.isfinite(trace[0, 3:]))) == 10
+    assert abs(float(r0["f"]) - obj[0]) <= 1e-9 * abs(obj[0])
+    assert np.allclose(r0["nn"], nn[0], rtol=0, atol=1e-8) and np.allclose(r0["cond"], cond[0], rtol=0, atol=1e-8)
+
+
 # ------------------------------------------------------------------ sharded SAEM (BASELINE configs[4]), 2 ranks, 1 GPU
 _SAEM_KW = dict(sigma=0.4, prior_eta=-0.6, prior_omega=0.8, iterations=6, n_burnin_iterations=2, n_mcmc_steps=3,
                 initial_mcmc_steps=4, proposal_std=0.3)
