@@ -212,7 +212,8 @@ struct cude_ctx {
     double scale[3] = {1, 1, 1};
     // tables
     DevBuf<int32_t> seg, obs_step, stepk;
-    DevBuf<double> phi, obs_w, stepd;
+    DevBuf<double> phi, obs_w, stepd, tp_dev;
+    double abstol = 1e-6, reltol = 1e-3;   // adaptive mode (n_steps == 0): OrdinaryDiffEq's defaults
     // parameters / gradients / optimiser
     DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;
     // chunked gradient path (cude_cpep2.hip)
@@ -267,6 +268,38 @@ bool supp_keep_activations(const cude_ctx* c, int64_t n_sets) {
 // both c-peptide models share the population layout, solver tables and the ensemble kernel
 bool is_cpep(const cude_ctx* c) { return c->cfg.model == CUDE_MODEL_CPEP || c->cfg.model == CUDE_MODEL_CPEP_SYM; }
 
+bool adaptive(const cude_ctx* c) { return c->cfg.n_steps == 0; }
+double step_size(const cude_ctx* c) { return adaptive(c) ? 0.0 : (c->tp.back() - c->tp.front()) / c->cfg.n_steps; }
+
+// population, tables and solver settings of a c-peptide launch; the caller adds parameters and outputs
+cude::CpepArgs cpep_args(const cude_ctx* c) {
+    cude::CpepArgs a{};
+    a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
+    a.N = c->N;
+    a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
+    a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+    a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+    a.stepk = c->stepk.p; a.stepd = c->stepd.p;
+    a.T = c->T; a.S = c->cfg.n_steps; a.h = step_size(c); a.inv_n = 1.0 / c->n_global;
+    a.tp = c->tp_dev.p; a.TG = c->T; a.out_times = c->tp_dev.p;
+    a.t_begin = c->tp.front(); a.t_end = c->tp.back();
+    a.abstol = c->abstol; a.reltol = c->reltol;
+    return a;
+}
+
+cude::SuppArgs supp_args(const cude_ctx* c) {
+    cude::SuppArgs a{};
+    a.N = c->N;
+    a.data = c->data.p;
+    a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+    a.T = c->T; a.S = c->cfg.n_steps; a.h = step_size(c); a.inv_n = 1.0 / c->n_global;
+    for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+    a.out_times = c->tp_dev.p;
+    a.t_begin = c->tp.front(); a.t_end = c->tp.back();
+    a.abstol = c->abstol; a.reltol = c->reltol;
+    return a;
+}
+
 int32_t bind(cude_ctx* c) {
     if (!c) return fail(CUDE_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -319,6 +352,12 @@ int32_t alloc_common(cude_ctx* c) {
 }
 
 int32_t upload_tables(cude_ctx* c, bool glucose) {
+    HIP_TRY(c->tp_dev.resize(c->tp.size()));
+    HIP_TRY(hipMemcpyAsync(c->tp_dev.p, c->tp.data(), c->tp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (adaptive(c)) {                       // no step grid: the kernels locate knots and outputs themselves
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return CUDE_OK;
+    }
     std::vector<int32_t> step;
     std::vector<double> w;
     locate_obs(c->tp, c->cfg.n_steps, step, w);
@@ -414,6 +453,7 @@ double launch_cost(double waves, double slots, double evals) {
 // stays at L = 1 (0.654 vs 0.683 for L = 2).
 int32_t setup_chunks(cude_ctx* c) {
     c->chunks = 1;
+    if (adaptive(c)) return CUDE_OK;
     const char* env = getenv("CUDE_CPEP_PATH");
     if (env && env[0] == '1') return CUDE_OK;
     if (!cude::cpep2_shape_supported(c->net, c->cfg.n_state)) return CUDE_OK;
@@ -429,6 +469,9 @@ int32_t setup_chunks(cude_ctx* c) {
         const double cost = launch_cost((double)c->nblocks * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
         if (cost < best * (1.0 - 1e-3)) { best = cost; L = d; }
     }
+    if (getenv("CUDE_DEBUG_SELECTOR"))
+        fprintf(stderr, "[cude] chunk selector: nblocks=%lld CUs=%d waves/CU one-lane=%d reverse=%d -> L=%d\n",
+                (long long)c->nblocks, n_cu, occ_one, occ_rev, L);
     if (env && env[0] == '2' && env[1] == ':') L = atoi(env + 2);
     if (L > S) L = S;
     if (L < 2) return CUDE_OK;
@@ -445,11 +488,7 @@ int32_t setup_chunks(cude_ctx* c) {
     HIP_TRY(c->partials2.resize((size_t)L * c->nblocks * c->P));
     HIP_TRY(hipMemcpyAsync(c->chunk_start.p, cs.data(), (L + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     c->chunks = L;
-    cude::CpepArgs a{};
-    a.N = N;
-    a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
-    a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-    a.T = T; a.S = S; a.h = (c->tp.back() - c->tp.front()) / S;
+    cude::CpepArgs a = cpep_args(c);
     cude::Cpep2Args a2 = chunk_args(c, a);
     HIP_TRY(cude::launch_cpep2_homog(a2, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));   // cs (host vector) dies here
@@ -463,8 +502,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                      const double* cond_ov = nullptr, double* sse_ov = nullptr) {
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!c->have_nn || (!c->have_cond && !cond_ov)) return fail(CUDE_ERR_STATE, "parameters not set");
-    const int S = c->cfg.n_steps;
-    const double h = (c->tp.back() - c->tp.front()) / S;
+    if (grad && adaptive(c))
+        return fail(CUDE_ERR_UNSUPPORTED, "adaptive mode (n_steps = 0) is forward-only: gradients need a fixed step count");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && !c->capturing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -479,21 +518,14 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
     if (is_cpep(c)) {
-        cude::CpepArgs a{};
-        a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
+        cude::CpepArgs a = cpep_args(c);
 #ifdef CUDE_WAVE_TIMING
         if (grad) {
             HIP_TRY(c->dbg.resize((size_t)c->nblocks * 4));
             a.dbg = c->dbg.p;
         }
 #endif
-        a.N = c->N;
-        a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
-        a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
         a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
-        a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-        a.stepk = c->stepk.p; a.stepd = c->stepd.p;
-        a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
         a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         if (c->chunks > 1 && (grad || traj_dev == nullptr)) {
@@ -503,12 +535,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, grad, a, c->stream));
         }
     } else {
-        cude::SuppArgs a{};
-        a.N = c->N;
-        a.data = c->data.p; a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
-        a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-        a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
-        for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+        cude::SuppArgs a = supp_args(c);
+        a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
         a.ckpt = c->ckpt.p; a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev;
         // allocated by cude_set_population_supp (never here: this function also runs under stream capture)
         if (grad && c->act.p && c->act.n >= supp_act_doubles(c)) a.act = c->act.p;
@@ -580,7 +608,9 @@ int32_t cude_n_params(int32_t nn_in, int32_t nn_width, int32_t nn_depth) {
 int32_t cude_create(const cude_config* cfg, cude_ctx** out) {
     if (!cfg || !out) return fail(CUDE_ERR_ARG, "null argument");
     *out = nullptr;
-    if (cfg->n_steps < 1 || cfg->n_steps > 100000) return fail(CUDE_ERR_ARG, "n_steps out of range");
+    if (cfg->n_steps < 0 || cfg->n_steps > 100000) return fail(CUDE_ERR_ARG, "n_steps out of range");
+    if (cfg->n_steps == 0 && cfg->model != CUDE_MODEL_SUPP && cfg->n_state != 2)
+        return fail(CUDE_ERR_UNSUPPORTED, "adaptive mode (n_steps = 0) integrates the reference's 2-state c-peptide model");
     cude::NetShape net{cfg->nn_in, cfg->nn_width, cfg->nn_depth};
     if (cfg->model == CUDE_MODEL_CPEP_SYM) {
         if (cfg->nn_width != 0 || cfg->nn_depth != 0)
@@ -784,7 +814,7 @@ int32_t cude_simulate(cude_ctx* c, int32_t n_times, const double* times, double*
     if (!c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "parameters not set");
     if (n_times < 1 || !times || !traj) return fail(CUDE_ERR_ARG, "null/empty input");
     const int S = c->cfg.n_steps, NS = c->cfg.n_state;
-    const double t0 = c->tp.front(), t1 = c->tp.back(), h = (t1 - t0) / S;
+    const double t0 = c->tp.front(), t1 = c->tp.back(), h = adaptive(c) ? (t1 - t0) : (t1 - t0) / S;
     for (int i = 0; i < n_times; i++) {
         if (!(times[i] >= t0 - 1e-9 * h && times[i] <= t1 + 1e-9 * h))
             return fail(CUDE_ERR_ARG, "output times must lie inside the time span of the population");
@@ -793,33 +823,34 @@ int32_t cude_simulate(cude_ctx* c, int32_t n_times, const double* times, double*
     const int64_t N = c->N;
     // output times per launch: ~1 GB of trajectory scratch at most (every launch integrates from t_0 again)
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_times, (int64_t)(1e9 / (8.0 * NS * (double)N))));
-    DevBuf<double> d_traj, d_w;
+    DevBuf<double> d_traj, d_w, d_times;
     DevBuf<int32_t> d_step;
     HIP_TRY(d_traj.resize((size_t)NS * chunk * N));
     HIP_TRY(d_w.resize((size_t)chunk * 7));
     HIP_TRY(d_step.resize((size_t)chunk));
+    HIP_TRY(d_times.resize((size_t)chunk));
     std::vector<int32_t> step(chunk);
     std::vector<double> w((size_t)chunk * 7);
     for (int64_t k0 = 0; k0 < n_times; k0 += chunk) {
         const int64_t kn = std::min<int64_t>(chunk, n_times - k0);
-        for (int64_t i = 0; i < kn; i++) {                  // as locate_obs: tau in (t_n, t_{n+1}]
-            const double x = (times[k0 + i] - t0) / h;
-            int n = (int)std::ceil(x - 1e-9) - 1;
-            n = std::min(std::max(n, 0), S - 1);
-            step[i] = n;
-            interp_weights((times[k0 + i] - (t0 + n * h)) / h, &w[(size_t)i * 7]);
+        if (adaptive(c)) {                                  // the kernel interpolates at the times themselves
+            HIP_TRY(hipMemcpyAsync(d_times.p, times + k0, kn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        } else {
+            for (int64_t i = 0; i < kn; i++) {              // as locate_obs: tau in (t_n, t_{n+1}]
+                const double x = (times[k0 + i] - t0) / h;
+                int n = (int)std::ceil(x - 1e-9) - 1;
+                n = std::min(std::max(n, 0), S - 1);
+                step[i] = n;
+                interp_weights((times[k0 + i] - (t0 + n * h)) / h, &w[(size_t)i * 7]);
+            }
+            HIP_TRY(hipMemcpyAsync(d_step.p, step.data(), kn * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_w.p, w.data(), kn * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
-        HIP_TRY(hipMemcpyAsync(d_step.p, step.data(), kn * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_w.p, w.data(), kn * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        cude::CpepArgs a{};
-        a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
-        a.N = N;
-        a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
-        a.dG = c->dG.p; a.obs = nullptr; a.age = c->age.p;
+        cude::CpepArgs a = cpep_args(c);
+        a.obs = nullptr;                                    // no residuals: outputs only
         a.cond = c->cond.p; a.nn = c->nn.p;
-        a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = d_step.p; a.obs_w = d_w.p;
-        a.stepk = c->stepk.p; a.stepd = c->stepd.p;
-        a.T = (int32_t)kn; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
+        a.obs_step = d_step.p; a.obs_w = d_w.p; a.out_times = d_times.p;
+        a.T = (int32_t)kn;
         a.traj = d_traj.p; a.partials = c->partials.p;
         HIP_TRY(cude::launch_cpep(c->net, NS, false, a, c->stream));
         // device chunk [NS x kn x N] -> rows k0..k0+kn of the caller's [NS x n_times x N]
@@ -938,33 +969,20 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
     HIP_TRY(d_part.resize((size_t)chunk * nb * (P + 2)));
     HIP_TRY(d_out.resize((size_t)chunk * 2));
     std::vector<double> h_out((size_t)chunk * 2);
-    const int S = c->cfg.n_steps;
-    const double h = (c->tp.back() - c->tp.front()) / S;
     double reg = 0.0;
     for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
         const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
         HIP_TRY(hipMemcpyAsync(d_nn.p, nn_sets + k0 * P, kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_cond.p, cond_sets + k0 * N, kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
         if (is_cpep(c)) {
-            cude::CpepArgs a{};
-            a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
-            a.N = N;
-            a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
-            a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+            cude::CpepArgs a = cpep_args(c);
             a.cond = d_cond.p; a.nn = d_nn.p;
-            a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-            a.stepk = c->stepk.p; a.stepd = c->stepd.p;
-            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
             a.partials = d_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
         } else {
-            cude::SuppArgs a{};
-            a.N = N;
-            a.data = c->data.p; a.cond = d_cond.p; a.nn = d_nn.p;
-            a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
-            for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+            cude::SuppArgs a = supp_args(c);
+            a.cond = d_cond.p; a.nn = d_nn.p;
             a.partials = d_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
@@ -994,9 +1012,10 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (n_sets < 1 || !nn_sets || !cond_sets || !losses || !g_nn_sets || !g_cond_sets)
         return fail(CUDE_ERR_ARG, "null/empty input");
+    if (adaptive(c))
+        return fail(CUDE_ERR_UNSUPPORTED, "adaptive mode (n_steps = 0) is forward-only: gradients need a fixed step count");
     const int P = c->P, S = c->cfg.n_steps;
     const int64_t N = c->N, nb = c->nblocks;
-    const double h = (c->tp.back() - c->tp.front()) / S;
     const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
     // sets per launch: bounded by the grid's y dimension and ~512 MB of scratch
     const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (supp ? (6.0 * S + 1) * 3 * N : 0.0));
@@ -1013,25 +1032,14 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
         HIP_TRY(hipMemcpyAsync(c->ms_nn.p, nn_sets + k0 * P, kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->ms_cond.p, cond_sets + k0 * N, kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
         if (!supp) {
-            cude::CpepArgs a{};
-            a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
-            a.N = N;
-            a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
-            a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+            cude::CpepArgs a = cpep_args(c);
             a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
-            a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-            a.stepk = c->stepk.p; a.stepd = c->stepd.p;
-            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
             a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));     // one-lane kernel: the sets fill the chip
         } else {
-            cude::SuppArgs a{};
-            a.N = N;
-            a.data = c->data.p; a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
-            a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
-            for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+            cude::SuppArgs a = supp_args(c);
+            a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
             a.ckpt = c->ms_ckpt.p; a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
             if (supp_keep_activations(c, kn)) {
                 HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
@@ -1080,9 +1088,8 @@ int32_t cude_profile_conditional(cude_ctx* c, int32_t n_points, const double* va
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!c->have_nn) return fail(CUDE_ERR_STATE, "shared parameters not set");
     if (n_points < 1 || !values || !sse_out) return fail(CUDE_ERR_ARG, "null/empty input");
-    const int P = c->P, S = c->cfg.n_steps;
+    const int P = c->P;
     const int64_t N = c->N, nb = c->nblocks;
-    const double h = (c->tp.back() - c->tp.front()) / S;
     // grid points per launch: the grid's y dimension and ~512 MB of scratch (conditional sets, SSEs, partial rows)
     const double per_point = 8.0 * (2.0 * N + (double)nb * (P + 2));
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_points, 32768), (int64_t)(512e6 / per_point)));
@@ -1096,25 +1103,14 @@ int32_t cude_profile_conditional(cude_ctx* c, int32_t n_points, const double* va
         HIP_TRY(hipMemcpyAsync(d_val.p, values + k0, kn * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(cude::launch_fill_rows(N, (int)kn, d_val.p, d_cond.p, c->stream));
         if (is_cpep(c)) {
-            cude::CpepArgs a{};
-            a.cond_raw = c->cfg.cond_space == CUDE_COND_RAW;
-            a.N = N;
-            a.k0 = c->k0.p; a.k1 = c->k1.p; a.k2 = c->k2.p; a.c0 = c->c0.p;
-            a.dG = c->dG.p; a.obs = c->obs.p; a.age = c->age.p;
+            cude::CpepArgs a = cpep_args(c);
             a.cond = d_cond.p; a.nn = c->nn.p;
-            a.seg = c->seg.p; a.phi = c->phi.p; a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-            a.stepk = c->stepk.p; a.stepd = c->stepd.p;
-            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
             a.sse = d_sse.p; a.partials = d_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = 0; a.set_stride_cond = N;      // one network, kn grid values
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
         } else {
-            cude::SuppArgs a{};
-            a.N = N;
-            a.data = c->data.p; a.cond = d_cond.p; a.nn = c->nn.p;
-            a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
-            a.T = c->T; a.S = S; a.h = h; a.inv_n = 1.0 / c->n_global;
-            for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
+            cude::SuppArgs a = supp_args(c);
+            a.cond = d_cond.p; a.nn = c->nn.p;
             a.sse = d_sse.p; a.partials = d_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = 0; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
@@ -1410,6 +1406,15 @@ int32_t cude_debug_wave_timing(cude_ctx* c, long long* out, int64_t n_waves) {
     return CUDE_OK;
 }
 #endif
+
+int32_t cude_set_tolerances(cude_ctx* c, double abstol, double reltol) {
+    if (!c) return fail(CUDE_ERR_ARG, "null context");
+    if (!(abstol > 0) || !(reltol > 0) || !std::isfinite(abstol) || !std::isfinite(reltol))
+        return fail(CUDE_ERR_ARG, "tolerances must be positive");
+    c->abstol = abstol;
+    c->reltol = reltol;
+    return CUDE_OK;
+}
 
 int32_t cude_synchronize(cude_ctx* c) {
     int32_t rc = bind(c);

@@ -50,6 +50,13 @@ struct CpepArgs {
     int32_t n_sets;
     int64_t set_stride_nn, set_stride_cond;
     int32_t cond_raw;        // symbolic model only: 1 = k is the conditional itself, 0 = k = exp(conditional)
+    // adaptive mode (S == 0, cude_adaptive.hip): glucose knot times, output times (T of them; obs[T][N] when the
+    // outputs are the observations) and the solver tolerances
+    const double* tp;        // [TG] knot times = the population's timepoints
+    int32_t TG;
+    const double* out_times; // [T]
+    double t_begin, t_end;   // integration span = the population's time span
+    double abstol, reltol;
 #ifdef CUDE_WAVE_TIMING
     long long* dbg;          // development builds only: [nblocks][4] = {start, end of forward, end, hw id} per wave
 #endif
@@ -93,6 +100,9 @@ struct SuppArgs {
     double* partials;        // [n_sets][nblocks][P+2]
     int32_t n_sets;          // multi-start evaluation, as CpepArgs
     int64_t set_stride_nn, set_stride_cond;
+    const double* out_times; // adaptive mode (S == 0): [T] observation times
+    double t_begin, t_end;
+    double abstol, reltol;
 };
 
 // returns hipSuccess, or hipErrorInvalidValue when the shape is not compiled in
@@ -100,6 +110,9 @@ hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepAr
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
 bool cpep_shape_supported(const NetShape& net, int n_state);
 bool supp_shape_supported(const NetShape& net);
+// adaptive Tsit5 (forward only); launch_cpep / launch_supp route here when args.S == 0
+hipError_t launch_cpep_adaptive(const NetShape& net, const CpepArgs& a, hipStream_t s);
+hipError_t launch_supp_adaptive(const NetShape& net, const SuppArgs& a, hipStream_t s);
 
 // common kernels
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "cude_n_params": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "cude_create": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "cude_destroy": (C.c_int32, [C.c_void_p]),
+    "cude_set_tolerances": (C.c_int32, [C.c_void_p, C.c_double, C.c_double]),
     "cude_set_population_cpep": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "cude_set_population_supp": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

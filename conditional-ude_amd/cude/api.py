@@ -19,12 +19,16 @@ Reference items mirrored (paths relative to the reference repo):
   CPeptideODEModel / production (symbolic) src/c-peptide-models.jl:68-75,118-142; c-peptide/03-symreg.jl:37-40
   train_symbolic (per-subject k, sigma)    c-peptide/03-symreg.jl:94-106
   SAEM_symbolic                            src/saem-symreg.jl:31-66,86-131,134-229
-Differences that are deliberate and documented in DESIGN.md: the ODE is solved with FIXED-step Tsit5
+Differences that are deliberate and documented in DESIGN.md: by default the ODE is solved with FIXED-step Tsit5
 (`n_steps`; default for the c-peptide model: 8 steps per observation interval, see default_steps; 30 for the
-suppression model) instead of the adaptive default; gradients are a discrete adjoint instead of
-ForwardDiff; the per-subject 1-D fits use a bracketing search instead of Fminbox(LBFGS).
+suppression model) so that the loss has an exact discrete adjoint; `n_steps=ADAPTIVE` (0) runs the reference's own
+adaptive Tsit5 on the device for everything that needs no gradient (loss values, simulations, profiles, per-subject
+fits, Metropolis steps).  Gradients are a discrete adjoint instead of ForwardDiff; the per-subject 1-D fits use a
+bracketing search instead of Fminbox(LBFGS).
 """
+import hashlib
 import math
+from collections import OrderedDict
 from types import SimpleNamespace
 
 import numpy as np
@@ -33,6 +37,7 @@ from .engine import Engine
 from .lbfgs import lbfgs, lbfgs_batched
 
 DEFAULT_STEPS = 30
+ADAPTIVE = 0      # n_steps = ADAPTIVE: the reference's own adaptive Tsit5 (abstol 1e-6, reltol 1e-3) -- forward-only calls
 
 
 def default_steps(timepoints, per_interval=8):
@@ -139,6 +144,7 @@ class CPeptideConditionalUDEModel:
             raise ValueError("glucose, cpeptide and timepoints must have the same length")
         if network.input_dims != (3 if covariate else 2):
             raise ValueError("network input_dims does not match the model (2: [dG, beta]; 3: [dG, beta, age])")
+        self._key = _model_key(self, ("cude", network.arch, covariate))
 
 
 CPeptideCUDEModel = CPeptideConditionalUDEModel        # name used in the reference's docstrings / stale script
@@ -182,12 +188,27 @@ class CPeptideODEModel:
         self.t2dm = bool(t2dm)
         if self.glucose.shape != self.timepoints.shape or self.cpeptide.shape != self.timepoints.shape:
             raise ValueError("glucose, cpeptide and timepoints must have the same length")
+        self._key = _model_key(self, ("sym", production_function.vmax))
+
+
+def _model_key(m, tag):
+    """Content digest of one subject's model (what the device population is built from)."""
+    h = hashlib.blake2b(repr(tag).encode(), digest_size=16)
+    for a in (m.glucose, m.timepoints, m.cpeptide, [m.age, float(m.t2dm)]):
+        h.update(np.ascontiguousarray(a, dtype=np.float64))
+    return h.digest()
 
 
 class _Pop:
-    """Device-resident population built from a list of models (cached per list object)."""
+    """Device-resident population built from a list of models (cached by content, see _population)."""
 
     def __init__(self, models, timepoints, cpeptide_data, n_steps, n_state, device, cond_space="log"):
+        tp = np.asarray(timepoints, dtype=np.float64)
+        for m in models:
+            # the reference solves model.problem (glucose knots = the model's timepoints) and saves at `timepoints`;
+            # the kernels take ONE grid for both
+            if m.timepoints.shape != tp.shape or not np.array_equal(m.timepoints, tp):
+                raise ValueError("timepoints must equal the timepoints the models were built with")
         if isinstance(models[0], CPeptideODEModel):
             self.engine = Engine("cpep_sym", n_steps=n_steps, n_state=n_state, device=device, cond_space=cond_space)
             self.shared = np.array([models[0].production.vmax])
@@ -195,13 +216,12 @@ class _Pop:
             self.engine = Engine("cpep", models[0].chain.arch, n_steps=n_steps, n_state=n_state, device=device)
         G = np.stack([m.glucose for m in models])
         cp = np.asarray(cpeptide_data, dtype=np.float64).reshape(len(models), -1)
-        self.engine.set_population_cpep(np.asarray(timepoints, dtype=np.float64), G, cp, [m.age for m in models],
-                                        [m.t2dm for m in models])
-        self.models = models          # keeps id(models) alive
+        self.engine.set_population_cpep(tp, G, cp, [m.age for m in models], [m.t2dm for m in models])
         self.N, self.T = cp.shape
 
 
-_CACHE = {}
+_CACHE = OrderedDict()        # content key -> population, least recently used first
+_CACHE_MAX = 8                # engines kept alive; an evicted one is closed (stream + device buffers freed)
 _DEVICE = 0
 
 
@@ -216,16 +236,41 @@ def clear_cache():
     _CACHE.clear()
 
 
+def _cached(key, build):
+    pop = _CACHE.get(key)
+    if pop is None:
+        pop = build()
+        _CACHE[key] = pop
+        while len(_CACHE) > _CACHE_MAX:
+            _, old = _CACHE.popitem(last=False)
+            old.engine.close()
+    else:
+        _CACHE.move_to_end(key)
+    return pop
+
+
+def _digest(*arrays):
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        h.update(str(a.shape).encode())
+        h.update(a)
+    return h.digest()
+
+
 def _population(models, timepoints, cpeptide_data, n_steps=None, n_state=2, cond_space="log"):
+    """The device population of (models, timepoints, data), built once per CONTENT: the key is a digest of every
+    model's data (a fresh list of the same models -- `[model]`, `[model] * steps` -- is the same population), of the
+    time grid and of all observations, so that calling `loss` in a loop neither rebuilds nor leaks engines, and
+    changed data is never answered from a stale population."""
     if n_steps is None:       # the analytic production has a kink at dG = 0: twice the steps of the smooth model
         n_steps = default_steps(timepoints, 16 if isinstance(models[0], CPeptideODEModel) else 8)
     cp = np.asarray(cpeptide_data, dtype=np.float64)
-    key = (id(models), len(models), n_steps, n_state, cp.tobytes()[:256], cp.shape, cond_space)
-    pop = _CACHE.get(key)
-    if pop is None:
-        pop = _Pop(models, timepoints, cp, n_steps, n_state, _DEVICE, cond_space)
-        _CACHE[key] = pop
-    return pop
+    h = hashlib.blake2b(digest_size=16)
+    for m in models:
+        h.update(m._key)
+    key = ("cpep", len(models), h.digest(), int(n_steps), n_state, cond_space, _digest(timepoints, cp))
+    return _cached(key, lambda: _Pop(models, timepoints, cp, n_steps, n_state, _DEVICE, cond_space))
 
 
 def _is_model(x):
@@ -513,12 +558,8 @@ class _SuppPop:
 def _supp_population(prob, data, timepoints, lam, n_steps=None):
     n_steps = DEFAULT_STEPS if n_steps is None else n_steps
     data = np.asarray(data, dtype=np.float64)
-    key = ("supp", id(prob), data.shape, data.tobytes()[:256], float(lam), n_steps)
-    pop = _CACHE.get(key)
-    if pop is None:
-        pop = _SuppPop(data, timepoints, prob.network, lam, n_steps, _DEVICE)
-        _CACHE[key] = pop
-    return pop
+    key = ("supp", prob.network.arch, float(lam), int(n_steps), _digest(timepoints, data))
+    return _cached(key, lambda: _SuppPop(data, timepoints, prob.network, lam, n_steps, _DEVICE))
 
 
 def SuppressionProblem(network):

@@ -112,6 +112,10 @@ class Engine:
         except Exception:
             pass
 
+    def set_tolerances(self, abstol=1e-6, reltol=1e-3):
+        """Tolerances of the adaptive mode (n_steps = 0)."""
+        check(self._lib.cude_set_tolerances(self._h, float(abstol), float(reltol)))
+
     # -- population
     def set_population_cpep(self, timepoints, glucose, cpeptide, age, t2dm):
         """glucose, cpeptide: (N, T) arrays (any strides are honoured without a host copy when

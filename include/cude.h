@@ -17,7 +17,8 @@
  *     a non-finite trajectory in any subject makes the returned loss +Inf with status 0;
  *     cude_n_failed() tells how many subjects failed.
  *   - discretisation: fixed-step Tsit5, n_steps uniform steps over [t[0], t[T-1]],
- *     observations by the Tsit5 dense-output interpolant (DESIGN.md "numerical contract").
+ *     observations by the Tsit5 dense-output interpolant (DESIGN.md "numerical contract"); n_steps = 0 selects the
+ *     reference's own adaptive Tsit5 for the forward-only entry points.
  */
 #ifndef CUDE_H
 #define CUDE_H
@@ -60,7 +61,11 @@ typedef struct cude_config {
                          src/c-peptide-models.jl:96-104); SUPP: 4 = [u1,u2,u3,exp(theta)] */
     int32_t nn_width; /* hidden width (0 for CUDE_MODEL_CPEP_SYM) */
     int32_t nn_depth; /* number of tanh hidden layers; output layer is softplus, 1 unit (0 for CPEP_SYM) */
-    int32_t n_steps;  /* fixed Tsit5 steps over the time span */
+    int32_t n_steps;  /* fixed Tsit5 steps over the time span; 0 = ADAPTIVE Tsit5 as the reference runs it
+                         (OrdinaryDiffEq defaults abstol 1e-6 / reltol 1e-3, PI controller, cude_set_tolerances):
+                         forward-only -- cude_forward, cude_simulate, cude_profile_conditional,
+                         cude_multistart_forward, cude_fit_conditional, cude_mh_estep / cude_mh_chain; the gradient
+                         entry points return CUDE_ERR_UNSUPPORTED (differentiate the fixed-step map instead) */
     int32_t device;   /* HIP device ordinal */
     int32_t cond_space; /* CUDE_COND_*; must be CUDE_COND_LOG (0) for the network models */
     double lambda;    /* L2 weight on the network parameters (suppression_loss :128); 0 for CPEP */
@@ -75,6 +80,10 @@ int32_t cude_n_params(int32_t nn_in, int32_t nn_width, int32_t nn_depth);
 
 int32_t cude_create(const cude_config* cfg, cude_ctx** out);
 int32_t cude_destroy(cude_ctx* ctx);
+/* Tolerances of the adaptive mode (cude_config.n_steps = 0): `solve(...; abstol, reltol)`; the defaults 1e-6 / 1e-3
+ * are OrdinaryDiffEq's, which every solve call of the reference uses (src/parameter-estimation.jl:59, src/saem.jl:52,
+ * suppression/src/suppression_model.jl:113,123). */
+int32_t cude_set_tolerances(cude_ctx* ctx, double abstol, double reltol);
 
 /* --- population (replaces the CPeptideConditionalUDEModel constructor loop,
  * src/c-peptide-models.jl:170-194 incl. van_cauter_parameters :30-42, u0, tspan and the

@@ -279,7 +279,8 @@ def test_builtin_rccl_path_single_rank():
 def test_builtin_rccl_path_reports_itself_and_runs_the_lbfgs_stage():
     """cude_comm_info returns what RCCL itself says about the communicator; cude_train_restarts with an L-BFGS stage
     on a context WITH a communicator (every inner product's conditional part goes through ncclAllReduce, sum and
-    max) must reproduce the no-communicator run exactly when there is one rank."""
+    max) must reproduce the no-communicator run when there is one rank -- up to the summation order of the inner
+    products, whose network and conditional parts are added separately on the sharded path."""
     from cude.engine import Engine
     c = make_cpep_case(150, (2, 4, 2))
 
@@ -296,8 +297,10 @@ def test_builtin_rccl_path_reports_itself_and_runs_the_lbfgs_stage():
         eng.close()
         return out
     a, b = run(False), run(True)
+    assert np.array_equal(a[3][:, :3], b[3][:, :3])          # the Adam stage is bit-identical
+    assert np.array_equal(np.isfinite(a[3]), np.isfinite(b[3]))    # same number of L-BFGS iterations
     for x, y in zip(a, b):
-        assert np.array_equal(x, y, equal_nan=True)
+        assert np.allclose(x, y, rtol=1e-9, atol=1e-9, equal_nan=True)
     assert np.isfinite(a[2][0]) and a[2][0] < a[3][0, 0]      # the objective went down
 
 

@@ -378,3 +378,42 @@ def test_two_rank_gloo_saem_matches_single_process(tmp_path):
     assert np.allclose(r0["nll"], one.total_nll_values, rtol=1e-11)
     assert abs(r0["sigma"] - one.sigma) < 1e-11 and abs(r0["omega"] - one.Omega) < 1e-12
     assert abs(r0["eta"] - one.eta) < 1e-13
+
+
+def test_population_cache_is_keyed_on_content_and_bounded(monkeypatch):
+    """cude.api builds one device population per CONTENT (a fresh `[model]` list per call used to miss the
+    cache and leak an engine per call; different observations with an equal prefix used to hit a stale one)."""
+    from cude import api
+
+    class FakeEngine:
+        live = 0
+
+        def __init__(self, *a, **k):
+            FakeEngine.live += 1
+
+        def set_population_cpep(self, *a):
+            pass
+
+        def close(self):
+            FakeEngine.live -= 1
+    monkeypatch.setattr(api, "Engine", FakeEngine)
+    api.clear_cache()
+    tp = np.array([0.0, 30.0, 60.0, 90.0, 120.0])
+    net = api.chain(4, 2)
+    mk = lambda s: api.CPeptideConditionalUDEModel(5 + s + np.arange(5.0), tp, 40 + s, net, 1 + 0.1 * np.arange(5.0), False)
+    models = [mk(s) for s in range(12)]
+    data = np.stack([m.cpeptide for m in models])
+    a = api._population([models[0]], tp, data[:1])
+    assert api._population([models[0]], tp, data[:1]) is a and FakeEngine.live == 1      # fresh list, same content
+    assert api._population([mk(0)], tp, data[:1]) is a                                   # equal model, new object
+    d2 = data.copy()
+    d2[7, 4] += 1e-3                                                                     # differs beyond any prefix
+    b, c = api._population(models, tp, data), api._population(models, tp, d2)
+    assert b is not c and api._population(models, tp, d2.copy()) is c
+    with pytest.raises(ValueError):
+        api._population(models, tp + 1.0, data)                                          # another time grid
+    for s in range(12):                                                                  # LRU: evicted engines are closed
+        api._population([models[s]], tp, data[s:s + 1])
+    assert len(api._CACHE) == api._CACHE_MAX and FakeEngine.live == api._CACHE_MAX
+    api.clear_cache()
+    assert FakeEngine.live == 0
