@@ -326,3 +326,93 @@ def test_external_symbolic_model_panels_and_objectives(data):
     # ~1 % (the trajectories above needed their k to 1e-6 to be matched; the 17 other subjects' k are not known)
     res, sse = _objective_residuals(subjects, data.fig["external_objectives"][:, 1])
     assert np.median(res) < 1e-2 and res.max() < 5e-2 and np.median(res / sse) < 1e-2, (np.median(res), res.max())
+
+
+# ------------------------------------------------------------------ likelihood_curves.svg: 117 likelihood profiles
+TOLP = 6e-4         # in units of the plotted quantity (0 ... 10): ~3 quantisation steps of the y coordinate (1.9e-4)
+# A profile holds 20 ... 400 loss values, each from its own adaptive solve.  The restatement reproduces almost all of
+# them to the quantisation (residuals +-1e-4), but a solve whose error estimate sits within rounding of the acceptance
+# threshold takes a different step in Julia (its tanh / exp round differently from libm's; one rounding moves a
+# trajectory by up to ~1e-6, tools/adaptive_conditioning.py), which a steep profile (scale 1 / (2 sigma^2) up to ~60)
+# magnifies to ~1e-3: hence quantiles, not the maximum.
+
+
+def _profile_vertices(fig, i):
+    """(grid index k, plotted value) of the on-grid vertices of profile curve i.  x: an unidentifiable profile spans
+    the whole of range(-10, 10, 1000), which calibrates the abscissa; every plotted vertex then sits on that grid to
+    1 % of its spacing, i.e. its index k is exact.  y: Cairo clipped the curves at the axis limits (ylims!(0, 10)), so
+    the extreme y coordinates are the values 10 and 0; the dashed 7.16 threshold line checks the map."""
+    v = fig["profiles_vertices"] / 256.0
+    ptr = fig["profiles_ptr"]
+    x0, x1 = fig["profiles_xspan"] / 256.0
+    y_top, y_bot = v[:, 1].min(), v[:, 1].max()
+    assert abs((y_bot - fig["profiles_threshold_y"][0] / 256.0) * 10.0 / (y_bot - y_top) - 7.16) < 2e-3
+    c = v[ptr[i]:ptr[i + 1]]
+    k = (c[:, 0] - x0) / ((x1 - x0) / 999.0)
+    kr = np.rint(k)
+    keep = (np.abs(k - kr) < 0.02) & (c[:, 1] > y_top + 1e-9) & (c[:, 1] < y_bot - 1e-9)
+    return kr[keep].astype(int), (y_bot - c[keep, 1]) * 10.0 / (y_bot - y_top)
+
+
+def _recover_profile(sub, k, y, n_fine=1001, half_width=5e-3, edge_width=0.0):
+    """The one free scalar of a plotted profile is the beta_i it is centred on (the reference's fitted value, not
+    stored); sigma_i only scales it.  Locate beta_i with the smooth fixed-step loss, then scan its neighbourhood with
+    the adaptive one (the profile resolves the ripple of the adaptive-step loss, so it matches at the figure's
+    resolution only where the restatement takes the reference's own steps).  Returns (beta_i, scale, max residual)."""
+    delta = -10.0 + 20.0 * k / 999.0
+    sel = np.unique(np.r_[np.linspace(0, k.size - 1, min(k.size, 24)).astype(int)])
+    sse_of = lambda betas, fn: np.sum((fn(betas, sub.tp) - sub.obs[None, :]) ** 2, axis=1)
+
+    def score(betas, fn, idx):
+        """per candidate beta: least-squares scale and max residual on the vertices `idx`."""
+        pts = (betas[:, None] + delta[None, idx]).ravel()
+        d = sse_of(pts, fn).reshape(betas.size, idx.size) - sse_of(betas, fn)[:, None]
+        s = (d @ y[idx]) / np.maximum(np.sum(d * d, axis=1), 1e-300)
+        return s, np.abs(y[idx][None, :] - s[:, None] * d)
+    b_star, _ = sub.argmin_sse()
+    at_edge = b_star < sub.box[0] + 0.05
+    centre = sub.box[0] if at_edge else b_star
+    if not at_edge:                          # coarse: smooth loss, +-0.1 around the subject's own optimum
+        cand = centre + np.linspace(-0.1, 0.1, 201)
+        _, res = score(cand, lambda b, t: sub.fixed(b, t, 60), sel)
+        centre = cand[int(np.argmin(res.max(axis=1)))]
+    if not at_edge:                          # fine: adaptive loss, 1e-5 then 1e-6 spacing
+        for half, n in ((half_width, n_fine), (2e-5, 41)):
+            cand = centre + np.linspace(-half, half, n)
+            _, res = score(cand, sub.adaptive_many, sel)
+            centre = cand[int(np.nanargmin(np.quantile(res, 0.75, axis=1)))]
+    elif edge_width > 0:                     # a box-constrained fit stops just inside its lower bound
+        for lo, hi, n in ((0.0, edge_width, n_fine), (-2e-5, 2e-5, 41)):
+            cand = np.maximum(centre + np.linspace(lo, hi, n), sub.box[0])
+            _, res = score(cand, sub.adaptive_many, sel)
+            centre = cand[int(np.nanargmin(np.quantile(res, 0.75, axis=1)))]
+    s, res_all = score(np.array([centre]), sub.adaptive_many, np.arange(k.size))
+    return centre, float(s[0]), res_all[0]
+
+
+def _check_profile(sub, fig, i, **scan):
+    k, y = _profile_vertices(fig, i)
+    assert k.size >= 3
+    beta, scale, res = _recover_profile(sub, k, y, **scan)
+    assert np.median(res) < 1.5e-4 and np.quantile(res, 0.9) < TOLP and res.max() < 5e-3, \
+        (i, beta, np.median(res), np.quantile(res, 0.9), res.max())
+    # the plotted quantity is (SSE(beta + d) - SSE(beta)) / (2 sigma^2) with the jointly fitted sigma^2 = SSE(beta) / n
+    sse = float(np.sum((sub.adaptive_many([beta], sub.tp)[0] - sub.obs) ** 2))
+    assert abs(scale * 2.0 * sse / len(sub.tp) - 1.0) < 0.05, (i, scale, sse)
+    return beta, float(np.median(res)), k.size
+
+
+def test_likelihood_profiles_reproduce_the_reference_curves(data):
+    """figures/revision/supplementary/likelihood_curves.svg (c-peptide/02-conditional.jl:361-423; src/likelihood-
+    profiles.jl:4-17): for every subject 1000 values of (SSE_i(beta_i + d) - SSE_i(beta_i)) / (2 sigma_i^2), computed
+    by the reference with its STORED best network -- the per-subject loss at ~20 ... 400 visible abscissae per subject,
+    each curve a function of stored quantities and one scalar.  A subset here (the adaptive scans cost ~1 s per
+    subject on the CPU); tests/test_gpu_adaptive.py does all 117 through cude_profile_conditional."""
+    n_pts = 0
+    for i in (0, 7, 11, 13, 26, 40, 63, 81):                       # training-data subjects (curves 0 ... 81)
+        _, res, n = _check_profile(_Subject(data, "train", i, covariate=False), data.fig, i)
+        n_pts += n
+    for i in (0, 2, 9, 16, 28, 31):                                 # test subjects (curves 82 ... 116)
+        beta, res, n = _check_profile(_Subject(data, "test", i, covariate=False), data.fig, 82 + i)
+        n_pts += n
+    assert n_pts > 500

@@ -16,6 +16,11 @@ graphics whose paths are the numbers its scripts computed, quantised by Cairo to
       the symbolic model (production 1.78 dG / (dG + k)) on the external data set (14 irregular time points from
       -10 min): quartile subjects' simulations on -10:0.1:240 min, their measurements, the 20 fitted objectives
 
+  figures/revision/supplementary/likelihood_curves.svg        (c-peptide/02-conditional.jl:361-423)
+      the likelihood profile of EVERY subject (82 training-data + 35 test subjects, drawn in that order): 1000 values
+      of (SSE_i(beta_i + d) - SSE_i(beta_i)) / (2 sigma_i^2) on d = range(-10, 10, 1000) (src/likelihood-profiles.jl:
+      4-17), clipped by Cairo to the axis limits 0 ... 10; the dashed line is the 7.16 threshold
+
 Only pixel coordinates are stored, as integers in units of 1/256 px (exactly what Cairo wrote): poly-line vertices
 and marker centres in drawing order.  Mapping them to data units is the test's job (tests/test_figure_pins.py: the
 markers are the subject's own measurements, which calibrates every axis without reading a tick label).  Runs only
@@ -139,8 +144,51 @@ def decode_small_markers_by_type(svg_file):
     return {t: np.array(v) for t, v in out.items()}
 
 
+PROFILE_COLOURS = {"rgb(90.196079%, 62.352943%, 0%)": 0,        # identifiable
+                   "rgb(0%, 44.705883%, 69.803923%)": 1,        # practically unidentifiable
+                   "rgb(80.000001%, 47.450981%, 65.490198%)": 2}  # unidentifiable
+
+
+def decode_likelihood_curves(svg_file):
+    """The 117 profile curves in drawing (= subject) order.  Cairo cuts every poly-line at the clip rectangle of the
+    axis, so a curve arrives as one or more left-to-right pieces (a profile that dips below 0 at its centre -- the
+    reference's optimum is not exact -- or exceeds 10 is split); a piece that starts left of the end of the previous
+    piece begins the next curve.  Returns (list of (class, [pieces (n, 2)]), threshold line (2, 2))."""
+    text = open(svg_file).read()
+    body = text[text.index("</defs>"):]
+    curves, hline = [], None
+    for before, d, after in PATH.findall(body):
+        attrs = before + " " + after
+        v = np.array([float(x) for x in NUM.findall(d)]).reshape(-1, 2)
+        if "stroke-dasharray" in attrs and 'stroke-width="2.5"' in attrs and hline is None:
+            hline = v
+            continue
+        m = re.search(r'stroke="([^"]*)"', attrs)
+        if not m or m.group(1) not in PROFILE_COLOURS or 'stroke-width="1.5"' not in attrs or 'fill="none"' not in attrs:
+            continue
+        if v[:, 0].min() > 320:                                      # the legend's line samples
+            continue
+        cls = PROFILE_COLOURS[m.group(1)]
+        if curves and curves[-1][0] == cls and v[0, 0] > curves[-1][1][-1][-1, 0] - 1e-9:
+            curves[-1][1].append(v)
+        else:
+            curves.append((cls, [v]))
+    return curves, hline
+
+
 def main():
     arrays = {}
+    # likelihood profiles of all 117 subjects: per curve its pieces' vertices, concatenated (CSR layout)
+    curves, hline = decode_likelihood_curves(os.path.join(REF, "supplementary/likelihood_curves.svg"))
+    assert len(curves) == 117 and hline is not None
+    full = [c for c in curves if c[0] == 2][0][1]                     # an unidentifiable profile spans all of -10 ... 10
+    arrays["profiles_xspan"] = _q(np.array([full[0][0, 0], full[-1][-1, 0]]))
+    arrays["profiles_threshold_y"] = _q(hline[:1, 1])
+    arrays["profiles_class"] = np.array([c[0] for c in curves], dtype=np.int32)
+    arrays["profiles_vertices"] = _q(np.concatenate([np.concatenate(c[1]) for c in curves]))
+    arrays["profiles_ptr"] = np.cumsum([0] + [sum(len(v) for v in c[1]) for c in curves]).astype(np.int64)
+    print("likelihood_curves", len(curves), "curves,", int(arrays["profiles_ptr"][-1]), "vertices; classes",
+          np.bincount(arrays["profiles_class"]))
     # figure_5 panel d (c-peptide/03-symreg.jl:100-112, :190-200): fitted objectives of the symbolic model for all 117
     # subjects ([train; test] order within each type)
     for t, v in decode_small_markers_by_type(os.path.join(REF, "figure_5/figure_5.svg")).items():
