@@ -354,40 +354,46 @@ def _profile_vertices(fig, i):
     return kr[keep].astype(int), (y_bot - c[keep, 1]) * 10.0 / (y_bot - y_top)
 
 
-def _recover_profile(sub, k, y, n_fine=1001, half_width=5e-3, edge_width=0.0):
+def _recover_profile(sub, k, y, n_fine=1001, half_width=5e-3, edge_width=0.0, coarse_width=0.1):
     """The one free scalar of a plotted profile is the beta_i it is centred on (the reference's fitted value, not
     stored); sigma_i only scales it.  Locate beta_i with the smooth fixed-step loss, then scan its neighbourhood with
     the adaptive one (the profile resolves the ripple of the adaptive-step loss, so it matches at the figure's
-    resolution only where the restatement takes the reference's own steps).  Returns (beta_i, scale, max residual)."""
+    resolution only where the restatement takes the reference's own steps).  A fit that ran into the optimiser's box
+    stopped just inside the bound: scanned from the bound inwards over `edge_width`.
+    Returns (beta_i, scale, residual of every vertex)."""
     delta = -10.0 + 20.0 * k / 999.0
     sel = np.unique(np.r_[np.linspace(0, k.size - 1, min(k.size, 24)).astype(int)])
     sse_of = lambda betas, fn: np.sum((fn(betas, sub.tp) - sub.obs[None, :]) ** 2, axis=1)
 
     def score(betas, fn, idx):
-        """per candidate beta: least-squares scale and max residual on the vertices `idx`."""
+        """per candidate beta: least-squares scale and the residual of the vertices `idx`."""
         pts = (betas[:, None] + delta[None, idx]).ravel()
         d = sse_of(pts, fn).reshape(betas.size, idx.size) - sse_of(betas, fn)[:, None]
         s = (d @ y[idx]) / np.maximum(np.sum(d * d, axis=1), 1e-300)
         return s, np.abs(y[idx][None, :] - s[:, None] * d)
+
+    def best(cand, fn, q):
+        _, res = score(cand, fn, sel)
+        return cand[int(np.nanargmin(np.quantile(res, q, axis=1)))]
     b_star, _ = sub.argmin_sse()
-    at_edge = b_star < sub.box[0] + 0.05
-    centre = sub.box[0] if at_edge else b_star
-    if not at_edge:                          # coarse: smooth loss, +-0.1 around the subject's own optimum
-        cand = centre + np.linspace(-0.1, 0.1, 201)
-        _, res = score(cand, lambda b, t: sub.fixed(b, t, 60), sel)
-        centre = cand[int(np.argmin(res.max(axis=1)))]
-    if not at_edge:                          # fine: adaptive loss, 1e-5 then 1e-6 spacing
-        for half, n in ((half_width, n_fine), (2e-5, 41)):
-            cand = centre + np.linspace(-half, half, n)
-            _, res = score(cand, sub.adaptive_many, sel)
-            centre = cand[int(np.nanargmin(np.quantile(res, 0.75, axis=1)))]
-    elif edge_width > 0:                     # a box-constrained fit stops just inside its lower bound
-        for lo, hi, n in ((0.0, edge_width, n_fine), (-2e-5, 2e-5, 41)):
-            cand = np.maximum(centre + np.linspace(lo, hi, n), sub.box[0])
-            _, res = score(cand, sub.adaptive_many, sel)
-            centre = cand[int(np.nanargmin(np.quantile(res, 0.75, axis=1)))]
-    s, res_all = score(np.array([centre]), sub.adaptive_many, np.arange(k.size))
-    return centre, float(s[0]), res_all[0]
+    edge = -1 if b_star < sub.box[0] + 0.05 else (1 if b_star > sub.box[1] - 0.05 else 0)
+    found = []
+    if edge == 0 or edge_width > 0:          # coarse on the smooth loss, then 1e-5 and 1e-6 spacing on the adaptive one
+        centre = best(np.clip(b_star + np.linspace(-coarse_width, coarse_width, 201), *sub.box),
+                      lambda b, t: sub.fixed(b, t, 60), 1.0)
+        for half, n in ((max(half_width, coarse_width / 100), n_fine), (2e-5, 41)):
+            centre = best(np.clip(centre + np.linspace(-half, half, n), *sub.box), sub.adaptive_many, 0.75)
+        found.append(centre)
+    if edge != 0:
+        centre = sub.box[0] if edge < 0 else sub.box[1]
+        if edge_width > 0:
+            for lo, hi, n in ((0.0, edge_width, n_fine), (-2e-5, 2e-5, 41)):
+                centre = best(np.clip(centre - edge * np.linspace(lo, hi, n), *sub.box), sub.adaptive_many, 0.75)
+        found.append(centre)
+    cand = np.array(found)
+    s, res_all = score(cand, sub.adaptive_many, np.arange(k.size))
+    j = int(np.argmin(np.median(res_all, axis=1)))
+    return cand[j], float(s[j]), res_all[j]
 
 
 def _check_profile(sub, fig, i, **scan):

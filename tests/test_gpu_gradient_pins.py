@@ -1,0 +1,71 @@
+"""The gradient of the product at the points the reference's own training stopped at.
+
+No gradient value of the reference is stored anywhere, but the END POINTS of its optimisations are: the 25 + 24 + 25
+trained parameter sets (network, 57 conditional parameters) of `source_data/cude_neural_parameters.jld2`,
+`cude_covariate_neural_parameters_2.jld2` and `cude_neural_parameters_sigma.jld2` -- where Adam x 1000 + L-BFGS x 1000
+on ForwardDiff gradients of the adaptive-step loss came to rest (c-peptide/02-conditional.jl:32-50,
+src/parameter-estimation.jl:170-183,340-386).  At such a point the gradient of the SAME loss must be at the noise level
+of the reference's solver; for the product's loss (the fixed-step discretisation of the same model) it may differ from
+zero by the gradient of the two losses' difference (~1e-3 of the loss).  Checked through libcude_hip.so for every
+stored run: (i) the discrete-adjoint gradient at the stored optimum is a fraction of a percent (median over the runs
+< 1 % for the network part, covariate runs < 3 %; conditional part, median over subjects, < 5 %) of what it is after a
+10 % perturbation of the network and 0.2 of the conditional parameters -- the product's loss is stationary where the
+reference's is; (ii) there, the directional derivative and the directional curvature from the adjoint gradients equal
+central differences of the loss (5e-3 / 1e-4 relative): the gradient that vanishes is the gradient of
+the loss that the other pins tie to the reference.  Which 57 of the 117 subjects a run was trained on is not stored:
+they are identified by matching the stored conditional parameters with per-subject refits (cude_fit_conditional)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RUNS = [("nn_2x4x4x1", "betas_train", (2, 4, 2), 0.01), ("nn_2x4x4x1_sigma", "betas_train_sigma", (2, 4, 2), 0.01),
+        ("nn_3x4x4x1_cov", "betas_train_cov", (3, 4, 2), 0.03)]
+
+
+@pytest.mark.parametrize("nn_key,beta_key,arch,bound", RUNS)
+def test_product_gradient_at_the_stored_optima(nn_key, beta_key, arch, bound):
+    import torch  # noqa: F401
+    from cude.engine import Engine
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    tp = g["timepoints"]
+    full = Engine("cpep", arch, n_steps=32, n_state=2)
+    full.set_population_cpep(tp, g["glucose"], g["cpeptide"], g["ages"], g["t2dm"])
+    ratios, ratios_cond = [], []
+    for k in range(g[nn_key].shape[0]):
+        nn, stored = g[nn_key][k], g[beta_key][k]
+        full.set_params(nn, None)
+        refit, _, _ = full.fit_conditional(-5.0, 3.0, 81, 48)
+        cost = np.abs(stored[:, None] - refit[None, :])
+        _, c = linear_sum_assignment(cost)
+        if np.median(cost[np.arange(57), c]) > 1e-2:
+            continue                                     # a run whose subjects cannot be identified pins nothing
+        eng = Engine("cpep", arch, n_steps=32, n_state=2)
+        eng.set_population_cpep(tp, g["glucose"][c], g["cpeptide"][c], g["ages"][c], g["t2dm"][c])
+        eng.set_params(nn, stored)
+        L0, gn0, gb0 = eng.loss_grad()
+        eng.set_params(nn * 1.1, stored + 0.2)
+        _, gn1, gb1 = eng.loss_grad()
+        ratios.append(np.max(np.abs(gn0)) / np.max(np.abs(gn1)))
+        ratios_cond.append(np.median(np.abs(gb0)) / np.median(np.abs(gb1)))     # (a few subjects are mis-identified)
+        # the adjoint gradient IS the gradient of the loss, at this point: first and second directional derivatives
+        rng = np.random.default_rng(k)
+        u_n, u_b = rng.standard_normal(nn.size), rng.standard_normal(57)
+        nrm = np.sqrt(u_n @ u_n + u_b @ u_b)
+        u_n, u_b, eps = u_n / nrm, u_b / nrm, 2e-4
+        eng.set_params(nn + eps * u_n, stored + eps * u_b)
+        Lp, gnp, gbp = eng.loss_grad()
+        eng.set_params(nn - eps * u_n, stored - eps * u_b)
+        Lm, gnm, gbm = eng.loss_grad()
+        eng.close()
+        d1_fd, d1 = (Lp - Lm) / (2 * eps), gn0 @ u_n + gb0 @ u_b
+        d2_fd, d2 = (Lp - 2 * L0 + Lm) / eps ** 2, ((gnp - gnm) @ u_n + (gbp - gbm) @ u_b) / (2 * eps)
+        assert abs(d1_fd - d1) <= 5e-3 * abs(d1) + 1e-6 * abs(d2), (k, d1_fd, d1)      # FD error ~ eps^2 * third derivative
+        assert abs(d2_fd - d2) <= 1e-4 * abs(d2), (k, d2_fd, d2)
+    full.close()
+    ratios, ratios_cond = np.array(ratios), np.array(ratios_cond)
+    assert ratios.size >= 20 and np.median(ratios) < bound and ratios.max() < 0.25, (np.median(ratios), ratios.max())
+    assert np.median(ratios_cond) < 0.05, np.median(ratios_cond)
