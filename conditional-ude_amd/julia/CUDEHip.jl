@@ -1,70 +1,131 @@
-# Julia shim over the C ABI of libcude_hip.so (see INTEGRATION.md).  Written, not executed in this pipeline
-# (Julia is not installed in the build image); mirrors conditional-ude_amd/cude/engine.py 1:1.
+# CUDEHip.jl -- the reference's Julia API for the accelerated path, on top of the C ABI of libcude_hip.so.
+#
+# Drop-in for the hot-path functions of Computational-Biology-TUe/conditional-ude with THEIR signatures:
+#   chain(width, depth, tanh; input_dims)                                        src/neural-network.jl:105-107
+#   CPeptideConditionalUDEModel(glucose, timepoints, age, chain, cpeptide, t2dm) src/c-peptide-models.jl:170-194
+#   loss(θ, (models, timepoints, cpeptide_data))   loss(θ, (model, timepoints, data))   loss(β, (model, t, data, nn))
+#   loss_sigma(θ, (...))                                                         src/parameter-estimation.jl:56-140
+#   train(models, timepoints, cpeptide_data, rng; ...)  train(models, t, data, nn; ...)  train_with_sigma  evaluate_model
+#                                                                                src/parameter-estimation.jl:272-433
+#   likelihood_profile(β, nn, model, timepoints, data, lower, upper, sigma; steps)   src/likelihood-profiles.jl:4-17
+#   suppression_loss(p, (prob, data, timepoints, λ))   simul(p, prob, data, timepoints)   fit_suppression_model
+#                                                                                suppression/src/suppression_model.jl:107-177
+#   simulate / individual_log_likelihood / SAEM(individuals, nn0, network; ...)  src/saem.jl:31-66,134-237
+# A script of the reference switches by replacing `include("src/parameter-estimation.jl")` (etc.) with
+# `include("CUDEHip.jl"); using .CUDEHip` -- models, timepoints and data are passed exactly as before; a device
+# population is built once per (models, timepoints, data) and cached.
+#
+# Written against include/cude.h, not executed in this pipeline (Julia is not installed in the build image): the same
+# ABI is exercised end to end by the Python host (conditional-ude_amd/cude/), and tests/test_julia_shim.py parses every
+# `ccall` below and checks symbol, arity and argument widths against the header.
 module CUDEHip
-const LIB = "libcude_hip.so"
+
+using Random: AbstractRNG, randn, rand, randperm
+using Statistics: mean, var
+
+export chain, neural_network_model, CPeptideConditionalUDEModel, CPeptideCUDEModel, CPeptideConditionalCovariateUDEModel,
+       loss, loss_sigma, loss_and_gradient!, train, train_with_sigma, evaluate_model, likelihood_profile,
+       SuppressionProblem, suppression_loss, simul, fit_suppression_model, simulate, individual_log_likelihood, SAEM
+
+const LIB = get(ENV, "CUDE_HIP_LIB", "libcude_hip.so")
+const MODEL_CPEP, MODEL_SUPP, MODEL_CPEP_SYM = Int32(0), Int32(1), Int32(2)
+const ADAPTIVE = 0                       # n_steps = ADAPTIVE: the reference's own adaptive Tsit5 (forward-only calls)
+
 struct Config
     model::Int32; n_state::Int32; nn_in::Int32; nn_width::Int32; nn_depth::Int32
     n_steps::Int32; device::Int32; cond_space::Int32; lambda::Float64
 end
+
 check(st) = st < 0 ? error(unsafe_string(ccall((:cude_last_error, LIB), Cstring, ()))) : st
 
-mutable struct Ctx; h::Ptr{Cvoid}; P::Int; N::Int; end
+# ----------------------------------------------------------------------------------------------- low-level context
+mutable struct Ctx
+    h::Ptr{Cvoid}; P::Int; N::Int; T::Int; n_state::Int
+end
+
 function Ctx(cfg::Config)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:cude_create, LIB), Int32, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, h))
     P = ccall((:cude_n_params, LIB), Int32, (Int32, Int32, Int32), cfg.nn_in, cfg.nn_width, cfg.nn_depth)
-    c = Ctx(h[], P, 0); finalizer(x -> ccall((:cude_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), c); c
+    c = Ctx(h[], P, 0, 0, cfg.n_state)
+    finalizer(x -> ccall((:cude_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), c)
+    c
 end
 
-# models' data as Julia column-major N×T matrices: ld_subject = 1, ld_time = N (no host copy)
+function device_count()
+    n = Ref{Int32}(0)
+    check(ccall((:cude_device_count, LIB), Int32, (Ref{Int32},), n))
+    Int(n[])
+end
+
+set_tolerances!(c::Ctx, abstol, reltol) =
+    check(ccall((:cude_set_tolerances, LIB), Int32, (Ptr{Cvoid}, Float64, Float64), c.h, abstol, reltol))
+
+# glucose / cpeptide as Julia column-major N×T matrices: ld_subject = 1, ld_time = N (no host copy)
 function set_population!(c::Ctx, timepoints::Vector{Float64}, glucose::Matrix{Float64}, cpeptide::Matrix{Float64},
                          ages::Vector{Float64}, t2dm::Vector{UInt8})
     N, T = size(glucose)
     GC.@preserve timepoints glucose cpeptide ages t2dm check(ccall((:cude_set_population_cpep, LIB), Int32,
         (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{UInt8}),
         c.h, N, T, timepoints, glucose, cpeptide, 1, N, ages, t2dm))
-    c.N = N
+    c.N = N; c.T = T
+    c
 end
 
-# drop-in for `loss(θ, (models, timepoints, cpeptide_data))`  (src/parameter-estimation.jl:126-140)
-function loss(c::Ctx, θ)
-    nn = Vector{Float64}(θ.neural); cond = vec(Matrix{Float64}(θ.conditional)); l = Ref{Float64}()
-    GC.@preserve nn cond begin
-        check(ccall((:cude_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond))
-        check(ccall((:cude_forward, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}), c.h, l, C_NULL, C_NULL))
-    end
-    l[]
+# individual_data[3 × T × N] exactly as the reference holds it (column-major)
+function set_population_supp!(c::Ctx, timepoints::Vector{Float64}, data::Array{Float64,3})
+    _, T, N = size(data)
+    GC.@preserve timepoints data check(ccall((:cude_set_population_supp, LIB), Int32,
+        (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}), c.h, N, T, timepoints, data))
+    c.N = N; c.T = T
+    c
 end
 
-# gradient hook:  OptimizationFunction((θ,p)->loss(ctx,θ); grad = (G,θ,p)->grad!(G,ctx,θ))
-function grad!(G, c::Ctx, θ)
-    nn = Vector{Float64}(θ.neural); cond = vec(Matrix{Float64}(θ.conditional))
-    gnn = Vector{Float64}(undef, c.P); gcond = Vector{Float64}(undef, c.N); l = Ref{Float64}()
-    GC.@preserve nn cond gnn gcond begin
-        check(ccall((:cude_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond))
-        check(ccall((:cude_loss_grad, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}), c.h, l, gnn, gcond))
-    end
-    G.neural .= gnn; G.conditional .= reshape(gcond, size(G.conditional)); G
+function set_params!(c::Ctx, nn, cond)
+    nnv = nn === nothing ? nothing : Vector{Float64}(vec(nn))
+    cv = cond === nothing ? nothing : Vector{Float64}(vec(cond))
+    GC.@preserve nnv cv check(ccall((:cude_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+        c.h, nnv === nothing ? C_NULL : pointer(nnv), cv === nothing ? C_NULL : pointer(cv)))
 end
 
-# fast path replacing Optimization.solve(prob, Optimisers.Adam(η), maxiters=K): parameters stay on the GPU
-function adam!(c::Ctx, θ0, η, iters; callback = (l)->false)
-    loss(c, θ0); check(ccall((:cude_adam_init, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Float64, Float64), c.h, η, 0.9, 0.999, 1e-8))
-    l = Ref{Float64}()
-    for _ in 1:iters
-        check(ccall((:cude_adam_step, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}), c.h, l)); callback(l[]) && break
-    end
+function get_params(c::Ctx)
     nn = Vector{Float64}(undef, c.P); cond = Vector{Float64}(undef, c.N)
-    check(ccall((:cude_get_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond)); (nn, cond, l[])
-end
+    GC.@preserve nn cond check(ccall((:cude_get_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, nn, cond))
+    nn, cond
 end
 
-# --- additional entry points (same module; appended for readability) -----------------------------------------
-module CUDEHipExtras
-import ..CUDEHip: LIB, Ctx, check
+# population loss at the context's parameters; optionally the per-subject SSEs and the states [n_state × T × N]
+function forward(c::Ctx; want_sse = false, want_traj = false)
+    l = Ref{Float64}()
+    sse = want_sse ? Vector{Float64}(undef, c.N) : nothing
+    traj = want_traj ? Array{Float64,3}(undef, c.n_state, c.T, c.N) : nothing
+    GC.@preserve sse traj check(ccall((:cude_forward, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, l, sse === nothing ? C_NULL : pointer(sse), traj === nothing ? C_NULL : pointer(traj)))
+    l[], sse, traj
+end
 
-# screening loop of `train` (src/parameter-estimation.jl:362-366): K candidate parameter sets in one launch.
-# nn_sets is P×K, cond_sets is N×K (Julia column-major = the row-major [K][P] / [K][N] the ABI expects).
+function loss_grad(c::Ctx)
+    l = Ref{Float64}(); gnn = Vector{Float64}(undef, c.P); gcond = Vector{Float64}(undef, c.N)
+    GC.@preserve gnn gcond check(ccall((:cude_loss_grad, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, l, gnn, gcond))
+    l[], gnn, gcond
+end
+
+function n_failed(c::Ctx)
+    n = Ref{Int64}(0)
+    check(ccall((:cude_n_failed, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), c.h, n))
+    Int(n[])
+end
+
+# states of every subject at arbitrary times inside the time span: [n_state × n_times × N]
+function simulate_dense(c::Ctx, times::Vector{Float64})
+    out = Array{Float64,3}(undef, c.n_state, length(times), c.N)
+    GC.@preserve times out check(ccall((:cude_simulate, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}),
+        c.h, length(times), times, out))
+    out
+end
+
+# screening: nn_sets is P×K, cond_sets N×K (column-major = the row-major [K][P] / [K][N] of the ABI)
 function multistart_forward(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{Float64})
     K = size(nn_sets, 2); losses = Vector{Float64}(undef, K)
     GC.@preserve nn_sets cond_sets losses check(ccall((:cude_multistart_forward, LIB), Int32,
@@ -72,10 +133,8 @@ function multistart_forward(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{
     losses
 end
 
-# restart loop of `train` (src/parameter-estimation.jl:372-383) with all restarts evaluated per optimiser iteration:
-# losses (K), ∂/∂neural (P×K) and ∂/∂conditional (N×K) of the K current points in one launch.
 function multistart_loss_grad(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{Float64})
-    K = size(nn_sets, 2); N = size(cond_sets, 1)
+    K = size(nn_sets, 2)
     losses = Vector{Float64}(undef, K); g_nn = similar(nn_sets); g_cond = similar(cond_sets)
     GC.@preserve nn_sets cond_sets losses g_nn g_cond check(ccall((:cude_multistart_loss_grad, LIB), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
@@ -83,20 +142,19 @@ function multistart_loss_grad(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matri
     losses, g_nn, g_cond
 end
 
-# second half of `train` (src/parameter-estimation.jl:368-383): the selected initial guesses (columns of nn_sets P×K and
-# cond_sets N×K) trained side by side with Adam(η) × adam_iters then LBFGS(BackTracking) × lbfgs_iters;
-# returns (neural P×K, conditional N×K, objectives K)
+# Adam(η) × adam_iters then LBFGS(BackTracking) × lbfgs_iters for all columns side by side; returns
+# (neural P×K, conditional N×K, objectives K, loss traces (adam_iters + lbfgs_iters)×K with NaN after a run stopped)
 function train_restarts(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{Float64}; adam_iters = 1000, η = 1e-2,
                         lbfgs_iters = 1000)
     K = size(nn_sets, 2); nn = similar(nn_sets); cond = similar(cond_sets); obj = Vector{Float64}(undef, K)
-    GC.@preserve nn_sets cond_sets nn cond obj check(ccall((:cude_train_restarts, LIB), Int32,
+    trace = Matrix{Float64}(undef, adam_iters + lbfgs_iters, K)
+    GC.@preserve nn_sets cond_sets nn cond obj trace check(ccall((:cude_train_restarts, LIB), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-         Ptr{Float64}), c.h, K, nn_sets, cond_sets, adam_iters, η, lbfgs_iters, nn, cond, obj, C_NULL))
-    nn, cond, obj
+         Ptr{Float64}), c.h, K, nn_sets, cond_sets, adam_iters, η, lbfgs_iters, nn, cond, obj, trace))
+    nn, cond, obj, trace
 end
 
-# `train(models, timepoints, data, neural_network_parameters)` (src/parameter-estimation.jl:272-288) for all models at
-# once: per-subject minimisers of SSE_i(β) + w (β - μ)^2 over [lower, upper]; returns (β, objective, SSE)
+# per-subject minimisers of SSE_i(β) + w (β - μ)^2 over [lower, upper]; returns (β, objective, SSE)
 function fit_conditional(c::Ctx, lower, upper; n_grid = 41, n_iters = 48, penalty_weight = 0.0, penalty_center = 0.0)
     β = Vector{Float64}(undef, c.N); obj = similar(β); sse = similar(β)
     GC.@preserve β obj sse check(ccall((:cude_fit_conditional, LIB), Int32,
@@ -105,7 +163,7 @@ function fit_conditional(c::Ctx, lower, upper; n_grid = 41, n_iters = 48, penalt
     β, obj, sse
 end
 
-# likelihood profiles (src/likelihood-profiles.jl:4-17) of all models at once: SSE_i(values[k]) as an N×K matrix
+# SSE_i(values[k]) as an N×K matrix
 function profile_conditional(c::Ctx, values::Vector{Float64})
     sse = Matrix{Float64}(undef, c.N, length(values))
     GC.@preserve values sse check(ccall((:cude_profile_conditional, LIB), Int32,
@@ -113,13 +171,24 @@ function profile_conditional(c::Ctx, values::Vector{Float64})
     sse
 end
 
-# `maxiters` Adam iterations in one call (hipGraph replay); returns the loss trace
-function adam_run!(c::Ctx, iters::Integer)
-    losses = Vector{Float64}(undef, iters)
-    check(ccall((:cude_adam_run, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}), c.h, iters, losses)); losses
+adam_init!(c::Ctx, η; β1 = 0.9, β2 = 0.999, ϵ = 1e-8) =
+    check(ccall((:cude_adam_init, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Float64, Float64), c.h, η, β1, β2, ϵ))
+
+function adam_step!(c::Ctx)
+    l = Ref{Float64}()
+    check(ccall((:cude_adam_step, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}), c.h, l))
+    l[]
 end
 
-# E-step of SAEM (src/saem.jl:177-186): n_mc Metropolis steps for every subject; draws are N×n_mc matrices
+function adam_run!(c::Ctx, iters::Integer)
+    losses = Vector{Float64}(undef, iters)
+    GC.@preserve losses check(ccall((:cude_adam_run, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}), c.h, iters, losses))
+    losses
+end
+
+synchronize(c::Ctx) = check(ccall((:cude_synchronize, LIB), Int32, (Ptr{Cvoid},), c.h))
+
+# E-step of SAEM: draws are N×n_mc matrices (= [n_mc][N] row-major)
 function mh_estep!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, σ, prior_η, Ω, proposal_std;
                    temperature = 1.0, γ = 1.0)
     N, n_mc = size(normals); accepted = zeros(Int64, N)
@@ -129,14 +198,401 @@ function mh_estep!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, 
     accepted
 end
 
-# posterior sampling after SAEM (c-peptide/06-saem.jl:107-112) for all individuals at once: every chain state is kept;
-# returns (accepted, samples) with samples N×n_mc
 function mh_chain!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, σ, prior_η, Ω, proposal_std;
                    temperature = 1.0, γ = 1.0)
     N, n_mc = size(normals); accepted = zeros(Int64, N); samples = similar(normals)
     GC.@preserve normals uniforms accepted samples check(ccall((:cude_mh_chain, LIB), Int32,
-        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64, Float64, Float64, Ptr{Int64}, Ptr{Float64}),
-        c.h, n_mc, normals, uniforms, σ, prior_η, Ω, proposal_std, temperature, γ, accepted, samples))
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64, Float64, Float64, Ptr{Int64},
+         Ptr{Float64}), c.h, n_mc, normals, uniforms, σ, prior_η, Ω, proposal_std, temperature, γ, accepted, samples))
     accepted, samples
 end
+
+# L-BFGS + BackTracking of the library for any Julia objective fg!(g, x) -> f (host only)
+function lbfgs_minimize(fg!, x0::Vector{Float64}; maxiters = 1000)
+    n = length(x0)
+    function thunk(xp::Ptr{Float64}, nn::Int32, fp::Ptr{Float64}, gp::Ptr{Float64}, ::Ptr{Cvoid})::Int32
+        x = unsafe_wrap(Array, xp, Int(nn)); g = unsafe_wrap(Array, gp, Int(nn))
+        unsafe_store!(fp, fg!(g, x)); Int32(0)
+    end
+    cb = @cfunction($thunk, Int32, (Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
+    x = similar(x0); f = Ref{Float64}(); it = Ref{Int32}(); calls = Ref{Int32}(); conv = Ref{Int32}()
+    GC.@preserve x0 x cb check(ccall((:cude_lbfgs_minimize, LIB), Int32,
+        (Int32, Ptr{Float64}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}),
+        n, x0, maxiters, cb, C_NULL, x, f, it, calls, conv))
+    (x = x, f = f[], iterations = Int(it[]), f_calls = Int(calls[]), converged = conv[] != 0)
 end
+
+# the same for a vector sharded over ranks: x = [shared (n_shared); local]; reduce!(values, op) sums (op 0) / maximises
+# (op 1) over the ranks in place, e.g.  (v, op) -> MPI.Allreduce!(v, op == 0 ? MPI.SUM : MPI.MAX, comm)
+function lbfgs_minimize_sharded(fg!, reduce!, x0::Vector{Float64}, n_shared::Integer; maxiters = 1000)
+    n = length(x0)
+    function thunk(xp::Ptr{Float64}, nn::Int32, fp::Ptr{Float64}, gp::Ptr{Float64}, ::Ptr{Cvoid})::Int32
+        x = unsafe_wrap(Array, xp, Int(nn)); g = unsafe_wrap(Array, gp, Int(nn))
+        unsafe_store!(fp, fg!(g, x)); Int32(0)
+    end
+    function red(vp::Ptr{Float64}, count::Int32, op::Int32, ::Ptr{Cvoid})::Int32
+        reduce!(unsafe_wrap(Array, vp, Int(count)), Int(op)); Int32(0)
+    end
+    cb = @cfunction($thunk, Int32, (Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
+    rcb = @cfunction($red, Int32, (Ptr{Float64}, Int32, Int32, Ptr{Cvoid}))
+    x = similar(x0); f = Ref{Float64}(); it = Ref{Int32}(); calls = Ref{Int32}(); conv = Ref{Int32}()
+    GC.@preserve x0 x cb rcb check(ccall((:cude_lbfgs_minimize_sharded, LIB), Int32,
+        (Int32, Int32, Ptr{Float64}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ref{Int32},
+         Ref{Int32}, Ref{Int32}), n, n_shared, x0, maxiters, cb, rcb, C_NULL, x, f, it, calls, conv))
+    (x = x, f = f[], iterations = Int(it[]), f_calls = Int(calls[]), converged = conv[] != 0)
+end
+
+# ---- multi-GPU: one process per GPU, subjects sharded (INTEGRATION.md "Multi-GPU launch")
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    GC.@preserve id check(ccall((:cude_comm_unique_id, LIB), Int32, (Ptr{UInt8},), id))
+    id
+end
+
+comm_init!(c::Ctx, n_ranks, rank, id::Vector{UInt8}) = GC.@preserve id check(ccall((:cude_comm_init, LIB), Int32,
+    (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), c.h, n_ranks, rank, id))
+
+function comm_info(c::Ctx)
+    n = Ref{Int32}(); r = Ref{Int32}(); v = Ref{Int32}()
+    check(ccall((:cude_comm_info, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}), c.h, n, r, v))
+    (ranks = Int(n[]), rank = Int(r[]), rccl_version = Int(v[]))
+end
+
+function comm_allreduce!(c::Ctx, values::Vector{Float64})
+    GC.@preserve values check(ccall((:cude_comm_allreduce_host, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32),
+        c.h, values, length(values)))
+    values
+end
+
+# bring-your-own collective (MPI.jl): partial = loss_grad_partial(c); MPI.Allreduce!(partial, +, comm); adam_apply!(c, partial)
+function set_global_subjects!(c::Ctx, n_global; scale = nothing)
+    sc = scale === nothing ? nothing : Vector{Float64}(scale)
+    GC.@preserve sc check(ccall((:cude_set_global_subjects, LIB), Int32, (Ptr{Cvoid}, Float64, Ptr{Float64}),
+        c.h, n_global, sc === nothing ? C_NULL : pointer(sc)))
+end
+
+function get_scale(c::Ctx)
+    sc = Vector{Float64}(undef, 3); n = Ref{Float64}()
+    GC.@preserve sc check(ccall((:cude_get_scale, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}), c.h, sc, n))
+    sc, n[]
+end
+
+function loss_grad_partial(c::Ctx; want_cond_grad = false)
+    part = Vector{Float64}(undef, c.P + 2); gc = want_cond_grad ? Vector{Float64}(undef, c.N) : nothing
+    GC.@preserve part gc check(ccall((:cude_loss_grad_partial, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+        c.h, part, gc === nothing ? C_NULL : pointer(gc)))
+    part, gc
+end
+
+function adam_apply!(c::Ctx, reduced::Vector{Float64})
+    l = Ref{Float64}()
+    GC.@preserve reduced check(ccall((:cude_adam_apply, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}), c.h, reduced, l))
+    l[]
+end
+
+set_kernel_timing!(c::Ctx, on::Bool) = check(ccall((:cude_set_kernel_timing, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on ? 1 : 0))
+
+function kernel_time_ms(c::Ctx)
+    ms = Ref{Float64}(); n = Ref{Int64}()
+    check(ccall((:cude_kernel_time_ms, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}), c.h, ms, n))
+    ms[], Int(n[])
+end
+
+# ----------------------------------------------------------------------------------------------- reference API: models
+# chain(width, depth, tanh; input_dims = 2): only what the kernels compile (equal widths, tanh, one softplus output)
+struct Chain
+    input_dims::Int; width::Int; depth::Int
+end
+chain(width::Integer, depth::Integer, activation = tanh; input_dims::Integer = 2, output_dims::Integer = 1) =
+    (output_dims == 1 && activation === tanh) ? Chain(input_dims, width, depth) :
+    error("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
+neural_network_model(depth::Integer, width::Integer; input_dims::Integer = 2) = Chain(input_dims, width, depth)
+n_params(c::Chain) = Int(ccall((:cude_n_params, LIB), Int32, (Int32, Int32, Int32), c.input_dims, c.width, c.depth))
+
+# SimpleChains.init_params restated (Glorot-normal weights, zero biases, [vec(W); b] per layer)
+function init_params(c::Chain; rng::AbstractRNG)
+    p = Float64[]; fan = c.input_dims
+    for _ in 1:c.depth
+        append!(p, randn(rng, c.width * fan) .* sqrt(2 / (fan + c.width))); append!(p, zeros(c.width)); fan = c.width
+    end
+    append!(p, randn(rng, fan) .* sqrt(2 / (fan + 1))); push!(p, 0.0)
+    p
+end
+
+abstract type CPeptideModel end
+struct CPeptideConditionalUDEModel <: CPeptideModel
+    glucose::Vector{Float64}; timepoints::Vector{Float64}; age::Float64; chain::Chain
+    cpeptide::Vector{Float64}; t2dm::Bool
+end
+CPeptideConditionalUDEModel(glucose_data::AbstractVector{<:Real}, glucose_timepoints::AbstractVector{<:Real}, age::Real,
+                            network::Chain, cpeptide_data::AbstractVector{<:Real}, t2dm::Bool) =
+    CPeptideConditionalUDEModel(Vector{Float64}(glucose_data), Vector{Float64}(glucose_timepoints), Float64(age),
+                                network, Vector{Float64}(cpeptide_data), t2dm)
+const CPeptideCUDEModel = CPeptideConditionalUDEModel          # the name of the reference's docstrings / stale script
+CPeptideConditionalCovariateUDEModel(g, t, age, network::Chain, c, t2dm) =
+    network.input_dims == 3 ? CPeptideConditionalUDEModel(g, t, age, network, c, t2dm) :
+    error("the covariate model takes a network with input_dims = 3")
+
+struct Solution{U}               # the fields of Optimization.jl's solution that the reference's scripts read
+    u::U; objective::Float64
+end
+
+# ----------------------------------------------------------------------------------------------- population cache
+const N_STEPS_DEFAULT = Ref(0)   # 0 = automatic: 8 fixed Tsit5 steps per observation interval (step_count)
+step_count(timepoints) = N_STEPS_DEFAULT[] > 0 ? N_STEPS_DEFAULT[] : 8 * (length(timepoints) - 1)
+const POPULATIONS = Dict{UInt64,Ctx}()
+
+function population(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints, cpeptide_data; n_steps = nothing)
+    S = n_steps === nothing ? step_count(timepoints) : n_steps
+    data = cpeptide_data isa AbstractVector ? reshape(Vector{Float64}(cpeptide_data), 1, :) : Matrix{Float64}(cpeptide_data)
+    key = hash((S, Vector{Float64}(timepoints), data, [(m.glucose, m.age, m.t2dm, m.chain) for m in models]))
+    get!(POPULATIONS, key) do
+        net = models[1].chain
+        all(m -> m.timepoints == timepoints, models) || error("timepoints must equal the models' own timepoints")
+        c = Ctx(Config(MODEL_CPEP, 2, net.input_dims, net.width, net.depth, S, 0, 0, 0.0))
+        G = Matrix{Float64}(undef, length(models), length(timepoints))
+        for (i, m) in enumerate(models); G[i, :] .= m.glucose; end
+        set_population!(c, Vector{Float64}(timepoints), G, data, [m.age for m in models], UInt8[m.t2dm for m in models])
+    end
+end
+clear_populations!() = empty!(POPULATIONS)
+
+# ----------------------------------------------------------------------------------------------- reference API: loss
+# loss(θ, (models, timepoints, cpeptide_data)): mean over subjects of the SSE; Inf when a solve fails (:126-140)
+function loss(θ, (models, timepoints, cpeptide_data)::Tuple{AbstractVector{CPeptideConditionalUDEModel},AbstractVector{T},AbstractMatrix{T}}) where T<:Real
+    c = population(models, timepoints, cpeptide_data)
+    set_params!(c, θ.neural, θ.conditional[1:length(models)])
+    forward(c)[1]
+end
+# loss(θ, (model, timepoints, cpeptide_data)): one subject's SSE (:56-68)
+function loss(θ, (model, timepoints, cpeptide_data)::Tuple{CPeptideConditionalUDEModel,AbstractVector{T},AbstractVector{T}}) where T<:Real
+    c = population([model], timepoints, cpeptide_data)
+    set_params!(c, θ.neural, [θ.conditional[1]])
+    forward(c)[1]
+end
+# loss(β, (model, timepoints, cpeptide_data, neural_network_parameters)): frozen network (:93-99)
+loss(θ, (model, timepoints, cpeptide_data, nn)::Tuple{CPeptideConditionalUDEModel,AbstractVector{T},AbstractVector{T},AbstractVector{T}}) where T<:Real =
+    loss((neural = nn, conditional = θ), (model, timepoints, cpeptide_data))
+function loss_sigma(θ, (model, timepoints, cpeptide_data)::Tuple{CPeptideConditionalUDEModel,AbstractVector{T},AbstractVector{T}}) where T<:Real
+    n = length(timepoints)
+    (n / 2) * log(θ.sigma^2) + loss(θ, (model, timepoints, cpeptide_data)) / (2 * θ.sigma^2)
+end
+function loss_sigma(θ, (model, timepoints, cpeptide_data, nn)::Tuple{CPeptideConditionalUDEModel,AbstractVector{T},AbstractVector{T},AbstractVector{T}}) where T<:Real
+    n = length(timepoints)
+    (n / 2) * log(θ.sigma^2) + loss(θ.ode, (model, timepoints, cpeptide_data, nn)) / (2 * θ.sigma^2)
+end
+
+# gradient hook for Optimization.jl in place of AutoForwardDiff():
+#   OptimizationFunction(loss; grad = (G, θ, p) -> loss_and_gradient!(G, θ, p))
+function loss_and_gradient!(G, θ, (models, timepoints, cpeptide_data))
+    c = population(models, timepoints, cpeptide_data)
+    set_params!(c, θ.neural, θ.conditional[1:length(models)])
+    l, gnn, gcond = loss_grad(c)
+    G.neural .= gnn; G.conditional .= reshape(gcond, size(G.conditional))
+    l
+end
+
+# ----------------------------------------------------------------------------------------------- reference API: train
+# QuasiMonteCarlo.LatinHypercubeSample restated: one stratified draw per interval and dimension, shuffled
+function initial_parameters(n_models::Integer, lb::Real, ub::Real, n_initials::Integer, rng::AbstractRNG)
+    u = Matrix{Float64}(undef, n_models, n_initials)
+    for i in 1:n_models; u[i, :] .= (randperm(rng, n_initials) .- rand(rng, n_initials)) ./ n_initials; end
+    lb .+ (ub - lb) .* u
+end
+initial_parameters(c::Chain, n_initials::Integer; rng::AbstractRNG) = [init_params(c; rng = rng) for _ in 1:n_initials]
+
+# train(models, timepoints, cpeptide_data, rng; ...) (:340-386): screening of `initial_guesses` candidates in one
+# multi-start launch, the best `selected_initials` trained side by side (Adam then L-BFGS) in one call
+function train(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints::AbstractVector{T},
+               cpeptide_data::AbstractVecOrMat{T}, rng::AbstractRNG;
+               initial_guesses::Int = 25_000, selected_initials::Int = 25, lhs_lower_bound = -2.0, lhs_upper_bound = 0.0,
+               n_conditional_parameters::Int = 1, number_of_iterations_adam::Int = 1000,
+               number_of_iterations_lbfgs::Int = 1000, learning_rate_adam::Real = 1e-2) where T<:Real
+    c = population(models, timepoints, cpeptide_data)
+    nn0 = reduce(hcat, initial_parameters(models[1].chain, initial_guesses; rng = rng))           # P × K
+    cond0 = initial_parameters(length(models), lhs_lower_bound, lhs_upper_bound, initial_guesses, rng)   # N × K
+    losses_initial = multistart_forward(c, nn0, cond0)
+    println("Initial parameters evaluated. Optimizing for the best $(selected_initials) initial parameters.")
+    best = partialsortperm(losses_initial, 1:selected_initials)
+    nn, cond, obj, _ = train_restarts(c, nn0[:, best], cond0[:, best]; adam_iters = number_of_iterations_adam,
+                                      η = learning_rate_adam, lbfgs_iters = number_of_iterations_lbfgs)
+    optsols = Solution[]
+    for k in eachindex(obj)
+        isfinite(obj[k]) || (println("Optimization failed... Skipping"); continue)
+        push!(optsols, Solution((neural = nn[:, k], conditional = repeat(cond[:, k], 1, n_conditional_parameters)), obj[k]))
+    end
+    optsols
+end
+
+# train(models, timepoints, cpeptide_data, neural_network_parameters; ...) (:272-288): every subject's β at once
+function train(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints::AbstractVector{T},
+               cpeptide_data::AbstractMatrix{T}, neural_network_parameters::AbstractVector{T};
+               initial_beta = -2.0, lbfgs_lower_bound = -4.0, lbfgs_upper_bound = 1.0, lbfgs_iterations::Int = 1000) where T<:Real
+    c = population(models, timepoints, cpeptide_data)
+    set_params!(c, neural_network_parameters, nothing)
+    lo = isfinite(lbfgs_lower_bound) ? lbfgs_lower_bound : initial_beta - 6.0
+    hi = isfinite(lbfgs_upper_bound) ? lbfgs_upper_bound : initial_beta + 6.0
+    β, _, sse = fit_conditional(c, lo, hi)
+    [Solution([β[i]], sse[i]) for i in eachindex(β)]
+end
+
+# train_with_sigma (:290-307): for fixed β the optimum is σ² = SSE / n, so the 2-D problem separates
+function train_with_sigma(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints::AbstractVector{T},
+                          cpeptide_data::AbstractMatrix{T}, neural_network_parameters::AbstractVector{T};
+                          initial_beta = -2.0, lbfgs_lower_bound = -4.0, lbfgs_upper_bound = 1.0,
+                          lbfgs_iterations::Int = 1000) where T<:Real
+    sols = train(models, timepoints, cpeptide_data, neural_network_parameters; initial_beta = initial_beta,
+                 lbfgs_lower_bound = lbfgs_lower_bound, lbfgs_upper_bound = lbfgs_upper_bound)
+    n = length(timepoints)
+    map(sols) do s
+        σ = sqrt(max(s.objective, 1e-300) / n)
+        Solution((ode = s.u, sigma = σ), (n / 2) * log(σ^2) + s.objective / (2 * σ^2))
+    end
+end
+
+# evaluate_model (:406-433): objectives of every candidate network on the validation subjects (n_subjects × n_networks)
+function evaluate_model(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints::AbstractVector{T},
+                        cpeptide_data::AbstractMatrix{T}, neural_network_parameters,
+                        betas_train::AbstractVector{<:AbstractVector{T}}) where T<:Real
+    cols = map(zip(betas_train, neural_network_parameters)) do (betas, p_nn)
+        try
+            [s.objective for s in train(models, timepoints, cpeptide_data, Vector{Float64}(p_nn); initial_beta = mean(betas),
+                                        lbfgs_lower_bound = -Inf, lbfgs_upper_bound = Inf)]
+        catch
+            fill(Inf, length(models))
+        end
+    end
+    reduce(hcat, cols)
+end
+
+# likelihood_profile (src/likelihood-profiles.jl:4-17): all `steps` values of β in one launch
+function likelihood_profile(β, neural_network_parameters, model::CPeptideConditionalUDEModel, timepoints, cpeptide_data,
+                            lower_bound, upper_bound, sigma; steps = 1000)
+    c = population([model], timepoints, cpeptide_data)
+    set_params!(c, neural_network_parameters, [β[1]])
+    nll_minimum = forward(c; want_sse = true)[2][1] / (2 * sigma^2)
+    parameter_values = range(lower_bound, stop = upper_bound, length = steps)
+    nll_values = vec(profile_conditional(c, collect(Float64, parameter_values))) ./ (2 * sigma^2)
+    nll_values, nll_minimum, parameter_values
+end
+
+# ----------------------------------------------------------------------------------------------- suppression model
+struct SuppressionProblem          # stands in for ODEProblem(ude_lsup!, u0, tspan) with the network closed over
+    network::Chain
+end
+const SUPP_POPULATIONS = Dict{UInt64,Ctx}()
+function supp_population(prob::SuppressionProblem, data::AbstractArray{<:Real,3}, timepoints, λ; n_steps = 30)
+    d = Array{Float64,3}(data)
+    key = hash((n_steps, prob.network, Vector{Float64}(timepoints), d, Float64(λ)))
+    get!(SUPP_POPULATIONS, key) do
+        c = Ctx(Config(MODEL_SUPP, 3, 4, prob.network.width, prob.network.depth, n_steps, 0, 0, Float64(λ)))
+        set_population_supp!(c, Vector{Float64}(timepoints), d)
+    end
+end
+
+# suppression_loss(p, (prob, individual_data, timepoints, λ)) with p.theta[N], p.neural[P] (:117-130)
+function suppression_loss(p, (prob, individual_data, timepoints, λ))
+    c = supp_population(prob, individual_data, timepoints, λ)
+    set_params!(c, p.neural, p.theta)
+    forward(c)[1]
+end
+function suppression_loss_and_gradient!(G, p, (prob, individual_data, timepoints, λ))
+    c = supp_population(prob, individual_data, timepoints, λ)
+    set_params!(c, p.neural, p.theta)
+    l, gnn, gθ = loss_grad(c)
+    G.neural .= gnn; G.theta .= gθ
+    l
+end
+# simul(p, prob, individual_data, timepoints) -> 3 × T × N (:107-115)
+function simul(p, prob::SuppressionProblem, individual_data, timepoints)
+    c = supp_population(prob, individual_data, timepoints, 0.0)
+    set_params!(c, p.neural, p.theta)
+    forward(c; want_traj = true)[3]
+end
+# fit_suppression_model(p_init, prob, data, timepoints, λ; select_best_n) (:132-177): Adam() [η = 1e-3] × 2000, L-BFGS × 2000
+function fit_suppression_model(p_init, prob::SuppressionProblem, data, timepoints, λ; select_best_n = 1,
+                               adam_iters = 2000, lbfgs_iters = 2000)
+    c = supp_population(prob, data, timepoints, λ)
+    nn0 = reduce(hcat, [Vector{Float64}(p.neural) for p in p_init]); θ0 = reduce(hcat, [Vector{Float64}(p.theta) for p in p_init])
+    initial_losses = multistart_forward(c, nn0, θ0)
+    best = select_best_n > 1 ? partialsortperm(initial_losses, 1:select_best_n) : [argmin(initial_losses)]
+    println("Selected best $(length(best)) initials")
+    nn, θ, obj, trace = train_restarts(c, nn0[:, best], θ0[:, best]; adam_iters = adam_iters, η = 1e-3, lbfgs_iters = lbfgs_iters)
+    optsols = Solution[]; loss_traces = Vector{Float64}[]
+    for k in eachindex(obj)
+        isfinite(obj[k]) ? push!(optsols, Solution((theta = θ[:, k], neural = nn[:, k]), obj[k])) : println("Optimization failed")
+        push!(loss_traces, filter(!isnan, trace[:, k]))
+    end
+    optsols, loss_traces
+end
+
+# ----------------------------------------------------------------------------------------------- SAEM
+# individuals: NamedTuples with glucose, timepoints, cpeptide, age, condition ("T2DM" or not), as c-peptide/06-saem.jl builds
+function individuals_population(individuals, network::Chain; n_steps = nothing)
+    models = [CPeptideConditionalUDEModel(i.glucose, i.timepoints, i.age, network, i.cpeptide, i.condition == "T2DM")
+              for i in individuals]
+    data = reduce(vcat, [reshape(Vector{Float64}(i.cpeptide), 1, :) for i in individuals])
+    population(models, Vector{Float64}(individuals[1].timepoints), data; n_steps = n_steps)
+end
+
+# simulate(p_neural, p_individual, individual, network; timepoints) (src/saem.jl:31-53): plasma c-peptide at `timepoints`
+function simulate(p_neural, p_individual, individual, network::Chain; timepoints = individual.timepoints)
+    c = individuals_population([individual], network)
+    set_params!(c, p_neural, [p_individual[1]])
+    vec(simulate_dense(c, Vector{Float64}(timepoints))[1, :, 1])
+end
+
+# individual_log_likelihood(p_individual, p_neural, individual, network, σ) (:55-66); -Inf on a failed solve
+function individual_log_likelihood(p_individual, p_neural, individual, network::Chain, σ)
+    c = individuals_population([individual], network)
+    set_params!(c, p_neural, [p_individual[1]])
+    sse = forward(c; want_sse = true)[2][1]
+    isfinite(sse) ? -(length(individual.timepoints) / 2) * log(σ^2) - sse / (2 * σ^2) : -Inf
+end
+
+# SAEM(individuals, initial_neural_params, network; ...) (:134-237): the E-step of all individuals is one call
+# (cude_mh_estep), the M-step's 5 Adam(1e-2) iterations on (neural, σ) use the device gradient
+function SAEM(individuals, initial_neural_params, network::Chain;
+              σ = 1.0, prior_η = 0.0, prior_Ω = 1.0, iterations = 500, n_burnin_iterations = 100, proposal_std = 0.1,
+              proposal_std_bounds = (1e-3, 1.0), α = 0.7, n_mcmc_steps = 1, initial_mcmc_steps = n_mcmc_steps,
+              target_acceptance_rate = 0.25, initial_temperature = 10.0, temperature_decay = 0.05, Ω_learning_rate = 0.04)
+    println("Initializing the SAEM algorithm...")
+    c = individuals_population(individuals, network)
+    N, T = c.N, c.T
+    p_individuals = fill(Float64(prior_η), N); p_neural = Vector{Float64}(initial_neural_params); Ω = Float64(prior_Ω)
+    total_nll_values = Float64[]; acceptance_rates = Float64[]
+    for iteration in 1:iterations
+        gamma = iteration <= n_burnin_iterations ? 1.0 : 1.0 / (iteration - n_burnin_iterations)^α
+        steps = iteration <= n_burnin_iterations ? initial_mcmc_steps : n_mcmc_steps
+        temperature = max(1, initial_temperature * exp(-temperature_decay * iteration))
+        set_params!(c, p_neural, p_individuals)
+        accepted = mh_estep!(c, randn(N, steps), rand(N, steps), σ, prior_η, Ω, proposal_std; temperature = temperature, γ = gamma)
+        p_individuals = get_params(c)[2]
+        sse = forward(c; want_sse = true)[2]
+        loglikelihood = sum(s -> isfinite(s) ? -(T / 2) * log(σ^2) - s / (2 * σ^2) : -Inf, sse)
+        # M-step (update_population_parameters :118-131): Optimisers.Adam(1e-2), maxiters = 5 on total_nll(neural, σ)
+        x = vcat(p_neural, σ); m = zero(x); v = zero(x)
+        for t in 1:5
+            set_params!(c, x[1:end-1], p_individuals)
+            mean_sse, g_nn, _ = loss_grad(c)
+            s = x[end]
+            g = vcat(g_nn .* (N / (2 * s^2)), N * T / s - mean_sse * N / s^3)
+            m .= 0.9 .* m .+ 0.1 .* g; v .= 0.999 .* v .+ 0.001 .* g .^ 2
+            x .-= 1e-2 .* (m ./ (1 - 0.9^t)) ./ (sqrt.(v ./ (1 - 0.999^t)) .+ 1e-8)
+        end
+        σ = x[end]
+        p_neural = (1 - gamma) .* p_neural .+ gamma .* x[1:end-1]
+        Ω = (1 - Ω_learning_rate) * Ω + Ω_learning_rate * var(p_individuals)
+        prior_η = (1 - Ω_learning_rate) * prior_η + Ω_learning_rate * mean(p_individuals)
+        acceptance_rate = sum(accepted) / (N * steps)
+        push!(total_nll_values, -loglikelihood); push!(acceptance_rates, acceptance_rate)
+        if iteration > n_burnin_iterations
+            proposal_std = clamp(exp(log(proposal_std) + gamma * (acceptance_rate - target_acceptance_rate)),
+                                 proposal_std_bounds[1], proposal_std_bounds[2])
+        end
+    end
+    (p_neural = p_neural, p_individuals = p_individuals, Ω = Ω, σ = σ, η = prior_η,
+     total_nll_values = total_nll_values, acceptance_rates = acceptance_rates)
+end
+
+end # module
