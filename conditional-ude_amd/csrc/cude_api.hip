@@ -1005,6 +1005,80 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
     return CUDE_OK;
 }
 
+int32_t cude_screen_candidates(cude_ctx* c, int64_t n_candidates, int32_t n_keep, cude_candidate_fn gen, void* user,
+                               int64_t* index_out, double* loss_out, double* nn_out, double* cond_out) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (n_candidates < 1 || n_keep < 1 || n_keep > 4096 || !gen || !index_out || !loss_out || !nn_out || !cond_out)
+        return fail(CUDE_ERR_ARG, "bad argument (1 <= n_keep <= 4096)");
+    if (n_keep > n_candidates) n_keep = (int32_t)n_candidates;
+    const int P = c->P;
+    const int64_t N = c->N, nb = c->nblocks;
+    // candidates per launch: the grid's y dimension and ~256 MB of partial rows; the host holds ONE chunk at a time
+    int64_t chunk = std::min<int64_t>(n_candidates, 32768);
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, (int64_t)(256e6 / ((double)nb * (P + 2) * 8.0))));
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, (int64_t)(512e6 / ((double)(P + N) * 8.0))));
+    DevBuf<double> d_nn, d_cond, d_part, d_sums, d_loss, d_work, b_loss[2], b_nn[2], b_cond[2];
+    DevBuf<long long> b_idx[2];
+    DevBuf<int> d_sel;
+    HIP_TRY(d_nn.resize((size_t)chunk * P));
+    HIP_TRY(d_cond.resize((size_t)chunk * N));
+    HIP_TRY(d_part.resize((size_t)chunk * nb * (P + 2)));
+    HIP_TRY(d_sums.resize((size_t)chunk * 2));
+    HIP_TRY(d_loss.resize((size_t)chunk));
+    HIP_TRY(d_work.resize((size_t)chunk + n_keep));
+    HIP_TRY(d_sel.resize((size_t)n_keep));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(b_loss[b].resize(n_keep));
+        HIP_TRY(b_idx[b].resize(n_keep));
+        HIP_TRY(b_nn[b].resize((size_t)n_keep * P));
+        HIP_TRY(b_cond[b].resize((size_t)n_keep * N));
+    }
+    std::vector<double> h_nn((size_t)chunk * P), h_cond((size_t)chunk * N);
+    int have = 0, cur = 0;
+    for (int64_t k0 = 0; k0 < n_candidates; k0 += chunk) {
+        const int64_t kn = std::min<int64_t>(chunk, n_candidates - k0);
+        if (gen(k0, (int32_t)kn, h_nn.data(), h_cond.data(), user) < 0)
+            return fail(CUDE_ERR_ARG, "candidate generator reported an error");
+        HIP_TRY(hipMemcpyAsync(d_nn.p, h_nn.data(), kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_cond.p, h_cond.data(), kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (is_cpep(c)) {
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = d_cond.p; a.nn = d_nn.p;
+            a.partials = d_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
+        } else {
+            cude::SuppArgs a = supp_args(c);
+            a.cond = d_cond.p; a.nn = d_nn.p;
+            a.partials = d_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
+        }
+        HIP_TRY(cude::launch_reduce_sets(d_part.p, (int)kn, nb, P + 2, P, d_sums.p, c->stream));
+        if (c->comm && (rc = allreduce_dev(c, d_sums.p, (size_t)kn * 2))) return rc;
+        HIP_TRY(cude::launch_set_losses((int)kn, d_sums.p, d_nn.p, P, c->cfg.lambda, c->n_global, d_loss.p, c->stream));
+        cude::TopkArgs t{};
+        t.n_keep = n_keep; t.n_have = have; t.n_new = (int)kn; t.first = k0;
+        t.best_loss = b_loss[cur].p; t.best_idx = b_idx[cur].p; t.chunk_loss = d_loss.p; t.work = d_work.p;
+        t.new_loss = b_loss[1 - cur].p; t.new_idx = b_idx[1 - cur].p; t.sel_src = d_sel.p;
+        HIP_TRY(cude::launch_topk_merge(t, P, N, b_nn[cur].p, b_cond[cur].p, d_nn.p, d_cond.p, b_nn[1 - cur].p,
+                                        b_cond[1 - cur].p, c->stream));
+        have = (int)std::min<int64_t>(n_keep, have + kn);
+        cur = 1 - cur;
+        HIP_TRY(hipStreamSynchronize(c->stream));            // the host chunk buffers are refilled by the next gen()
+    }
+    std::vector<long long> idx(n_keep);
+    HIP_TRY(hipMemcpyAsync(idx.data(), b_idx[cur].p, n_keep * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(loss_out, b_loss[cur].p, n_keep * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(nn_out, b_nn[cur].p, (size_t)n_keep * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(cond_out, b_cond[cur].p, (size_t)n_keep * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < n_keep; r++) index_out[r] = idx[r];
+    return CUDE_OK;
+}
+
 int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                                   double* losses, double* g_nn_sets, double* g_cond_sets) {
     int32_t rc = bind(c);

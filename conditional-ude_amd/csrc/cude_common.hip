@@ -5,6 +5,8 @@
 //   van_cauter_parameters     src/c-peptide-models.jl:30-42 (dup src/saem.jl:7-21)
 //   Optimisers.Adam update    used at src/parameter-estimation.jl:176, suppression_model.jl:164, saem.jl:128
 //   lambda*sum(abs2, neural)  suppression/src/suppression_model.jl:128
+#include <algorithm>
+
 #include "cude_device.h"
 #include "cude_kernels.h"
 
@@ -86,6 +88,98 @@ __global__ __launch_bounds__(64) void reduce_sets_kernel(const double* __restric
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s) {
     hipLaunchKernelGGL(reduce_sets_kernel, dim3(n_sets), dim3(64), 0, s, partials, nblocks, stride, col0, out);
+    return hipGetLastError();
+}
+
+// ---- screening (first phase of `train`, src/parameter-estimation.jl:359-372): candidate losses and a running
+// top-k on the device.
+// loss[k] = sum_k / n_global + lambda * |nn_k|^2, +Inf for a set with a failed subject (the reference's convention)
+__global__ void set_losses_kernel(int n_sets, const double* __restrict__ sums, const double* __restrict__ nn, int P,
+                                  double lambda, double n_global, double* __restrict__ loss) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_sets) return;
+    double reg = 0.0;
+    if (lambda != 0.0)
+        for (int q = 0; q < P; q++) reg = fma(nn[(int64_t)k * P + q], nn[(int64_t)k * P + q], reg);
+    const double sum = sums[2 * k], nf = sums[2 * k + 1];
+    const bool bad = nf > 0.0 || !(fabs(sum) <= 1.79769313486231570815e308);
+    loss[k] = bad ? __builtin_inf() : fma(lambda, reg, sum / n_global);
+}
+
+hipError_t launch_set_losses(int n_sets, const double* sums, const double* nn, int P, double lambda, double n_global,
+                             double* loss, hipStream_t s) {
+    hipLaunchKernelGGL(set_losses_kernel, dim3((n_sets + 255) / 256), dim3(256), 0, s, n_sets, sums, nn, P, lambda,
+                       n_global, loss);
+    return hipGetLastError();
+}
+
+// `partialsortperm(losses, 1:n_keep)` as a running merge: the n_keep smallest of {current best (n_have)} U {this chunk
+// (n_new)} by (loss, global index) -- n_keep passes of a block-wide arg-min over the union (n_keep is a few dozen).
+// Union entry u < n_have is best slot u, otherwise chunk row u - n_have with global index first + (u - n_have).
+// work[n_have + n_new] is scratch; sel_src[r] receives the union entry chosen for rank r.
+__global__ __launch_bounds__(1024) void topk_merge_kernel(TopkArgs a) {
+    __shared__ double s_v[1024];
+    __shared__ long long s_i[1024];
+    __shared__ int s_u[1024];
+    const int tid = threadIdx.x, M = a.n_have + a.n_new;
+    for (int u = tid; u < M; u += 1024) a.work[u] = u < a.n_have ? a.best_loss[u] : a.chunk_loss[u - a.n_have];
+    __syncthreads();
+    const int n_out = M < a.n_keep ? M : a.n_keep;
+    for (int r = 0; r < n_out; r++) {
+        double bv = __builtin_inf();
+        long long bi = 0x7fffffffffffffffLL;
+        int bu = -1;
+        for (int u = tid; u < M; u += 1024) {
+            const double v = a.work[u];
+            if (v != v) continue;                                   // taken
+            const long long gi = u < a.n_have ? a.best_idx[u] : a.first + (u - a.n_have);
+            if (v < bv || (v == bv && gi < bi)) { bv = v; bi = gi; bu = u; }
+        }
+        s_v[tid] = bv; s_i[tid] = bi; s_u[tid] = bu;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {
+            if (tid < off) {
+                const bool take = s_u[tid + off] >= 0 &&
+                                  (s_u[tid] < 0 || s_v[tid + off] < s_v[tid] ||
+                                   (s_v[tid + off] == s_v[tid] && s_i[tid + off] < s_i[tid]));
+                if (take) { s_v[tid] = s_v[tid + off]; s_i[tid] = s_i[tid + off]; s_u[tid] = s_u[tid + off]; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.new_loss[r] = s_v[0];
+            a.new_idx[r] = s_i[0];
+            a.sel_src[r] = s_u[0];
+            a.work[s_u[0]] = __builtin_nan("");
+        }
+        __syncthreads();
+    }
+}
+
+// new_nn[r] / new_cond[r] <- the parameter set chosen for rank r (from the previous best buffers or from the chunk)
+__global__ void topk_gather_kernel(TopkArgs a, int n_out, int P, int64_t N, const double* __restrict__ old_nn,
+                                   const double* __restrict__ old_cond, const double* __restrict__ chunk_nn,
+                                   const double* __restrict__ chunk_cond, double* __restrict__ new_nn,
+                                   double* __restrict__ new_cond) {
+    const int r = blockIdx.y;
+    if (r >= n_out) return;
+    const int u = a.sel_src[r];
+    const double* snn = u < a.n_have ? old_nn + (int64_t)u * P : chunk_nn + (int64_t)(u - a.n_have) * P;
+    const double* scd = u < a.n_have ? old_cond + (int64_t)u * N : chunk_cond + (int64_t)(u - a.n_have) * N;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < P + N; q += (int64_t)gridDim.x * blockDim.x) {
+        if (q < P) new_nn[(int64_t)r * P + q] = snn[q];
+        else new_cond[(int64_t)r * N + (q - P)] = scd[q - P];
+    }
+}
+
+hipError_t launch_topk_merge(const TopkArgs& a, int P, int64_t N, const double* old_nn, const double* old_cond,
+                             const double* chunk_nn, const double* chunk_cond, double* new_nn, double* new_cond,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(1024), 0, s, a);
+    const int M = a.n_have + a.n_new, n_out = M < a.n_keep ? M : a.n_keep;
+    const unsigned gx = (unsigned)std::min<int64_t>(64, (P + N + 255) / 256);
+    hipLaunchKernelGGL(topk_gather_kernel, dim3(gx, n_out), dim3(256), 0, s, a, n_out, P, N, old_nn, old_cond, chunk_nn,
+                       chunk_cond, new_nn, new_cond);
     return hipGetLastError();
 }
 

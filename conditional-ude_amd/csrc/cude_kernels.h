@@ -122,6 +122,20 @@ hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int strid
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s);
+// screening: per-set losses and the running top-k of `partialsortperm(losses, 1:n_keep)`
+hipError_t launch_set_losses(int n_sets, const double* sums, const double* nn, int P, double lambda, double n_global,
+                             double* loss, hipStream_t s);
+struct TopkArgs {
+    int n_keep, n_have, n_new;
+    long long first;                 // global index of the chunk's first candidate
+    const double* best_loss; const long long* best_idx;     // [n_have]
+    const double* chunk_loss;                                // [n_new]
+    double* work;                                            // [n_have + n_new]
+    double* new_loss; long long* new_idx; int* sel_src;      // [n_keep]
+};
+hipError_t launch_topk_merge(const TopkArgs& a, int P, int64_t N, const double* old_nn, const double* old_cond,
+                             const double* chunk_nn, const double* chunk_cond, double* new_nn, double* new_cond,
+                             hipStream_t s);
 // g_nn[q] += 2*lambda*nn[q];  out[P] += lambda*sum(nn^2)*n_global   (so that loss = out[P]/n_global)
 hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s);
 struct AdamArgs {

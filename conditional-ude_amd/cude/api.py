@@ -339,6 +339,32 @@ def initial_parameters(*args, rng=None):
     return lb + (ub - lb) * u
 
 
+class _LatinHypercube:
+    """QuasiMonteCarlo.LatinHypercubeSample(n_models x n_initials) generated column block by column block: the
+    stratum permutations (int32) are drawn once, the jitter per block, so the (n_models x n_initials) sample itself
+    is never held (above 2^28 entries even the permutations are dropped for independent uniform draws)."""
+
+    def __init__(self, n_models, n, rng):
+        self.n_models, self.n, self.rng = n_models, n, rng
+        self.perm = rng.permuted(np.tile(np.arange(n, dtype=np.int32), (n_models, 1)), axis=1) \
+            if n_models * n <= 2 ** 28 else None
+
+    def columns(self, first, count):
+        """(n_models, count) block of the unit-cube sample."""
+        u = self.rng.random((self.n_models, count))
+        return u if self.perm is None else (self.perm[:, first:first + count] + u) / self.n
+
+
+class _Columns:
+    """ode_inits[:, k] of the selected candidates only (the full table no longer exists)."""
+
+    def __init__(self, cols):
+        self.cols = cols
+
+    def __getitem__(self, key):
+        return self.cols[key[1]]
+
+
 # ----------------------------------------------------------------------------- training drivers
 def _adam_then_lbfgs(eng, nn0, cond0, adam_iters, lbfgs_iters, lr, callback=None):
     eng.set_params(nn0, cond0)
@@ -429,14 +455,20 @@ def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_00
         rng = rng_or_nn
         pop = _population(models, timepoints, cpeptide_data, n_steps)
         eng, N = pop.engine, pop.N
-        nn_inits = initial_parameters(models[0].chain, initial_guesses, rng=rng)
-        ode_inits = initial_parameters(N, lhs_lower_bound, lhs_upper_bound, initial_guesses, rng)
-        # screening (:362-366): all candidates in one multi-start launch
-        losses = eng.multistart_forward(np.stack(nn_inits), np.ascontiguousarray(ode_inits.T))
-        order = np.argsort(losses, kind="stable")[:selected_initials]
+        # screening (:351-372): candidates are generated chunk by chunk and never held all at once; the losses and the
+        # selection `partialsortperm(losses_initial, 1:selected_initials)` stay on the device (cude_screen_candidates)
+        strata = _LatinHypercube(N, initial_guesses, rng)
+        net = models[0].chain
+
+        def candidates(first, count):
+            nn = np.stack([init_params(net, rng) for _ in range(count)])
+            return nn, lhs_lower_bound + (lhs_upper_bound - lhs_lower_bound) * strata.columns(first, count).T
+        order, _, nn_sel, cond_sel = eng.screen_candidates(initial_guesses, selected_initials, candidates)
+        nn_inits = dict(zip(order, nn_sel))
+        ode_inits = _Columns(dict(zip(order, cond_sel)))
         sols = []
         if side_by_side and len(order) > 1:
-            fits = _batched_adam_then_lbfgs(eng, np.stack([nn_inits[k] for k in order]), ode_inits[:, order].T,
+            fits = _batched_adam_then_lbfgs(eng, nn_sel, cond_sel,
                                             number_of_iterations_adam, number_of_iterations_lbfgs, learning_rate_adam)
             for fit in fits:
                 if fit is None:

@@ -45,6 +45,7 @@ def lbfgs_minimize(fg, x0, maxiters=1000):
     return dict(x=x, f=f.value, iterations=it.value, f_calls=calls.value, converged=bool(conv.value))
 
 
+_CANDIDATES = C.CFUNCTYPE(C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 _REDUCE = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p)
 
 
@@ -194,6 +195,30 @@ class Engine:
         losses = np.empty(nn.shape[0])
         check(self._lib.cude_multistart_forward(self._h, nn.shape[0], _ptr(nn), _ptr(cd), _ptr(losses)))
         return losses
+
+    def screen_candidates(self, n_candidates, n_keep, gen):
+        """Screening with the selection on the device: gen(first, count) -> (nn (count, P), cond (count, N)) is asked
+        for one chunk at a time; returns (indices, losses, nn (n_keep, P), cond (n_keep, N)) of the n_keep best
+        candidates in increasing order of loss (ties: lower index first, as partialsortperm)."""
+        P, N = self.P, self.N
+
+        def thunk(first, count, nn_p, cond_p, _user):
+            try:
+                nn, cond = gen(int(first), int(count))
+                np.ctypeslib.as_array(nn_p, shape=(count, P))[:] = nn
+                np.ctypeslib.as_array(cond_p, shape=(count, N))[:] = cond
+                return 0
+            except Exception:      # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+        cb = _CANDIDATES(thunk)
+        n_keep = min(int(n_keep), int(n_candidates))
+        idx, loss = np.empty(n_keep, dtype=np.int64), np.empty(n_keep)
+        nn_out, cond_out = np.empty((n_keep, P)), np.empty((n_keep, N))
+        check(self._lib.cude_screen_candidates(self._h, int(n_candidates), n_keep, C.cast(cb, C.c_void_p), None,
+                                               _ptr(idx), _ptr(loss), _ptr(nn_out), _ptr(cond_out)))
+        return idx, loss, nn_out, cond_out
 
     def multistart_loss_grad(self, nn_sets, cond_sets):
         """Loss and gradient of K parameter sets in one launch (restarts trained side by side).

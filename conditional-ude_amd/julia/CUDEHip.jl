@@ -133,6 +133,23 @@ function multistart_forward(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{
     losses
 end
 
+# screening with the selection on the device: gen!(nn P×count, cond N×count, first) fills one chunk of candidates
+# (first is 0-based); returns (indices (1-based), losses, neural P×n_keep, conditional N×n_keep) of the best n_keep
+function screen_candidates(c::Ctx, gen!, n_candidates::Integer, n_keep::Integer)
+    P, N = c.P, c.N
+    function thunk(first::Int64, count::Int32, nnp::Ptr{Float64}, cp::Ptr{Float64}, ::Ptr{Cvoid})::Int32
+        gen!(unsafe_wrap(Array, nnp, (P, Int(count))), unsafe_wrap(Array, cp, (N, Int(count))), first); Int32(0)
+    end
+    cb = @cfunction($thunk, Int32, (Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
+    k = min(n_keep, n_candidates)
+    idx = Vector{Int64}(undef, k); losses = Vector{Float64}(undef, k)
+    nn = Matrix{Float64}(undef, P, k); cond = Matrix{Float64}(undef, N, k)
+    GC.@preserve cb idx losses nn cond check(ccall((:cude_screen_candidates, LIB), Int32,
+        (Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, n_candidates, k, cb, C_NULL, idx, losses, nn, cond))
+    idx .+ 1, losses, nn, cond
+end
+
 function multistart_loss_grad(c::Ctx, nn_sets::Matrix{Float64}, cond_sets::Matrix{Float64})
     K = size(nn_sets, 2)
     losses = Vector{Float64}(undef, K); g_nn = similar(nn_sets); g_cond = similar(cond_sets)

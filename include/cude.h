@@ -132,6 +132,18 @@ int32_t cude_simulate(cude_ctx* ctx, int32_t n_times, const double* times, doubl
 int32_t cude_multistart_forward(cude_ctx* ctx, int32_t n_sets, const double* nn_sets, const double* cond_sets,
                                 double* losses);
 
+/* The whole screening phase with the selection on the device: `losses_initial = [loss(p, ...) for p in initials]` followed
+ * by `partialsortperm(losses_initial, 1:selected_initials)` (src/parameter-estimation.jl:359-372; suppression_model.jl:
+ * 135-145; c-peptide/06-saem.jl:41-45).  Candidates are STREAMED: `gen` is asked for one chunk at a time (candidates
+ * first ... first+count-1 as rows nn_sets[count][P], cond_sets[count][N]; return < 0 to abort), so the host never holds
+ * the 25 000 x (P + N) candidate table; each chunk is evaluated in one multi-start launch, its losses stay on the device
+ * and are merged into a running top-n_keep (ties broken by the lower candidate index, as partialsortperm does), whose
+ * parameter sets are kept on the device as well.  Out: index_out / loss_out [n_keep] in increasing order of loss, and
+ * the selected parameter sets nn_out[n_keep][P], cond_out[n_keep][N] -- ready for cude_train_restarts. */
+typedef int32_t (*cude_candidate_fn)(int64_t first, int32_t count, double* nn_sets, double* cond_sets, void* user);
+int32_t cude_screen_candidates(cude_ctx* ctx, int64_t n_candidates, int32_t n_keep, cude_candidate_fn gen, void* user,
+                               int64_t* index_out, double* loss_out, double* nn_out, double* cond_out);
+
 /* Restarts trained side by side: loss AND gradient of n_sets independent parameter sets over the resident
  * population in one launch (the grid's second dimension is the set).  The reference trains its selected
  * initial guesses one after the other (`for p in initials[selected] ... _optimize(...)`,

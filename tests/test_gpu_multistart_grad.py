@@ -104,3 +104,46 @@ def test_suppression_restarts_side_by_side():
         assert len(tr) >= 60 and tr[-1] <= tr[0] and np.isfinite(s.objective)
         assert abs(api.suppression_loss(s.u, (prob, c["data"], c["tp"], 0.0)) - s.objective) <= 1e-10 * s.objective
     api.clear_cache()
+
+
+def test_device_screening_keeps_the_best_candidates_across_chunks():
+    """cude_screen_candidates = `losses_initial = [loss(p, ...) for p in initials]` + `partialsortperm(losses_initial,
+    1:selected_initials)` (src/parameter-estimation.jl:359-372) with candidates streamed chunk by chunk and the running
+    top-k kept on the device: must equal the losses of cude_multistart_forward sorted stably -- across chunk boundaries
+    (70 000 candidates = 3 chunks), with ties (duplicated candidates: the lower index wins) and failed candidates."""
+    import torch  # noqa: F401
+    from cude.engine import Engine
+    arch = (2, 4, 2)
+    c = make_cpep_case(19, arch)
+    K, keep = 70_000, 25
+    eng = Engine("cpep", arch, n_steps=12, n_state=2)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+
+    def block(first, count):
+        rng = np.random.default_rng(first)                      # deterministic per block, whatever the chunking
+        nn = c["nn"][None, :] * (1 + 0.5 * rng.standard_normal((count, c["nn"].size)))
+        cond = c["beta"][None, :] + rng.standard_normal((count, 19))
+        return nn, cond
+    B = 10_000
+    table = [block(f, B) for f in range(0, K, B)]
+    nn_all, cond_all = np.concatenate([t[0] for t in table]), np.concatenate([t[1] for t in table])
+    nn_all[40_001], cond_all[40_001] = nn_all[7], cond_all[7]    # a tie across chunks
+    nn_all[123, 3] = np.nan                                      # a failed candidate
+    calls = []
+
+    def gen(first, count):
+        calls.append((first, count))
+        return nn_all[first:first + count], cond_all[first:first + count]
+    idx, loss, nn_sel, cond_sel = eng.screen_candidates(K, keep, gen)
+    assert len(calls) >= 3 and sum(n for _, n in calls) == K and max(n for _, n in calls) < K
+    ref = np.concatenate([eng.multistart_forward(nn_all[f:f + B], cond_all[f:f + B]) for f in range(0, K, B)])
+    assert np.isinf(ref[123])
+    order = np.argsort(ref, kind="stable")[:keep]
+    assert np.array_equal(idx, order) and np.array_equal(loss, ref[order])
+    assert np.array_equal(nn_sel, nn_all[order]) and np.array_equal(cond_sel, cond_all[order])
+    if 7 in order:
+        assert list(order).index(7) + 1 == list(order).index(40_001)
+    # fewer candidates than requested
+    idx2, loss2, _, _ = eng.screen_candidates(10, 25, lambda f, n: (nn_all[f:f + n], cond_all[f:f + n]))
+    assert np.array_equal(idx2, np.argsort(ref[:10], kind="stable")) and loss2.size == 10
+    eng.close()

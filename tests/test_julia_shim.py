@@ -33,7 +33,7 @@ def _c_kind(decl):
         "double", "int32_t", "int64_t", "uint8_t", "void", "cude_ctx", "cude_config", "char") else " ".join(parts)
     if stars:
         return ("ptr", base + "*" * (stars - 1))
-    if base in ("cude_objective_fn", "cude_reduce_fn"):
+    if re.fullmatch(r"cude_\w+_fn", base):                   # callback typedefs are function pointers
         return ("ptr", "fn")
     return {"int32_t": "i32", "int64_t": "i64", "double": "f64"}[base]
 
