@@ -330,7 +330,9 @@ def test_size_limits_and_missing_values():
     with pytest.raises(CudeError):
         Engine("cpep_sym", (1, 4, 2))                  # the symbolic model has no network
     with pytest.raises(CudeError):
-        Engine("cpep", (2, 6, 2), n_steps=0)
+        Engine("cpep", (2, 6, 2), n_steps=-1)
+    with pytest.raises(CudeError):
+        Engine("cpep", (2, 6, 2), n_steps=0, n_state=3)     # n_steps = 0 is the adaptive mode: 2-state model only
 
 
 def test_argument_errors_are_statuses():
