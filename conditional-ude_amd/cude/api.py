@@ -108,13 +108,17 @@ def neural_network_model(depth, width, *, input_dims=2):
 
 
 def init_params(net, rng=None):
-    """SimpleChains.init_params restated: Glorot-normal weights, zero biases, SimpleChains layout."""
+    """SimpleChains.init_params restated.  A `TurboDense{true}` layer keeps weights and bias in ONE out x (in + 1)
+    matrix [W b] and initialises all of it Glorot-normal, sigma = sqrt(2 / (out + in + 1)) -- the biases are random
+    too.  (SimpleChains is third-party; this reading is the one under which the reference's suppression experiment
+    is reproduced in distribution -- with zero biases 4 ... 9 of the 25 kept runs stall on the constant-production
+    plateau above 0.7, which none of the reference's 125 stored runs does: profiles/r02/e2e_suppression.txt.)"""
     rng = np.random.default_rng() if rng is None else rng
     parts, fan = [], net.input_dims
-    for _ in range(net.depth):
-        parts += [rng.standard_normal(net.width * fan) * math.sqrt(2.0 / (fan + net.width)), np.zeros(net.width)]
-        fan = net.width
-    parts += [rng.standard_normal(fan) * math.sqrt(2.0 / (fan + 1)), np.zeros(1)]
+    for out in [net.width] * net.depth + [1]:
+        sigma = math.sqrt(2.0 / (out + fan + 1))
+        parts += [rng.standard_normal(out * fan) * sigma, rng.standard_normal(out) * sigma]
+        fan = out
     return np.concatenate(parts)
 
 

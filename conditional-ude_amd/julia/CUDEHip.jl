@@ -326,13 +326,12 @@ chain(width::Integer, depth::Integer, activation = tanh; input_dims::Integer = 2
 neural_network_model(depth::Integer, width::Integer; input_dims::Integer = 2) = Chain(input_dims, width, depth)
 n_params(c::Chain) = Int(ccall((:cude_n_params, LIB), Int32, (Int32, Int32, Int32), c.input_dims, c.width, c.depth))
 
-# SimpleChains.init_params restated (Glorot-normal weights, zero biases, [vec(W); b] per layer)
+# SimpleChains.init_params restated: a TurboDense{true} layer is ONE out × (in + 1) matrix [W b], all of it Glorot-normal
 function init_params(c::Chain; rng::AbstractRNG)
     p = Float64[]; fan = c.input_dims
-    for _ in 1:c.depth
-        append!(p, randn(rng, c.width * fan) .* sqrt(2 / (fan + c.width))); append!(p, zeros(c.width)); fan = c.width
+    for out in vcat(fill(c.width, c.depth), 1)
+        append!(p, randn(rng, out * (fan + 1)) .* sqrt(2 / (out + fan + 1))); fan = out
     end
-    append!(p, randn(rng, fan) .* sqrt(2 / (fan + 1))); push!(p, 0.0)
     p
 end
 
