@@ -287,8 +287,16 @@ cude::CpepArgs cpep_args(const cude_ctx* c) {
     return a;
 }
 
+// CUDE_SUPP_CKPT=steps: gradient launches of the suppression model keep only the step states (744 B per subject at
+// S = 30) and re-run the stages in the reverse sweep, instead of keeping every stage input (4.3 KB per subject)
+bool supp_steps_only() {
+    const char* env = getenv("CUDE_SUPP_CKPT");
+    return env && std::strcmp(env, "steps") == 0;
+}
+
 cude::SuppArgs supp_args(const cude_ctx* c) {
     cude::SuppArgs a{};
+    a.ckpt_steps_only = supp_steps_only() ? 1 : 0;
     a.N = c->N;
     a.data = c->data.p;
     a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
@@ -539,7 +547,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
         a.ckpt = c->ckpt.p; a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev;
         // allocated by cude_set_population_supp (never here: this function also runs under stream capture)
-        if (grad && c->act.p && c->act.n >= supp_act_doubles(c)) a.act = c->act.p;
+        if (grad && !a.ckpt_steps_only && c->act.p && c->act.n >= supp_act_doubles(c)) a.act = c->act.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         HIP_TRY(cude::launch_supp(c->net, grad, a, c->stream));
     }
@@ -1115,7 +1123,7 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
             cude::SuppArgs a = supp_args(c);
             a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
             a.ckpt = c->ms_ckpt.p; a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
-            if (supp_keep_activations(c, kn)) {
+            if (!a.ckpt_steps_only && supp_keep_activations(c, kn)) {
                 HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
                 a.act = c->ms_act.p;
             }

@@ -332,19 +332,8 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
             Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy, tab, &E1);
         }
 
-        double g[P + 2];
-        double dcond;
-        {
-            double gp[P];
-            Net::expand(p, acc, cst, gp, &dcond);
-            const double keep = active ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < P; q++) g[q] = gp[q] * keep;
-        }
-        g[P] = red_loss;
-        g[P + 1] = red_fail;
-        if (active) a.g_cond[set * a.set_stride_cond + i] = dcond;
-        block_reduce_store<P + 2>(g, s_red, out, lane);
+        if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(p, acc, cst);
+        block_reduce_expand<Net, NC>(acc, cst, active ? 1.0 : 0.0, red_loss, red_fail, s_red, out, lane);
 #ifdef CUDE_WAVE_TIMING
         if (a.dbg != nullptr && lane == 0 && blockIdx.y == 0) {
             long long* d = a.dbg + 4 * (long long)blockIdx.x;

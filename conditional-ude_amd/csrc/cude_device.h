@@ -340,6 +340,29 @@ struct Mlp {
         }
     }
 
+    // Entry q of the gradient in the SimpleChains parameter order, read off the accumulators (q is a compile-time
+    // constant wherever this is called from an unrolled loop, so it folds to one register or one multiply).
+    __device__ static __forceinline__ double grad_elem(int q, const double (&acc)[NACC],
+                                                       const double (&cst)[NC > 0 ? NC : 1]) {
+        if (q < W * NIN) {
+            const int j = q % W, i = q / W;
+            return i < NV ? acc[G_W1V + i * W + j] : acc[G_C + j] * cst[i - NV < NC ? i - NV : 0];
+        }
+        if (q < L1) return acc[G_C + (q - W * NIN)];
+        return acc[G_H + (q - L1)];
+    }
+    // d/d(conditional) through cst[0] = exp(conditional):  cst0 * sum_j dc_j * W1[j,NV]
+    __device__ static __forceinline__ double grad_cond(cptr_t p, const double (&acc)[NACC],
+                                                       const double (&cst)[NC > 0 ? NC : 1]) {
+        double s = 0.0;
+        if (NC > 0) {
+#pragma unroll
+            for (int j = 0; j < W; j++) s = fma(acc[G_C + j], p[j + W * NV], s);
+            s *= cst[0];
+        }
+        return s;
+    }
+
     // Expand the accumulators into the SimpleChains parameter order; also d/d(conditional) through
     // cst[0] = exp(conditional):  dcond = cst0 * sum_j dc_j * W1[j,NV].
     __device__ static __forceinline__ void expand(cptr_t p, const double (&acc)[NACC],
@@ -406,6 +429,10 @@ struct MmProd {
         g[0] = acc[0];
         *dcond = RAW ? acc[1] : acc[1] * cst[0];
     }
+    __device__ static __forceinline__ double grad_elem(int, const double (&acc)[NACC], const double (&)[1]) { return acc[0]; }
+    __device__ static __forceinline__ double grad_cond(cptr_t, const double (&acc)[NACC], const double (&cst)[1]) {
+        return RAW ? acc[1] : acc[1] * cst[0];
+    }
 };
 
 // ------------------------------------------------------------------------------------ reductions
@@ -428,6 +455,34 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], double
 #pragma unroll 8
             for (int l = 0; l < kBlockLanes; l++) acc += s_red[lane * kBlockLanes + ((l + lane) & (kBlockLanes - 1))];
             out[c0 + lane] = acc;
+        }
+    }
+}
+
+// The same reduction for a gradient that is still in accumulator form: rows are expanded kRedRows at a time straight
+// into the LDS transpose, so the P-vector never exists in registers next to the accumulators (the epilogue used to be
+// the register peak of the gradient kernels: 336 VGPRs = one wave per SIMD for the suppression model).
+// out[0..P) = sum over lanes of keep * grad_elem(q); out[P], out[P+1] = sum of extra0, extra1.
+template <class Net, int NCST>
+__device__ __forceinline__ void block_reduce_expand(const double (&acc)[Net::NACC], const double (&cst)[NCST], double keep,
+                                                    double extra0, double extra1, double* s_red, double* out, int lane) {
+    constexpr int NV = Net::P + 2;
+#pragma unroll
+    for (int c0 = 0; c0 < NV; c0 += kRedRows) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRedRows; r++) {
+            const int q = c0 + r;
+            if (q < Net::P) s_red[r * kBlockLanes + lane] = Net::grad_elem(q, acc, cst) * keep;
+            else if (q == Net::P) s_red[r * kBlockLanes + lane] = extra0;
+            else if (q == Net::P + 1) s_red[r * kBlockLanes + lane] = extra1;
+        }
+        __syncthreads();
+        if (lane < kRedRows && c0 + lane < NV) {
+            double a = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < kBlockLanes; l++) a += s_red[lane * kBlockLanes + ((l + lane) & (kBlockLanes - 1))];
+            out[c0 + lane] = a;
         }
     }
 }

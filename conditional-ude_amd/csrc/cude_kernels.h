@@ -94,6 +94,7 @@ struct SuppArgs {
     double iscale2[3];       // 1/scale_s^2
     double* ckpt;            // [n_sets][6S+1][3][N] stage inputs (linearisation points of the reverse sweep)
     double* act;             // [n_sets][6S+1][D*W+1][N] kept network activations, or nullptr = recompute them
+    int32_t ckpt_steps_only; // 1: ckpt holds only the step states [S+1][3][N]; the reverse sweep re-runs the stages
     double* sse;             // [N] or nullptr (already divided by scale^2)
     double* traj;            // [3 x T x N] column-major or nullptr
     double* g_cond;          // [n_sets][N]

@@ -65,7 +65,10 @@ constexpr int kSuppRowsFixed = 42;
 // re-evaluating the network: 2/3 of the reverse sweep's instructions for 8*(D*W+1) bytes per evaluation and subject.
 // Pays when the launch is latency-bound (few waves, e.g. the reference's 37 subjects); the host enables it when the
 // buffer is small.
-template <int W, int D, bool GRAD, bool STORE>
+// YONLY (gradient only, SuppArgs::ckpt_steps_only): the forward sweep keeps only the step states y_0 ... y_S (744 B per
+// subject at S = 30 instead of 4.3 KB of stage inputs) and the reverse sweep re-runs the six stage evaluations of the
+// step it is reversing: the low-traffic / high-arithmetic end of the trade (profiles/r02/supp_scratch_tradeoff.txt).
+template <int W, int D, bool GRAD, bool STORE, bool YONLY>
 __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     using R = SuppRhs<W, D>;
     using Net = typename R::Net;
@@ -124,9 +127,13 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
 #pragma unroll
             for (int s = 0; s < 3; s++) u[s] = fma(h, t[s], y[s]);
         }
-        if (GRAD) {      // linearisation point of evaluation e = 6n+st, reloaded by the reverse sweep
+        if (GRAD && !YONLY) {      // linearisation point of evaluation e = 6n+st, reloaded by the reverse sweep
 #pragma unroll
             for (int s = 0; s < 3; s++) ckpt[((int64_t)e * 3 + s) * N + i] = u[s];
+        }
+        if (GRAD && YONLY && (e == 0 || st == 6)) {     // step states only: y_0, then y_{n+1} at the end of step n
+#pragma unroll
+            for (int s = 0; s < 3; s++) ckpt[((int64_t)(e == 0 ? 0 : n + 1) * 3 + s) * N + i] = u[s];
         }
         double du[3];
         if (STORE) {
@@ -195,6 +202,37 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
         // idx = 0 is k_1 of step 0 = f(y_0).
 #pragma unroll 1
         for (int idx = 6 * S; idx >= 0; idx--) {
+            if (YONLY && idx > 0 && st == 6) {
+                // ---- re-run stages 1..6 of step n from y_n: their inputs Y_0..Y_5 and Y_6 = y_{n+1} go to s_Y
+                double yn[3];
+#pragma unroll
+                for (int s = 0; s < 3; s++) yn[s] = ckpt[((int64_t)n * 3 + s) * N + i];
+#pragma unroll 1
+                for (int sq = 0; sq <= 6; sq++) {
+                    double uu[3];
+                    if (sq == 0) {
+#pragma unroll
+                        for (int s = 0; s < 3; s++) uu[s] = yn[s];
+                    } else {
+                        double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+                        for (int j = 0; j < sq; j++) {
+                            const double aj = TS_A[sq][j];
+#pragma unroll
+                            for (int s = 0; s < 3; s++) t[s] = fma(aj, KROW(j, s), t[s]);
+                        }
+#pragma unroll
+                        for (int s = 0; s < 3; s++) uu[s] = fma(h, t[s], yn[s]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 3; s++) YROW(sq, s) = uu[s];
+                    if (sq == 6) break;
+                    double dd[3];
+                    R::f(p, c, uu, dd);
+#pragma unroll
+                    for (int s = 0; s < 3; s++) KROW(sq, s) = dd[s];
+                }
+            }
             if (idx > 0 && st == 6) {
                 // ---- seed the stage adjoints (stored over the stage derivatives)
 #pragma unroll 1
@@ -224,7 +262,10 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
             double u[3], kb[3], ub[3];
             if (idx > 0) {
 #pragma unroll
-                for (int s = 0; s < 3; s++) { u[s] = ckpt[((int64_t)idx * 3 + s) * N + i]; kb[s] = KROW(st, s); }
+                for (int s = 0; s < 3; s++) {
+                    u[s] = YONLY ? YROW(st, s) : ckpt[((int64_t)idx * 3 + s) * N + i];
+                    kb[s] = KROW(st, s);
+                }
             } else {
 #pragma unroll
                 for (int s = 0; s < 3; s++) { u[s] = y0[s]; kb[s] = kap[s]; }
@@ -267,30 +308,20 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
                 n--;
             }
         }
-        double g[P + 2];
-        double dcond;
-        {
-            double gp[P];
-            Net::expand(p, acc, cst, gp, &dcond);
-            const double keep = active ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < P; q++) g[q] = gp[q] * keep;
-        }
-        g[P] = red_loss;
-        g[P + 1] = red_fail;
-        if (active) a.g_cond[set * a.set_stride_cond + i] = dcond;
-        block_reduce_store<P + 2>(g, s_red, out, lane);
+        __syncthreads();                   // s_red aliases s_Y, which the YONLY reverse sweep has just been reading
+        if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(p, acc, cst);
+        block_reduce_expand<Net, 1>(acc, cst, active ? 1.0 : 0.0, red_loss, red_fail, s_red, out, lane);
     }
 #undef KROW
 #undef YROW
 }
 
-template <int W, int D, bool GRAD, bool STORE>
+template <int W, int D, bool GRAD, bool STORE, bool YONLY = false>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(kSuppRowsFixed + (GRAD ? 3 * a.T : 0)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
-    hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE, YONLY>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
 
@@ -310,7 +341,8 @@ hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStr
 #define X(W, D)                                                                                   \
     if (net.width == W && net.depth == D)                                                         \
         return !grad ? launch_one<W, D, false, false>(a, s)                                       \
-                     : (a.act != nullptr ? launch_one<W, D, true, true>(a, s) : launch_one<W, D, true, false>(a, s));
+                     : (a.ckpt_steps_only ? launch_one<W, D, true, false, true>(a, s)             \
+                        : (a.act != nullptr ? launch_one<W, D, true, true>(a, s) : launch_one<W, D, true, false>(a, s)));
     CUDE_SUPP_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
