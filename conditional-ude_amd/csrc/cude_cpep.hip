@@ -82,6 +82,13 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     typename Net::Exps A, E1;
     int kind = 0;
     bool run_ok = false;                         // wave-uniform: the current run is inside the table's exact range
+#ifndef CUDE_NO_VW
+    constexpr bool kVW = GRAD && Net::HAS_VW;    // only where the reverse sweep already pays for the registers
+#else
+    constexpr bool kVW = false;
+#endif
+    typename Net::VW vw;
+    if constexpr (kVW) Net::load_vw(p, vw);
 #pragma unroll 1
     for (int e = -1; e < 5 * S; e++) {
         double xv = 0.0;
@@ -124,7 +131,9 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
             }
         }
         const double x[1] = {xv};
-        const double v = Net::eval(p, c, x, tab, &E1);
+        double v;
+        if constexpr (kVW) v = Net::eval_vw(p, vw, c, x, tab, &E1);
+        else v = Net::eval(p, c, x, tab, &E1);
         if (e < 0) { base = v; s = 0; continue; }
         s_q[s * kBlock + lane] = v - base;
         if (++s < 5) continue;

@@ -101,8 +101,14 @@ __device__ __forceinline__ SCol<W> ld_col(cptr_t p, int off) {
 #define CUDE_FENCE()
 #endif
 
+#ifndef CUDE_COLGROUP
+#define CUDE_COLGROUP 3       // three columns per scalar load + wait: -1 % (125 000 subjects) ... -1.7 % (1e6) on 2-6-6-1
+#endif
+
 template <int NIN, int W, int D, int NV>
 struct Mlp {
+    // weight columns fetched per scalar load (a column = W doubles); W must be a multiple of it
+    static constexpr int CG = (W % CUDE_COLGROUP == 0) ? CUDE_COLGROUP : 1;
     static constexpr int NC = NIN - NV;
     static constexpr int NCST = W;                  // per-subject constants kept in registers (first-layer offsets)
     // the conditional parameter enters the network as exp(beta) (src/c-peptide-models.jl:90)
@@ -223,11 +229,15 @@ struct Mlp {
                 for (int j = 0; j < W; j++) z[j] = b.v[j];
             }
 #pragma unroll
-            for (int i = 0; i < W; i++) {
+            for (int i0 = 0; i0 < W; i0 += CG) {               // CG weight columns per scalar load + wait
                 CUDE_FENCE();
-                const SCol<W> col = ld_col<W>(p, o + W * i);
+                constexpr int kG = CG;
+                const SCol<W * kG> col = ld_col<W * kG>(p, o + W * i0);
 #pragma unroll
-                for (int j = 0; j < W; j++) z[j] = fma(col.v[j], h[l - 1][i], z[j]);
+                for (int g = 0; g < kG; g++)
+#pragma unroll
+                    for (int j = 0; j < W; j++)
+                        if (i0 + g < W) z[j] = fma(col.v[g * W + j], h[l - 1][i0 + g], z[j]);
             }
             CUDE_FENCE();
             m_tanh_vec<W>(z, h[l]);
@@ -241,6 +251,62 @@ struct Mlp {
             else z0 = fma(wo.v[i], h[D - 1][i], z0);
         }
         return z0 + z1;
+    }
+
+    // ---- layers 2..D and the output layer with the weights RESIDENT IN VGPRS (forward sweep of the gradient kernel:
+    // its registers are sized by the reverse sweep's accumulators and sit idle during the forward sweep, so every lane
+    // can afford its own copy of the (D-1)(W*W+W)+W+1 upper-layer weights -- no scalar loads, no s_waitcnt, no SGPR
+    // pressure in the forward evaluations)
+    // Measured on MI355X (tools/abl_bench.py, 2-6-6-1): gradient launch 0.641 -> 0.614 ms at 125 000 subjects, 4.56 ->
+    // 4.30 ms at 1e6 (bit-identical results).  Enabled where it does not cost a resident wave: the 2-4-4-1 kernels sit
+    // at 151 VGPRs = 3 waves per SIMD and would drop to 2.
+    static constexpr int NVW = (D - 1) * LH + W + 1;
+    static constexpr bool HAS_VW = (NV == 1 && NVW <= 49 && (W >= 6 || D >= 3));
+    struct VW {
+        double w[NVW];
+    };
+    __device__ static __forceinline__ void load_vw(cptr_t p, VW& v) {
+#pragma unroll
+        for (int q = 0; q < NVW; q++) {
+            double t = p[L1 + q];
+            asm volatile("" : "+v"(t));              // pin the copy in a VGPR pair (no re-materialising scalar load)
+            v.w[q] = t;
+        }
+    }
+    __device__ static __forceinline__ double eval_vw(cptr_t p, const VW& v, const double (&c)[W], const double (&x)[NV],
+                                                     bool use_tab, const Exps* E1) {
+        double h[W], z[W];
+        if (use_tab) {
+            m_tanh_from_exp<W>(E1->v, h);
+        } else {
+            p = launder(p);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const SCol<W> col = ld_col<W>(p, W * i);
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
+            }
+            m_tanh_vec<W>(z, h);
+        }
+#pragma unroll
+        for (int l = 1; l < D; l++) {
+            const int o = (l - 1) * LH;
+#pragma unroll
+            for (int j = 0; j < W; j++) z[j] = v.w[o + W * W + j];
+#pragma unroll
+            for (int i = 0; i < W; i++)
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = fma(v.w[o + W * i + j], h[i], z[j]);
+            m_tanh_vec<W>(z, h);
+        }
+        constexpr int oo = (D - 1) * LH;
+        double z0 = v.w[oo + W], z1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (i & 1) z1 = fma(v.w[oo + i], h[i], z1);
+            else z0 = fma(v.w[oo + i], h[i], z0);
+        }
+        return act_softplus_val(z0 + z1);
     }
 
     // value only
@@ -302,17 +368,24 @@ struct Mlp {
                 acc[go + W * W + j] += d[j];
             }
 #pragma unroll
-            for (int i = 0; i < W; i++) {
+            for (int i0 = 0; i0 < W; i0 += CG) {
                 CUDE_FENCE();
-                const SCol<W> col = ld_col<W>(p, o + W * i);
-                double s0 = 0.0, s1 = 0.0;
+                constexpr int kG = CG;
+                const SCol<W * kG> col = ld_col<W * kG>(p, o + W * i0);
 #pragma unroll
-                for (int j = 0; j < W; j++) {
-                    acc[go + j + W * i] = fma(d[j], h[l - 1][i], acc[go + j + W * i]);
-                    if (j & 1) s1 = fma(col.v[j], d[j], s1);
-                    else s0 = fma(col.v[j], d[j], s0);
+                for (int g = 0; g < kG; g++) {
+                    const int i = i0 + g;
+                    if (i < W) {
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < W; j++) {
+                            acc[go + j + W * i] = fma(d[j], h[l - 1][i], acc[go + j + W * i]);
+                            if (j & 1) s1 = fma(col.v[g * W + j], d[j], s1);
+                            else s0 = fma(col.v[g * W + j], d[j], s0);
+                        }
+                        dh[i] = s0 + s1;
+                    }
                 }
-                dh[i] = s0 + s1;
             }
             CUDE_FENCE();
         }
@@ -398,6 +471,8 @@ struct MmProd {
     static constexpr int NC = 1, NCST = 1, P = 1;
     static constexpr int NACC = 2;                  // [d/dp0, d/dk]
     static constexpr bool HAS_TAB = false;          // one division per evaluation: nothing to tabulate
+    static constexpr bool HAS_VW = false;
+    struct VW {};
     struct Exps {
         double v[1];
     };
