@@ -292,6 +292,21 @@ def extras(Engine, device, steps=20, warm=40):
                                "value": n / dt, "unit": "subject-trajectories/s", "ms_per_call": dt * 1e3,
                                "roofline": hbm, "roofline_valu": valu}
     eng.close()
+    # ---- configs[2] at its exact size: the headline model, 1e5 subjects, fwd + adjoint + Adam (time-split path, L chosen
+    # by the library's launch-cost model)
+    n = 100000
+    nn6 = glorot(ARCH, 1234)
+    eng, pop = cpep_engine(Engine, ARCH, N_STATE, n, 776, device, nn6)
+    eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+    eng.set_params(nn6, pop["beta0"])
+    eng.adam_init(1e-2)
+    dt, ms, launches = timed_adam(eng, n, steps, warm)
+    hbm, valu = rooflines("cpep2_fwd + cpep2_scan + cpep2_rev <2,6,2,3> (time-split gradient launch)", ms, launches, n,
+                          cpep_algo_bytes(T_OBS, N_STATE, True), cpep_flops())
+    out["train_step_1e5"] = {"config": "BASELINE configs[2]: CPEP3 2x6x6x1, exactly 1e5 subjects, fwd + adjoint + Adam",
+                             "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
+                             "roofline": hbm, "roofline_valu": valu}
+    eng.close()
     # ---- reference-faithful c-peptide instance: 2->4->4->1, 2 states, 1e5 subjects, fwd + adjoint + Adam
     n, arch = 100000, (2, 4, 2)
     nn4 = glorot(arch, 1234)

@@ -905,11 +905,11 @@ int32_t cude_adam_step(cude_ctx* c, double* loss) {
     if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
     if ((rc = run_ensemble(c, true, nullptr))) return rc;
     c->adam_t += 1;
-    if (loss) {
-        // read the loss of this iterate before the update kernel is queued behind it
-        if ((rc = finish_loss(c, loss, nullptr))) return rc;
-    }
-    return enqueue_adam(c);
+    // the update is queued BEFORE the host waits for the loss: the update kernel only reads g_nn (where the loss sum
+    // and the failure count live), so the value read back is still the loss of the iterate the gradient was taken
+    // at, and the GPU is not left idle while the host turns around
+    if ((rc = enqueue_adam(c))) return rc;
+    return loss ? finish_loss(c, loss, nullptr) : CUDE_OK;
 }
 
 // n_iters optimiser iterations without any host round trip: one iteration (gradient kernels, reductions, L2

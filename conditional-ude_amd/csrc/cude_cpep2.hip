@@ -324,7 +324,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     constexpr int P = Net::P;
     constexpr int NC = NIN - 1;
     extern __shared__ double smem[];
-    double* s_red = smem;                       // [kRedRows][kBlock]
+    double* s_red = smem;                       // [kRedRows][kBlock] after the sweep ...
+    double* s_tab = smem;                       // ... [5][W][kBlock] layer-1 factor table during it (Net::HAS_TAB)
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
@@ -336,6 +337,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     cptr_t phi = as_const(b.phi);
     ciptr_t seg = as_const(b.seg);
     ciptr_t cs = as_const(a.chunk_start);
+    ciptr_t stepk = as_const(b.stepk);
+    cptr_t stepd = as_const(b.stepd);
     const int n0 = cs[c_idx], n1 = cs[c_idx + 1];
 
     double cst[NC];
@@ -350,12 +353,48 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     double wtot = 0.0;
     int cur_seg = -1;
     double g_lo = 0.0, g_d = 0.0;
+    // layer-1 exponent table, exactly as the reverse sweep of cpep_kernel (cude_cpep.hip): anchor = exp(2 z_j) at the
+    // END of the step, factors reach back from there; a run that continues from a later chunk is re-anchored here
+#ifndef CUDE_NO_TAB2
+    constexpr bool kTab = Net::HAS_TAB;
+#else
+    constexpr bool kTab = false;
+#endif
+    typename Net::Exps A, E1;
+    int kind = 0, s = 4, n = n1 - 1;
+    bool run_ok = false, have_anchor = false;
     // own stage times in reverse order; e = 5 n0 - 1 stands for the baseline with weight -sum(own w)
 #pragma unroll 1
     for (int e = 5 * n1 - 1; e >= 5 * n0 - 1; e--) {
         const bool own = e >= 5 * n0;
         double xv = 0.0, wv;
+        bool tab = false;
         if (own) {
+            if constexpr (kTab) {
+                if (s == 4) {                    // first evaluation (in reverse order) of step n
+                    kind = stepk[3 * n + 1];     // 0 = straddles a knot, 1 = a run starts here (in reverse), 2 = continues
+                    if (kind == 0) have_anchor = false;
+                    if (kind == 2 && !have_anchor) kind = 1;      // the run started in a later chunk: anchor it here
+                    if (kind == 2 && !run_ok) kind = 0;
+                    if (kind == 1) {
+                        const int s0 = stepk[3 * n + 2];
+                        const double lo = b.dG[(int64_t)s0 * N + i];
+                        const double d = b.dG[(int64_t)(s0 + 1) * N + i] - lo;
+                        run_ok = !__any(!Net::tab_safe(p, c, lo, d, stepd[3 * n + 2]));
+                        have_anchor = true;
+                        if (run_ok) {
+                            const double cr[5] = {Tab::c(1) - 1.0, Tab::c(2) - 1.0, Tab::c(3) - 1.0, Tab::c(4) - 1.0, -1.0};
+                            Net::tab_build(p, d * stepd[3 * n + 2], cr, s_tab, lane);
+                            Net::tab_anchor(p, c, fma(stepd[3 * n + 1], d, lo), A);
+                        } else {
+                            kind = 0;
+                        }
+                    } else if (kind == 2) {
+#pragma unroll
+                        for (int j = 0; j < W; j++) A.v[j] *= s_tab[(4 * W + j) * kBlock + lane];
+                    }
+                }
+            }
             const int sg = seg[e];
             if (sg != cur_seg) {
                 cur_seg = sg;
@@ -365,24 +404,45 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
             xv = fma(phi[e], g_d, g_lo);
             wv = a.wts[(int64_t)e * N + i];
             wtot += wv;
+            if constexpr (kTab) {
+                tab = kind != 0;
+                if (tab) {
+                    const int sr = s < 4 ? s : 0;
+#pragma unroll
+                    for (int j = 0; j < W; j++) {
+                        const double f = s_tab[(sr * W + j) * kBlock + lane];
+                        E1.v[j] = s < 4 ? A.v[j] * f : A.v[j];      // stage 5 sits at the anchor time itself
+                    }
+                }
+            }
+            if (s == 0) { s = 4; n--; } else s--;
         } else {
             wv = -wtot;
         }
         const double x[1] = {xv};
-        Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy);
+        Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy, tab, &E1);
     }
-    double g[P];
-    double dcond;
+    if (active) a.g_cond_part[(int64_t)c_idx * N + i] = Net::grad_cond(p, acc, cst);
+    double* out = a.partials2 + ((int64_t)c_idx * gridDim.x + blockIdx.x) * P;
+    __syncthreads();                            // the table rows become the reduction buffer
     {
-        double gp[P];
-        Net::expand(p, acc, cst, gp, &dcond);
+        // P columns only (the loss / failure columns belong to the scan kernel): expand 16 rows at a time into LDS
         const double keep = active ? 1.0 : 0.0;
 #pragma unroll
-        for (int q = 0; q < P; q++) g[q] = gp[q] * keep;
+        for (int c0 = 0; c0 < P; c0 += kRedRows) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kRedRows; r++)
+                if (c0 + r < P) s_red[r * kBlockLanes + lane] = Net::grad_elem(c0 + r, acc, cst) * keep;
+            __syncthreads();
+            if (lane < kRedRows && c0 + lane < P) {
+                double v = 0.0;
+#pragma unroll 8
+                for (int l = 0; l < kBlockLanes; l++) v += s_red[lane * kBlockLanes + ((l + lane) & (kBlockLanes - 1))];
+                out[c0 + lane] = v;
+            }
+        }
     }
-    if (active) a.g_cond_part[(int64_t)c_idx * N + i] = dcond;
-    double* out = a.partials2 + ((int64_t)c_idx * gridDim.x + blockIdx.x) * P;
-    block_reduce_store<P>(g, s_red, out, lane);
 }
 
 // g_cond[i] = sum_c part[c][i]
@@ -408,7 +468,8 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks), dim3(kBlock),
                        sizeof(double) * (size_t)(kRedRows + a.base.T) * kBlock, s, as);
     if (!grad) return hipGetLastError();
-    const size_t lds_r = sizeof(double) * (size_t)kRedRows * kBlock;
+    constexpr int TABROWS = Net::HAS_TAB ? 5 * W : 0;
+    const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;
     hipLaunchKernelGGL((cpep2_rev_kernel<NIN, W, D>), grid2, dim3(kBlock), lds_r, s, a);
     const int bs = 256;
     hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N + bs - 1) / bs)), dim3(bs), 0, s,
@@ -430,7 +491,8 @@ bool cpep2_shape_supported(const NetShape& net, int n_state) {
 template <int NIN, int W, int D>
 static int rev_occupancy() {
     int n = 0;
-    const size_t lds_r = sizeof(double) * (size_t)kRedRows * kBlock;
+    constexpr int TABROWS = Mlp<NIN, W, D, 1>::HAS_TAB ? 5 * W : 0;
+    const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpep2_rev_kernel<NIN, W, D>, kBlock, lds_r) != hipSuccess) return 0;
     return n;
 }

@@ -32,7 +32,7 @@ for N in sizes:
         eng.set_population_cpep(tp, G, cp, age, t2)
         eng.set_params(nn, bt)
         eng.adam_init(1e-2)
-        for _ in range(3):
+        for _ in range(48):                          # reach the steady GPU clock (profiles/r02/clock_ramp.txt)
             eng.adam_step(want_loss=False)
         eng.set_kernel_timing(True)
         for _ in range(20):
