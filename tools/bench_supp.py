@@ -13,7 +13,7 @@ eng = Engine("supp", c["arch"], n_steps=30, lam=0.01)
 eng.set_population_supp(c["tp"], c["data"])
 eng.set_params(c["nn"], c["theta"])
 eng.adam_init(1e-3)
-for _ in range(3): eng.adam_step()
+for _ in range(40): eng.adam_step()
 eng.set_kernel_timing(True)
 K = 10
 eng.synchronize(); t = time.perf_counter()
@@ -25,6 +25,8 @@ t = time.perf_counter()
 for _ in range(K): eng.forward()
 dt = (time.perf_counter() - t) / K
 print(f"SUPP forward-only {dt*1e3:.3f} ms traj/s {N/dt:.3e}")
+if "--no-cpu" in sys.argv:
+    sys.exit(0)
 import c_oracle as co
 n = min(N, 20000)
 t = time.perf_counter(); co.supp(c["tp"], c["data"][:, :, :n], c["arch"], c["nn"], c["theta"][:n], 0.01, 30); dt = time.perf_counter() - t

@@ -1,6 +1,17 @@
-"""Condenses rocprofv3 CSV output (kernel stats + PMC passes) into a short text summary."""
-import csv, glob, os, sys, collections
+"""Condenses rocprofv3 CSV output (kernel stats + PMC passes, tools/profile_r02.sh) into a short text summary and
+profiles-ready pmc_traffic.json (HBM bytes per launch of the dominant kernels, tagged with the digest of the kernel
+sources they were measured on)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
 out = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
 
 def rows(pattern):
     for f in glob.glob(os.path.join(out, pattern), recursive=True):
@@ -8,39 +19,75 @@ def rows(pattern):
             for r in csv.DictReader(fh):
                 yield r
 
-print("== kernel stats (rocprofv3 --kernel-trace --stats)")
-for r in rows("stats/**/*kernel_stats.csv"):
-    print(f"{r.get('Name','')[:70]:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
-for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", None)):
+
+def kernel_stats(tag):
+    print(f"== kernel stats ({tag}: rocprofv3 --kernel-trace --stats)")
+    res = {}
+    for r in rows(f"{tag}/**/*kernel_stats.csv"):
+        print(f"{r.get('Name','')[:86]:86s} calls={r.get('Calls'):>5s} total_ns={r.get('TotalDurationNs'):>12s} "
+              f"avg_ns={r.get('AverageNs'):>12s} pct={r.get('Percentage')}")
+        res[r.get("Name", "")] = float(r.get("AverageNs", 0))
+    return res
+
+
+def counters(tag):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows(f"{tag}/**/*counter_collection.csv"):
-        acc[r.get("Kernel_Name", "")[:60]][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
-    print(f"== {tag}")
-    for k, d in acc.items():
-        for c, v in d.items():
-            print(f"{k:60s} {c:22s} n={len(v)} mean={sum(v)/len(v):.6g}")
+        acc[r.get("Kernel_Name", "")][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
+    return acc
 
-# HBM traffic of the dominant kernel per launch, corrected as MI355X_MICROARCH.md "HBM" prescribes:
-# FETCH_SIZE (KB) counts 64 B per 128-B request on gfx950 -> x2 (calibrated below on prepare_cpep_kernel,
-# whose byte count is known exactly); WRITE_SIZE (KB) is exact.
-import json
-def mean_ctr(tag, kern_sub, ctr):
+
+def mean_ctr(tag, kern_sub, ctr, skip=0):
+    """mean over the launches of the kernel whose name contains kern_sub (the first `skip` launches dropped)."""
     v = [float(r["Counter_Value"]) for r in rows(f"{tag}/**/*counter_collection.csv")
          if kern_sub in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr]
-    return sum(v) / len(v) if v else None
-f = mean_ctr("pmc_fetch", "true>(cude::CpepArgs)", "FETCH_SIZE")
-w = mean_ctr("pmc_write", "true>(cude::CpepArgs)", "WRITE_SIZE")
-pf = mean_ctr("pmc_fetch", "prepare_cpep_kernel", "FETCH_SIZE")
+    v = v[skip:] if len(v) > skip else v
+    return (sum(v) / len(v), len(v)) if v else (None, 0)
+
+
+stats = kernel_stats("stats")
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    print(f"== {tag}")
+    for k, d in counters(tag).items():
+        if "cude::" not in k:
+            continue
+        for c, v in sorted(d.items()):
+            print(f"{k[:70]:70s} {c:24s} n={len(v)} mean={sum(v)/len(v):.6g}")
+
+# HBM traffic per launch, corrected as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE (KB) counts 64 B per 128-B
+# request on gfx950 -> x2, calibrated below on prepare_cpep_kernel whose byte count is known exactly in THIS access
+# pattern (8 B per lane, subject-major); WRITE_SIZE (KB) is exact.
+import bench  # noqa: E402
+
+rec = {"source_sha": bench.kernel_source_sha(), "fetch_correction": 2.0, "kernels": {}}
+n = None
+try:
+    n = json.loads(open(os.path.join(out, "bench_stats.json")).read().strip().splitlines()[-1])["config"]["subjects_per_gpu"]
+except Exception as e:
+    print("no bench line:", e)
+GRAD = "true>(cude::CpepArgs)"
+f, nf = mean_ctr("pmc_fetch", GRAD, "FETCH_SIZE")
+w, nw = mean_ctr("pmc_write", GRAD, "WRITE_SIZE")
+pf, _ = mean_ctr("pmc_fetch", "prepare_cpep_kernel", "FETCH_SIZE")
 if f is not None and w is not None:
-    n = None
+    rec["kernels"]["headline"] = {"kernel": "cpep_kernel<Mlp<2,6,2,1>,3,grad>", "subjects_per_gpu": n, "launches": nf,
+                                  "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "source_sha": rec["source_sha"],
+                                  "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024}
+    if pf and n:
+        rec["calibration"] = {"kernel": "prepare_cpep_kernel", "known_read_bytes": n * (7 * 8 + 1), "FETCH_SIZE_KB": pf,
+                              "ratio": pf * 1024 / (n * (7 * 8 + 1))}
+for mode in ("stage_inputs", "steps"):
+    kernel_stats(f"supp_{mode}_stats")
+    f, nf = mean_ctr(f"supp_{mode}_fetch", "supp_kernel", "FETCH_SIZE", skip=3)
+    w, nw = mean_ctr(f"supp_{mode}_write", "supp_kernel", "WRITE_SIZE", skip=3)
+    if f is not None and w is not None:
+        rec["kernels"][f"supp_{mode}"] = {"kernel": "supp_kernel<3,5,grad> (+ forward-only launches of the same run)",
+                                         "subjects_per_gpu": 100000, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                                         "source_sha": rec["source_sha"],
+                                         "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024}
     try:
-        n = json.load(open(os.path.join(out, "bench_stats.json")))["config"]["subjects_per_gpu"]
+        print(open(os.path.join(out, f"supp_{mode}.log")).read().strip())
     except Exception:
         pass
-    rec = {"subjects_per_gpu": n, "kernel": "cpep_kernel<2,6,2,3,grad>", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
-           "fetch_correction": 2.0, "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024}
-    if pf and n:
-        rec["calibration"] = {"kernel": "prepare_cpep_kernel", "known_read_bytes": n * (7 * 8 + 1),
-                              "FETCH_SIZE_KB": pf, "ratio": pf * 1024 / (n * (7 * 8 + 1))}
-    json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-    print("== pmc_traffic.json", rec)
+json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print("== pmc_traffic.json", json.dumps(rec, indent=1))
