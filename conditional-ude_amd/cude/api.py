@@ -848,7 +848,8 @@ def load_data(path):
 def save_parameters(path, width, depth, parameters, betas=None, best_model_index=None, **extra):
     """The checkpoint the training scripts write (c-peptide/02-conditional.jl:44-50, 07-covariate-inclusion.jl:59-65):
     width, depth, parameters, betas, best_model_index (1-based, as in the reference).  Lists of vectors are stored
-    as matrices with one column per vector (`eachcol(file["parameters"])` in Julia)."""
+    as Vector{Vector{Float64}}, so the reference's `file["parameters"][best_model_index]` reads them unchanged; with
+    the reference's content the file is byte-identical to the one JLD2.jl wrote (tests/test_jld2.py)."""
     from . import jld2
     entries = {"width": int(width), "depth": int(depth), "parameters": parameters}
     if betas is not None:
@@ -860,7 +861,8 @@ def save_parameters(path, width, depth, parameters, betas=None, best_model_index
 
 
 def load_parameters(path):
-    """Reads a checkpoint written by the reference (vectors of vectors) or by save_parameters (matrix columns):
+    """Reads a checkpoint written by the reference or by save_parameters (vectors of vectors; a matrix is taken as
+    one vector per column):
     namespace with width, depth, parameters (list of vectors, or one vector), betas, best_model_index."""
     from . import jld2
     d = jld2.load(path)

@@ -405,19 +405,131 @@ def _dataset_header(value, data_rel):
     return _ohdr([_FILL, _msg(0x01, space), _msg(0x03, dt, 1), _msg(0x08, layout), _TRAILER])
 
 
-def save(path, entries, julia_version="1.11.1"):
-    """Write `entries` (ordered dict name -> int | float | float64/int64 ndarray) as a JLD2 file with the layout
-    JLD2.jl itself produces for `jldopen(path, "w") do f; f[name] = value; ...; end` on these types: datasets in
-    insertion order (scalars compact, arrays contiguous and 8-byte aligned after their header), the root group
-    last.  An (n1, n2, ...) ndarray becomes the Julia Array of the same size (written in column-major order).
-    Vectors of vectors are written as matrices (one column per inner vector)."""
+# ---- Vector{Vector{Float64}} (the reference's `parameters` / `betas` checkpoints, c-peptide/02-conditional.jl:44-50):
+# JLD2.jl stores the outer vector as a dataset of object references with a `julia_type` attribute that points at a
+# description of the element type Array{Float64,1}; that description is a small graph of objects of the committed
+# compound datatype for Core.DataType {name::String, parameters::Vector{Any}} whose strings and reference lists live
+# in a 4 KiB global heap.  The block is written once, in front of the first such dataset, and `_types/00000001` in
+# the root group links the committed datatype.
+_DT_REFERENCE = bytes.fromhex("3700000008000000")
+# compound {name: variable-length string @0, parameters: variable-length sequence of references @16}, 32 bytes
+_DT_DATATYPE = bytes.fromhex("36020000200000006e616d65000039110100100000003000000001000000000008007061"
+                             "72616d6574657273001039000000100000003700000008000000")
+_HEAP_BYTES = 4096
+
+
+def _vlen(length, heap_rel, index):
+    return struct.pack("<IQI", length, heap_rel if length else 0, index if length else 0)
+
+
+def _pad8(out):
+    out += b"\x00" * (-len(out) % 8)
+
+
+def _type_block(out):
+    """Appends the Array{Float64,1} type description; returns (address of the committed datatype, address of the
+    Array{Float64,1} DataType object), both relative to the end of the file header."""
+    t0 = len(out) - HEADER_BYTES
+    # sizes are fixed, so the addresses of everything that follows are known up front
+    committed_len = 6 + (4 + len(_DT_DATATYPE)) + (4 + 65) + 4
+    heap = (t0 + committed_len + 7) // 8 * 8
+    array_obj = heap + _HEAP_BYTES + 16
+    dt_obj_len = len(_datatype_object(0, 0, 0, 0, (0, 0)))
+    float_obj = array_obj + dt_obj_len
+    one_obj = float_obj + dt_obj_len
+    shared = b"\x03\x02" + struct.pack("<Q", t0)
+    attr = (bytes.fromhex("02010b000a000400") + b"julia_type\x00" + shared + bytes([2, 0, 0, 0]) +
+            _vlen(13, heap, 1) + _vlen(0, 0, 0))
+    out += _ohdr([_msg(0x03, _DT_DATATYPE, 0x40), _msg(0x0C, attr)])
+    _pad8(out)
+    assert len(out) - HEADER_BYTES == heap
+    objects = [b"Core.DataType", b"Core.Array", b"Core.Float64", struct.pack("<QQ", float_obj, one_obj)]
+    blob = bytearray(b"GCOL\x01\x00\x00\x00" + struct.pack("<Q", _HEAP_BYTES))
+    for k, data in enumerate(objects, 1):
+        blob += struct.pack("<HHIQ", k, 1, 0, len(data)) + data + b"\x00" * (-len(data) % 8)
+    blob += struct.pack("<HHIQ", 0, 0, 0, _HEAP_BYTES - len(blob))        # free space, its own header included
+    out += bytes(blob).ljust(_HEAP_BYTES, b"\x00") + b"\x00" * 16
+    out += _datatype_object(t0, heap, 10, 2, (2, 4))                      # Core.Array, parameters = heap object 4
+    out += _datatype_object(t0, heap, 12, 3, (0, 0))                      # Core.Float64, no parameters
+    assert len(out) - HEADER_BYTES == one_obj
+    out += _dataset_header(1, 0)
+    return t0, array_obj
+
+
+def _datatype_object(t0, heap, name_len, name_idx, params):
+    """A Core.DataType instance: scalar dataset of the committed compound type, compact layout."""
+    shared = b"\x03\x02" + struct.pack("<Q", t0)
+    data = _vlen(name_len, heap, name_idx) + _vlen(params[0], heap, params[1])
+    return _ohdr([_FILL, _msg(0x01, bytes([2, 0, 0, 0])), _msg(0x03, shared, 3),
+                  _msg(0x08, b"\x04\x00" + struct.pack("<H", len(data)) + data), _TRAILER])
+
+
+def _reference_vector_header(n, julia_type_rel, data_rel):
+    attr = (bytes.fromhex("02000b0008000400") + b"julia_type\x00" + _DT_REFERENCE + bytes([2, 0, 0, 0]) +
+            struct.pack("<Q", julia_type_rel))
+    space = bytes([2, 1, 0, 1]) + struct.pack("<Q", n)
+    return _ohdr([_FILL, _msg(0x01, space), _msg(0x0C, attr), _msg(0x03, _DT_REFERENCE, 1),
+                  _msg(0x08, b"\x04\x01" + struct.pack("<QQ", data_rel, n * 8)), _TRAILER])
+
+
+def _append_array(out, value):
+    """dense array dataset: header, then the data 8-byte aligned; returns its relative address."""
+    addr = len(out)
+    hdr_len = len(_dataset_header(value, 0))
+    data_at = (addr + hdr_len + 7) // 8 * 8
+    out += _dataset_header(value, data_at - HEADER_BYTES)
+    out += b"\x00" * (data_at - len(out))
+    out += value.tobytes(order="F")
+    return addr - HEADER_BYTES
+
+
+def _group_header(links):
+    msgs = [_msg(0x02, b"\x00\x00" + b"\xff" * 16), _msg(0x0A, b"\x00\x00")]
+    for name, rel in links:
+        nb = name.encode("utf-8")
+        if len(nb) > 255:
+            raise ValueError("link name too long")
+        msgs.append(_msg(0x06, b"\x01\x10\x01" + bytes([len(nb)]) + nb + struct.pack("<Q", rel)))
+    if len(links) < 4:                                          # JLD2.jl reserves room for 4 links of 8-char names
+        msgs.append(_msg(0x00, b"\x00" * ((4 - len(links)) * 24 - 4)))
+    msgs.append(_TRAILER)
+    return _ohdr(msgs)
+
+
+def save(path, entries, julia_version="1.11.1", vectors_as_matrix=False):
+    """Write `entries` (ordered dict name -> int | float | float64/int64 ndarray | list of float64 vectors) as a JLD2
+    file with the layout JLD2.jl itself produces for `jldopen(path, "w") do f; f[name] = value; ...; end` on these
+    types: datasets in insertion order (scalars compact, arrays contiguous and 8-byte aligned after their header), the
+    root group last.  An (n1, n2, ...) ndarray becomes the Julia Array of the same size (written in column-major
+    order).  A list of 1-D float vectors is written as Julia's Vector{Vector{Float64}} -- a dataset of object
+    references, one dataset per inner vector, the element-type description in front of the first one and linked from
+    `_types` -- which is how the reference's scripts store and index `parameters` / `betas`
+    (c-peptide/02-conditional.jl:44-62: `parameters[best_model_index]`); vectors_as_matrix=True stores it as a matrix
+    with one column per vector instead."""
     header = (b"HDF5-based Julia Data Format, version 0.2.0\x00 (Julia " + julia_version.encode() + b" 64-bit LE)\x00")
     out = bytearray(header.ljust(HEADER_BYTES, b"\x00"))
     out += b"\x00" * 48                                         # superblock, filled in at the end
     links = []
+    types = None                                                # (committed datatype, Array{Float64,1} description)
     for name, value in entries.items():
         if isinstance(value, (list, tuple)) and len(value) and isinstance(value[0], np.ndarray):
-            value = np.stack(value, axis=1)
+            if vectors_as_matrix:
+                value = np.stack(value, axis=1)
+            else:
+                vecs = [np.asarray(v, dtype=np.float64).reshape(-1) for v in value]
+                if any(np.asarray(v).dtype.kind != "f" for v in value):
+                    raise TypeError(f"{name}: only vectors of Float64 vectors are supported")
+                if types is None:
+                    types = _type_block(out)
+                addr = len(out) - HEADER_BYTES
+                refs_at = (len(out) + len(_reference_vector_header(len(vecs), 0, 0)) + 7) // 8 * 8
+                out += _reference_vector_header(len(vecs), types[1], refs_at - HEADER_BYTES)
+                out += b"\x00" * (refs_at - len(out))
+                out += b"\x00" * (8 * len(vecs))                # the references, known once the vectors are placed
+                rels = [_append_array(out, v) for v in vecs]
+                out[refs_at:refs_at + 8 * len(vecs)] = struct.pack(f"<{len(vecs)}Q", *rels)
+                links.append((name, addr))
+                continue
         if isinstance(value, (bool, np.bool_)):
             raise TypeError("Bool is not supported")
         if isinstance(value, (np.integer,)):
@@ -431,27 +543,16 @@ def save(path, entries, julia_version="1.11.1"):
             value = np.asarray(value, dtype=np.float64 if kind == "f" else np.int64)
         elif not isinstance(value, (int, float)):
             raise TypeError(f"{name}: unsupported type {type(value).__name__}")
-        addr = len(out)
         if isinstance(value, np.ndarray):
-            hdr_len = len(_dataset_header(value, 0))
-            data_at = (addr + hdr_len + 7) // 8 * 8
-            out += _dataset_header(value, data_at - HEADER_BYTES)
-            out += b"\x00" * (data_at - len(out))
-            out += value.tobytes(order="F")
+            links.append((name, _append_array(out, value)))
         else:
+            links.append((name, len(out) - HEADER_BYTES))
             out += _dataset_header(value, 0)
-        links.append((name, addr - HEADER_BYTES))
-    msgs = [_msg(0x02, b"\x00\x00" + b"\xff" * 16), _msg(0x0A, b"\x00\x00")]
-    for name, rel in links:
-        nb = name.encode("utf-8")
-        if len(nb) > 255:
-            raise ValueError("link name too long")
-        msgs.append(_msg(0x06, b"\x01\x10\x01" + bytes([len(nb)]) + nb + struct.pack("<Q", rel)))
-    if len(links) < 4:                                          # JLD2.jl reserves room for 4 links of 8-char names
-        msgs.append(_msg(0x00, b"\x00" * ((4 - len(links)) * 24 - 4)))
-    msgs.append(_TRAILER)
+    if types is not None:
+        links.append(("_types", len(out) - HEADER_BYTES))
+        out += _group_header([("00000001", types[0])])
     root = len(out) - HEADER_BYTES
-    out += _ohdr(msgs)
+    out += _group_header(links)
     sb = _SIG + bytes([2, 8, 8, 0]) + struct.pack("<QQQQ", HEADER_BYTES, UNDEF, len(out), root)
     out[HEADER_BYTES:HEADER_BYTES + 48] = sb + struct.pack("<I", lookup3(sb))
     with open(path, "wb") as fh:

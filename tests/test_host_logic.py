@@ -36,7 +36,11 @@ def test_init_params_and_latin_hypercube():
     rng = np.random.default_rng(3)
     net = api.chain(6, 2, "tanh")
     p = api.init_params(net, rng)
-    assert p.size == 67 and np.all(p[12:18] == 0) and np.all(p[54:60] == 0) and p[66] == 0
+    # Glorot normal over each layer's whole [W b] matrix: biases are random too, sigma = sqrt(2 / (out + in + 1))
+    assert p.size == 67 and np.all(p != 0)
+    big = api.init_params(api.chain(64, 3, "tanh"), rng)              # 2->64, 64->64 x2, 64->1
+    hidden = big[192:192 + 64 * 65]
+    assert abs(hidden.std() / np.sqrt(2.0 / 129) - 1) < 0.05 and abs(big[:192].std() / np.sqrt(2.0 / 67) - 1) < 0.15
     lhs = api.initial_parameters(7, -2.0, 0.0, 50, rng)
     assert lhs.shape == (7, 50) and lhs.min() >= -2.0 and lhs.max() <= 0.0
     for row in lhs:       # exactly one sample per stratum

@@ -117,6 +117,14 @@ def main():
     _save("jld2_known_file.npz", width=np.int64(f["width"]),
                         depth=np.int64(f["depth"]), parameters=f["parameters"], julia_version=f.julia_version,
                         n_bytes=np.int64(len(raw)), sha256=hashlib.sha256(raw).hexdigest())
+    # the training checkpoints (Vector{Vector{Float64}} entries): digests only -- their content is already in
+    # ohashi_cude.npz (nn_2x4x4x1 / betas_train) or regenerated from a decode when the reference is present
+    names, sizes, digests = [], [], []
+    for name in ("cude_neural_parameters", "cude_neural_parameters_sigma", "cude_covariate_neural_parameters_2"):
+        raw = open(os.path.join(REF, "source_data", name + ".jld2"), "rb").read()
+        names.append(name), sizes.append(len(raw)), digests.append(hashlib.sha256(raw).hexdigest())
+    _save("jld2_checkpoint_digests.npz", names=np.array(names), n_bytes=np.array(sizes, dtype=np.int64),
+                        sha256=np.array(digests))
     print(glucose.shape, nn.shape, betas.shape, snn.shape, group.shape, "best model", cude["best_model_index"])
     print("losses", supp["losses"][:4], "group_data[:,0,0]", group[:, 0, 0])
 
