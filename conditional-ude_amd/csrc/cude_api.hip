@@ -749,7 +749,7 @@ int32_t cude_set_population_supp(cude_ctx* c, int64_t N, int32_t n_obs, const do
     c->n_global = ssum[3];
     for (int s = 0; s < 3; s++) c->scale[s] = ssum[s] / ssum[3];
     HIP_TRY(c->data.resize(d.size()));
-    HIP_TRY(c->ckpt.resize((size_t)(6 * c->cfg.n_steps + 1) * 3 * N));   // every stage input
+    HIP_TRY(c->ckpt.resize((size_t)cude::supp_ckpt_rows(c->cfg.n_steps, c->T) * N));   // every stage input + residuals
     HIP_TRY(c->act.resize(supp_keep_activations(c, 1) ? supp_act_doubles(c) : 0));   // kept activations (small N)
     HIP_TRY(hipMemcpyAsync(c->data.p, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if ((rc = alloc_common(c))) return rc;
@@ -1100,14 +1100,14 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     const int64_t N = c->N, nb = c->nblocks;
     const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
     // sets per launch: bounded by the grid's y dimension and ~512 MB of scratch
-    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (supp ? (6.0 * S + 1) * 3 * N : 0.0));
+    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (supp ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0));
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_sets, 32768), (int64_t)(512e6 / per_set)));
     HIP_TRY(c->ms_nn.reserve((size_t)chunk * P));
     HIP_TRY(c->ms_cond.reserve((size_t)chunk * N));
     HIP_TRY(c->ms_gcond.reserve((size_t)chunk * N));
     HIP_TRY(c->ms_part.reserve((size_t)chunk * nb * (P + 2)));
     HIP_TRY(c->ms_out.reserve((size_t)chunk * (P + 2)));
-    if (supp) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * (6 * S + 1) * 3 * N));
+    if (supp) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * cude::supp_ckpt_rows(S, c->T) * N));
     c->ms_host.resize((size_t)chunk * (P + 2));
     for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
         const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
@@ -1411,10 +1411,16 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     m.ll_const = -(c->T / 2.0) * std::log(sigma * sigma);
     m.inv_2s2 = 1.0 / (2.0 * sigma * sigma);
     m.temperature = temperature; m.gamma = gamma;
+    // The reference re-evaluates the likelihood of the current state in every step (saem.jl:96-97).  With gamma == 1
+    // (its burn-in phase, and posterior sampling) the next state is exactly the accepted proposal or the unchanged
+    // current one, and the solve is deterministic, so that value is already known: it is carried over instead of
+    // recomputed -- the same bits, half the forward launches.  With gamma < 1 the state is a blend and is re-evaluated.
+    m.carry_sse = gamma == 1.0 ? 1 : 0;
+    if (m.carry_sse && (rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;
     for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
         HIP_TRY(cude::launch_mh_propose(N, c->cond.p, d_z.p + (size_t)k * N, proposal_std, d_prop.p, c->stream));
         if ((rc = run_ensemble(c, false, nullptr, true, d_prop.p, d_sn.p))) return rc;
-        if ((rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;   // re-evaluated as the reference does
+        if (!m.carry_sse && (rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;
         m.u = d_u.p + (size_t)k * N;
         HIP_TRY(cude::launch_mh_accept(m, c->stream));
         if (samples)       // chain state after step k (the draws of this step are no longer needed: reuse their row)

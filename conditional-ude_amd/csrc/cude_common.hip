@@ -225,7 +225,10 @@ __global__ void mh_accept_kernel(MhArgs a) {
     const double ratio = ll_new / a.temperature - ll_cur / a.temperature;
     const bool acc = log(a.u[i]) < prior_ratio + ratio;                 // NaN compares false
     a.p[i] = (1.0 - a.gamma) * p + a.gamma * (acc ? q : p);
-    if (acc) a.accepted[i] += 1;
+    if (acc) {
+        a.accepted[i] += 1;
+        if (a.carry_sse) a.sse_cur[i] = sn;
+    }
 }
 
 hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, double proposal_std, double* prop,

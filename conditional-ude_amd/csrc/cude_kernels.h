@@ -82,6 +82,9 @@ hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s);
 hipError_t launch_cpep2(const NetShape& net, int n_state, bool grad, const Cpep2Args& a, hipStream_t s);
 
 // suppression cUDE (nonlinear: NN input is the state)
+// rows of N doubles in one parameter set's gradient scratch
+inline __host__ __device__ int64_t supp_ckpt_rows(int S, int T) { return (int64_t)(6 * S + 1) * 3 + 3 * (int64_t)T; }
+
 struct SuppArgs {
     int64_t N;
     const double* data;      // [3][T][N]
@@ -92,7 +95,8 @@ struct SuppArgs {
     int32_t T, S;
     double h, inv_n;
     double iscale2[3];       // 1/scale_s^2
-    double* ckpt;            // [n_sets][6S+1][3][N] stage inputs (linearisation points of the reverse sweep)
+    double* ckpt;            // [n_sets][supp_ckpt_rows][N]: [6S+1][3] stage inputs (linearisation points of the
+                             // reverse sweep), then [T][3] residuals
     double* act;             // [n_sets][6S+1][D*W+1][N] kept network activations, or nullptr = recompute them
     int32_t ckpt_steps_only; // 1: ckpt holds only the step states [S+1][3][N]; the reverse sweep re-runs the stages
     double* sse;             // [N] or nullptr (already divided by scale^2)
@@ -155,7 +159,8 @@ struct MhArgs {
     double* p;                 // chain state (conditional parameters), updated in place
     const double* prop;        // proposals
     const double* u;           // uniform draws of this step
-    const double* sse_new; const double* sse_cur;
+    const double* sse_new; double* sse_cur;
+    int32_t carry_sse;         // gamma == 1: the accepted proposal IS the next state, so its SSE is carried over
     int64_t* accepted;         // per-subject acceptance counter
     double prior_mean, prior_sd, ll_const, inv_2s2, temperature, gamma;
 };

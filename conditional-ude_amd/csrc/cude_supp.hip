@@ -55,10 +55,12 @@ struct SuppRhs {
 };
 
 // LDS rows of kBlock doubles (one per lane):
-//   s_K [7][3]  stage derivatives k_i (forward) / their adjoints (reverse)
-//   s_Y [7][3]  stage inputs Y_i of the step being reversed (also the reduction scratch)
-//   s_res[T][3] residuals kept for the reverse sweep
-constexpr int kSuppRowsFixed = 42;
+//   s_K [7][3]  stage derivatives k_i (forward) / their adjoints (reverse); after the time loops: reduction scratch
+//   s_Y [7][3]  stage inputs Y_i of the step being reversed (YONLY only)
+// 10.5 KB per wave (21 KB in the step-state mode).  The residuals kept for the reverse sweep (3T doubles per subject)
+// live behind the stage inputs in the HBM scratch, not in LDS: with them the kernel needed 33 KB per wave = 4 waves
+// per CU whatever its register count.
+constexpr int kSuppRowsK = 21;
 
 // STORE (gradient only): the forward sweep also writes the D*W tanh outputs and the output unit's logistic derivative
 // of every evaluation to HBM ([evaluation][value][subject]) and the reverse sweep reads them back instead of
@@ -68,16 +70,18 @@ constexpr int kSuppRowsFixed = 42;
 // YONLY (gradient only, SuppArgs::ckpt_steps_only): the forward sweep keeps only the step states y_0 ... y_S (744 B per
 // subject at S = 30 instead of 4.3 KB of stage inputs) and the reverse sweep re-runs the six stage evaluations of the
 // step it is reversing: the low-traffic / high-arithmetic end of the trade (profiles/r02/supp_scratch_tradeoff.txt).
+#ifndef CUDE_SUPP_WAVES
+#define CUDE_SUPP_WAVES 1
+#endif
 template <int W, int D, bool GRAD, bool STORE, bool YONLY>
-__global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUPP_WAVES))) void supp_kernel(SuppArgs a) {
     using R = SuppRhs<W, D>;
     using Net = typename R::Net;
     constexpr int P = Net::P;
     extern __shared__ double smem[];
     double* s_K = smem;
-    double* s_Y = smem + 21 * kBlock;
-    double* s_res = smem + 42 * kBlock;
-    double* s_red = s_Y;
+    double* s_Y = smem + kSuppRowsK * kBlock;
+    double* s_red = s_K;
 
     const int lane = threadIdx.x;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
     ciptr_t obs_step = as_const(a.obs_step);
     const int S = a.S, T = a.T;
     const double h = a.h;
-    double* ckpt = GRAD ? a.ckpt + set * ((int64_t)(6 * S + 1) * 3 * N) : nullptr;   // one scratch per parameter set
+    double* ckpt = GRAD ? a.ckpt + set * (supp_ckpt_rows(S, T) * N) : nullptr;        // one scratch per parameter set
+    double* res = GRAD ? ckpt + (int64_t)(6 * S + 1) * 3 * N : nullptr;               // [T][3][N] residuals
     constexpr int NACT = D * W + 1;
     double* act = STORE ? a.act + set * ((int64_t)(6 * S + 1) * NACT * N) : nullptr;
 #define KROW(j, s) s_K[((j) * 3 + (s)) * kBlock + lane]
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
                 const double ov = fma(h, o[s], y[s]);
                 const double r = ov - a.data[((int64_t)s * T + oi) * N + i];
                 sse = fma(r * a.iscale2[s], r, sse);
-                if (GRAD) s_res[(oi * 3 + s) * kBlock + lane] = r;
+                if (GRAD) res[(int64_t)(oi * 3 + s) * N + i] = r;
                 if (a.traj != nullptr && active) a.traj[s + 3 * (oi + (int64_t)T * i)] = ov;
             }
             oi++;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
                     double hg[3];
 #pragma unroll
                     for (int s = 0; s < 3; s++) {
-                        const double g = gs * a.iscale2[s] * s_res[(oi * 3 + s) * kBlock + lane];
+                        const double g = gs * a.iscale2[s] * res[(int64_t)(oi * 3 + s) * N + i];
                         yb[s] += g;
                         hg[s] = h * g;
                     }
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
                 n--;
             }
         }
-        __syncthreads();                   // s_red aliases s_Y, which the YONLY reverse sweep has just been reading
+        __syncthreads();                   // s_red aliases s_K, which the reverse sweep has just been using
         if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(p, acc, cst);
         block_reduce_expand<Net, 1>(acc, cst, active ? 1.0 : 0.0, red_loss, red_fail, s_red, out, lane);
     }
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void supp_kernel(SuppArgs a) {
 template <int W, int D, bool GRAD, bool STORE, bool YONLY = false>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
-    const size_t lds = sizeof(double) * (size_t)(kSuppRowsFixed + (GRAD ? 3 * a.T : 0)) * kBlock;
+    const size_t lds = sizeof(double) * (size_t)(kSuppRowsK * (YONLY ? 2 : 1)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE, YONLY>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();

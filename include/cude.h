@@ -223,9 +223,12 @@ int32_t cude_fit_conditional(cude_ctx* ctx, double lower, double upper, int32_t 
  * network is the context's current one.  normals / uniforms are the host's randn() / rand() draws, [n_mc][N]
  * row-major.  log-likelihood = -(T/2) log sigma^2 - SSE/(2 sigma^2) (:55-66), -Inf on a failed solve; prior
  * Normal(prior_mean, prior_sd); accept iff log u < prior ratio + (ll_new - ll_cur)/temperature; state <-
- * (1-gamma) state + gamma (accepted ? proposal : state).  As in the reference the current state's likelihood is
- * re-evaluated at every step.  accepted[N] (optional) receives per-subject acceptance counts.  All 5 n_mc
- * launches are queued on the stream; the call synchronises once at the end. */
+ * (1-gamma) state + gamma (accepted ? proposal : state).  The reference re-evaluates the current state's likelihood
+ * at every step (:96-97); here that happens only for gamma != 1 (the state is then a blend that was never solved
+ * at).  For gamma == 1 -- its burn-in phase and the posterior sampling loop -- the next state is exactly the
+ * accepted proposal or the unchanged state and the solve is deterministic, so the known SSE is carried over: same
+ * bits, n_mc + 1 ensemble solves instead of 2 n_mc.  accepted[N] (optional) receives per-subject acceptance
+ * counts.  All launches are queued on the stream; the call synchronises once at the end. */
 int32_t cude_mh_estep(cude_ctx* ctx, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
                       double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
                       int64_t* accepted);
