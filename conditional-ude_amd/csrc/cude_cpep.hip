@@ -95,13 +95,14 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         bool tab = false;
         if (e >= 0) {
             const int sg = seg[e];
+            const double ph = phi[e];     // requested together with seg[e]: one scalar round trip, not two
             if (sg != cur_seg) {                 // wave-uniform: a handful of times per trajectory
                 cur_seg = sg;
                 g_lo = a.dG[(int64_t)sg * N + i];
                 g_d = a.dG[(int64_t)(sg + 1) * N + i] - g_lo;
                 chk = fma(g_d, 0.0, fma(g_lo, 0.0, chk));
             }
-            xv = fma(phi[e], g_d, g_lo);
+            xv = fma(ph, g_d, g_lo);
             if constexpr (Net::HAS_TAB) {
                 if (s == 0) {                    // first evaluation of step n
                     kind = stepk[3 * n];
@@ -314,23 +315,29 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
             bool tab = false;
             if (e >= 0) {
                 const int sg = seg[e];
+                const double ph = phi[e];
                 if (sg != cur_seg) {
                     cur_seg = sg;
                     g_lo = a.dG[(int64_t)sg * N + i];
                     g_d = a.dG[(int64_t)(sg + 1) * N + i] - g_lo;
                 }
-                xv = fma(phi[e], g_d, g_lo);
+                xv = fma(ph, g_d, g_lo);
                 wv = s_q[s * kBlock + lane];
                 wtot += wv;
                 if constexpr (Net::HAS_TAB) {
                     tab = kind != 0;
                     if (tab) {
+                        // all W factors are requested together and unconditionally (left to itself the compiler
+                        // branches on the wave-uniform s around every single read: six exposed LDS round trips)
                         const int sr = s < 4 ? s : 0;
+                        double f[Net::NCST];
 #pragma unroll
-                        for (int j = 0; j < Net::NCST; j++) {
-                            const double f = s_tab[(sr * Net::NCST + j) * kBlock + lane];
-                            E1.v[j] = s < 4 ? A.v[j] * f : A.v[j];      // stage 5 sits at the anchor time itself
-                        }
+                        for (int j = 0; j < Net::NCST; j++) f[j] = s_tab[(sr * Net::NCST + j) * kBlock + lane];
+#pragma unroll
+                        for (int j = 0; j < Net::NCST; j++) asm volatile("" : "+v"(f[j]));
+#pragma unroll
+                        for (int j = 0; j < Net::NCST; j++)
+                            E1.v[j] = s < 4 ? A.v[j] * f[j] : A.v[j];   // stage 5 sits at the anchor time itself
                     }
                 }
                 s = (s == 0) ? 4 : s - 1;

@@ -407,12 +407,14 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
             if constexpr (kTab) {
                 tab = kind != 0;
                 if (tab) {
-                    const int sr = s < 4 ? s : 0;
+                    const int sr = s < 4 ? s : 0;           // reads grouped and unconditional, as in cpep_kernel
+                    double f[W];
 #pragma unroll
-                    for (int j = 0; j < W; j++) {
-                        const double f = s_tab[(sr * W + j) * kBlock + lane];
-                        E1.v[j] = s < 4 ? A.v[j] * f : A.v[j];      // stage 5 sits at the anchor time itself
-                    }
+                    for (int j = 0; j < W; j++) f[j] = s_tab[(sr * W + j) * kBlock + lane];
+#pragma unroll
+                    for (int j = 0; j < W; j++) asm volatile("" : "+v"(f[j]));
+#pragma unroll
+                    for (int j = 0; j < W; j++) E1.v[j] = s < 4 ? A.v[j] * f[j] : A.v[j];   // stage 5 sits at the anchor time
                 }
             }
             if (s == 0) { s = 4; n--; } else s--;

@@ -95,6 +95,13 @@ __device__ __forceinline__ SCol<W> ld_col(cptr_t p, int off) {
     for (int j = 0; j < W; j++) c.v[j] = p[off + j];
     return c;
 }
+// A use of the first loaded double: scalar loads return out of order, so the only wait there is is lgkmcnt(0), and it
+// is placed before the first use.  Touching a group BEFORE the next group's loads are issued keeps that wait from
+// covering the new loads as well.
+template <int W>
+__device__ __forceinline__ void touch(const SCol<W>& c) {
+    asm volatile("" ::"s"(c.v[0]));
+}
 #ifndef CUDE_NO_FENCE
 #define CUDE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -314,7 +321,166 @@ struct Mlp {
                                                   bool use_tab = false, const Exps* E1 = nullptr) {
         p = launder(p);
         double h[D][W];
+        // (the pipelined weight stream of eval_grad_pf does not pay here: measured +1 ... +7 % on the forward-only
+        // kernels, which run at 3-4 waves per SIMD and lose a wave or spill SGPRs to the extra groups in flight)
         return act_softplus_val(forward(p, c, x, h, use_tab, E1));
+    }
+
+    // ---- value + weighted reverse sweep with a SOFTWARE-PIPELINED weight stream.
+    // In `forward` / `backward` every column group is loaded right where it is used: the wave then sits out the whole
+    // scalar-cache latency ~7 times per evaluation (s_load ... s_waitcnt lgkmcnt(0) back to back), which is most of
+    // what a lone wave loses against the VALU issue rate; with two waves per SIMD the second one only partly fills
+    // those holes.  Here the loads of the NEXT group (or the next layer's bias + first group, or the output weights)
+    // are issued before the FMAs of the current one, and the first group of a layer before the previous layer's
+    // activation functions, so each wait finds its data landed.  At most two groups are in flight.
+    // Measured on MI355X (tools/abl_bench.py, A/B in one process, bit-identical results), gradient launch at 125 000
+    // subjects: 2-6-6-1 0.6086 -> 0.5926 ms (-2.6 %; -1.4 % at 1e6, -1.2 % on the time-split path at 1e5), 2-4-4-1
+    // -2.4 %, 3-4-4-1 -1.9 %, 2-8-8-1 -0.9 %, 2-4-4-4-1 -4.8 %; with the wait of a group placed before the next group's
+    // request (`touch`) 0.5826 ms (-3.8 %; 2-8-8-1 -4 %); suppression 4-3x5-1 at 1e5 subjects 1.612 -> 1.564 ms.
+    // Groups of two columns: with three in flight twice (36 + 36 SGPRs) the allocator spills to VGPR lanes and the gain
+    // is lost (0.6088 ms).
+    static constexpr int CGP = (W == 3) ? 3 : (W % 2 == 0) ? 2 : 1;  // columns per group of the pipelined stream
+    static constexpr int NG = W / CGP;                // column groups per hidden layer
+    static constexpr bool HAS_PF = (D >= 2);
+    // forward half: hidden activations h, output pre-activation returned; wo and (KEEP) the last hidden layer's last
+    // column group stay loaded for the backward half
+    template <bool KEEP>
+    __device__ static __forceinline__ double forward_pf(cptr_t p, const double (&c)[W], const double (&x)[NV],
+                                                        double (&h)[D][W], bool use_tab, const Exps* E1, SCol<W>& wo,
+                                                        SCol<W * CGP>& glast) {
+        double z[W];
+        SCol<W> bias[D];                 // bias[l]: hidden layer l (l >= 1)
+        SCol<W * CGP> grp[D][NG];        // grp[l][g]: column group g of hidden layer l (l >= 1)
+        double bo = 0.0;
+        bias[1] = ld_col<W>(p, L1 + W * W);
+        grp[1][0] = ld_col<W * CGP>(p, L1);
+        CUDE_FENCE();
+        if (use_tab) {
+            m_tanh_from_exp<W>(E1->v, h[0]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const SCol<W> col = ld_col<W>(p, W * i);
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
+            }
+            m_tanh_vec<W>(z, h[0]);
+        }
+#pragma unroll
+        for (int l = 1; l < D; l++) {
+            const int o = L1 + (l - 1) * LH;
+#pragma unroll
+            for (int j = 0; j < W; j++) z[j] = bias[l].v[j];
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                CUDE_FENCE();
+                touch(grp[l][g]);        // the wait for THIS group goes here, before the next one is requested
+                if (g + 1 < NG) {
+                    grp[l][g + 1] = ld_col<W * CGP>(p, o + W * CGP * (g + 1));
+                } else if (l + 1 < D) {
+                    bias[l + 1] = ld_col<W>(p, o + LH + W * W);
+                    grp[l + 1][0] = ld_col<W * CGP>(p, o + LH);
+                } else {
+                    wo = ld_col<W>(p, OUT);
+                    bo = launder(p)[OUT + W];
+                }
+                CUDE_FENCE();
+#pragma unroll
+                for (int k = 0; k < CGP; k++)
+#pragma unroll
+                    for (int j = 0; j < W; j++) z[j] = fma(grp[l][g].v[k * W + j], h[l - 1][g * CGP + k], z[j]);
+            }
+            CUDE_FENCE();
+            m_tanh_vec<W>(z, h[l]);
+        }
+        CUDE_FENCE();
+        // the last hidden layer's last column group is needed again right after the output unit
+        if (KEEP) glast = ld_col<W * CGP>(p, L1 + (D - 2) * LH + W * CGP * (NG - 1));
+        CUDE_FENCE();
+        double z0 = bo, z1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (i & 1) z1 = fma(wo.v[i], h[D - 1][i], z1);
+            else z0 = fma(wo.v[i], h[D - 1][i], z0);
+        }
+        return z0 + z1;
+    }
+
+    template <bool WANT_DX>
+    __device__ static __forceinline__ double eval_grad_pf(cptr_t p, const double (&c)[W], const double (&x)[NV],
+                                                          double wgt, double (&acc)[NACC], double (&dx)[NV],
+                                                          bool use_tab, const Exps* E1) {
+        p = launder(p);
+        double h[D][W];
+        SCol<W * CGP> grp[D][NG];        // grp[l][g]: column group g of hidden layer l (l >= 1), backward order
+        SCol<W> wo;
+        const double zo = forward_pf<true>(p, c, x, h, use_tab, E1, wo, grp[D - 1][NG - 1]);
+        double sig;
+        const double y = act_softplus(zo, &sig);
+        // ------------------------------------------------ backward (column groups from the last to the first)
+        const double dz = wgt * sig;
+        acc[G_OUT + W] += dz;
+        double dh[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            acc[G_OUT + i] = fma(dz, h[D - 1][i], acc[G_OUT + i]);
+            dh[i] = dz * wo.v[i];
+        }
+#pragma unroll
+        for (int l = D - 1; l >= 1; l--) {
+            const int o = L1 + (l - 1) * LH;
+            const int go = G_H + (l - 1) * LH;
+            double d[W];
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                d[j] = dh[j] * fma(-h[l][j], h[l][j], 1.0);
+                acc[go + W * W + j] += d[j];
+            }
+#pragma unroll
+            for (int g = NG - 1; g >= 0; g--) {
+                CUDE_FENCE();
+                touch(grp[l][g]);
+                if (g > 0) grp[l][g - 1] = ld_col<W * CGP>(p, o + W * CGP * (g - 1));
+                else if (l > 1) grp[l - 1][NG - 1] = ld_col<W * CGP>(p, o - LH + W * CGP * (NG - 1));
+                CUDE_FENCE();
+#pragma unroll
+                for (int k = 0; k < CGP; k++) {
+                    const int i = g * CGP + k;
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < W; j++) {
+                        acc[go + j + W * i] = fma(d[j], h[l - 1][i], acc[go + j + W * i]);
+                        if (j & 1) s1 = fma(grp[l][g].v[k * W + j], d[j], s1);
+                        else s0 = fma(grp[l][g].v[k * W + j], d[j], s0);
+                    }
+                    dh[i] = s0 + s1;
+                }
+            }
+            CUDE_FENCE();
+        }
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const double d = dh[j] * fma(-h[0][j], h[0][j], 1.0);
+            dh[j] = d;
+            acc[G_C + j] += d;
+#pragma unroll
+            for (int i = 0; i < NV; i++) acc[G_W1V + i * W + j] = fma(d, x[i], acc[G_W1V + i * W + j]);
+        }
+        if (WANT_DX) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                CUDE_FENCE();
+                const SCol<W> col = ld_col<W>(p, W * i);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < W; j++) {
+                    if (j & 1) s1 = fma(col.v[j], dh[j], s1);
+                    else s0 = fma(col.v[j], dh[j], s0);
+                }
+                dx[i] += s0 + s1;
+            }
+        }
+        return y;
     }
 
     // value + weighted reverse sweep:  acc += wgt * d(out)/d(params);  if WANT_DX,
@@ -323,6 +489,9 @@ struct Mlp {
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                        double wgt, double (&acc)[NACC], double (&dx)[NV],
                                                        bool use_tab = false, const Exps* E1 = nullptr) {
+#ifndef CUDE_NO_PREFETCH
+        if constexpr (HAS_PF) return eval_grad_pf<WANT_DX>(p, c, x, wgt, acc, dx, use_tab, E1);
+#endif
         p = launder(p);
         double h[D][W];
         const double zo = forward(p, c, x, h, use_tab, E1);
