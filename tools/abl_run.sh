@@ -1,1 +1,4 @@
-for n in 125000 10000 64; do for a in 2,6,2 2,4,2 2,8,2; do for v in pf2d pf2e; do python tools/abl_bench.py $v $n $a; done; done; done
+for r in 1 2; do for v in pf2d pf2f; do python tools/abl_bench.py $v 125000; done; done
+for v in pf2d pf2f; do python tools/abl_bench.py $v 1000000; done
+export CUDE_CPEP_PATH=1
+for v in pf2d pf2f; do python tools/abl_bench.py $v 64; done
