@@ -339,7 +339,11 @@ struct Mlp {
     // request (`touch`) 0.5826 ms (-3.8 %; 2-8-8-1 -4 %); suppression 4-3x5-1 at 1e5 subjects 1.612 -> 1.564 ms.
     // Groups of two columns: with three in flight twice (36 + 36 SGPRs) the allocator spills to VGPR lanes and the gain
     // is lost (0.6088 ms).
+#ifdef CUDE_PF_GROUP
+    static constexpr int CGP = (W % CUDE_PF_GROUP == 0) ? CUDE_PF_GROUP : 1;
+#else
     static constexpr int CGP = (W == 3) ? 3 : (W % 2 == 0) ? 2 : 1;  // columns per group of the pipelined stream
+#endif
     static constexpr int NG = W / CGP;                // column groups per hidden layer
     static constexpr bool HAS_PF = (D >= 2);
     // forward half: hidden activations h, output pre-activation returned; wo and (KEEP) the last hidden layer's last

@@ -304,6 +304,35 @@ def test_builtin_rccl_path_reports_itself_and_runs_the_lbfgs_stage():
     assert np.isfinite(a[2][0]) and a[2][0] < a[3][0, 0]      # the objective went down
 
 
+def test_queued_adam_run_with_a_communicator_equals_the_plain_run():
+    """bench.py times K optimiser steps queued by cude_adam_run; with more than one rank every step carries the RCCL
+    all-reduce on the context's stream (no hipGraph then).  With a one-rank communicator that path must reproduce the
+    plain (graph-replayed) run bit for bit: same K losses, same parameters, with and without kernel timing."""
+    from cude.engine import Engine
+    c = make_cpep_case(300, (2, 6, 2))
+
+    def run(with_comm, timing):
+        eng = Engine("cpep", (2, 6, 2), n_steps=30, n_state=3)
+        if with_comm:
+            eng.comm_init(1, 0, Engine.comm_unique_id())
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], c["beta"])
+        eng.adam_init(1e-2)
+        eng.set_kernel_timing(timing)
+        losses = np.concatenate([eng.adam_run(7), eng.adam_run(5)])
+        ms, n = eng.kernel_time_ms()
+        assert n == (12 if timing else 0)
+        nn, cond = eng.get_params()
+        eng.close()
+        return losses, nn, cond
+    ref = run(False, False)
+    for with_comm, timing in ((True, False), (True, True), (False, True)):
+        got = run(with_comm, timing)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), (with_comm, timing)
+    assert ref[0][-1] < ref[0][0]
+
+
 def _gpu_lbfgs_rank(rank, world, port, n_total, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     here = os.path.dirname(os.path.abspath(__file__))
