@@ -410,9 +410,9 @@ struct Mlp {
         return z0 + z1;
     }
 
-    template <bool WANT_DX>
+    template <bool WANT_DX, class A>
     __device__ static __forceinline__ double eval_grad_pf(cptr_t p, const double (&c)[W], const double (&x)[NV],
-                                                          double wgt, double (&acc)[NACC], double (&dx)[NV],
+                                                          double wgt, A& acc, double (&dx)[NV],
                                                           bool use_tab, const Exps* E1) {
         p = launder(p);
         double h[D][W];
@@ -489,9 +489,9 @@ struct Mlp {
 
     // value + weighted reverse sweep:  acc += wgt * d(out)/d(params);  if WANT_DX,
     // dx[i] += wgt * d(out)/dx_i.  Returns the network output.
-    template <bool WANT_DX>
+    template <bool WANT_DX, class A>
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[W], const double (&x)[NV],
-                                                       double wgt, double (&acc)[NACC], double (&dx)[NV],
+                                                       double wgt, A& acc, double (&dx)[NV],
                                                        bool use_tab = false, const Exps* E1 = nullptr) {
 #ifndef CUDE_NO_PREFETCH
         if constexpr (HAS_PF) return eval_grad_pf<WANT_DX>(p, c, x, wgt, acc, dx, use_tab, E1);
@@ -515,9 +515,9 @@ struct Mlp {
 
     // weighted reverse sweep from kept activations:  acc += wgt * d(out)/d(params);  if WANT_DX,
     // dx[i] += wgt * d(out)/dx_i
-    template <bool WANT_DX>
+    template <bool WANT_DX, class A>
     __device__ static __forceinline__ void backward(cptr_t p, const double (&x)[NV], const double (&h)[D][W], double sig,
-                                                    double wgt, double (&acc)[NACC], double (&dx)[NV]) {
+                                                    double wgt, A& acc, double (&dx)[NV]) {
         const double dz = wgt * sig;
         acc[G_OUT + W] += dz;
         double dh[W];
@@ -588,7 +588,8 @@ struct Mlp {
 
     // Entry q of the gradient in the SimpleChains parameter order, read off the accumulators (q is a compile-time
     // constant wherever this is called from an unrolled loop, so it folds to one register or one multiply).
-    __device__ static __forceinline__ double grad_elem(int q, const double (&acc)[NACC],
+    template <class A>
+    __device__ static __forceinline__ double grad_elem(int q, const A& acc,
                                                        const double (&cst)[NC > 0 ? NC : 1]) {
         if (q < W * NIN) {
             const int j = q % W, i = q / W;
@@ -598,7 +599,8 @@ struct Mlp {
         return acc[G_H + (q - L1)];
     }
     // d/d(conditional) through cst[0] = exp(conditional):  cst0 * sum_j dc_j * W1[j,NV]
-    __device__ static __forceinline__ double grad_cond(cptr_t p, const double (&acc)[NACC],
+    template <class A>
+    __device__ static __forceinline__ double grad_cond(cptr_t p, const A& acc,
                                                        const double (&cst)[NC > 0 ? NC : 1]) {
         double s = 0.0;
         if (NC > 0) {
@@ -659,9 +661,9 @@ struct MmProd {
         const double v = (p[0] * x[0]) / (x[0] + c[0]);
         return x[0] >= 0.0 ? v : 0.0;
     }
-    template <bool WANT_DX>
+    template <bool WANT_DX, class A>
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[1], const double (&x)[1],
-                                                       double wgt, double (&acc)[NACC], double (&dx)[1], bool = false,
+                                                       double wgt, A& acc, double (&dx)[1], bool = false,
                                                        const Exps* = nullptr) {
         const double r = 1.0 / (x[0] + c[0]);
         const double f = x[0] * r;                  // d/dp0
@@ -677,9 +679,32 @@ struct MmProd {
         g[0] = acc[0];
         *dcond = RAW ? acc[1] : acc[1] * cst[0];
     }
-    __device__ static __forceinline__ double grad_elem(int, const double (&acc)[NACC], const double (&)[1]) { return acc[0]; }
-    __device__ static __forceinline__ double grad_cond(cptr_t, const double (&acc)[NACC], const double (&cst)[1]) {
+    template <class A>
+    __device__ static __forceinline__ double grad_elem(int, const A& acc, const double (&)[1]) { return acc[0]; }
+    template <class A>
+    __device__ static __forceinline__ double grad_cond(cptr_t, const A& acc, const double (&cst)[1]) {
         return RAW ? acc[1] : acc[1] * cst[0];
+    }
+};
+
+// ------------------------------------------------------------------------------------ accumulator containers
+// The gradient functions above take any container with operator[] for the NACC partial sums: a plain register array,
+// or this one, which keeps the hidden layers' accumulators in registers and the first- and output-layer ones -- each
+// touched once per evaluation, at the two ends of the backward sweep -- in LDS rows (lds = row base + lane).  For a
+// kernel that already sits at one wave per SIMD with registers to spare nowhere (suppression 4-3x5-1: 64 accumulators
+// = 128 VGPRs), every accumulator that leaves the register file is one the compiler no longer shuttles through AGPRs.
+template <class Net, int NHL = 0>        // NHL: how many of the LAST hidden layers' accumulators also live in LDS
+struct SplitAcc {
+    static constexpr int HI = Net::G_OUT - NHL * Net::LH;            // accumulators [G_H, HI) stay in registers
+    static constexpr int NREG = HI - Net::G_H;
+    static constexpr int NLDS = Net::NACC - NREG;                    // first layer, last NHL hidden layers, output layer
+    double r[NREG > 0 ? NREG : 1];
+    double* lds;
+    __device__ __forceinline__ double& operator[](int q) {
+        return q < Net::G_H ? lds[q * 64] : (q >= HI ? lds[(q - NREG) * 64] : r[q - Net::G_H]);
+    }
+    __device__ __forceinline__ const double& operator[](int q) const {
+        return q < Net::G_H ? lds[q * 64] : (q >= HI ? lds[(q - NREG) * 64] : r[q - Net::G_H]);
     }
 };
 
@@ -711,8 +736,8 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], double
 // into the LDS transpose, so the P-vector never exists in registers next to the accumulators (the epilogue used to be
 // the register peak of the gradient kernels: 336 VGPRs = one wave per SIMD for the suppression model).
 // out[0..P) = sum over lanes of keep * grad_elem(q); out[P], out[P+1] = sum of extra0, extra1.
-template <class Net, int NCST>
-__device__ __forceinline__ void block_reduce_expand(const double (&acc)[Net::NACC], const double (&cst)[NCST], double keep,
+template <class Net, int NCST, class A>
+__device__ __forceinline__ void block_reduce_expand(const A& acc, const double (&cst)[NCST], double keep,
                                                     double extra0, double extra1, double* s_red, double* out, int lane) {
     constexpr int NV = Net::P + 2;
 #pragma unroll

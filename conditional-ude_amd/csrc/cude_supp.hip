@@ -26,8 +26,9 @@ struct SuppRhs {
         du[2] = fma(-0.3, u[2], uh);
     }
     // ub += J_f(u)^T kb ; acc += (df/dparams)^T kb
+    template <class A>
     __device__ static __forceinline__ void vjp(cptr_t p, const double (&c)[W], const double (&u)[3],
-                                               const double (&kb)[3], double (&ub)[3], double (&acc)[Net::NACC]) {
+                                               const double (&kb)[3], double (&ub)[3], A& acc) {
         const double wgt = kb[2] - kb[1];
         double dx[3] = {0.0, 0.0, 0.0};
         Net::template eval_grad<true>(p, c, u, wgt, acc, dx);
@@ -43,8 +44,9 @@ struct SuppRhs {
         du[1] = fma(0.4, u[0], -uh);
         du[2] = fma(-0.3, u[2], uh);
     }
+    template <class A>
     __device__ static __forceinline__ void vjp_kept(cptr_t p, const double (&u)[3], const double (&h)[D][W], double sig,
-                                                    const double (&kb)[3], double (&ub)[3], double (&acc)[Net::NACC]) {
+                                                    const double (&kb)[3], double (&ub)[3], A& acc) {
         const double wgt = kb[2] - kb[1];
         double dx[3] = {0.0, 0.0, 0.0};
         Net::template backward<true>(launder(p), u, h, sig, wgt, acc, dx);
@@ -61,6 +63,24 @@ struct SuppRhs {
 // live behind the stage inputs in the HBM scratch, not in LDS: with them the kernel needed 33 KB per wave = 4 waves
 // per CU whatever its register count.
 constexpr int kSuppRowsK = 21;
+
+// accumulator container per network shape: registers while they fit next to two resident waves, split otherwise
+template <class Net, bool SPLIT = (Net::NACC > 48)>
+struct SuppAcc {
+    struct type {
+        double a[Net::NACC];
+        __device__ __forceinline__ double& operator[](int q) { return a[q]; }
+        __device__ __forceinline__ const double& operator[](int q) const { return a[q]; }
+    };
+    static constexpr int rows = 0;
+    __device__ static __forceinline__ void init(type&, double*) {}
+};
+template <class Net>
+struct SuppAcc<Net, true> {
+    using type = SplitAcc<Net, 0>;
+    static constexpr int rows = type::NLDS;
+    __device__ static __forceinline__ void init(type& acc, double* lds) { acc.lds = lds; }
+};
 
 // STORE (gradient only): the forward sweep also writes the D*W tanh outputs and the output unit's logistic derivative
 // of every evaluation to HBM ([evaluation][value][subject]) and the reverse sweep reads them back instead of
@@ -81,6 +101,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
     extern __shared__ double smem[];
     double* s_K = smem;
     double* s_Y = smem + kSuppRowsK * kBlock;
+    double* s_S = smem + kSuppRowsK * (YONLY ? 2 : 1) * kBlock;     // [9] cold adjoint state of the reverse sweep
     double* s_red = s_K;
 
     const int lane = threadIdx.x;
@@ -100,6 +121,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
     double* act = STORE ? a.act + set * ((int64_t)(6 * S + 1) * NACT * N) : nullptr;
 #define KROW(j, s) s_K[((j) * 3 + (s)) * kBlock + lane]
 #define YROW(j, s) s_Y[((j) * 3 + (s)) * kBlock + lane]
+#define LAM(s) s_S[(s) * kBlock + lane]           /* adjoint of y_{n+1} */
+#define KAP(s) s_S[(3 + (s)) * kBlock + lane]     /* adjoint of k_7 of step n from step n+1's use as k_1 */
+#define YB(s) s_S[(6 + (s)) * kBlock + lane]      /* adjoint of y_n being assembled */
 
     double cst[1] = {exp(a.cond[set * a.set_stride_cond + i])};
     double c[W];
@@ -108,7 +132,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
     double y[3];
 #pragma unroll
     for (int s = 0; s < 3; s++) y[s] = a.data[((int64_t)s * T + 0) * N + i];
-    const double y0[3] = {y[0], y[1], y[2]};
 
     // ------------------------------------------------------------------ forward
     // One network call site: evaluation e = 0 is k_1 of step 0; e = 6n+st (st = 1..6) is stage
@@ -193,12 +216,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
         return;
     } else {
         // -------------------------------------------------------------- reverse sweep
-        double acc[Net::NACC];
+        // first- and output-layer accumulators in LDS rows behind the adjoint state where the register file cannot hold
+        // them all (measured at 1e5 subjects, 4-3x5-1: 1.563 -> 1.506 ms; also moving the last hidden layer's, which are
+        // updated while the next weight group is in flight, costs more than it frees: 1.85 ms)
+        typename SuppAcc<Net>::type acc;
+        SuppAcc<Net>::init(acc, s_S + 9 * kBlock + lane);
 #pragma unroll
         for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
-        double lam[3] = {0.0, 0.0, 0.0};   // adjoint of y_{n+1}
-        double kap[3] = {0.0, 0.0, 0.0};   // adjoint of k_7 of step n from step n+1's use as k_1
-        double yb[3] = {0.0, 0.0, 0.0};
+        // lam / kap / yb are touched once per evaluation or per step: they live in LDS (there is room -- one wave per
+        // SIMD -- and every VGPR saved is one less accumulator shuttled through the AGPRs)
+#pragma unroll
+        for (int s = 0; s < 3; s++) { LAM(s) = 0.0; KAP(s) = 0.0; YB(s) = 0.0; }
         const double gs = 2.0 * a.inv_n;
         oi = T - 1;
         n = S - 1;
@@ -246,13 +274,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
                     for (int s = 0; s < 3; s++) KROW(j, s) = 0.0;
                 }
 #pragma unroll
-                for (int s = 0; s < 3; s++) { KROW(6, s) = kap[s]; yb[s] = 0.0; }
+                for (int s = 0; s < 3; s++) { KROW(6, s) = KAP(s); YB(s) = 0.0; }
                 while (oi >= 0 && obs_step[oi] == n) {
                     double hg[3];
 #pragma unroll
                     for (int s = 0; s < 3; s++) {
                         const double g = gs * a.iscale2[s] * res[(int64_t)(oi * 3 + s) * N + i];
-                        yb[s] += g;
+                        YB(s) += g;
                         hg[s] = h * g;
                     }
 #pragma unroll 1
@@ -273,11 +301,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < 3; s++) { u[s] = y0[s]; kb[s] = kap[s]; }
+                for (int s = 0; s < 3; s++) { u[s] = a.data[((int64_t)s * T + 0) * N + i]; kb[s] = KAP(s); }
             }
             if (idx > 0 && st == 6) {
 #pragma unroll
-                for (int s = 0; s < 3; s++) ub[s] = lam[s];     // stage 7 adds into the adjoint of y_{n+1}
+                for (int s = 0; s < 3; s++) ub[s] = LAM(s);     // stage 7 adds into the adjoint of y_{n+1}
             } else {
 #pragma unroll
                 for (int s = 0; s < 3; s++) ub[s] = 0.0;
@@ -296,7 +324,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
             if (idx == 0) break;
             // propagate ub through  Y_st = y_n + h sum_{j<st} a(st,j) k_j
 #pragma unroll
-            for (int s = 0; s < 3; s++) yb[s] += ub[s];
+            for (int s = 0; s < 3; s++) YB(s) += ub[s];
             const int nj = st < 6 ? st : 6;
 #pragma unroll 1
             for (int j = 0; j < nj; j++) {
@@ -308,23 +336,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
                 st--;
             } else {
 #pragma unroll
-                for (int s = 0; s < 3; s++) { lam[s] = yb[s]; kap[s] = KROW(0, s); }
+                for (int s = 0; s < 3; s++) { LAM(s) = YB(s); KAP(s) = KROW(0, s); }
                 st = 6;
                 n--;
             }
         }
         __syncthreads();                   // s_red aliases s_K, which the reverse sweep has just been using
-        if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(p, acc, cst);
-        block_reduce_expand<Net, 1>(acc, cst, active ? 1.0 : 0.0, red_loss, red_fail, s_red, out, lane);
+        const double cst_end[1] = {exp(a.cond[set * a.set_stride_cond + i])};      // not kept live across the sweeps
+        if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(p, acc, cst_end);
+        block_reduce_expand<Net, 1>(acc, cst_end, active ? 1.0 : 0.0, red_loss, red_fail, s_red, out, lane);
     }
 #undef KROW
 #undef YROW
+#undef LAM
+#undef KAP
+#undef YB
 }
 
 template <int W, int D, bool GRAD, bool STORE, bool YONLY = false>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
-    const size_t lds = sizeof(double) * (size_t)(kSuppRowsK * (YONLY ? 2 : 1)) * kBlock;
+    const size_t lds = sizeof(double) * (size_t)(kSuppRowsK * (YONLY ? 2 : 1) +
+                                                 (GRAD ? 9 + SuppAcc<Mlp<4, W, D, 3>>::rows : 0)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE, YONLY>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();

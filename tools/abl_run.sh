@@ -1,1 +1,1 @@
-for r in 1 2; do for v in cur pfg1 pfg3 magic; do python tools/abl_bench.py $v 125000; done; done
+for v in suppacc suppa1 suppa2 suppa1; do python tools/abl_supp.py $v 100000 131072 37; done
