@@ -350,9 +350,15 @@ def extras(Engine, device, steps=20, warm=40):
     rng = np.random.default_rng(5)
     z, u = rng.standard_normal((n_mc, n)), rng.random((n_mc, n))
     eng.mh_estep(z[:10], u[:10], 0.5, -0.6, 0.8, 0.3)
+    t0 = time.perf_counter()
+    eng.mh_estep(z, u, 0.5, -0.6, 0.8, 0.3)          # host-supplied draws: 16 MB cross PCIe inside the call
+    dt_host_draws = time.perf_counter() - t0
+    eng.set_params(nn4, pop["beta0"])
+    eng.set_rng(20250905)
+    eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
     eng.set_kernel_timing(True)
     t0 = time.perf_counter()
-    acc = eng.mh_estep(z, u, 0.5, -0.6, 0.8, 0.3)
+    acc = eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=n_mc)    # draws generated on the device (Philox4x32-10)
     dt = time.perf_counter() - t0
     ms, launches = eng.kernel_time_ms()
     eng.set_kernel_timing(False)
@@ -360,7 +366,8 @@ def extras(Engine, device, steps=20, warm=40):
                           cpep_algo_bytes(T_OBS, 2, False), cpep_flops(arch, N_STEPS, T_OBS, 2, False))
     out["saem_estep_1e4x100"] = {"config": "BASELINE configs[4] on one GPU: SAEM E-step (saem.jl:86-108,177-186), 1e4 "
                                            "subjects x 100 Metropolis steps (gamma = 1: burn-in phase), 2x4x4x1, "
-                                           "host-supplied draws uploaded inside the timed call",
+                                           "draws generated on the device (counter-based Philox4x32-10)",
+                                 "ms_per_estep_with_host_supplied_draws": dt_host_draws * 1e3,
                                  "value": n * n_mc / dt, "unit": "Metropolis draws/s", "ms_per_estep": dt * 1e3,
                                  "forward_solves_per_s": n * launches / dt,
                                  "reference_equivalent_solves_per_s": 2 * n * n_mc / dt,

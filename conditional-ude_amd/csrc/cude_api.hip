@@ -237,6 +237,8 @@ struct cude_ctx {
     // timing of the dominant kernel
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t rng_seed = 0x243F6A8885A308D3ull;      // device-side draws of the Metropolis steps (cude_set_rng)
+    int64_t rng_offset = 0, rng_step = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double host_red[3];
@@ -1394,16 +1396,20 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     int32_t rc = bind(c);
     if (rc) return rc;
     if (!c->have_pop || !c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "population / parameters not set");
-    if (n_mc < 1 || !normals || !uniforms) return fail(CUDE_ERR_ARG, "null/empty draws");
+    if (n_mc < 1) return fail(CUDE_ERR_ARG, "n_mc must be >= 1");
+    if ((normals == nullptr) != (uniforms == nullptr)) return fail(CUDE_ERR_ARG, "pass both draw arrays or neither");
+    const bool device_rng = normals == nullptr;     // draws from the context's counter-based generator (cude_set_rng)
     if (!(sigma > 0) || !(prior_sd > 0) || !(temperature > 0)) return fail(CUDE_ERR_ARG, "sigma, prior_sd, temperature must be > 0");
     const int64_t N = c->N;
     DevBuf<double> d_z, d_u, d_prop, d_sn, d_sc;
     DevBuf<int64_t> d_acc;
-    HIP_TRY(d_z.resize((size_t)n_mc * N));
-    HIP_TRY(d_u.resize((size_t)n_mc * N));
+    if (!device_rng || samples) HIP_TRY(d_z.resize((size_t)n_mc * N));     // draws, then (samples) the chain states
+    if (!device_rng) HIP_TRY(d_u.resize((size_t)n_mc * N));
     HIP_TRY(d_prop.resize(N)); HIP_TRY(d_sn.resize(N)); HIP_TRY(d_sc.resize(N)); HIP_TRY(d_acc.resize(N));
-    HIP_TRY(hipMemcpyAsync(d_z.p, normals, (size_t)n_mc * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_u.p, uniforms, (size_t)n_mc * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!device_rng) {
+        HIP_TRY(hipMemcpyAsync(d_z.p, normals, (size_t)n_mc * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_u.p, uniforms, (size_t)n_mc * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipMemsetAsync(d_acc.p, 0, N * sizeof(int64_t), c->stream));
     cude::MhArgs m{};
     m.N = N; m.p = c->cond.p; m.prop = d_prop.p; m.sse_new = d_sn.p; m.sse_cur = d_sc.p; m.accepted = d_acc.p;
@@ -1418,10 +1424,12 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     m.carry_sse = gamma == 1.0 ? 1 : 0;
     if (m.carry_sse && (rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;
     for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
-        HIP_TRY(cude::launch_mh_propose(N, c->cond.p, d_z.p + (size_t)k * N, proposal_std, d_prop.p, c->stream));
+        m.key = cude::RngKey{c->rng_seed, c->rng_offset, c->rng_step + k};
+        HIP_TRY(cude::launch_mh_propose(N, c->cond.p, device_rng ? nullptr : d_z.p + (size_t)k * N, m.key, proposal_std,
+                                        d_prop.p, c->stream));
         if ((rc = run_ensemble(c, false, nullptr, true, d_prop.p, d_sn.p))) return rc;
         if (!m.carry_sse && (rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;
-        m.u = d_u.p + (size_t)k * N;
+        m.u = device_rng ? nullptr : d_u.p + (size_t)k * N;
         HIP_TRY(cude::launch_mh_accept(m, c->stream));
         if (samples)       // chain state after step k (the draws of this step are no longer needed: reuse their row)
             HIP_TRY(hipMemcpyAsync(d_z.p + (size_t)k * N, c->cond.p, N * sizeof(double), hipMemcpyDeviceToDevice,
@@ -1430,6 +1438,35 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     if (samples)
         HIP_TRY(hipMemcpyAsync(samples, d_z.p, (size_t)n_mc * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (device_rng) c->rng_step += n_mc;            // the next call continues the stream
+    return CUDE_OK;
+}
+
+int32_t cude_set_rng(cude_ctx* c, uint64_t seed, int64_t subject_offset) {
+    if (!c) return fail(CUDE_ERR_ARG, "null context");
+    if (subject_offset < 0) return fail(CUDE_ERR_ARG, "subject_offset must be >= 0");
+    c->rng_seed = seed;
+    c->rng_offset = subject_offset;
+    c->rng_step = 0;
+    return CUDE_OK;
+}
+
+int32_t cude_rng_draws(cude_ctx* c, int64_t first_step, int32_t n_steps, double* normals, double* uniforms) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    if (first_step < 0 || n_steps < 1 || (!normals && !uniforms)) return fail(CUDE_ERR_ARG, "bad argument");
+    const int64_t N = c->N;
+    DevBuf<double> d_z, d_u;
+    if (normals) HIP_TRY(d_z.resize((size_t)n_steps * N));
+    if (uniforms) HIP_TRY(d_u.resize((size_t)n_steps * N));
+    for (int k = 0; k < n_steps; k++)
+        HIP_TRY(cude::launch_rng_draws(N, cude::RngKey{c->rng_seed, c->rng_offset, first_step + k},
+                                       normals ? d_z.p + (size_t)k * N : nullptr, uniforms ? d_u.p + (size_t)k * N : nullptr,
+                                       c->stream));
+    if (normals) HIP_TRY(hipMemcpyAsync(normals, d_z.p, (size_t)n_steps * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (uniforms) HIP_TRY(hipMemcpyAsync(uniforms, d_u.p, (size_t)n_steps * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CUDE_OK;
 }

@@ -154,6 +154,12 @@ struct AdamArgs {
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 // SAEM E-step (Metropolis-Hastings) helper kernels
+// z == nullptr / MhArgs::u == nullptr: the draw comes from the counter-based generator (RngKey) instead of a host row
+struct RngKey {
+    uint64_t seed;             // Philox key
+    int64_t subject_offset;    // global index of local subject 0 (draws do not depend on how subjects are sharded)
+    int64_t step;              // index of the Metropolis step since cude_set_rng
+};
 struct MhArgs {
     int64_t N;
     double* p;                 // chain state (conditional parameters), updated in place
@@ -163,9 +169,12 @@ struct MhArgs {
     int32_t carry_sse;         // gamma == 1: the accepted proposal IS the next state, so its SSE is carried over
     int64_t* accepted;         // per-subject acceptance counter
     double prior_mean, prior_sd, ll_const, inv_2s2, temperature, gamma;
+    RngKey key;                // used when u == nullptr
 };
-hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, double proposal_std, double* prop,
+hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, RngKey key, double proposal_std, double* prop,
                              hipStream_t s);
+// the draws themselves (normals[N], uniforms[N] of one step), for reproducing a device-generated chain elsewhere
+hipError_t launch_rng_draws(int64_t N, RngKey key, double* normals, double* uniforms, hipStream_t s);
 hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s);
 // per-subject 1-D fits (cude_fit_conditional): device-resident search state, all arrays [N]
 struct FitArgs {

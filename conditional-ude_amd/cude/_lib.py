@@ -38,6 +38,8 @@ _SIGNATURES = {
     "cude_create": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "cude_destroy": (C.c_int32, [C.c_void_p]),
     "cude_set_tolerances": (C.c_int32, [C.c_void_p, C.c_double, C.c_double]),
+    "cude_set_rng": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64]),
+    "cude_rng_draws": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "cude_set_population_cpep": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "cude_set_population_supp": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -233,18 +233,39 @@ class Engine:
                                                   _ptr(g_cond)))
         return losses, g_nn, g_cond
 
-    def mh_estep(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0):
+    def mh_estep(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0,
+                 n_mc=None):
         """n_mc Metropolis-Hastings steps for every subject on the device (chain state = the context's
-        conditional parameters, updated in place).  normals/uniforms: (n_mc, N).  Returns acceptance counts."""
-        z = _f64(normals)
-        u = _f64(uniforms)
-        if z.ndim != 2 or z.shape[1] != self.N or u.shape != z.shape:
-            raise ValueError(f"expected draws of shape (n_mc, {self.N})")
+        conditional parameters, updated in place).  normals/uniforms: (n_mc, N) host draws, or both None with n_mc
+        given: the draws come from the device-side generator (set_rng).  Returns acceptance counts."""
         acc = np.zeros(self.N, dtype=np.int64)
-        check(self._lib.cude_mh_estep(self._h, z.shape[0], _ptr(z), _ptr(u), float(sigma), float(prior_mean),
+        if normals is None and uniforms is None:
+            if n_mc is None:
+                raise ValueError("n_mc is required when the draws are generated on the device")
+            z = u = None
+            steps = int(n_mc)
+        else:
+            z = _f64(normals)
+            u = _f64(uniforms)
+            if z.ndim != 2 or z.shape[1] != self.N or u.shape != z.shape:
+                raise ValueError(f"expected draws of shape (n_mc, {self.N})")
+            steps = z.shape[0]
+        check(self._lib.cude_mh_estep(self._h, steps, _ptr(z), _ptr(u), float(sigma), float(prior_mean),
                                       float(prior_sd), float(proposal_std), float(temperature), float(gamma),
                                       _ptr(acc)))
         return acc
+
+    def set_rng(self, seed, subject_offset=0):
+        """Seed / rewind the device-side draws of mh_estep / mh_chain; subject_offset = global index of this
+        context's first subject (draws do not depend on the sharding)."""
+        check(self._lib.cude_set_rng(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(subject_offset)))
+
+    def rng_draws(self, first_step, n_steps):
+        """(normals, uniforms), each (n_steps, N): the draws steps first_step ... of the device stream use."""
+        z = np.empty((int(n_steps), self.N))
+        u = np.empty((int(n_steps), self.N))
+        check(self._lib.cude_rng_draws(self._h, int(first_step), int(n_steps), _ptr(z), _ptr(u)))
+        return z, u
 
     def train_restarts(self, nn_sets, cond_sets, adam_iters, learning_rate, lbfgs_iters, want_trace=False):
         """K restarts trained side by side inside the library (Adam, then L-BFGS + BackTracking in lock step):
@@ -278,15 +299,24 @@ class Engine:
                                              _ptr(sse)))
         return x, obj, sse
 
-    def mh_chain(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0):
-        """mh_estep that also returns every state of the chain: (accepted (N,), samples (n_mc, N))."""
-        z = _f64(normals)
-        u = _f64(uniforms)
-        if z.ndim != 2 or z.shape[1] != self.N or u.shape != z.shape:
-            raise ValueError(f"expected draws of shape (n_mc, {self.N})")
+    def mh_chain(self, normals, uniforms, sigma, prior_mean, prior_sd, proposal_std, temperature=1.0, gamma=1.0,
+                 n_mc=None):
+        """mh_estep that also returns every state of the chain: (accepted (N,), samples (n_mc, N)).  normals =
+        uniforms = None with n_mc given: device-side draws."""
+        if normals is None and uniforms is None:
+            if n_mc is None:
+                raise ValueError("n_mc is required when the draws are generated on the device")
+            z = u = None
+            shape = (int(n_mc), self.N)
+        else:
+            z = _f64(normals)
+            u = _f64(uniforms)
+            if z.ndim != 2 or z.shape[1] != self.N or u.shape != z.shape:
+                raise ValueError(f"expected draws of shape (n_mc, {self.N})")
+            shape = z.shape
         acc = np.zeros(self.N, dtype=np.int64)
-        samples = np.empty(z.shape)
-        check(self._lib.cude_mh_chain(self._h, z.shape[0], _ptr(z), _ptr(u), float(sigma), float(prior_mean),
+        samples = np.empty(shape)
+        check(self._lib.cude_mh_chain(self._h, shape[0], _ptr(z), _ptr(u), float(sigma), float(prior_mean),
                                       float(prior_sd), float(proposal_std), float(temperature), float(gamma),
                                       _ptr(acc), _ptr(samples)))
         return acc, samples

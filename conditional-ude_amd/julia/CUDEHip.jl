@@ -215,6 +215,14 @@ function mh_estep!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, 
     accepted
 end
 
+function mh_estep!(c::Ctx, n_mc::Integer, σ, prior_η, Ω, proposal_std; temperature = 1.0, γ = 1.0)
+    accepted = zeros(Int64, c.N)
+    GC.@preserve accepted check(ccall((:cude_mh_estep, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64, Float64, Float64, Ptr{Int64}),
+        c.h, Int32(n_mc), C_NULL, C_NULL, σ, prior_η, Ω, proposal_std, temperature, γ, accepted))
+    accepted
+end
+
 function mh_chain!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, σ, prior_η, Ω, proposal_std;
                    temperature = 1.0, γ = 1.0)
     N, n_mc = size(normals); accepted = zeros(Int64, N); samples = similar(normals)
@@ -222,6 +230,17 @@ function mh_chain!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, 
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64, Float64, Float64, Ptr{Int64},
          Ptr{Float64}), c.h, n_mc, normals, uniforms, σ, prior_η, Ω, proposal_std, temperature, γ, accepted, samples))
     accepted, samples
+end
+
+# device-side draws of the Metropolis steps: mh_estep!(c, n_mc, σ, ...) without draw matrices
+set_rng!(c::Ctx, seed::Integer, subject_offset::Integer = 0) =
+    check(ccall((:cude_set_rng, LIB), Int32, (Ptr{Cvoid}, UInt64, Int64), c.h, UInt64(seed), Int64(subject_offset)))
+
+function rng_draws(c::Ctx, first_step::Integer, n_steps::Integer)
+    z = Matrix{Float64}(undef, c.N, n_steps); u = Matrix{Float64}(undef, c.N, n_steps)
+    GC.@preserve z u check(ccall((:cude_rng_draws, LIB), Int32, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}),
+        c.h, Int64(first_step), Int32(n_steps), z, u))
+    z, u
 end
 
 # L-BFGS + BackTracking of the library for any Julia objective fg!(g, x) -> f (host only)

@@ -228,7 +228,8 @@ int32_t cude_fit_conditional(cude_ctx* ctx, double lower, double upper, int32_t 
  * at).  For gamma == 1 -- its burn-in phase and the posterior sampling loop -- the next state is exactly the
  * accepted proposal or the unchanged state and the solve is deterministic, so the known SSE is carried over: same
  * bits, n_mc + 1 ensemble solves instead of 2 n_mc.  accepted[N] (optional) receives per-subject acceptance
- * counts.  All launches are queued on the stream; the call synchronises once at the end. */
+ * counts.  All launches are queued on the stream; the call synchronises once at the end.
+ * normals == uniforms == NULL: the draws are generated on the device (cude_set_rng) -- nothing crosses PCIe. */
 int32_t cude_mh_estep(cude_ctx* ctx, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
                       double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
                       int64_t* accepted);
@@ -240,6 +241,20 @@ int32_t cude_mh_estep(cude_ctx* ctx, int32_t n_mc, const double* normals, const 
 int32_t cude_mh_chain(cude_ctx* ctx, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
                       double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
                       int64_t* accepted, double* samples);
+
+/* Device-side random draws for cude_mh_estep / cude_mh_chain (the `randn()` / `rand()` of mcmc_step, src/saem.jl:88,103)
+ * when the caller passes no draw arrays: counter-based Philox4x32-10, key = seed, counter = (global subject index,
+ * index of the Metropolis step since this call, kind); standard normals by Box-Muller on two 53-bit uniforms, uniforms
+ * from 53 bits, both strictly inside (0, 1).  A draw depends only on (seed, subject_offset + local index, step): the
+ * chain of a subject is the same whatever the launch shape and however the population is sharded (subject_offset =
+ * global index of this context's first subject).  Successive calls continue the stream; this call rewinds it.
+ * Default: seed 0x243F6A8885A308D3, offset 0. */
+int32_t cude_set_rng(cude_ctx* ctx, uint64_t seed, int64_t subject_offset);
+
+/* The draws steps first_step ... first_step + n_steps - 1 of that stream use, [n_steps][N] row-major each (either
+ * pointer may be NULL): lets a caller replay a device-generated chain elsewhere (the parity tests feed them to the
+ * oracle chain and to the host-supplied-draws path). */
+int32_t cude_rng_draws(cude_ctx* ctx, int64_t first_step, int32_t n_steps, double* normals, double* uniforms);
 
 /* Loss and gradient: replaces ForwardDiff.gradient(loss, theta) under AutoForwardDiff()
  * (parameter-estimation.jl:370; suppression_model.jl:155; saem.jl:120) by a discrete adjoint

@@ -126,3 +126,64 @@ def test_config5_size_estep_invariants():
     assert np.array_equal(p1, p2) and np.array_equal(acc1, acc2)
     assert np.all(np.isfinite(p1)) and 0.02 < acc1.mean() / steps < 0.98
     assert np.median(sse1) < np.median(sse0)
+
+
+def test_device_side_draws():
+    """normals = uniforms = NULL: Philox4x32-10 draws generated on the device (cude_set_rng).  (i) The draws are the
+    ones the published algorithm gives for (seed, global subject index, step) -- uniforms bit for bit, normals to the
+    rounding of log / cos; (ii) an E-step with device draws IS the E-step with those draws supplied by the host (same
+    accept counts, same states), so everything proved about that path carries over; (iii) successive calls continue the
+    stream, cude_set_rng rewinds it; (iv) a shard with subject_offset draws what the full population draws for its
+    subjects; (v) first moments and range of 2e5 draws."""
+    from conftest import device_draw
+    from cude.engine import Engine
+    arch, N = (2, 4, 2), 96
+    c = make_cpep_case(N, arch)
+
+    def engine(lo=0, hi=N):
+        eng = Engine("cpep", arch, n_steps=30)
+        eng.set_population_cpep(c["tp"], c["G"][lo:hi], c["obs"][lo:hi], c["age"][lo:hi], c["t2dm"][lo:hi])
+        eng.set_params(c["nn"], c["beta"][lo:hi])
+        return eng
+    seed = 0x9E3779B97F4A7C15
+    eng = engine()
+    eng.set_rng(seed)
+    z, u = eng.rng_draws(0, 9)
+    for step, i in ((0, 0), (0, 95), (3, 17), (8, 64)):
+        zn, un = device_draw(seed, i, step)
+        assert u[step, i] == un and abs(z[step, i] - zn) <= 4e-15 * max(1.0, abs(zn))
+    # (ii) + (iii)
+    acc_a = eng.mh_estep(None, None, 0.4, -0.6, 0.9, 0.3, n_mc=5)
+    acc_b, samples_b = eng.mh_chain(None, None, 0.4, -0.6, 0.9, 0.3, n_mc=4)          # steps 5 ... 8 of the stream
+    _, p_dev = eng.get_params()
+    ref = engine()
+    acc_ra = ref.mh_estep(z[:5], u[:5], 0.4, -0.6, 0.9, 0.3)
+    acc_rb, samples_rb = ref.mh_chain(z[5:9], u[5:9], 0.4, -0.6, 0.9, 0.3)
+    _, p_ref = ref.get_params()
+    assert np.array_equal(acc_a, acc_ra) and np.array_equal(acc_b, acc_rb)
+    assert np.array_equal(samples_b, samples_rb) and np.array_equal(p_dev, p_ref)
+    assert 0 < acc_a.sum() < 5 * N
+    eng.set_rng(seed)                                                                   # rewind: the same chain again
+    eng.set_params(c["nn"], c["beta"])
+    assert np.array_equal(eng.mh_estep(None, None, 0.4, -0.6, 0.9, 0.3, n_mc=5), acc_a)
+    # (iv)
+    part = engine(40, N)
+    part.set_rng(seed, subject_offset=40)
+    zp, up = part.rng_draws(2, 3)
+    assert np.array_equal(zp, z[2:5, 40:]) and np.array_equal(up, u[2:5, 40:])
+    acc_p = part.mh_estep(None, None, 0.4, -0.6, 0.9, 0.3, n_mc=5)
+    assert np.array_equal(acc_p, acc_a[40:])
+    for e in (eng, ref, part):
+        e.close()
+    # (v)
+    big = Engine("cpep", arch, n_steps=30)
+    cb = make_cpep_case(2000, arch)
+    big.set_population_cpep(cb["tp"], cb["G"], cb["obs"], cb["age"], cb["t2dm"])
+    zz, uu = big.rng_draws(0, 100)
+    big.close()
+    n = zz.size
+    assert abs(zz.mean()) < 4 / np.sqrt(n) and abs(zz.var() - 1) < 4 * np.sqrt(2 / n)
+    assert abs(uu.mean() - 0.5) < 4 / np.sqrt(12 * n) and 0 < uu.min() and uu.max() < 1
+    assert abs(np.corrcoef(zz[:-1].ravel(), zz[1:].ravel())[0, 1]) < 4 / np.sqrt(n)       # step-to-step
+    assert abs(np.corrcoef(zz[:, :-1].ravel(), zz[:, 1:].ravel())[0, 1]) < 4 / np.sqrt(n)  # subject-to-subject
+    assert np.abs(zz).max() < 6.5

@@ -421,3 +421,13 @@ def test_population_cache_is_keyed_on_content_and_bounded(monkeypatch):
     assert len(api._CACHE) == api._CACHE_MAX and FakeEngine.live == api._CACHE_MAX
     api.clear_cache()
     assert FakeEngine.live == 0
+
+
+def test_philox_restatement_hits_the_published_known_answers():
+    """Random123's known-answer vectors for philox4x32-10 (kat_vectors): the Python restatement in conftest.py, which
+    tests/test_gpu_saem.py uses to predict the device-side draws bit for bit."""
+    from conftest import philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]

@@ -30,12 +30,12 @@ def _c_kind(decl):
     d = d.replace("*", " ").strip()
     parts = d.split()
     base = parts[0] if len(parts) == 1 else " ".join(parts[:-1]) if not parts[-1] in (
-        "double", "int32_t", "int64_t", "uint8_t", "void", "cude_ctx", "cude_config", "char") else " ".join(parts)
+        "double", "int32_t", "int64_t", "uint64_t", "uint8_t", "void", "cude_ctx", "cude_config", "char") else " ".join(parts)
     if stars:
         return ("ptr", base + "*" * (stars - 1))
     if re.fullmatch(r"cude_\w+_fn", base):                   # callback typedefs are function pointers
         return ("ptr", "fn")
-    return {"int32_t": "i32", "int64_t": "i64", "double": "f64"}[base]
+    return {"int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "double": "f64"}[base]
 
 
 def header_prototypes():
@@ -92,8 +92,8 @@ def julia_ccalls():
 
 def _jl_kind(t):
     t = t.strip()
-    if t in ("Int32", "Int64", "Float64"):
-        return {"Int32": "i32", "Int64": "i64", "Float64": "f64"}[t]
+    if t in ("Int32", "Int64", "UInt64", "Float64"):
+        return {"Int32": "i32", "Int64": "i64", "UInt64": "u64", "Float64": "f64"}[t]
     m = re.match(r"(Ptr|Ref)\{(.*)\}$", t)
     if m:
         return ("ptr", m.group(2))
