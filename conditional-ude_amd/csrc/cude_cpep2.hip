@@ -18,6 +18,8 @@
 //     once, storing the weight of every network evaluation (cpep2_scan_kernel);
 //   * the reverse lane of chunk c evaluates the network reverse sweeps of its own stage times with those
 //     weights and accumulates its share of the gradient (cpep2_rev_kernel).
+#include <cstdlib>
+
 #include "cude_device.h"
 #include "cude_kernels.h"
 
@@ -91,7 +93,10 @@ __global__ __launch_bounds__(kBlock) void cpep2_homog_kernel(Cpep2Args a) {
 }
 
 // ---------------------------------------------------------------------------------- forward (forced, zero entry)
-template <int NIN, int W, int D, int NS>
+// VWR: the upper-layer weights live in VGPRs (Mlp::VW) -- no scalar loads in the evaluations.  Costs ~100 VGPRs (two
+// waves per SIMD instead of four), so the launcher picks it only while the grid fits two waves per SIMD anyway: the
+// latency-bound regime of small populations (forward launch at 1e4 subjects 46.4 -> 45.0 us, 2e4 64.2 -> 61.5 us).
+template <int NIN, int W, int D, int NS, bool VWR = false>
 __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     using Net = Mlp<NIN, W, D, 1>;
     constexpr int NC = NIN - 1;
@@ -123,6 +128,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     Net::first_layer_offset(p, cst, c);
     double chk = fma(cst[0], 0.0, Net::param_check(p));   // NaN iff a parameter / beta is non-finite
     if (NC > 1) chk = fma(cst[1], 0.0, chk);
+    typename Net::VW vw;
+    if constexpr (VWR) Net::load_vw(p, vw);
 
     double y1 = 0.0, y2 = 0.0, y3 = 0.0;                  // forced response from a ZERO entry state
     double qprev = 0.0, base = 0.0;
@@ -150,7 +157,9 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             xv = fma(phi[e], g_d, g_lo);
         }
         const double x[1] = {xv};
-        const double v = Net::eval(p, c, x);
+        double v;
+        if constexpr (VWR) v = Net::eval_vw(p, vw, c, x, false, nullptr);
+        else v = Net::eval(p, c, x);
         if (idx == -2) { base = v; continue; }
         if (idx == -1) {
             qprev = v - base;
@@ -224,9 +233,28 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
     double y1 = c0, y2 = (k2 / k1) * c0, y3 = 0.0, sse = 0.0;
     int oi = 0;
+    // The scan is a chain of L dependent affine maps, but what it READS does not depend on the chain: the summary and
+    // the transfer matrix of chunk c + 1 are requested while chunk c is applied (left in program order every chunk paid
+    // a full HBM round trip: 17 us for L = 30, more than the forward chunks themselves at small populations).
+    double nx[7];
+    {
+        const double* f = a.fsum + i;
+        const double* M = a.hom_M + i;
+        nx[0] = f[0]; nx[1] = f[N]; nx[2] = f[2 * N];
+        nx[3] = M[0]; nx[4] = M[N]; nx[5] = M[2 * N]; nx[6] = M[3 * N];
+    }
     for (int c = 0; c < a.L; c++) {
         const double* f = a.fsum + (int64_t)c * (3 + T) * N + i;
         const int n1 = cs[c + 1];
+        double cu[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) cu[q] = nx[q];
+        if (c + 1 < a.L) {
+            const double* fn = f + (int64_t)(3 + T) * N;
+            const double* Mn = a.hom_M + (int64_t)(c + 1) * 4 * N + i;
+            nx[0] = fn[0]; nx[1] = fn[N]; nx[2] = fn[2 * N];
+            nx[3] = Mn[0]; nx[4] = Mn[N]; nx[5] = Mn[2 * N]; nx[6] = Mn[3 * N];
+        }
         while (oi < T && obs_step[oi] < n1) {
             const double hy = fma(a.hom_obs[((int64_t)oi * 2) * N + i], y1, a.hom_obs[((int64_t)oi * 2 + 1) * N + i] * y2);
             const double r = (f[(int64_t)(3 + oi) * N] + hy) - b.obs[(int64_t)oi * N + i];
@@ -234,11 +262,10 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
             s_res[oi * kBlock + lane] = r;
             oi++;
         }
-        const double* M = a.hom_M + (int64_t)c * 4 * N + i;
-        const double n1y = f[0] + fma(M[0], y1, M[N] * y2);
-        const double n2y = f[N] + fma(M[2 * N], y1, M[3 * N] * y2);
+        const double n1y = cu[0] + fma(cu[3], y1, cu[4] * y2);
+        const double n2y = cu[1] + fma(cu[5], y1, cu[6] * y2);
         y1 = n1y; y2 = n2y;
-        y3 += f[2 * N];
+        y3 += cu[2];
     }
     const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);
     if (active) {
@@ -463,8 +490,18 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
     const dim3 grid2((unsigned)nblocks, (unsigned)a.L);
     const size_t lds_f = sizeof(double) * 5 * kBlock;
-    if (n_state == 3) hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 3>), grid2, dim3(kBlock), lds_f, s, a);
-    else hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 2>), grid2, dim3(kBlock), lds_f, s, a);
+    static const bool no_vw = getenv("CUDE_NO_VW2") != nullptr;
+    const bool vwr = Net::HAS_VW && !no_vw && nblocks * a.L <= 2 * 1024;       // fits two waves per SIMD at once
+    if (vwr) {
+        if constexpr (Net::HAS_VW) {
+            if (n_state == 3) hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 3, true>), grid2, dim3(kBlock), lds_f, s, a);
+            else hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 2, true>), grid2, dim3(kBlock), lds_f, s, a);
+        }
+    } else if (n_state == 3) {
+        hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 3>), grid2, dim3(kBlock), lds_f, s, a);
+    } else {
+        hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 2>), grid2, dim3(kBlock), lds_f, s, a);
+    }
     Cpep2Args as = a;
     if (!grad) as.wts = nullptr;
     hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks), dim3(kBlock),
