@@ -1423,8 +1423,41 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     // recomputed -- the same bits, half the forward launches.  With gamma < 1 the state is a blend and is re-evaluated.
     m.carry_sse = gamma == 1.0 ? 1 : 0;
     if (m.carry_sse && (rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;
+    // Time-split forward path + carried SSE: the proposal is formed inside the forward chunks and accepted inside the
+    // scan (Cpep2Args::mh_fused) -- two launches per Metropolis step instead of four, same bits.
+    const bool fused = m.carry_sse && is_cpep(c) && !adaptive(c) && c->chunks > 1 && getenv("CUDE_NO_MH_FUSE") == nullptr;
     for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
         m.key = cude::RngKey{c->rng_seed, c->rng_offset, c->rng_step + k};
+        if (fused) {
+            m.u = device_rng ? nullptr : d_u.p + (size_t)k * N;
+            m.prop = nullptr; m.sse_new = nullptr;
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = c->cond.p; a.nn = c->nn.p; a.sse = d_sn.p; a.traj = nullptr; a.auc = c->auc.p;
+            a.g_cond = c->g_cond.p; a.partials = c->partials.p;
+            cude::Cpep2Args a2 = chunk_args(c, a);
+            a2.mh_fused = 1;
+            a2.mh_z = device_rng ? nullptr : d_z.p + (size_t)k * N;
+            a2.mh_std = proposal_std;
+            a2.mh = m;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->timing) {
+                if (c->ev_used == c->ev_pool.size()) {
+                    hipEvent_t ea, eb;
+                    HIP_TRY(hipEventCreate(&ea));
+                    HIP_TRY(hipEventCreate(&eb));
+                    c->ev_pool.emplace_back(ea, eb);
+                }
+                e0 = c->ev_pool[c->ev_used].first; e1 = c->ev_pool[c->ev_used].second;
+                c->ev_used++;
+                HIP_TRY(hipEventRecord(e0, c->stream));
+            }
+            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, false, a2, c->stream));
+            if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+            if (samples)
+                HIP_TRY(hipMemcpyAsync(d_z.p + (size_t)k * N, c->cond.p, N * sizeof(double), hipMemcpyDeviceToDevice,
+                                       c->stream));
+            continue;
+        }
         HIP_TRY(cude::launch_mh_propose(N, c->cond.p, device_rng ? nullptr : d_z.p + (size_t)k * N, m.key, proposal_std,
                                         d_prop.p, c->stream));
         if ((rc = run_ensemble(c, false, nullptr, true, d_prop.p, d_sn.p))) return rc;

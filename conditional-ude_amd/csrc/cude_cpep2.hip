@@ -22,6 +22,7 @@
 
 #include "cude_device.h"
 #include "cude_kernels.h"
+#include "cude_rng.h"
 
 namespace cude {
 
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
     const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};
     double cst[NC];
-    cst[0] = exp(b.cond[i]);
+    cst[0] = exp(a.mh_fused ? mh_proposal(a.mh.p, a.mh_z, a.mh.key, a.mh_std, i) : b.cond[i]);
     if (NC > 1) cst[1] = b.age[i];
     double c[W];
     Net::first_layer_offset(p, cst, c);
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     if (active) {
         if (b.sse != nullptr) b.sse[i] = sse;
         if (b.auc != nullptr) b.auc[i] = y3;
+        if (a.mh_fused) mh_accept_one(a.mh, i, mh_proposal(a.mh.p, a.mh_z, a.mh.key, a.mh_std, i), sse);
     }
     if (a.wts != nullptr) {
         const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};

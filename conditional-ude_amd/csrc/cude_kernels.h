@@ -62,6 +62,25 @@ struct CpepArgs {
 #endif
 };
 
+// SAEM E-step (Metropolis-Hastings)
+// z == nullptr / MhArgs::u == nullptr: the draw comes from the counter-based generator (RngKey) instead of a host row
+struct RngKey {
+    uint64_t seed;             // Philox key
+    int64_t subject_offset;    // global index of local subject 0 (draws do not depend on how subjects are sharded)
+    int64_t step;              // index of the Metropolis step since cude_set_rng
+};
+struct MhArgs {
+    int64_t N;
+    double* p;                 // chain state (conditional parameters), updated in place
+    const double* prop;        // proposals
+    const double* u;           // uniform draws of this step
+    const double* sse_new; double* sse_cur;
+    int32_t carry_sse;         // gamma == 1: the accepted proposal IS the next state, so its SSE is carried over
+    int64_t* accepted;         // per-subject acceptance counter
+    double prior_mean, prior_sd, ll_const, inv_2s2, temperature, gamma;
+    RngKey key;                // used when u == nullptr
+};
+
 // chunked loss+gradient path (cude_cpep2.hip): the S steps of every subject are split into L chunks
 struct Cpep2Args {
     CpepArgs base;
@@ -73,6 +92,13 @@ struct Cpep2Args {
     double* wts;                 // [5S][N]     adjoint weight of every network evaluation (gradient only)
     double* g_cond_part;         // [L][N]
     double* partials2;           // [L][nblocks][P]
+    // fused Metropolis step (forward-only launches): the forward chunks evaluate at the PROPOSAL state + std * draw
+    // instead of base.cond, and the scan accepts / rejects it right where the SSE is formed -- two launches per
+    // Metropolis step instead of four (propose, forward, scan, accept)
+    int32_t mh_fused;
+    const double* mh_z;          // [N] normals of this step, or nullptr = device stream (mh.key)
+    double mh_std;
+    MhArgs mh;
 };
 bool cpep2_shape_supported(const NetShape& net, int n_state);
 int cpep2_rev_waves_per_cu(const NetShape& net);
@@ -154,23 +180,6 @@ struct AdamArgs {
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 // SAEM E-step (Metropolis-Hastings) helper kernels
-// z == nullptr / MhArgs::u == nullptr: the draw comes from the counter-based generator (RngKey) instead of a host row
-struct RngKey {
-    uint64_t seed;             // Philox key
-    int64_t subject_offset;    // global index of local subject 0 (draws do not depend on how subjects are sharded)
-    int64_t step;              // index of the Metropolis step since cude_set_rng
-};
-struct MhArgs {
-    int64_t N;
-    double* p;                 // chain state (conditional parameters), updated in place
-    const double* prop;        // proposals
-    const double* u;           // uniform draws of this step
-    const double* sse_new; double* sse_cur;
-    int32_t carry_sse;         // gamma == 1: the accepted proposal IS the next state, so its SSE is carried over
-    int64_t* accepted;         // per-subject acceptance counter
-    double prior_mean, prior_sd, ll_const, inv_2s2, temperature, gamma;
-    RngKey key;                // used when u == nullptr
-};
 hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, RngKey key, double proposal_std, double* prop,
                              hipStream_t s);
 // the draws themselves (normals[N], uniforms[N] of one step), for reproducing a device-generated chain elsewhere
