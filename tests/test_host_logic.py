@@ -245,9 +245,10 @@ def _rank_main(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_two_rank_gloo_training_matches_single_process(tmp_path, world):
-    """world = 3 shards the 23 subjects unevenly (8 / 8 / 7)."""
+    """world = 3 shards the 23 subjects unevenly (8 / 8 / 7); world = 8 is the node the headline is quoted on (3 / 3 / 3
+    / 3 / 3 / 3 / 3 / 2 subjects)."""
     import torch.multiprocessing as mp
     import c_oracle as co
     import cude_oracle as o
@@ -296,7 +297,7 @@ def _lbfgs_rank_main(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_lbfgs_follows_the_single_process_iterates(tmp_path, world):
     """Adam x2 then L-BFGS x6 (`_optimize`, src/parameter-estimation.jl:170-183) with the subjects sharded over
     2 / 3 gloo ranks: every inner product of the L-BFGS recursion takes its conditional part through the collective
@@ -364,13 +365,15 @@ def _saem_rank_main(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_saem_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_rank_gloo_saem_matches_single_process(tmp_path, world):
+    """BASELINE configs[4] is SAEM on 8 GPUs: world = 8 shards the 11 subjects 2 / 2 / 2 / 1 / 1 / 1 / 1 / 1."""
     import torch.multiprocessing as mp
     from cude.parallel import saem_loop
-    n_total, world = 11, 2
-    port = 31500 + (os.getpid() % 2000)
+    n_total = 11
+    port = 31500 + (os.getpid() % 2000) + world
     mp.spawn(_saem_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
-    r0, r1 = np.load(tmp_path / "saem0.npz"), np.load(tmp_path / "saem1.npz")
+    r0, r1 = np.load(tmp_path / "saem0.npz"), np.load(tmp_path / f"saem{world - 1}.npz")
     for k in r0.files:
         assert np.array_equal(r0[k], r1[k]), k                  # replicas stay identical
     case = make_cpep_case(n_total, (2, 4, 2))
