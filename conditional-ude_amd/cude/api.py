@@ -712,11 +712,13 @@ def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0,
          iterations=500, n_burnin_iterations=100, proposal_std=0.1, proposal_std_bounds=(1e-3, 1.0), alpha=0.7,
          n_mcmc_steps=1, initial_mcmc_steps=None, target_acceptance_rate=0.25, initial_temperature=10.0,
          temperature_decay=0.05, omega_learning_rate=0.04, rng=None, n_steps=None, m_step_iters=5, m_step_lr=1e-2,
-         collective=None):
+         collective=None, device_seed=None, subject_offset=0):
     """SAEM(individuals, initial_neural_params, network; ...) (src/saem.jl:134-237) with the population on the
     GPU: every Metropolis step evaluates all subjects in one forward launch; the M-step's 5 Adam iterations on
     (network, sigma) use the device gradient.  The loop itself is cude.parallel.saem_loop, shared with the
-    subject-sharded multi-GPU form (`collective`: this process holds one shard of `models`)."""
+    subject-sharded multi-GPU form (`collective`: this process holds one shard of `models`).  device_seed: the
+    Metropolis draws are generated on the device (counter-based, independent of the sharding given subject_offset)
+    instead of by `rng` on the host."""
     from .parallel import saem_loop
     pop = _population(models, timepoints, cpeptide_data, n_steps)
     return saem_loop(pop.engine, pop.T, initial_neural_params, collective=collective, sigma=sigma,
@@ -725,7 +727,8 @@ def SAEM(models, timepoints, cpeptide_data, initial_neural_params, *, sigma=1.0,
                      proposal_std_bounds=proposal_std_bounds, alpha=alpha, n_mcmc_steps=n_mcmc_steps,
                      initial_mcmc_steps=initial_mcmc_steps, target_acceptance_rate=target_acceptance_rate,
                      initial_temperature=initial_temperature, temperature_decay=temperature_decay,
-                     omega_learning_rate=omega_learning_rate, rng=rng, m_step_iters=m_step_iters, m_step_lr=m_step_lr)
+                     omega_learning_rate=omega_learning_rate, rng=rng, m_step_iters=m_step_iters, m_step_lr=m_step_lr,
+                     device_seed=device_seed, subject_offset=subject_offset)
 
 
 def individual_effects(models, timepoints, cpeptide_data, saem_result, *, n_samples=3000, proposal_std=0.3,

@@ -152,7 +152,8 @@ class ShardedTrainer:
 def saem_loop(engine, n_obs, initial_neural_params, *, collective=None, sigma=1.0, prior_eta=0.0, prior_omega=1.0,
               iterations=500, n_burnin_iterations=100, proposal_std=0.1, proposal_std_bounds=(1e-3, 1.0), alpha=0.7,
               n_mcmc_steps=1, initial_mcmc_steps=None, target_acceptance_rate=0.25, initial_temperature=10.0,
-              temperature_decay=0.05, omega_learning_rate=0.04, rng=None, draws=None, m_step_iters=5, m_step_lr=1e-2):
+              temperature_decay=0.05, omega_learning_rate=0.04, rng=None, draws=None, m_step_iters=5, m_step_lr=1e-2,
+              device_seed=None, subject_offset=0):
     """`SAEM` of src/saem.jl:134-237 over the subjects resident in `engine` -- the whole population
     (collective=None) or this rank's shard of it (BASELINE configs[4]: the E-step needs no communication).
 
@@ -160,10 +161,14 @@ def saem_loop(engine, n_obs, initial_neural_params, *, collective=None, sigma=1.
     after the E-step (acceptance rate, total NLL, Omega <- var(p), eta <- mean(p), :204-205) and the P+2 doubles
     of the network gradient in each of the `m_step_iters` Adam iterations of the M-step (:118-131); every rank
     then applies identical updates to its replica of (network, sigma, Omega, eta, proposal_std).
-    `draws(iteration, steps) -> (normals, uniforms)` of shape (steps, N_local) overrides the rank-local rng.
-    Quirks of the reference are preserved: the 'current' likelihood is re-evaluated each Metropolis step, the
-    stochastic-approximation update is applied inside the chain (:185), Omega is updated as a variance but used
-    as a standard deviation (:91,:204)."""
+    `draws(iteration, steps) -> (normals, uniforms)` of shape (steps, N_local) overrides the rank-local rng;
+    `device_seed` (an int, the same on every rank) makes the Metropolis draws come from the library's counter-based
+    generator instead (cude_set_rng: nothing crosses PCIe; `subject_offset` = global index of this shard's first
+    subject, so the chains do not depend on the sharding).
+    Quirks of the reference are preserved: the stochastic-approximation update is applied inside the chain (:185),
+    Omega is updated as a variance but used as a standard deviation (:91,:204); the 'current' likelihood it
+    re-evaluates each Metropolis step is re-evaluated here only when gamma < 1 (for gamma = 1 the value is carried,
+    bit-identical)."""
     import math
     from types import SimpleNamespace
     rng = np.random.default_rng() if rng is None else rng
@@ -178,14 +183,19 @@ def saem_loop(engine, n_obs, initial_neural_params, *, collective=None, sigma=1.
     P = p_nn.size
     omega = float(prior_omega)
     nll_values, acc_rates = [], []
+    if device_seed is not None:
+        eng.set_rng(int(device_seed), int(subject_offset))
     for it in range(1, iterations + 1):
         gamma = 1.0 if it <= n_burnin_iterations else 1.0 / (it - n_burnin_iterations) ** alpha
         steps = initial_mcmc_steps if it <= n_burnin_iterations else n_mcmc_steps
         temperature = max(1.0, initial_temperature * math.exp(-temperature_decay * it))
         # E-step (:177-186) fused on the device: all Metropolis steps queued on the stream, one synchronisation
-        z, u = draws(it, steps) if draws is not None else (rng.standard_normal((steps, N)), rng.random((steps, N)))
         eng.set_params(p_nn, p_ind)
-        n_acc = eng.mh_estep(z, u, sigma, prior_eta, omega, proposal_std, temperature, gamma)
+        if device_seed is not None:
+            n_acc = eng.mh_estep(None, None, sigma, prior_eta, omega, proposal_std, temperature, gamma, n_mc=steps)
+        else:
+            z, u = draws(it, steps) if draws is not None else (rng.standard_normal((steps, N)), rng.random((steps, N)))
+            n_acc = eng.mh_estep(z, u, sigma, prior_eta, omega, proposal_std, temperature, gamma)
         _, p_ind = eng.get_params()
         sse = eng.forward(want_sse=True)["sse"]
         ll = np.where(np.isfinite(sse), -(T / 2) * math.log(sigma ** 2) - sse / (2 * sigma ** 2), -np.inf)

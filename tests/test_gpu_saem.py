@@ -187,3 +187,38 @@ def test_device_side_draws():
     assert abs(np.corrcoef(zz[:-1].ravel(), zz[1:].ravel())[0, 1]) < 4 / np.sqrt(n)       # step-to-step
     assert abs(np.corrcoef(zz[:, :-1].ravel(), zz[:, 1:].ravel())[0, 1]) < 4 / np.sqrt(n)  # subject-to-subject
     assert np.abs(zz).max() < 6.5
+
+
+def test_saem_loop_with_device_draws_equals_the_same_loop_fed_those_draws():
+    """cude.parallel.saem_loop(device_seed=...) -- the whole SAEM iteration with the Metropolis draws generated on the
+    device -- against the same loop fed, through its `draws` hook, the draws cude_rng_draws reports for that stream."""
+    from cude.engine import Engine
+    from cude.parallel import saem_loop
+    arch, N = (2, 4, 2), 70
+    c = make_cpep_case(N, arch)
+    kw = dict(iterations=6, n_burnin_iterations=3, n_mcmc_steps=2, initial_mcmc_steps=3, proposal_std=0.2, sigma=0.5,
+              prior_eta=-0.6, prior_omega=0.8, m_step_iters=2)
+
+    def engine():
+        eng = Engine("cpep", arch, n_steps=30)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        return eng
+    seed = 424242
+    dev = engine()
+    a = saem_loop(dev, len(c["tp"]), c["nn"], device_seed=seed, **kw)
+    dev.close()
+    src, host = engine(), engine()
+    src.set_rng(seed)
+    pos = [0]
+
+    def draws(it, steps):
+        z, u = src.rng_draws(pos[0], steps)
+        pos[0] += steps
+        return z, u
+    b = saem_loop(host, len(c["tp"]), c["nn"], draws=draws, **kw)
+    src.close()
+    host.close()
+    assert pos[0] == 3 * 3 + 3 * 2
+    assert np.array_equal(a.acceptance_rates, b.acceptance_rates) and np.array_equal(a.p_individuals, b.p_individuals)
+    assert np.array_equal(a.p_neural, b.p_neural) and a.sigma == b.sigma and a.Omega == b.Omega
+    assert 0.0 < a.acceptance_rates[-1] < 1.0
