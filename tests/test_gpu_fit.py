@@ -94,3 +94,51 @@ def test_failed_solves_and_argument_errors():
         with pytest.raises(CudeError):
             eng.fit_conditional(*bad)
     eng.close()
+
+
+@pytest.mark.parametrize("model", ["cpep", "supp"])
+def test_fit_and_profile_against_the_oracle(model):
+    """The per-subject fits and likelihood profiles against the CPU ORACLE (not the device's own forward kernel):
+    cude_profile_conditional rows equal the oracle's per-subject SSE at every scan value (1e-10), and the fitted
+    conditional parameter of every subject is the minimiser of the oracle's own per-subject objective -- found
+    independently with scipy's bounded Brent search on the C oracle -- wherever that minimum is interior and unique."""
+    import c_oracle as co
+    from scipy.optimize import minimize_scalar
+    from cude.engine import Engine
+    if model == "cpep":
+        arch, N = (2, 4, 2), 24
+        c = make_cpep_case(N, arch)
+        eng = Engine("cpep", arch, n_steps=30)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+
+        def sse_all(x):
+            return co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], x, 30, 2, want_grad=False)["sse"]
+        lo, hi = -3.0, 2.0
+    else:
+        arch, N = (4, 3, 5), 16
+        c = make_supp_case(N, arch)
+        eng = Engine("supp", arch, n_steps=30)
+        eng.set_population_supp(c["tp"], c["data"])
+
+        def sse_all(x):          # the oracle's per-subject SSE is already divided by scale^2 (suppression_model.jl:126-128)
+            return co.supp(c["tp"], c["data"], arch, c["nn"], x, 0.0, 30, want_grad=False)["sse"]
+        lo, hi = -2.0, 2.0
+    eng.set_params(c["nn"], np.zeros(N))
+    values = np.linspace(lo, hi, 41)
+    prof = eng.profile_conditional(values)
+    ref = np.stack([sse_all(np.full(N, v)) for v in values])
+    assert prof.shape == ref.shape and np.max(np.abs(prof - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref)))
+    x_dev, f_dev, sse_dev = eng.fit_conditional(lo, hi, 41, 48)
+    eng.close()
+    assert np.max(np.abs(sse_dev - sse_all(x_dev))) <= 1e-10 * max(1.0, np.max(sse_dev))
+    checked = 0
+    for i in range(N):
+        k = int(np.argmin(ref[:, i]))
+        others = np.delete(ref[:, i], [max(k - 1, 0), k, min(k + 1, 40)])
+        if k in (0, 40) or others.min() < ref[k, i] * (1 + 1e-3) + 1e-9:
+            continue                                    # boundary minimum or a second basin as deep: nothing unique to compare
+        one = lambda v, i=i: sse_all(np.where(np.arange(N) == i, v, 0.0))[i]       # noqa: E731
+        r = minimize_scalar(one, bounds=(values[k - 1], values[k + 1]), method="bounded", options=dict(xatol=1e-10))
+        assert abs(x_dev[i] - r.x) < 2e-6 and f_dev[i] <= r.fun * (1 + 1e-10) + 1e-14, (i, x_dev[i], r.x)
+        checked += 1
+    assert checked >= N // 2
