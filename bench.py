@@ -223,7 +223,7 @@ def cpep_engine(Engine, arch, n_state, n, seed, device, nn):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(pop, nn, sample):
+def cpu_baseline(pop, nn, sample, eng=None):
     """Times the CPU port on a bounded sample of the same population: the per-subject reverse-mode gradient with OpenMP
     static scheduling over subjects (oracle/cude_oracle_rev.c), and -- for the record -- the
     reference's own AD method, forward-mode duals with P+1 partials per subject (oracle/cude_oracle.c).  Baseline only."""
@@ -238,18 +238,27 @@ def cpu_baseline(pop, nn, sample):
     reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
-        co.cpep(*a, method="reverse")
+        ref = co.cpep(*a, method="reverse")
     dt = (time.perf_counter() - t0) / reps
     rev = {"value": n / dt, "unit": "subject-trajectories/s", "cores": threads, "kind": "port",
            "sample": f"{n} subjects of the same population, {reps} loss+gradient evaluations (per-subject reverse-mode "
                      f"discrete adjoint, OpenMP static over subjects), {dt:.2f} s each"}
+    parity = None
+    if eng is not None and n == eng.N:
+        # max relative error of loss and gradients against the CPU backend, same run, same inputs
+        eng.set_params(nn, pop["beta0"])
+        loss, g_nn, g_cond = eng.loss_grad()
+        parity = {"subjects": n, "loss_rel": abs(loss - ref["loss"]) / abs(ref["loss"]),
+                  "g_nn_rel_maxnorm": float(np.max(np.abs(g_nn - ref["g_nn"])) / np.max(np.abs(ref["g_nn"]))),
+                  "g_cond_rel_maxnorm": float(np.max(np.abs(g_cond - ref["g_beta"])) / np.max(np.abs(ref["g_beta"]))),
+                  "north_star_rtol": 1e-6}
     t0 = time.perf_counter()
     co.cpep(*a)
     dt = time.perf_counter() - t0
     fwd = {"value": n / dt, "unit": "subject-trajectories/s", "cores": threads, "kind": "port",
            "sample": f"{n} subjects, 1 loss+gradient evaluation by the reference's AD method (forward-mode duals, P+1 "
                      f"partials per subject; the reference itself carries N+P), {dt:.2f} s"}
-    return rev, fwd
+    return rev, fwd, parity
 
 
 # ------------------------------------------------------------------------------------------ extra configurations
@@ -571,7 +580,9 @@ def main():
             out["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
         if world == 1:
             if not args.no_cpu_baseline:
-                out["cpu_baseline"], out["cpu_baseline_forward_mode"] = cpu_baseline(pop, nn, args.cpu_sample)
+                out["cpu_baseline"], out["cpu_baseline_forward_mode"], parity = cpu_baseline(pop, nn, args.cpu_sample, eng)
+                if parity is not None:
+                    out["parity_vs_cpu_baseline"] = parity
             if not args.no_extra:
                 eng.close()
                 eng = None
