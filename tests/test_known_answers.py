@@ -116,6 +116,44 @@ def test_adaptive_restatement_reproduces_the_validation_objectives():
             assert abs(total / N - stored[n]) < 2e-9, (n, total / N, stored[n])
 
 
+def test_adaptive_restatement_reproduces_the_reference_noise_free_data():
+    """A third kind of stored output: `validation_data_nonoise` (suppression/suppression.jl:31-34) is what the reference's
+    OWN solver returned -- `Array(solve(ODEProblem(lsup!, [10, 0, 0], (0, 30), p), Tsit5(), saveat = timepoints))` for the
+    ground-truth model `lsup!` (suppression_model.jl:16-20,39-63), no noise added -- for 30 subjects whose fourth
+    parameter is stored (`gt_validation_param_nonoise`) and whose first three (0.4 / 0.9 / 0.3 +- 0.1) are not.  24 stored
+    values per subject against 3 unknowns: the oracle's adaptive Tsit5 (OrdinaryDiffEq defaults restated) reproduces all
+    of them to ~1e-8 once the three rates are fitted, four orders below the solver's own truncation error (~1e-4: the
+    fixed-step solution of the same problem differs by that much) -- i.e. it walks the reference's accepted steps on a
+    nonlinear three-state problem as well.  (This model is the data generator, not part of the product path: the pin is
+    on the solver restatement that the product's adaptive kernel is held to.)"""
+    import cude_oracle as o
+    from scipy.optimize import least_squares
+    g = np.load(os.path.join(GOLD, "suppression_lambda0.npz"))
+    data, p4, tp = g["validation_data_nonoise"], g["gt_validation_param_nonoise"], g["timepoints"]
+    assert data.shape == (3, 8, 30) and np.all(data[:, 0, :] == np.array([10.0, 0.0, 0.0])[:, None])
+
+    def rhs_of(p):
+        def rhs(t, u):
+            a = p[1] * u[1] / (1.0 + p[3] * u[2])
+            return np.array([-p[0] * u[0], p[0] * u[0] - a, a - p[2] * u[2]])
+        return rhs
+    worst, worst_fixed = 0.0, 0.0
+    for i in range(0, 30, 3):                                     # two subjects of each of the five + one groups
+        y = data[:, :, i]
+        p1 = float(np.mean(-np.log(y[0, 1:] / 10.0) / tp[1:]))    # u1 = 10 exp(-p1 t) up to the solver's error
+
+        def resid(q):
+            sol = np.asarray(o.solve_adaptive(rhs_of([q[0], q[1], q[2], p4[i]]), np.array([10.0, 0.0, 0.0]), tp))
+            return ((sol if sol.shape == (3, 8) else sol.T) - y).ravel()
+        fit = least_squares(resid, [p1, 0.9, 0.3], xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        assert np.all(np.abs(fit.x - np.array([0.4, 0.9, 0.3])) < 0.45) and fit.x.min() >= 0.05
+        worst = max(worst, float(np.max(np.abs(fit.fun))))
+        fixed = np.asarray(o.solve_fixed(rhs_of([*fit.x, p4[i]]), np.array([10.0, 0.0, 0.0]), tp, 960))
+        worst_fixed = max(worst_fixed, float(np.max(np.abs((fixed if fixed.shape == (3, 8) else fixed.T) - y))))
+    assert worst < 1e-7, worst
+    assert 1e-6 < worst_fixed < 1e-2, worst_fixed                # the converged solution is NOT what was stored
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_the_reference_validation_objectives():
     """... and through the product path: the loss itself, and `validate_suppression_model` end to end (the objective
