@@ -474,6 +474,35 @@ def mh_chain(nn, beta0, pop, arch, n_steps, sigma, prior_eta, omega, proposal_st
 
 
 # ----------------------------------------------------------------------------- synthetic data
+def generate_suppression_data(group_means, group_sizes, timepoints, noise_multiplicative=0.1, seed=232705, n_steps=240):
+    """`generate_data` of suppression/src/suppression_model.jl:33-63 restated (BASELINE configs[0] / SURVEY.md 8(d)):
+    per group, parameters max(mu + sd * randn, 0.05) with mu = [0.4, 0.9, 0.3, mu_sup], sd = [0.1, 0.1, 0.1, mu_sup / 8]
+    (get_group_parameters :33-37); every subject's data = solution of the ground-truth model lsup! (:16-20) from
+    u0 = (10, 0, 0) at `timepoints`, times (1 + noise * randn), clamped at 0.  Returns (data 3 x T x N, the subjects'
+    fourth parameter).  The random stream is numpy's, not StableRNG's, and the solve is fixed-step Tsit5 (vectorised over
+    subjects) -- this generates inputs of the reference's distribution, it reproduces no stored number (the adaptive
+    restatement does that: tests/test_known_answers.py)."""
+    rng = np.random.default_rng(seed)
+    tp = np.asarray(timepoints, dtype=np.float64)
+    cols, sup = [], []
+    for mu_sup, size in zip(group_means, group_sizes):
+        mu = np.array([0.4, 0.9, 0.3, mu_sup])[:, None]
+        sd = np.array([0.1, 0.1, 0.1, mu_sup / 8.0])[:, None]
+        p = np.maximum(mu + sd * rng.standard_normal((4, size)), 0.05)
+
+        def rhs(t, u, p=p):
+            a = p[1] * u[1] / (1.0 + p[3] * u[2])
+            return np.stack([-p[0] * u[0], p[0] * u[0] - a, a - p[2] * u[2]])
+        u0 = np.stack([np.full(size, 10.0), np.zeros(size), np.zeros(size)])
+        sol = np.asarray(solve_fixed(rhs, u0, tp, n_steps))                 # (T, 3, size) or (3, T, size)
+        if sol.shape[0] != 3:
+            sol = np.moveaxis(sol, 0, 1)
+        sol = sol + noise_multiplicative * sol * rng.standard_normal(sol.shape)
+        cols.append(np.maximum(sol, 0.0))
+        sup.append(p[3])
+    return np.concatenate(cols, axis=2), np.concatenate(sup)
+
+
 def synthetic_cpep_population(N, seed=20250905):
     """Seeded synthetic population of the c-peptide shape; observations are
     filled with a smooth placeholder and should be replaced by a forward solve + noise."""

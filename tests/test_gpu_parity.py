@@ -65,6 +65,33 @@ def test_supp_loss_and_gradient(arch, N, lam):
     eng.close()
 
 
+def test_baseline_config0_suppression_20_subjects():
+    """BASELINE configs[0]: the reference's own CPU-sized case -- suppression/suppression.jl's synthetic cUDE with 20
+    subjects from its data generator (`generate_data`, restated in the oracle module: six groups of suppression strength,
+    lsup! from u0 = (10, 0, 0), 8 observations on [0, 30], 10 % multiplicative noise), 4 -> 3x5 -> 1 network, lambda from
+    its regularisation grid -- loss, per-subject SSE, trajectories and both gradients against the CPU oracle."""
+    import c_oracle as co
+    import cude_oracle as o
+    from cude.engine import Engine
+    tp = np.linspace(0.0, 30.0, 8)
+    data, sup = o.generate_suppression_data([0.5, 2.5, 5.0, 7.5, 10.0, 12.5], [4, 4, 3, 3, 3, 3], tp)
+    assert data.shape == (3, 8, 20) and np.all(np.diff(sup[[0, 4, 8, 11, 14, 17]]) > 0)
+    arch = (4, 3, 5)
+    nn = o.glorot_params(arch, 27052023)
+    theta = np.random.default_rng(27052023).standard_normal(20)
+    for lam in (0.0, 0.01):
+        ref = co.supp(tp, data, arch, nn, theta, lam, 30, want_grad=True, want_traj=True)
+        eng = Engine("supp", arch, n_steps=30, lam=lam)
+        eng.set_population_supp(tp, data)
+        eng.set_params(nn, theta)
+        f = eng.forward(want_sse=True, want_traj=True)
+        loss, g_nn, g_cond = eng.loss_grad()
+        eng.close()
+        assert abs(f["loss"] - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"]) and loss == f["loss"]
+        assert _rel(f["sse"], ref["sse"]) < 1e-10 and _rel(f["traj"], ref["traj"]) < 1e-11
+        assert _rel(g_nn, ref["g_nn"]) < GRAD_RTOL and _rel(g_cond, ref["g_theta"]) < GRAD_RTOL
+
+
 def test_adam_steps_match_oracle():
     """10 fused device Adam steps vs oracle gradient + restated Optimisers.Adam on the host."""
     import c_oracle as co
