@@ -179,21 +179,37 @@ def synthetic_population(n, seed):
 
 
 def synthetic_suppression(n, seed):
-    """Suppression-model data of the reference's shape (3 x 8 x N on [0, 30], u0 = (10, 0, 0) + noise; smooth
-    closed-form curves + 10 % multiplicative noise stand in for `generate_data`, suppression_model.jl:39-63)."""
+    """Suppression-model data as the reference generates it (`generate_data`, suppression/src/suppression_model.jl:33-63,
+    restated: SURVEY.md 8(d)): subjects cycle through the six suppression strengths of suppression.jl:27-28, parameters
+    max(mu + sd * randn, 0.05) with mu = [0.4, 0.9, 0.3, mu_sup], sd = [0.1, 0.1, 0.1, mu_sup / 8], data = the ground-truth
+    model lsup! (:16-20) from u0 = (10, 0, 0) at 8 times on [0, 30], 10 % multiplicative noise, clamped at 0.  (numpy's
+    random stream and a fixed-step RK4 solve: inputs of the reference's distribution, not its numbers.)"""
     rng = np.random.default_rng(seed)
     T = 8
     tp = np.linspace(0.0, 30.0, T)
-    t = tp[None, :, None]
-    k = 0.3 + 0.2 * rng.random((1, 1, n))
+    mu_sup = np.array([0.5, 2.5, 5.0, 7.5, 10.0, 12.5])[np.arange(n) % 6]
+    mu = np.stack([np.full(n, 0.4), np.full(n, 0.9), np.full(n, 0.3), mu_sup])
+    sd = np.stack([np.full(n, 0.1), np.full(n, 0.1), np.full(n, 0.1), mu_sup / 8.0])
+    p = np.maximum(mu + sd * rng.standard_normal((4, n)), 0.05)
+
+    def f(u):
+        a = p[1] * u[1] / (1.0 + p[3] * u[2])
+        return np.stack([-p[0] * u[0], p[0] * u[0] - a, a - p[2] * u[2]])
+    sub = 60                                             # RK4 sub-steps per observation interval (h = 0.071)
+    h = (tp[1] - tp[0]) / sub
+    u = np.stack([np.full(n, 10.0), np.zeros(n), np.zeros(n)])
     data = np.empty((3, T, n))
-    data[0] = (10.0 * np.exp(-0.4 * t))[0]
-    data[1] = (6.0 * t * np.exp(-k * t) / 3.0)[0] + 0.2
-    data[2] = (4.0 * (1 - np.exp(-0.15 * t)) * np.exp(-0.02 * t))[0] + 0.1
-    data *= 1.0 + 0.1 * rng.standard_normal(data.shape)
-    data = np.maximum(data, 0.0)
-    data[0, 0] = 10.0 * (1 + 0.05 * rng.standard_normal(n))
-    return tp, data, 0.5 * rng.standard_normal(n)
+    data[:, 0] = u
+    for k in range(1, T):
+        for _ in range(sub):
+            k1 = f(u)
+            k2 = f(u + 0.5 * h * k1)
+            k3 = f(u + 0.5 * h * k2)
+            k4 = f(u + h * k3)
+            u = u + (h / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+        data[:, k] = u
+    data = np.maximum(data * (1.0 + 0.1 * rng.standard_normal(data.shape)), 0.0)
+    return tp, data, rng.standard_normal(n)              # theta ~ randn as in suppression.jl:38
 
 
 def glorot(arch, seed):
