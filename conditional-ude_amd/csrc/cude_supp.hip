@@ -128,6 +128,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
     double cst[1] = {exp(a.cond[set * a.set_stride_cond + i])};
     double c[W];
     Net::first_layer_offset(p, cst, c);
+    // the stage rows are read six at a time with the tableau row zero-padded (below): they must hold finite numbers
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+#pragma unroll
+        for (int s = 0; s < 3; s++) KROW(j, s) = 0.0;
 
     double y[3];
 #pragma unroll
@@ -145,13 +150,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
 #pragma unroll
             for (int s = 0; s < 3; s++) u[s] = y[s];
         } else {
-            double t[3] = {0.0, 0.0, 0.0};
-#pragma unroll 1
-            for (int j = 0; j < st; j++) {
-                const double aj = TS_A[st][j];
+            // all six stage rows and the (zero-padded) tableau row at once: one LDS and one scalar round trip per
+            // evaluation instead of one pair per earlier stage
+            double kk[6][3], aj[6];
 #pragma unroll
-                for (int s = 0; s < 3; s++) t[s] = fma(aj, KROW(j, s), t[s]);
+            for (int j = 0; j < 6; j++) {
+                aj[j] = TS_A[st][j];
+#pragma unroll
+                for (int s = 0; s < 3; s++) kk[j][s] = KROW(j, s);
             }
+            double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+#pragma unroll
+                for (int s = 0; s < 3; s++) t[s] = fma(aj[j], kk[j][s], t[s]);
 #pragma unroll
             for (int s = 0; s < 3; s++) u[s] = fma(h, t[s], y[s]);
         }
