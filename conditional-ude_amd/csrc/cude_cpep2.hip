@@ -431,8 +431,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
                 g_d = b.dG[(int64_t)(sg + 1) * N + i] - g_lo;
             }
             xv = fma(phi[e], g_d, g_lo);
-            wv = a.wts[(int64_t)e * N + i];
-            wtot += wv;
+            wv = a.wts[(int64_t)e * N + i];           // needed at the end of the evaluation only: the load stays in flight
             if constexpr (kTab) {
                 tab = kind != 0;
                 if (tab) {
@@ -452,6 +451,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
         }
         const double x[1] = {xv};
         Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy, tab, &E1);
+        if (own) wtot += wv;
     }
     if (active) a.g_cond_part[(int64_t)c_idx * N + i] = Net::grad_cond(p, acc, cst);
     double* out = a.partials2 + ((int64_t)c_idx * gridDim.x + blockIdx.x) * P;

@@ -245,6 +245,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
         st = 6;
         // VJP evaluations in reverse order: idx = 6n+st (st = 6..1) is stage st+1 of step n;
         // idx = 0 is k_1 of step 0 = f(y_0).
+        // stage inputs of the NEXT evaluation are requested one evaluation ahead: each is an HBM round trip that the
+        // evaluation would otherwise start with (evaluation 0's input y_0 is row 0 of the same scratch)
+        constexpr bool kAhead = !YONLY && !STORE;       // (with kept activations the extra live registers cost more)
+        double un[3] = {0.0, 0.0, 0.0};
+        if (kAhead) {
+#pragma unroll
+            for (int s = 0; s < 3; s++) un[s] = ckpt[((int64_t)(6 * S) * 3 + s) * N + i];
+        }
 #pragma unroll 1
         for (int idx = 6 * S; idx >= 0; idx--) {
             if (YONLY && idx > 0 && st == 6) {
@@ -308,12 +316,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
             if (idx > 0) {
 #pragma unroll
                 for (int s = 0; s < 3; s++) {
-                    u[s] = YONLY ? YROW(st, s) : ckpt[((int64_t)idx * 3 + s) * N + i];
+                    u[s] = YONLY ? YROW(st, s) : (kAhead ? un[s] : ckpt[((int64_t)idx * 3 + s) * N + i]);
                     kb[s] = KROW(st, s);
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < 3; s++) { u[s] = a.data[((int64_t)s * T + 0) * N + i]; kb[s] = KAP(s); }
+                for (int s = 0; s < 3; s++) { u[s] = kAhead ? un[s] : a.data[((int64_t)s * T + 0) * N + i]; kb[s] = KAP(s); }
+            }
+            if (kAhead && idx > 0) {
+#pragma unroll
+                for (int s = 0; s < 3; s++) un[s] = ckpt[((int64_t)(idx - 1) * 3 + s) * N + i];
             }
             if (idx > 0 && st == 6) {
 #pragma unroll
