@@ -1,0 +1,66 @@
+"""The counted figures bench.py divides by ("the bench must print the exact counted figures from
+constants"): algorithmic bytes per subject-trajectory and executed flops per subject-trajectory of the kernels, pinned
+against an independent tally so that they cannot drift silently with the code that reports the roofline fractions."""
+import importlib.util
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_bytes():
+    b = _bench()
+    # CPEP3, T = 5, fwd + adjoint: k0 k1 k2 c0 (32) + beta (8) + glucose (40) + observations (40) read; sse, dL/dbeta, auc written
+    assert b.cpep_algo_bytes(5, 3, True) == 120 + 24 == 144
+    assert b.cpep_algo_bytes(5, 3, False) == 120 + 16
+    assert b.cpep_algo_bytes(5, 2, True) == 120 + 16                 # the reference's 2-state model: 136 B
+    # SUPP, T = 8: theta (8) + data 3 x 8 x 8 (192; u0 is its first row) read; sse, dL/dtheta written
+    assert b.supp_algo_bytes(8, True) == 200 + 16
+    assert b.supp_algo_bytes(8, False) == 200 + 8
+
+
+def test_executed_flops_of_the_headline_kernel():
+    b = _bench()
+    w, d, S, T = 6, 2, 30, 5
+    # one network evaluation as executed (cude_math.h): per tanh neuron 7 single-flop ops + 13 FMAs, per layer one shared
+    # reciprocal (rcp + 3 FMAs) and 3 (W - 1) prefix / back-substitution multiplies; softplus 26 FMAs + 22 other ops
+    tanh_layer = w * (7 + 26) + 7 + 3 * (w - 1)
+    fwd = 2 * (w * 1 + w * w + w) + d * tanh_layer + (26 * 2 + 22)
+    assert b.mlp_flops(1, w, d) == (fwd, (2 * w + w + 2) + w * (4 + 4 * w) + w * (4 + 2))
+    assert fwd == 610
+    # table bookkeeping of the headline grid: 30 steps over 4 glucose pieces of 7.5 steps: 2 straddle a knot (steps 7, 22),
+    # step 15 starts exactly on one: 28 steps inside a piece, in 4 runs
+    assert b.table_steps(S, T) == (28, 4)
+    assert b.cpep_flops() == 184560                                  # the figure quoted in DESIGN.md / profiles
+    # without the layer-1 table the same kernel would execute the round-1 count
+    n_eval = 5 * S + 1
+    plain = n_eval * (2 * fwd + b.mlp_flops(1, w, d)[1]) + S * (2 * (2 * 21 + 2 * 6 + 7 * 4) + 12 + 2 * (2 * 21 + 6 * 4 + 12) + 12) \
+        + 2 * T * (2 * 3 * 7 + 8)
+    assert plain == 228864                                          # "228.9 k per trajectory" before the table
+    saved_per_eval, per_run = w * (7 + 26) + 2 * w - 3 * w, 6 * w * (6 + 24) + 10 * w
+    assert plain - b.cpep_flops() == 2 * (5 * 28 * saved_per_eval - 4 * per_run - 28 * w)
+    # forward-only and the 2-state / width-4 instances scale as their structure says
+    assert b.cpep_flops(grad=False) < 0.45 * b.cpep_flops()
+    assert b.cpep_flops((2, 4, 2), S, T, 2, True) == 154374
+    assert b.supp_flops((4, 3, 5), S, 8, True) == 322853
+
+
+def test_kernel_source_digest_matches_the_committed_pmc_record():
+    """bench.py quotes roofline.traffic only for the sources the PMC passes were taken on: the committed record must be
+    the one of the committed sources (otherwise the driver's line would carry traffic = null)."""
+    import json
+    b = _bench()
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert rec["source_sha"] == b.kernel_source_sha()
+    t, note = b.pmc_traffic("headline", 125000)
+    assert note is None or t is not None
+    assert 18.0e6 < t < 23.0e6                                       # 18.0 MB algorithmic + the partial rows
+    assert abs(rec["calibration"]["ratio"] - 0.5) < 0.03             # FETCH_SIZE counts half of the bytes on gfx950
