@@ -29,7 +29,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("arch", [(2, 4, 2), (2, 6, 2), (3, 4, 2), (2, 8, 2), (2, 4, 3)])
+@pytest.mark.parametrize("arch", [(2, 4, 2), (2, 6, 2), (3, 4, 2), (2, 8, 2), (2, 4, 3), (2, 5, 2), (2, 7, 2), (2, 6, 1),
+                                  (3, 6, 2)])
 def test_cpep_adaptive_matches_the_oracle(arch):
     import torch  # noqa: F401
     import c_oracle as co

@@ -22,7 +22,11 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("arch,n_state,N", [((2, 6, 2), 3, 1000), ((2, 6, 2), 2, 333), ((2, 4, 2), 2, 64),
                                              ((2, 4, 2), 3, 65), ((3, 4, 2), 2, 200), ((2, 8, 2), 2, 130),
-                                             ((2, 4, 3), 2, 77), ((2, 6, 2), 3, 1)])
+                                             ((2, 4, 3), 2, 77), ((2, 6, 2), 3, 1),
+                                             # further chain(width, depth, tanh) shapes compiled since round 2
+                                             ((2, 3, 2), 2, 70), ((2, 5, 2), 3, 129), ((2, 7, 2), 2, 66),
+                                             ((3, 6, 2), 3, 90), ((2, 4, 1), 2, 100), ((2, 6, 1), 3, 64),
+                                             ((2, 6, 3), 2, 65)])
 def test_cpep_loss_and_gradient(arch, n_state, N):
     import c_oracle as co
     from cude.engine import Engine
@@ -45,7 +49,8 @@ def test_cpep_loss_and_gradient(arch, n_state, N):
 
 
 @pytest.mark.parametrize("arch,N,lam", [((4, 3, 5), 500, 0.01), ((4, 3, 5), 37, 0.0), ((4, 3, 2), 64, 0.1),
-                                         ((4, 6, 2), 129, 0.0)])
+                                         ((4, 6, 2), 129, 0.0), ((4, 5, 2), 70, 0.01), ((4, 3, 3), 65, 0.0),
+                                         ((4, 8, 2), 64, 0.1)])
 def test_supp_loss_and_gradient(arch, N, lam):
     import c_oracle as co
     from cude.engine import Engine
@@ -366,7 +371,7 @@ def test_argument_errors_are_statuses():
     from cude.engine import Engine
     from cude._lib import CudeError
     with pytest.raises(CudeError):
-        Engine("cpep", (2, 5, 2))                      # shape not compiled in -> CUDE_ERR_UNSUPPORTED
+        Engine("cpep", (2, 9, 2))                      # shape not compiled in -> CUDE_ERR_UNSUPPORTED
     eng = Engine("cpep", (2, 4, 2))
     with pytest.raises(CudeError):
         eng.forward()                                  # population not set

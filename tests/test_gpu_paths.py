@@ -34,7 +34,9 @@ def _run(path, c, arch, n_state, n_steps):
     return dict(fwd=f["loss"], sse=f["sse"], loss=loss, g_nn=g_nn, g_cond=g_cond, steps=steps, nn=nn, cond=cond)
 
 
-@pytest.mark.parametrize("arch,n_state,n_steps,N", [((2, 6, 2), 3, 30, 700), ((2, 4, 2), 2, 14, 130), ((3, 4, 2), 2, 30, 65)])
+@pytest.mark.parametrize("arch,n_state,n_steps,N", [((2, 6, 2), 3, 30, 700), ((2, 4, 2), 2, 14, 130), ((3, 4, 2), 2, 30, 65),
+                                                     ((2, 7, 2), 3, 30, 70), ((2, 5, 2), 2, 12, 64), ((2, 6, 1), 2, 30, 65),
+                                                     ((2, 6, 3), 3, 30, 64), ((3, 6, 2), 2, 30, 66)])
 def test_paths_agree_with_oracle_and_each_other(arch, n_state, n_steps, N):
     import c_oracle as co
     c = make_cpep_case(N, arch, n_steps=n_steps)
