@@ -338,8 +338,8 @@ static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, hip
     return hipGetLastError();
 }
 
-#define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3)
-#define CUDE_SUPP_AD_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2)
+#define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
+#define CUDE_SUPP_AD_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
 
 hipError_t launch_cpep_adaptive(const NetShape& net, const CpepArgs& a, hipStream_t s) {
     if (a.TG < 2 || a.TG > kMaxObs || a.T < 1) return hipErrorInvalidValue;

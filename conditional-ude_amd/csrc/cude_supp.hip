@@ -387,7 +387,7 @@ static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#define CUDE_SUPP_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2)
+#define CUDE_SUPP_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
 
 bool supp_shape_supported(const NetShape& net) {
     if (net.nin != 4) return false;

@@ -70,6 +70,58 @@ def test_supp_loss_and_gradient(arch, N, lam):
     eng.close()
 
 
+CPEP_SHAPES = [(2, 4, 2), (2, 6, 2), (3, 4, 2), (2, 8, 2), (2, 4, 3), (2, 3, 2), (2, 5, 2), (2, 7, 2), (3, 6, 2), (2, 4, 1),
+               (2, 6, 1), (2, 6, 3), (2, 8, 1), (2, 8, 3), (3, 8, 2), (2, 3, 1), (2, 5, 1), (2, 7, 1), (2, 3, 3), (2, 5, 3),
+               (2, 7, 3), (3, 4, 1), (3, 6, 1), (3, 4, 3)]
+SUPP_SHAPES = [(3, 5), (3, 2), (4, 2), (6, 2), (5, 2), (3, 3), (8, 2), (3, 4), (4, 3), (4, 4), (5, 3), (6, 3), (3, 1), (4, 1),
+               (6, 1), (8, 1)]
+
+
+def test_every_compiled_shape_against_the_oracle(monkeypatch):
+    """`chain(width, depth, tanh; input_dims)` (src/neural-network.jl:105-107) for every (inputs, width, depth) the
+    library is compiled for (the CUDE_*_SHAPES lists of csrc/): loss and both gradients against the CPU oracle on the
+    one-lane path and on the time-split path, forward loss in adaptive mode against the oracle's adaptive solve."""
+    import c_oracle as co
+    from cude.engine import Engine
+    for k, arch in enumerate(CPEP_SHAPES):
+        N, n_state = 66 + k, 2 + (k % 2)
+        c = make_cpep_case(N, arch)
+        # the forward-mode oracle carries at most 128 partials: the two largest shapes go to the reverse-mode one
+        method = "forward" if c["nn"].size + 1 <= 128 else "reverse"
+        ref = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], c["beta"], 30, n_state,
+                      covariate=(arch[0] == 3), method=method)
+        for path in ("1", "2:3"):
+            monkeypatch.setenv("CUDE_CPEP_PATH", path)
+            eng = Engine("cpep", arch, n_steps=30, n_state=n_state)
+            eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+            eng.set_params(c["nn"], c["beta"])
+            loss, g_nn, g_cond = eng.loss_grad()
+            eng.close()
+            assert abs(loss - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"]), (arch, path)
+            assert _rel(g_nn, ref["g_nn"]) < GRAD_RTOL and _rel(g_cond, ref["g_beta"]) < GRAD_RTOL, (arch, path)
+        monkeypatch.delenv("CUDE_CPEP_PATH")
+        eng = Engine("cpep", arch, n_steps=0, n_state=2)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], c["beta"])
+        out = eng.forward(want_sse=True)
+        eng.close()
+        ad = co.cpep_adaptive(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], np.exp(c["beta"]), c["tp"],
+                              covariate=(arch[0] == 3))
+        sse = np.sum((ad - c["obs"]) ** 2, axis=1)
+        assert abs(out["loss"] - sse.mean()) <= 1e-4 * sse.mean(), arch     # adaptive solves are compared loosely (DESIGN 2)
+    for k, (w, d) in enumerate(SUPP_SHAPES):
+        arch = (4, w, d)
+        c = make_supp_case(40 + k, arch)
+        ref = co.supp(c["tp"], c["data"], arch, c["nn"], c["theta"], 0.01, 30)
+        eng = Engine("supp", arch, n_steps=30, lam=0.01)
+        eng.set_population_supp(c["tp"], c["data"])
+        eng.set_params(c["nn"], c["theta"])
+        loss, g_nn, g_cond = eng.loss_grad()
+        eng.close()
+        assert abs(loss - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"]), arch
+        assert _rel(g_nn, ref["g_nn"]) < GRAD_RTOL and _rel(g_cond, ref["g_theta"]) < GRAD_RTOL, arch
+
+
 def test_baseline_config0_suppression_20_subjects():
     """BASELINE configs[0]: the reference's own CPU-sized case -- suppression/suppression.jl's synthetic cUDE with 20
     subjects from its data generator (`generate_data`, restated in the oracle module: six groups of suppression strength,
