@@ -92,11 +92,63 @@ def chain(width, depth=None, activation="tanh", *, input_dims=2, output_dims=1, 
                 raise NotImplementedError("only tanh hidden layers are compiled into the HIP kernels")
             activation = "tanh"
         if len(set(widths)) != 1:
-            raise NotImplementedError("only equal hidden widths are compiled into the HIP kernels")
+            raise NotImplementedError("only equal hidden widths are compiled into the HIP kernels; an unequal-width "
+                                      "network is the zero-padded equal-width one: see pad_network / unpad_network")
         width, depth = widths[0], len(widths)
     if _act_name(activation) != "tanh" or _act_name(output_activation) != "softplus" or output_dims != 1:
         raise NotImplementedError("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
     return Chain(input_dims, width, depth)
+
+
+def _layer_slices(input_dims, widths):
+    """(weight slice, bias slice, out, in) of every layer of a SimpleChains parameter vector, output layer last."""
+    out, at, fan = [], 0, int(input_dims)
+    for w in list(widths) + [1]:
+        out.append((slice(at, at + w * fan), slice(at + w * fan, at + w * fan + w), w, fan))
+        at += w * fan + w
+        fan = w
+    return out, at
+
+
+def pad_network(widths, params, *, input_dims=2):
+    """Unequal hidden widths, `chain([w1, w2, ...], tanh)` (src/neural-network.jl:42-58), on kernels that are compiled
+    for equal widths: the network IS the equal-width network of width W = max(widths) whose extra units have zero
+    weights and biases: nothing they compute reaches the output, and the gradient entries touching them vanish --
+    exactly for the weights into a padded unit, at the rounding of the device's tanh(0) (~1e-16) for the weights
+    leaving one.  Use it for loss / gradient / simulation calls and optimise in the UNPADDED parameters (gradient =
+    unpad_network(gradient of the padded network): exact).  The library's own optimisers (train, cude_train_restarts)
+    work on the padded vector, and Adam's scale invariance amplifies those ~1e-17 gradients until the padding comes
+    alive: they then train the equal-width network, not the unequal-width one (tests/test_gpu_api.py).
+    Returns (Chain(input_dims, W, depth), padded parameter vector)."""
+    widths = [int(w) for w in widths]
+    p = np.asarray(params, dtype=np.float64).reshape(-1)
+    small, n_small = _layer_slices(input_dims, widths)
+    if p.size != n_small:
+        raise ValueError(f"expected {n_small} parameters for widths {widths}, got {p.size}")
+    W = max(widths)
+    big, n_big = _layer_slices(input_dims, [W] * len(widths))
+    out = np.zeros(n_big)
+    for (ws, bs, o, i), (wb, bb, ob, ib) in zip(small, big):
+        M = np.zeros((ob, ib))
+        M[:o, :i] = p[ws].reshape(i, o).T                    # SimpleChains stores W column-major: vec(W)[j + o*k] = W[j,k]
+        out[wb] = M.T.reshape(-1)
+        out[bb][:o] = p[bs]
+    return Chain(input_dims, W, len(widths)), out
+
+
+def unpad_network(widths, padded, *, input_dims=2):
+    """Inverse of pad_network for a parameter (or gradient) vector of the padded network."""
+    widths = [int(w) for w in widths]
+    P = np.asarray(padded, dtype=np.float64).reshape(-1)
+    small, n_small = _layer_slices(input_dims, widths)
+    big, n_big = _layer_slices(input_dims, [max(widths)] * len(widths))
+    if P.size != n_big:
+        raise ValueError(f"expected {n_big} parameters of the padded network, got {P.size}")
+    out = np.empty(n_small)
+    for (ws, bs, o, i), (wb, bb, ob, ib) in zip(small, big):
+        out[ws] = P[wb].reshape(ib, ob).T[:o, :i].T.reshape(-1)
+        out[bs] = P[bb][:o]
+    return out
 
 
 def _act_name(a):

@@ -333,6 +333,50 @@ def test_queued_adam_run_with_a_communicator_equals_the_plain_run():
     assert ref[0][-1] < ref[0][0]
 
 
+def test_unequal_width_network_through_zero_padding():
+    """chain([6, 3], tanh) on the 2-6-6-1 kernels (api.pad_network): the gradient entries of the padded units vanish
+    (exactly for everything flowing INTO a padded unit; at the rounding of the device's tanh(0) ~ 1e-16 for the output
+    weights LEAVING one), the others equal central differences of the loss in the UNPADDED parameters; optimising in the
+    unpadded parameters from the host keeps the padding exact, the library's own Adam does not (documented)."""
+    from cude import api
+    from cude.engine import Engine
+    widths, N = [6, 3], 80
+    c = make_cpep_case(N, (2, 6, 2))
+    rng = np.random.default_rng(9)
+    n = sum(w * f + w for w, f in zip(widths + [1], [2] + widths))
+    p = 0.7 * rng.standard_normal(n)
+    net, P = api.pad_network(widths, p)
+    pad = P == 0.0
+    eng = Engine("cpep", net.arch, n_steps=30, n_state=2)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(P, c["beta"])
+    loss, g_nn, _ = eng.loss_grad()
+    assert np.max(np.abs(g_nn[pad])) <= 1e-14 * np.max(np.abs(g_nn)) and np.count_nonzero(g_nn[~pad]) == n
+    g_small = api.unpad_network(widths, g_nn)
+    for k in rng.choice(n, 6, replace=False):
+        e = np.zeros(n)
+        e[k] = 1e-5
+        vals = []
+        for sgn in (1.0, -1.0):
+            eng.set_params(api.pad_network(widths, p + sgn * e)[1], None)
+            vals.append(eng.forward()["loss"])
+        assert abs((vals[0] - vals[1]) / 2e-5 - g_small[k]) <= 1e-6 * max(1.0, abs(g_small[k]))
+    # optimising in the UNPADDED parameters (host-side steps on unpad(gradient)) keeps the padding exact by construction
+    q, cond = p.copy(), c["beta"].copy()
+    for _ in range(25):
+        eng.set_params(api.pad_network(widths, q)[1], cond)
+        l, g, gc = eng.loss_grad()
+        q -= 2e-3 * api.unpad_network(widths, g)
+        cond -= 2e-3 * N * gc
+    eng.set_params(api.pad_network(widths, q)[1], cond)
+    assert eng.forward()["loss"] < 0.9 * loss
+    # the library's own optimisers work on the padded vector: Adam's scale invariance amplifies the ~1e-17 gradients of
+    # the padding, so it does NOT stay zero there -- documented in api.pad_network
+    nn_t, _, obj, _ = eng.train_restarts(P[None, :], c["beta"][None, :], 30, 1e-2, 0, want_trace=True)
+    eng.close()
+    assert obj[0] < loss and np.max(np.abs(nn_t[0][pad])) > 1e-12
+
+
 def _gpu_lbfgs_rank(rank, world, port, n_total, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     here = os.path.dirname(os.path.abspath(__file__))

@@ -434,3 +434,30 @@ def test_philox_restatement_hits_the_published_known_answers():
     assert philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     assert philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_unequal_widths_are_the_zero_padded_equal_width_network():
+    """`chain([w1, w2, ...], tanh)` (src/neural-network.jl:42-58): api.pad_network embeds it in the equal-width network
+    the kernels are compiled for; outputs equal those of a general-width MLP written out here, for several shapes."""
+    import cude_oracle as o
+    from cude import api
+    rng = np.random.default_rng(5)
+    for nin, widths in ((2, [6, 3]), (2, [3, 6]), (3, [4, 2, 4]), (4, [5, 3]), (2, [7])):
+        n = sum(w * f + w for w, f in zip(widths + [1], [nin] + widths))
+        p = rng.standard_normal(n)
+        net, P = api.pad_network(widths, p, input_dims=nin)
+        assert net.arch == (nin, max(widths), len(widths)) and P.size == net.n_params
+        assert np.array_equal(api.unpad_network(widths, P, input_dims=nin), p)
+        assert np.count_nonzero(P) == n                                     # everything else is exactly zero
+        x, h, at, fan = rng.standard_normal((nin, 9)), None, 0, nin
+        h = x
+        for k, w in enumerate(widths + [1]):
+            Wm, b = p[at:at + w * fan].reshape(fan, w).T, p[at + w * fan:at + w * fan + w]
+            at, fan = at + w * fan + w, w
+            z = Wm @ h + b[:, None]
+            h = np.tanh(z) if k < len(widths) else np.log1p(np.exp(z))
+        assert np.max(np.abs(h[0] - o.mlp(np, x, P, net.arch))) < 1e-14
+    with pytest.raises(ValueError):
+        api.pad_network([6, 3], np.zeros(5))
+    with pytest.raises(NotImplementedError):
+        api.chain([6, 3], "tanh")
