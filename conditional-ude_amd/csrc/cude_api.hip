@@ -218,6 +218,8 @@ struct cude_ctx {
     DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;
     // chunked gradient path (cude_cpep2.hip)
     int chunks = 1;
+    DevBuf<double> param_mask;                      // frozen shared parameters (cude_set_param_mask); empty = none
+    std::vector<double> mask_host;
     DevBuf<int32_t> chunk_start;
     DevBuf<double> hom_M, hom_obs, fsum, res, g_cond_part, partials2;
     DevBuf<double> m_nn, v_nn, m_cond, v_cond;
@@ -557,10 +559,12 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     if (sse_ov) return CUDE_OK;
     const int P = c->P;
     if (grad && is_cpep(c) && c->chunks > 1) {
-        HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
+                                         c->param_mask.p, P));
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
     } else if (grad) {
-        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream, 1,
+                                         c->param_mask.p, P));
     } else {
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
     }
@@ -571,7 +575,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     }
     if (c->cfg.lambda != 0.0) {
         if (!grad) HIP_TRY(hipMemsetAsync(c->g_nn.p, 0, P * sizeof(double), c->stream));
-        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream, c->param_mask.p));
     }
     return CUDE_OK;
 }
@@ -1132,7 +1136,8 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
         }
-        HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, c->ms_out.p, c->stream, (int)kn));
+        HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, c->ms_out.p, c->stream, (int)kn,
+                                         c->param_mask.p, P));
         if (c->comm && (rc = allreduce_dev(c, c->ms_out.p, (size_t)kn * (P + 2)))) return rc;
         HIP_TRY(hipMemcpyAsync(c->ms_host.data(), c->ms_out.p, kn * (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(g_cond_sets + k0 * N, c->ms_gcond.p, kn * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1155,7 +1160,8 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
                     std::memcpy(part, tmp, sizeof(part));
                 }
                 sum = std::fma(c->cfg.lambda * c->n_global, part[0], sum);
-                for (int q = 0; q < P; q++) g[q] = std::fma(2.0 * c->cfg.lambda, w[q], r[q]);
+                for (int q = 0; q < P; q++)
+                    g[q] = std::fma(2.0 * c->cfg.lambda * (c->mask_host.empty() ? 1.0 : c->mask_host[q]), w[q], r[q]);
             } else {
                 for (int q = 0; q < P; q++) g[q] = r[q];
             }
@@ -1476,6 +1482,24 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     return CUDE_OK;
 }
 
+int32_t cude_set_param_mask(cude_ctx* c, const double* mask) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    drop_graph(c);                                  // the mask pointer is baked into captured launches
+    if (!mask) {
+        HIP_TRY(c->param_mask.resize(0));
+        c->mask_host.clear();
+        return CUDE_OK;
+    }
+    for (int q = 0; q < c->P; q++)
+        if (!std::isfinite(mask[q])) return fail(CUDE_ERR_ARG, "mask entries must be finite");
+    c->mask_host.assign(mask, mask + c->P);
+    HIP_TRY(c->param_mask.resize((size_t)c->P));
+    HIP_TRY(hipMemcpyAsync(c->param_mask.p, c->mask_host.data(), c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
 int32_t cude_set_rng(cude_ctx* c, uint64_t seed, int64_t subject_offset) {
     if (!c) return fail(CUDE_ERR_ARG, "null context");
     if (subject_offset < 0) return fail(CUDE_ERR_ARG, "subject_offset must be >= 0");
@@ -1547,7 +1571,7 @@ int32_t cude_adam_apply(cude_ctx* c, const double* reduced, double* loss) {
     const int P = c->P;
     HIP_TRY(hipMemcpyAsync(c->g_nn.p, reduced, (P + 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (c->cfg.lambda != 0.0)
-        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream, c->param_mask.p));
     c->adam_t += 1;
     if ((rc = finish_loss(c, loss, nullptr))) return rc;   // also synchronises: `reduced` may be freed after return
     return enqueue_adam(c);

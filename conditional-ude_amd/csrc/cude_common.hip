@@ -44,8 +44,10 @@ hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const
 }
 
 // One workgroup per column; fixed-shape tree => bitwise reproducible for a given nblocks.
+// mask (optional, n_mask entries): frozen shared parameters (cude_set_param_mask) -- column q < n_mask is scaled by mask[q]
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
-                                                              int stride, int col0, double* __restrict__ out) {
+                                                              int stride, int col0, double* __restrict__ out,
+                                                              const double* __restrict__ mask, int n_mask) {
     __shared__ double s[256];
     const int q = col0 + blockIdx.x;
     partials += (int64_t)blockIdx.y * nblocks * stride;      // multi-start: one row of the grid per parameter set
@@ -58,14 +60,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
         if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[q] = s[0];
+    if (threadIdx.x == 0) out[q] = (mask != nullptr && q < n_mask) ? s[0] * mask[q] : s[0];
 }
 
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s, int n_sets) {
+                              hipStream_t s, int n_sets, const double* mask, int n_mask) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol, n_sets), dim3(256), 0, s, partials, nblocks, stride, col0,
-                       out);
+                       out, mask, n_mask);
     return hipGetLastError();
 }
 
@@ -185,21 +187,22 @@ hipError_t launch_topk_merge(const TopkArgs& a, int P, int64_t N, const double* 
 }
 
 __global__ void l2_term_kernel(const double* __restrict__ nn, int P, double lambda, double n_global,
-                               double* __restrict__ out) {
+                               double* __restrict__ out, const double* __restrict__ mask) {
     // single wave
     const int lane = threadIdx.x;
     double ss = 0.0;
     for (int q = lane; q < P; q += 64) {
         const double w = nn[q];
         ss = fma(w, w, ss);
-        out[q] = fma(2.0 * lambda, w, out[q]);
+        out[q] = fma(2.0 * lambda * (mask != nullptr ? mask[q] : 1.0), w, out[q]);
     }
     ss = wave_sum(ss);
     if (lane == 0) out[P] = fma(lambda * n_global, ss, out[P]);
 }
 
-hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(l2_term_kernel, dim3(1), dim3(64), 0, s, nn, P, lambda, n_global, out);
+hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s,
+                          const double* mask) {
+    hipLaunchKernelGGL(l2_term_kernel, dim3(1), dim3(64), 0, s, nn, P, lambda, n_global, out, mask);
     return hipGetLastError();
 }
 

@@ -149,7 +149,7 @@ hipError_t launch_supp_adaptive(const NetShape& net, const SuppArgs& a, hipStrea
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1
 // the same for every set k: partials + k*nblocks*stride -> out + k*stride
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s, int n_sets = 1);
+                              hipStream_t s, int n_sets = 1, const double* mask = nullptr, int n_mask = 0);
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s);
@@ -168,7 +168,8 @@ hipError_t launch_topk_merge(const TopkArgs& a, int P, int64_t N, const double* 
                              const double* chunk_nn, const double* chunk_cond, double* new_nn, double* new_cond,
                              hipStream_t s);
 // g_nn[q] += 2*lambda*nn[q];  out[P] += lambda*sum(nn^2)*n_global   (so that loss = out[P]/n_global)
-hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s);
+hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s,
+                          const double* mask = nullptr);
 struct AdamArgs {
     int64_t N; int P;
     double* cond; double* m_cond; double* v_cond; const double* g_cond;

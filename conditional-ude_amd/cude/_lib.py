@@ -39,6 +39,7 @@ _SIGNATURES = {
     "cude_destroy": (C.c_int32, [C.c_void_p]),
     "cude_set_tolerances": (C.c_int32, [C.c_void_p, C.c_double, C.c_double]),
     "cude_set_rng": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64]),
+    "cude_set_param_mask": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "cude_rng_draws": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "cude_set_population_cpep": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

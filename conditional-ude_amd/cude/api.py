@@ -58,14 +58,32 @@ def softplus(x):
 
 
 class Chain:
-    """SimpleChain(static(input_dims), TurboDense{true}(tanh, width) x depth, TurboDense{true}(softplus, 1))."""
+    """SimpleChain(static(input_dims), TurboDense{true}(tanh, width) x depth, TurboDense{true}(softplus, 1)).
 
-    def __init__(self, input_dims, width, depth):
+    `widths` (unequal hidden widths, src/neural-network.jl:42-58): the network is carried as the equal-width network
+    of width max(widths) whose extra units have zero weights, frozen by the library's parameter mask
+    (cude_set_param_mask): parameter vectors have THAT layout (n_params entries, `mask` marks the live ones;
+    pad_network / unpad_network convert to and from SimpleChains' own layout)."""
+
+    def __init__(self, input_dims, width, depth, widths=None):
         self.input_dims, self.width, self.depth = int(input_dims), int(width), int(depth)
+        self.widths = None if widths is None else [int(w) for w in widths]
+
+    @property
+    def mask(self):
+        """1 for the live entries of the padded parameter vector, 0 for the padding; None for equal widths."""
+        if self.widths is None:
+            return None
+        n = sum(w * f + w for w, f in zip(self.widths + [1], [self.input_dims] + self.widths))
+        return (pad_network(self.widths, np.ones(n), input_dims=self.input_dims)[1] != 0.0).astype(np.float64)
 
     @property
     def arch(self):
         return (self.input_dims, self.width, self.depth)
+
+    @property
+    def key(self):
+        return self.arch + (tuple(self.widths) if self.widths else ())
 
     @property
     def n_params(self):
@@ -92,8 +110,9 @@ def chain(width, depth=None, activation="tanh", *, input_dims=2, output_dims=1, 
                 raise NotImplementedError("only tanh hidden layers are compiled into the HIP kernels")
             activation = "tanh"
         if len(set(widths)) != 1:
-            raise NotImplementedError("only equal hidden widths are compiled into the HIP kernels; an unequal-width "
-                                      "network is the zero-padded equal-width one: see pad_network / unpad_network")
+            if _act_name(activation) != "tanh" or _act_name(output_activation) != "softplus" or output_dims != 1:
+                raise NotImplementedError("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
+            return Chain(input_dims, max(widths), len(widths), widths=widths)     # zero-padded + masked (class Chain)
         width, depth = widths[0], len(widths)
     if _act_name(activation) != "tanh" or _act_name(output_activation) != "softplus" or output_dims != 1:
         raise NotImplementedError("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
@@ -167,11 +186,12 @@ def init_params(net, rng=None):
     plateau above 0.7, which none of the reference's 125 stored runs does: profiles/r02/e2e_suppression.txt.)"""
     rng = np.random.default_rng() if rng is None else rng
     parts, fan = [], net.input_dims
-    for out in [net.width] * net.depth + [1]:
+    for out in (net.widths if getattr(net, "widths", None) else [net.width] * net.depth) + [1]:
         sigma = math.sqrt(2.0 / (out + fan + 1))
         parts += [rng.standard_normal(out * fan) * sigma, rng.standard_normal(out) * sigma]
         fan = out
-    return np.concatenate(parts)
+    p = np.concatenate(parts)
+    return pad_network(net.widths, p, input_dims=net.input_dims)[1] if getattr(net, "widths", None) else p
 
 
 def ComponentArray(**kw):
@@ -200,7 +220,7 @@ class CPeptideConditionalUDEModel:
             raise ValueError("glucose, cpeptide and timepoints must have the same length")
         if network.input_dims != (3 if covariate else 2):
             raise ValueError("network input_dims does not match the model (2: [dG, beta]; 3: [dG, beta, age])")
-        self._key = _model_key(self, ("cude", network.arch, covariate))
+        self._key = _model_key(self, ("cude", network.key, covariate))
 
 
 CPeptideCUDEModel = CPeptideConditionalUDEModel        # name used in the reference's docstrings / stale script
@@ -270,6 +290,8 @@ class _Pop:
             self.shared = np.array([models[0].production.vmax])
         else:
             self.engine = Engine("cpep", models[0].chain.arch, n_steps=n_steps, n_state=n_state, device=device)
+            if models[0].chain.mask is not None:
+                self.engine.set_param_mask(models[0].chain.mask)
         G = np.stack([m.glucose for m in models])
         cp = np.asarray(cpeptide_data, dtype=np.float64).reshape(len(models), -1)
         self.engine.set_population_cpep(tp, G, cp, [m.age for m in models], [m.t2dm for m in models])
@@ -639,6 +661,8 @@ def likelihood_profiles(betas, neural_network_parameters, models, timepoints, cp
 class _SuppPop:
     def __init__(self, data, timepoints, net, lam, n_steps, device):
         self.engine = Engine("supp", net.arch, n_steps=n_steps, lam=lam, device=device)
+        if net.mask is not None:
+            self.engine.set_param_mask(net.mask)
         self.engine.set_population_supp(np.asarray(timepoints, dtype=np.float64), data)
         self.data = data
 
@@ -646,7 +670,7 @@ class _SuppPop:
 def _supp_population(prob, data, timepoints, lam, n_steps=None):
     n_steps = DEFAULT_STEPS if n_steps is None else n_steps
     data = np.asarray(data, dtype=np.float64)
-    key = ("supp", prob.network.arch, float(lam), int(n_steps), _digest(timepoints, data))
+    key = ("supp", prob.network.key, float(lam), int(n_steps), _digest(timepoints, data))
     return _cached(key, lambda: _SuppPop(data, timepoints, prob.network, lam, n_steps, _DEVICE))
 
 

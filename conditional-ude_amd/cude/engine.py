@@ -255,6 +255,14 @@ class Engine:
                                       _ptr(acc)))
         return acc
 
+    def set_param_mask(self, mask):
+        """Freeze shared parameters: network-gradient entries are multiplied by mask (P entries of 0 / 1; None lifts
+        it), so frozen entries keep their value under every optimiser of the library."""
+        m = None if mask is None else _f64(mask).reshape(-1)
+        if m is not None and m.size != self.P:
+            raise ValueError(f"expected a mask of {self.P} entries")
+        check(self._lib.cude_set_param_mask(self._h, _ptr(m)))
+
     def set_rng(self, seed, subject_offset=0):
         """Seed / rewind the device-side draws of mh_estep / mh_chain; subject_offset = global index of this
         context's first subject (draws do not depend on the sharding)."""

@@ -232,6 +232,13 @@ function mh_chain!(c::Ctx, normals::Matrix{Float64}, uniforms::Matrix{Float64}, 
     accepted, samples
 end
 
+# freeze shared parameters (mask of 0 / 1, length P; `nothing` lifts it)
+function set_param_mask!(c::Ctx, mask)
+    m = mask === nothing ? nothing : Vector{Float64}(vec(mask))
+    GC.@preserve m check(ccall((:cude_set_param_mask, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}),
+        c.h, m === nothing ? C_NULL : pointer(m)))
+end
+
 # device-side draws of the Metropolis steps: mh_estep!(c, n_mc, σ, ...) without draw matrices
 set_rng!(c::Ctx, seed::Integer, subject_offset::Integer = 0) =
     check(ccall((:cude_set_rng, LIB), Int32, (Ptr{Cvoid}, UInt64, Int64), c.h, UInt64(seed), Int64(subject_offset)))

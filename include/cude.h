@@ -242,6 +242,14 @@ int32_t cude_mh_chain(cude_ctx* ctx, int32_t n_mc, const double* normals, const 
                       double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
                       int64_t* accepted, double* samples);
 
+/* Freeze shared parameters: every network-gradient entry the library forms -- cude_loss_grad, the Adam updates, the
+ * restarts of cude_train_restarts / cude_multistart_loss_grad, the partial rows of cude_loss_grad_partial -- is
+ * multiplied by mask[q] (0 = frozen, 1 = free; mask[P], or NULL to lift it).  Frozen entries keep exactly the value
+ * cude_set_params gave them under Adam and L-BFGS.  Use: `chain([w1, w2, ...], tanh)` with unequal widths
+ * (src/neural-network.jl:42-58) is the equal-width network of width max(w) whose extra units have zero weights; frozen at
+ * zero they stay that network (the host mirror's chain(widths) does exactly this). */
+int32_t cude_set_param_mask(cude_ctx* ctx, const double* mask);
+
 /* Device-side random draws for cude_mh_estep / cude_mh_chain (the `randn()` / `rand()` of mcmc_step, src/saem.jl:88,103)
  * when the caller passes no draw arrays: counter-based Philox4x32-10, key = seed, counter = (global subject index,
  * index of the Metropolis step since this call, kind); standard normals by Box-Muller on two 53-bit uniforms, uniforms

@@ -370,11 +370,44 @@ def test_unequal_width_network_through_zero_padding():
         cond -= 2e-3 * N * gc
     eng.set_params(api.pad_network(widths, q)[1], cond)
     assert eng.forward()["loss"] < 0.9 * loss
-    # the library's own optimisers work on the padded vector: Adam's scale invariance amplifies the ~1e-17 gradients of
-    # the padding, so it does NOT stay zero there -- documented in api.pad_network
+    # the library's own optimisers work on the padded vector: without a mask Adam's scale invariance amplifies the
+    # ~1e-17 gradients of the padding until it comes alive; with the mask (cude_set_param_mask) it stays exactly zero
     nn_t, _, obj, _ = eng.train_restarts(P[None, :], c["beta"][None, :], 30, 1e-2, 0, want_trace=True)
-    eng.close()
     assert obj[0] < loss and np.max(np.abs(nn_t[0][pad])) > 1e-12
+    eng.set_param_mask((~pad).astype(float))
+    eng.set_params(P, c["beta"])
+    _, g_m, _ = eng.loss_grad()
+    assert np.all(g_m[pad] == 0.0) and np.array_equal(g_m[~pad], g_nn[~pad])
+    nn_m, cond_m, obj_m, _ = eng.train_restarts(P[None, :], c["beta"][None, :], 30, 1e-2, 20, want_trace=True)
+    assert obj_m[0] < loss and np.all(nn_m[0][pad] == 0.0)
+    eng.adam_init(1e-2)
+    eng.set_params(P, c["beta"])
+    losses = eng.adam_run(25)
+    nn_a, _ = eng.get_params()
+    assert losses[-1] < losses[0] and np.all(nn_a[pad] == 0.0) and np.max(np.abs(nn_a[~pad] - P[~pad])) > 1e-3
+    eng.set_param_mask(None)
+    eng.close()
+
+
+def test_train_with_unequal_widths_through_the_api():
+    """api.chain([6, 3], tanh) end to end: models built on it, `loss`, `train` (screening + Adam + L-BFGS inside the
+    library) -- the trained parameter vectors keep exact zeros at the padding and unpad to a 43-parameter network whose
+    loss, evaluated as a padded network again, is the reported objective."""
+    from cude import api
+    c = make_cpep_case(40, (2, 6, 2))
+    net = api.chain([6, 3], "tanh")
+    models = [api.CPeptideConditionalUDEModel(c["G"][i], c["tp"], c["age"][i], net, c["obs"][i], bool(c["t2dm"][i]))
+              for i in range(40)]
+    sols = api.train(models, c["tp"], c["obs"], np.random.default_rng(3), initial_guesses=200, selected_initials=3,
+                     number_of_iterations_adam=40, number_of_iterations_lbfgs=30, n_steps=30)
+    assert len(sols) == 3
+    for sol in sols:
+        nn = np.asarray(sol.u.neural)
+        assert nn.size == 67 and np.all(nn[net.mask == 0.0] == 0.0) and np.count_nonzero(nn) == 43
+        small = api.unpad_network([6, 3], nn)
+        theta = api.ComponentArray(neural=api.pad_network([6, 3], small)[1], conditional=sol.u.conditional)
+        assert abs(api.loss(theta, (models, c["tp"], c["obs"]), n_steps=30) - sol.objective) <= 1e-12 * sol.objective
+    api.clear_cache()
 
 
 def _gpu_lbfgs_rank(rank, world, port, n_total, out_dir):

@@ -20,8 +20,9 @@ def test_chain_mirrors_reference_argument_errors():
         api.chain([], "tanh")
     with pytest.raises(ValueError):
         api.chain([4, 4], ["tanh"])
+    assert api.chain([4, 5], "tanh").arch == (2, 5, 2)                 # unequal widths: zero-padded + masked (class Chain)
     with pytest.raises(NotImplementedError):
-        api.chain([4, 5], "tanh")
+        api.chain([4, 5], ["tanh", "relu"])
     with pytest.raises(NotImplementedError):
         api.chain(4, 2, "relu")
     net = api.chain(4, 2, "tanh")
@@ -459,5 +460,11 @@ def test_unequal_widths_are_the_zero_padded_equal_width_network():
         assert np.max(np.abs(h[0] - o.mlp(np, x, P, net.arch))) < 1e-14
     with pytest.raises(ValueError):
         api.pad_network([6, 3], np.zeros(5))
+    # chain(widths) itself: carried as the padded network + a mask of its live parameters
+    net = api.chain([6, 3], "tanh")
+    assert net.arch == (2, 6, 2) and net.widths == [6, 3] and net.n_params == 67 and int(net.mask.sum()) == 43
+    p0 = api.init_params(net, np.random.default_rng(1))
+    assert p0.size == 67 and np.array_equal(p0 != 0.0, net.mask == 1.0)
+    assert api.chain([4, 4], "tanh").mask is None and api.chain(4, 2, "tanh").widths is None
     with pytest.raises(NotImplementedError):
-        api.chain([6, 3], "tanh")
+        api.chain([6, 3], "relu")
