@@ -345,20 +345,44 @@ end
 # chain(width, depth, tanh; input_dims = 2): only what the kernels compile (equal widths, tanh, one softplus output)
 struct Chain
     input_dims::Int; width::Int; depth::Int
+    widths::Vector{Int}     # empty = equal widths; otherwise the network is carried zero-padded to width = maximum(widths)
 end
+Chain(input_dims::Integer, width::Integer, depth::Integer) = Chain(input_dims, width, depth, Int[])
 chain(width::Integer, depth::Integer, activation = tanh; input_dims::Integer = 2, output_dims::Integer = 1) =
     (output_dims == 1 && activation === tanh) ? Chain(input_dims, width, depth) :
     error("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
+# chain(widths, tanh) (src/neural-network.jl:42-58): unequal widths = the equal-width network of width maximum(widths)
+# whose extra units have zero weights, frozen through cude_set_param_mask; parameter vectors carry THAT layout
+function chain(widths::AbstractVector{<:Integer}, activation = tanh; input_dims::Integer = 2, output_dims::Integer = 1)
+    isempty(widths) && throw(ArgumentError("Input widths must be non-empty."))
+    (output_dims == 1 && activation === tanh) || error("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
+    all(==(widths[1]), widths) ? Chain(input_dims, widths[1], length(widths)) :
+                                 Chain(input_dims, maximum(widths), length(widths), collect(Int, widths))
+end
 neural_network_model(depth::Integer, width::Integer; input_dims::Integer = 2) = Chain(input_dims, width, depth)
 n_params(c::Chain) = Int(ccall((:cude_n_params, LIB), Int32, (Int32, Int32, Int32), c.input_dims, c.width, c.depth))
+
+# SimpleChains' layout of an unequal-width network -> the padded layout (and the 0 / 1 mask of its live entries)
+function pad_network(c::Chain, p::AbstractVector{<:Real})
+    out = zeros(n_params(c)); at = 0; bt = 0; fan = c.input_dims; W = c.width
+    for (k, w) in enumerate(vcat(c.widths, 1))
+        wb = k <= c.depth ? W : 1; fb = k == 1 ? c.input_dims : W
+        M = zeros(wb, fb); M[1:w, 1:fan] .= reshape(p[at+1:at+w*fan], w, fan)
+        out[bt+1:bt+wb*fb] .= vec(M); out[bt+wb*fb+1:bt+wb*fb+w] .= p[at+w*fan+1:at+w*fan+w]
+        at += w * fan + w; bt += wb * fb + wb; fan = w
+    end
+    out
+end
+param_mask(c::Chain) = isempty(c.widths) ? nothing :
+    Float64.(pad_network(c, ones(sum(w * f + w for (w, f) in zip(vcat(c.widths, 1), vcat(c.input_dims, c.widths))))) .!= 0)
 
 # SimpleChains.init_params restated: a TurboDense{true} layer is ONE out × (in + 1) matrix [W b], all of it Glorot-normal
 function init_params(c::Chain; rng::AbstractRNG)
     p = Float64[]; fan = c.input_dims
-    for out in vcat(fill(c.width, c.depth), 1)
+    for out in vcat(isempty(c.widths) ? fill(c.width, c.depth) : c.widths, 1)
         append!(p, randn(rng, out * (fan + 1)) .* sqrt(2 / (out + fan + 1))); fan = out
     end
-    p
+    isempty(c.widths) ? p : pad_network(c, p)
 end
 
 abstract type CPeptideModel end
@@ -395,6 +419,8 @@ function population(models::AbstractVector{CPeptideConditionalUDEModel}, timepoi
         G = Matrix{Float64}(undef, length(models), length(timepoints))
         for (i, m) in enumerate(models); G[i, :] .= m.glucose; end
         set_population!(c, Vector{Float64}(timepoints), G, data, [m.age for m in models], UInt8[m.t2dm for m in models])
+        isempty(net.widths) || set_param_mask!(c, param_mask(net))
+        c
     end
 end
 clear_populations!() = empty!(POPULATIONS)
