@@ -246,6 +246,7 @@ struct cude_ctx {
     double host_red[3];
     // scratch of cude_multistart_loss_grad (kept between calls: it is called once per optimiser iteration)
     DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt, ms_act;
+    DevBuf<double> ms_fsum, ms_wts, ms_gcp, ms_p2;   // time-split path with parameter sets (small populations)
     DevBuf<double> act;     // SUPP: kept network activations of the gradient launch (small populations only)
     DevBuf<double> red_tmp; // staging of small host vectors reduced through the communicator
     std::vector<double> ms_host;
@@ -1105,9 +1106,22 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     const int P = c->P, S = c->cfg.n_steps;
     const int64_t N = c->N, nb = c->nblocks;
     const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
-    // sets per launch: bounded by the grid's y dimension and ~512 MB of scratch
-    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (supp ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0));
-    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_sets, 32768), (int64_t)(512e6 / per_set)));
+    // Small populations: K restarts of a few dozen subjects are K single-wave chains on the one-lane kernel (25 waves on
+    // 1024 SIMDs, each paying the full single-wave latency).  When the population itself runs time-split (chunks > 1) and
+    // the sets do not fill the chip either, the time-split kernels take the set index as a third grid dimension: K x L
+    // short waves instead.  Same kernels as cude_loss_grad on this context, so a set's result is bit-identical to it.
+    const int L = c->chunks;
+    const bool split = !supp && L > 1 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 && getenv("CUDE_NO_MS_SPLIT") == nullptr;
+    // sets per launch: bounded by the grid's y / z dimension and ~512 MB of scratch
+    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (supp ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
+                                  (split ? (double)L * (3 + c->T) * N + 5.0 * S * N + (double)L * N + (double)L * nb * P : 0.0));
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_sets, split ? 16384 : 32768), (int64_t)(512e6 / per_set)));
+    if (split) {
+        HIP_TRY(c->ms_fsum.reserve((size_t)chunk * L * (3 + c->T) * N));
+        HIP_TRY(c->ms_wts.reserve((size_t)chunk * 5 * S * N));
+        HIP_TRY(c->ms_gcp.reserve((size_t)chunk * L * N));
+        HIP_TRY(c->ms_p2.reserve((size_t)chunk * L * nb * P));
+    }
     HIP_TRY(c->ms_nn.reserve((size_t)chunk * P));
     HIP_TRY(c->ms_cond.reserve((size_t)chunk * N));
     HIP_TRY(c->ms_gcond.reserve((size_t)chunk * N));
@@ -1119,7 +1133,20 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
         const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
         HIP_TRY(hipMemcpyAsync(c->ms_nn.p, nn_sets + k0 * P, kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->ms_cond.p, cond_sets + k0 * N, kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (!supp) {
+        if (split) {
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
+            a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
+            a.sse = nullptr; a.traj = nullptr; a.auc = nullptr;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            cude::Cpep2Args a2 = chunk_args(c, a);
+            a2.fsum = c->ms_fsum.p; a2.wts = c->ms_wts.p; a2.g_cond_part = c->ms_gcp.p; a2.partials2 = c->ms_p2.p;
+            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, true, a2, c->stream));
+            // network gradient: the reverse chunks' partial rows; loss / failure columns: the scan's
+            HIP_TRY(cude::launch_reduce_cols(c->ms_p2.p, nb * L, P, 0, P, c->ms_out.p, c->stream, (int)kn, c->param_mask.p, P,
+                                             P + 2));
+            HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, P, 2, c->ms_out.p, c->stream, (int)kn));
+        } else if (!supp) {
             cude::CpepArgs a = cpep_args(c);
             a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
             a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
@@ -1136,8 +1163,9 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
         }
-        HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, c->ms_out.p, c->stream, (int)kn,
-                                         c->param_mask.p, P));
+        if (!split)
+            HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, c->ms_out.p, c->stream, (int)kn,
+                                             c->param_mask.p, P));
         if (c->comm && (rc = allreduce_dev(c, c->ms_out.p, (size_t)kn * (P + 2)))) return rc;
         HIP_TRY(hipMemcpyAsync(c->ms_host.data(), c->ms_out.p, kn * (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(g_cond_sets + k0 * N, c->ms_gcond.p, kn * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -47,11 +47,11 @@ hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const
 // mask (optional, n_mask entries): frozen shared parameters (cude_set_param_mask) -- column q < n_mask is scaled by mask[q]
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
                                                               int stride, int col0, double* __restrict__ out,
-                                                              const double* __restrict__ mask, int n_mask) {
+                                                              const double* __restrict__ mask, int n_mask, int out_stride) {
     __shared__ double s[256];
     const int q = col0 + blockIdx.x;
     partials += (int64_t)blockIdx.y * nblocks * stride;      // multi-start: one row of the grid per parameter set
-    out += (int64_t)blockIdx.y * stride;
+    out += (int64_t)blockIdx.y * out_stride;
     double v = 0.0;
     for (int64_t b = threadIdx.x; b < nblocks; b += 256) v += partials[b * stride + q];
     s[threadIdx.x] = v;
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s, int n_sets, const double* mask, int n_mask) {
+                              hipStream_t s, int n_sets, const double* mask, int n_mask, int out_stride) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol, n_sets), dim3(256), 0, s, partials, nblocks, stride, col0,
-                       out, mask, n_mask);
+                       out, mask, n_mask, out_stride > 0 ? out_stride : stride);
     return hipGetLastError();
 }
 

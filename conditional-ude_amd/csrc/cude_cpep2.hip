@@ -110,7 +110,10 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     const int64_t i = active ? gid : b.N - 1;
     const int64_t N = b.N;
     const int c_idx = blockIdx.y;
-    cptr_t p = as_const(b.nn);
+    // side-by-side parameter sets (restarts trained together on a small population): grid z = set; every per-set array
+    // is [set][...] with the strides of one set (single evaluations are set 0 of 1)
+    const int64_t set = blockIdx.z;
+    cptr_t p = as_const(b.nn + set * b.set_stride_nn);
     cptr_t phi = as_const(b.phi);
     cptr_t obs_w = as_const(b.obs_w);
     ciptr_t seg = as_const(b.seg);
@@ -123,7 +126,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
     const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};
     double cst[NC];
-    cst[0] = exp(a.mh_fused ? mh_proposal(a.mh.p, a.mh_z, a.mh.key, a.mh_std, i) : b.cond[i]);
+    cst[0] = exp(a.mh_fused ? mh_proposal(a.mh.p, a.mh_z, a.mh.key, a.mh_std, i) : b.cond[set * b.set_stride_cond + i]);
+    double* const fsum = a.fsum + set * ((int64_t)a.L * (3 + b.T) * b.N);
     if (NC > 1) cst[1] = b.age[i];
     double c[W];
     Net::first_layer_offset(p, cst, c);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             double o1 = 0.0;
 #pragma unroll
             for (int j = 0; j < 7; j++) o1 = fma(obs_w[oi * 7 + j], K[j][0], o1);
-            if (active) a.fsum[((int64_t)c_idx * (3 + T) + 3 + oi) * N + i] = fma(h, o1, y1) + chk;
+            if (active) fsum[((int64_t)c_idx * (3 + T) + 3 + oi) * N + i] = fma(h, o1, y1) + chk;
             oi++;
         }
         y1 = Y1; y2 = Y2; y3 = y3n;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
         n++;
     }
     if (active) {
-        double* f = a.fsum + (int64_t)c_idx * (3 + T) * N + i;
+        double* f = fsum + (int64_t)c_idx * (3 + T) * N + i;
         f[0] = y1 + chk;
         f[N] = y2;
         f[2 * N] = y3;
@@ -230,6 +234,9 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     ciptr_t obs_step = as_const(b.obs_step);
     ciptr_t cs = as_const(a.chunk_start);
     const int T = b.T;
+    const int64_t set = blockIdx.y;             // parameter set (see cpep2_fwd_kernel)
+    const double* const fsum = a.fsum + set * ((int64_t)a.L * (3 + T) * N);
+    double* const wts = a.wts != nullptr ? a.wts + set * ((int64_t)5 * b.S * N) : nullptr;
     double* s_res = smem + kRedRows * kBlock;   // [T][kBlock]
     const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
     double y1 = c0, y2 = (k2 / k1) * c0, y3 = 0.0, sse = 0.0;
@@ -239,13 +246,13 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     // a full HBM round trip: 17 us for L = 30, more than the forward chunks themselves at small populations).
     double nx[7];
     {
-        const double* f = a.fsum + i;
+        const double* f = fsum + i;
         const double* M = a.hom_M + i;
         nx[0] = f[0]; nx[1] = f[N]; nx[2] = f[2 * N];
         nx[3] = M[0]; nx[4] = M[N]; nx[5] = M[2 * N]; nx[6] = M[3 * N];
     }
     for (int c = 0; c < a.L; c++) {
-        const double* f = a.fsum + (int64_t)c * (3 + T) * N + i;
+        const double* f = fsum + (int64_t)c * (3 + T) * N + i;
         const int n1 = cs[c + 1];
         double cu[7];
 #pragma unroll
@@ -270,11 +277,11 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     }
     const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);
     if (active) {
-        if (b.sse != nullptr) b.sse[i] = sse;
-        if (b.auc != nullptr) b.auc[i] = y3;
+        if (b.sse != nullptr) b.sse[set * b.set_stride_cond + i] = sse;
+        if (b.auc != nullptr && set == 0) b.auc[i] = y3;
         if (a.mh_fused) mh_accept_one(a.mh, i, mh_proposal(a.mh.p, a.mh_z, a.mh.key, a.mh_std, i), sse);
     }
-    if (a.wts != nullptr) {
+    if (wts != nullptr) {
         const Kin kin{-(k0 + k2), k1, k2, -k1, k0 * c0};
         cptr_t obs_w = as_const(b.obs_w);
         double lam1 = 0.0, lam2 = 0.0, kap1 = 0.0, kap2 = 0.0, w[5];
@@ -285,12 +292,12 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
             adj_step(kin, b.h, gscale, obs_w, obs_step, s_res, lane, n, oi, lam1, lam2, kap1, kap2, w);
             if (active) {
 #pragma unroll
-                for (int j = 0; j < 5; j++) a.wts[(int64_t)(5 * n + j) * N + i] = w[j];
+                for (int j = 0; j < 5; j++) wts[(int64_t)(5 * n + j) * N + i] = w[j];
             }
         }
     }
     const double v2[2] = {active ? sse : 0.0, (active && failed) ? 1.0 : 0.0};
-    block_reduce_store<2>(v2, smem, b.partials + (int64_t)blockIdx.x * (P + 2) + P, lane);
+    block_reduce_store<2>(v2, smem, b.partials + (set * gridDim.x + blockIdx.x) * (P + 2) + P, lane);
 }
 
 // ---------------------------------------------------------------------------------- reverse sweep
@@ -362,7 +369,9 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     const int64_t i = active ? gid : b.N - 1;
     const int64_t N = b.N;
     const int c_idx = blockIdx.y;
-    cptr_t p = as_const(b.nn);
+    const int64_t set = blockIdx.z;             // parameter set (see cpep2_fwd_kernel)
+    cptr_t p = as_const(b.nn + set * b.set_stride_nn);
+    const double* const wts = a.wts + set * ((int64_t)5 * b.S * b.N);
     cptr_t phi = as_const(b.phi);
     ciptr_t seg = as_const(b.seg);
     ciptr_t cs = as_const(a.chunk_start);
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     const int n0 = cs[c_idx], n1 = cs[c_idx + 1];
 
     double cst[NC];
-    cst[0] = exp(b.cond[i]);
+    cst[0] = exp(b.cond[set * b.set_stride_cond + i]);
     if (NC > 1) cst[1] = b.age[i];
     double c[W];
     Net::first_layer_offset(p, cst, c);
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
                 g_d = b.dG[(int64_t)(sg + 1) * N + i] - g_lo;
             }
             xv = fma(phi[e], g_d, g_lo);
-            wv = a.wts[(int64_t)e * N + i];           // needed at the end of the evaluation only: the load stays in flight
+            wv = wts[(int64_t)e * N + i];             // needed at the end of the evaluation only: the load stays in flight
             if constexpr (kTab) {
                 tab = kind != 0;
                 if (tab) {
@@ -453,8 +462,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
         Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy, tab, &E1);
         if (own) wtot += wv;
     }
-    if (active) a.g_cond_part[(int64_t)c_idx * N + i] = Net::grad_cond(p, acc, cst);
-    double* out = a.partials2 + ((int64_t)c_idx * gridDim.x + blockIdx.x) * P;
+    if (active) a.g_cond_part[(set * a.L + c_idx) * N + i] = Net::grad_cond(p, acc, cst);
+    double* out = a.partials2 + ((set * a.L + c_idx) * gridDim.x + blockIdx.x) * P;
     __syncthreads();                            // the table rows become the reduction buffer
     {
         // P columns only (the loss / failure columns belong to the scan kernel): expand 16 rows at a time into LDS
@@ -477,12 +486,14 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
 }
 
 // g_cond[i] = sum_c part[c][i]
-__global__ void cpep2_sum_chunks_kernel(const double* __restrict__ part, int L, int64_t N, double* __restrict__ out) {
+__global__ void cpep2_sum_chunks_kernel(const double* __restrict__ part, int L, int64_t N, double* __restrict__ out,
+                                        int64_t out_set_stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    part += (int64_t)blockIdx.y * L * N;        // parameter set
     double s = 0.0;
     for (int c = 0; c < L; c++) s += part[(int64_t)c * N + i];
-    out[i] = s;
+    out[(int64_t)blockIdx.y * out_set_stride + i] = s;
 }
 
 // ---------------------------------------------------------------------------------- dispatch
@@ -490,10 +501,11 @@ template <int NIN, int W, int D>
 static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStream_t s) {
     using Net = Mlp<NIN, W, D, 1>;
     const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
-    const dim3 grid2((unsigned)nblocks, (unsigned)a.L);
+    const unsigned n_sets = a.base.n_sets > 0 ? (unsigned)a.base.n_sets : 1u;
+    const dim3 grid2((unsigned)nblocks, (unsigned)a.L, n_sets);
     const size_t lds_f = sizeof(double) * 5 * kBlock;
     static const bool no_vw = getenv("CUDE_NO_VW2") != nullptr;
-    const bool vwr = Net::HAS_VW && !no_vw && nblocks * a.L <= 2 * 1024;       // fits two waves per SIMD at once
+    const bool vwr = Net::HAS_VW && !no_vw && nblocks * a.L * n_sets <= 2 * 1024;       // fits two waves per SIMD at once
     if (vwr) {
         if constexpr (Net::HAS_VW) {
             if (n_state == 3) hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 3, true>), grid2, dim3(kBlock), lds_f, s, a);
@@ -506,15 +518,15 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     }
     Cpep2Args as = a;
     if (!grad) as.wts = nullptr;
-    hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks), dim3(kBlock),
+    hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kBlock),
                        sizeof(double) * (size_t)(kRedRows + a.base.T) * kBlock, s, as);
     if (!grad) return hipGetLastError();
     constexpr int TABROWS = Net::HAS_TAB ? 5 * W : 0;
     const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;
     hipLaunchKernelGGL((cpep2_rev_kernel<NIN, W, D>), grid2, dim3(kBlock), lds_r, s, a);
     const int bs = 256;
-    hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N + bs - 1) / bs)), dim3(bs), 0, s,
-                       a.g_cond_part, a.L, a.base.N, a.base.g_cond);
+    hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N + bs - 1) / bs), n_sets), dim3(bs), 0, s,
+                       a.g_cond_part, a.L, a.base.N, a.base.g_cond, a.base.set_stride_cond);
     return hipGetLastError();
 }
 

@@ -149,7 +149,8 @@ hipError_t launch_supp_adaptive(const NetShape& net, const SuppArgs& a, hipStrea
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1
 // the same for every set k: partials + k*nblocks*stride -> out + k*stride
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s, int n_sets = 1, const double* mask = nullptr, int n_mask = 0);
+                              hipStream_t s, int n_sets = 1, const double* mask = nullptr, int n_mask = 0,
+                              int out_stride = 0 /* doubles between the sets' output rows; 0 = stride */);
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s);

@@ -54,6 +54,39 @@ def test_every_set_equals_its_own_loss_grad_call(model):
         del os.environ["CUDE_CPEP_PATH"]
 
 
+@pytest.mark.parametrize("arch,n_state,N", [((2, 6, 2), 3, 150), ((2, 4, 2), 2, 57), ((3, 4, 2), 2, 117)])
+def test_sets_on_the_time_split_path(arch, n_state, N, monkeypatch):
+    """Small populations run time-split, and so do their restarts: the set index is a third grid dimension of the
+    chunk kernels (K x L short waves instead of K single-wave chains).  Every set must be bit-identical to its own
+    cude_loss_grad on the same context (same kernels, same chunking), agree with the one-lane multi-start to rounding,
+    and a failing subject must fail its set only."""
+    from cude.engine import Engine
+    rng = np.random.default_rng(18)
+    c = make_cpep_case(N, arch)
+    eng = Engine("cpep", arch, n_steps=30, n_state=n_state)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    K = 9
+    nn_sets = c["nn"][None, :] * (1.0 + 0.2 * rng.standard_normal((K, c["nn"].size)))
+    cond_sets = c["beta"][None, :] + 0.3 * rng.standard_normal((K, N))
+    cond_sets[4, N // 3] = np.nan
+    loss, g_nn, g_cond = eng.multistart_loss_grad(nn_sets, cond_sets)
+    assert np.isinf(loss[4]) and np.all(np.isfinite(np.delete(loss, 4)))
+    for k in range(K):
+        if k == 4:
+            continue
+        eng.set_params(nn_sets[k], cond_sets[k])
+        l1, gn1, gc1 = eng.loss_grad()
+        assert l1 == loss[k] and np.array_equal(gn1, g_nn[k]) and np.array_equal(gc1, g_cond[k])
+    monkeypatch.setenv("CUDE_NO_MS_SPLIT", "1")                  # the one-lane kernel with the sets in grid y
+    loss1, g_nn1, g_cond1 = eng.multistart_loss_grad(nn_sets, cond_sets)
+    eng.close()
+    ok = np.arange(K) != 4
+    assert np.isinf(loss1[4]) and np.max(np.abs(loss1[ok] / loss[ok] - 1)) < 1e-12
+    assert np.max(np.abs(g_nn1[ok] - g_nn[ok])) <= 1e-10 * np.max(np.abs(g_nn[ok]))
+    assert np.max(np.abs(g_cond1[ok] - g_cond[ok])) <= 1e-10 * np.max(np.abs(g_cond[ok]))
+    assert not np.array_equal(g_nn1[ok], g_nn[ok])              # ... and it IS a different path
+
+
 def test_side_by_side_training_follows_the_serial_restarts():
     """_batched_adam_then_lbfgs vs the one-after-the-other loop: the first Adam iterations agree to rounding (host
     Adam vs the device Adam kernel), and a full short training ends at comparable objectives for every restart."""
