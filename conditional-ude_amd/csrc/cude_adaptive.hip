@@ -7,9 +7,18 @@
 //   solve(ensemble, Tsit5(), EnsembleThreads(); saveat, trajectories = N)        suppression/src/suppression_model.jl:113,123
 // i.e. Tsit5 with abstol 1e-6 / reltol 1e-3, the PI step controller (beta1 = 7/50, beta2 = 2/25, gamma = 0.9,
 // qmin = 0.2, qmax = 10), Hairer's initial-step heuristic, `saveat` through the free 4th-order interpolant, failure
-// (non-finite error estimate, more than 1e5 steps) => +Inf loss.  Selected by cude_config.n_steps = 0; forward only
-// (loss, per-subject SSE, trajectories, dense output, profiles, screening, Metropolis E-step): gradients use the
-// fixed-step kernels.
+// (non-finite error estimate, more than 1e5 steps) => +Inf loss.  Selected by cude_config.n_steps = 0: loss,
+// per-subject SSE, trajectories, dense output, profiles, screening, Metropolis E-step, and -- GRAD -- the gradient.
+//
+// Gradient of the adaptive solve = what the reference's AutoForwardDiff computes (src/parameter-estimation.jl:165,
+// suppression_model.jl:155): under ForwardDiff only p = theta carries partials, tspan and dt stay Float64, so the
+// derivative is that of the accepted step sequence as fixed arithmetic (controller and initial-step heuristic are not
+// differentiated).  Here: the forward sweep writes (t_n, dt_n, y_n) of every accepted step to a per-subject tape in
+// HBM ([step][2 + NS][subject], coalesced); the reverse sweep walks the tape backwards, re-runs the seven stage
+// evaluations of the step and applies their VJPs in reverse order, including the `saveat` interpolation weights of the
+// observations that fell into the step.  (OrdinaryDiffEq's error norm under duals also weighs the partials -- its
+// documented behaviour -- so the reference's accepted steps during a gradient call can differ from those of a plain
+// solve; the sequence here is the plain solve's.)  Lanes with more accepted steps than the tape holds fail (+Inf).
 //
 // One lane = one subject, each with its own (t, dt, controller state): the lanes of a wave walk the same sequence of
 // phases (k1, the f1 probe of the initial step, then stages 2..7 of step after step) with ONE inlined network body;
@@ -106,6 +115,35 @@ struct CpepAd {
         const double r = o[0] - a.obs[(int64_t)oi * a.N + i];
         return r * r;
     }
+    // ---- gradient
+    static constexpr bool NEED_Y = false;          // J_f = A: the stage inputs are not linearisation points
+    using NetT = Net;
+    static constexpr int NCST = Net::NC;
+    // d residual2 / d o
+    __device__ __forceinline__ void residual_bar(const Args& a, int oi, int64_t i, const double (&o)[NS], double (&ob)[NS]) const {
+        ob[0] = 2.0 * (o[0] - a.obs[(int64_t)oi * a.N + i]);
+        ob[1] = 0.0;
+    }
+    // ub += J_f^T kb,  acc += kb . d f / d params  at time te (the baseline term is collected in wsum)
+    template <class A>
+    __device__ __forceinline__ void vjp(double te, const double (&)[NS], const double (&kb)[NS], double (&ub)[NS], A& acc,
+                                        double& wsum) const {
+        ub[0] += fma(a11, kb[0], a21 * kb[1]);
+        ub[1] += fma(a12, kb[0], a22 * kb[1]);
+        const double xx[1] = {forcing_input(te)};
+        double dx[1] = {0.0};
+        Net::template eval_grad<false>(p, c, xx, kb[0], acc, dx);
+        wsum += kb[0];
+    }
+    template <class A>
+    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A& acc, double wsum,
+                                                double (&cst)[NCST]) const {
+        const double xx[1] = {0.0};
+        double dx[1] = {0.0};
+        Net::template eval_grad<false>(p, c, xx, -wsum, acc, dx);       // - sum(kb) * d NN([0; e^beta]) / d params
+        cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
+        if (NCST > 1) cst[NCST - 1] = a.age[i];
+    }
 };
 
 // suppression cUDE: f(u) = [-0.4 u1, 0.4 u1 - NN(u, e^theta), NN(u, e^theta) - 0.3 u3]
@@ -140,6 +178,28 @@ struct SuppAd {
         }
         return s2;
     }
+    // ---- gradient
+    static constexpr bool NEED_Y = true;
+    using NetT = Net;
+    static constexpr int NCST = 1;
+    __device__ __forceinline__ void residual_bar(const Args& a, int oi, int64_t i, const double (&o)[NS], double (&ob)[NS]) const {
+#pragma unroll
+        for (int s = 0; s < 3; s++) ob[s] = 2.0 * a.iscale2[s] * (o[s] - a.data[((int64_t)s * a.T + oi) * a.N + i]);
+    }
+    template <class A>
+    __device__ __forceinline__ void vjp(double, const double (&u)[NS], const double (&kb)[NS], double (&ub)[NS], A& acc,
+                                        double&) const {
+        const double wgt = kb[2] - kb[1];
+        double dx[3] = {0.0, 0.0, 0.0};
+        Net::template eval_grad<true>(p, c, u, wgt, acc, dx);
+        ub[0] += fma(-0.4, kb[0], fma(0.4, kb[1], dx[0]));
+        ub[1] += dx[1];
+        ub[2] += fma(-0.3, kb[2], dx[2]);
+    }
+    template <class A>
+    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A&, double, double (&cst)[NCST]) const {
+        cst[0] = exp(a.cond[set * a.set_stride_cond + i]);
+    }
 };
 
 __device__ __forceinline__ double rms(const double* v, int n) {
@@ -150,14 +210,24 @@ __device__ __forceinline__ double rms(const double* v, int n) {
 
 // ---------------------------------------------------------------------------------- the integrator
 // LDS: s_K [7][NS] stage derivatives (one row of kBlock doubles each; >= kRedRows rows for the final reduction),
-// then the model's own rows.
-template <class M, bool IS_CPEP>
+// GRAD: s_B [7][NS] their adjoints and (models whose Jacobian depends on the state) s_Y [7][NS] the stage inputs of the
+// step being reversed; then the model's own rows.
+template <class M>
+constexpr int adaptive_rows(bool grad) {
+    constexpr int KROWS = 7 * M::NS > kRedRows ? 7 * M::NS : kRedRows;
+    return KROWS + (grad ? 7 * M::NS * (M::NEED_Y ? 2 : 1) : 0);
+}
+
+template <class M, bool IS_CPEP, bool GRAD>
 __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
     constexpr int NS = M::NS;
     constexpr int P = M::P;
     constexpr int KROWS = 7 * NS > kRedRows ? 7 * NS : kRedRows;
+    constexpr int TROWS = 2 + NS;                  // tape entry: t_n, dt_n, y_n
     extern __shared__ double smem[];
     double* s_K = smem;
+    double* s_B = smem + KROWS * kBlock;
+    double* s_Y = s_B + 7 * NS * kBlock;
     const int lane = threadIdx.x;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
     const bool active = gid < a.N;
@@ -169,7 +239,16 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
 
     M m;
     double y[NS];
-    const double chk = m.init(a, smem + KROWS * kBlock, lane, i, set, y);
+    const double chk = m.init(a, smem + adaptive_rows<M>(GRAD) * kBlock, lane, i, set, y);
+    double* const tape = GRAD ? a.tape + ((int64_t)set * a.tape_cap * TROWS) * a.N + i : nullptr;
+#define TAPE(n, r) tape[((int64_t)(n) * TROWS + (r)) * a.N]
+    int n_acc = 0;
+    if (GRAD) {                                    // entry 0 always holds finite numbers (parked lanes read it)
+        TAPE(0, 0) = a.t_begin;
+        TAPE(0, 1) = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) TAPE(0, 2 + s) = y[s];
+    }
     const double abstol = a.abstol, reltol = a.reltol;
     const double t0 = a.t_begin, t1 = a.t_end;
     const double t_stop = t1 - 1e-14 * fmax(1.0, fabs(t1));
@@ -300,6 +379,17 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
                 }
             }
         }
+        if (GRAD && live && !failed && accept) {
+            if (n_acc < a.tape_cap) {
+                TAPE(n_acc, 0) = t;
+                TAPE(n_acc, 1) = dt;
+#pragma unroll
+                for (int s = 0; s < NS; s++) TAPE(n_acc, 2 + s) = y[s];
+                n_acc++;
+            } else {
+                failed = true;                    // more accepted steps than the tape holds
+            }
+        }
         if (live && !failed) {
             if (accept) {
                 double q = q11 / pow(qold, 2.0 / 25.0);
@@ -318,44 +408,174 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
         if (__all(done || failed)) break;
         st = 1;
     }
-#undef KROW
     if (failed || nxt < n_out) sse = __builtin_nan("");      // failed solve => non-finite SSE => loss +Inf (reference :61-64)
     const bool bad = !(fabs(sse) <= 1.79769313486231570815e308);
     if (active && a.sse != nullptr) a.sse[set * a.set_stride_cond + i] = sse;
-    const double v2[2] = {active ? sse : 0.0, (active && bad) ? 1.0 : 0.0};
     double* out = a.partials + ((int64_t)set * gridDim.x + blockIdx.x) * (P + 2);
-    block_reduce_store<2>(v2, smem, out + P, lane);
+    if constexpr (!GRAD) {
+        const double v2[2] = {active ? sse : 0.0, (active && bad) ? 1.0 : 0.0};
+        block_reduce_store<2>(v2, smem, out + P, lane);
+    } else {
+        // ------------------------------------------------------------------ reverse sweep over the tape
+        using Net = typename M::NetT;
+#define BROW(j, s) s_B[((j) * NS + (s)) * kBlock + lane]
+#define YROW(j, s) s_Y[((j) * NS + (s)) * kBlock + lane]
+        double acc[Net::NACC];
+#pragma unroll
+        for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
+        double lam[NS], wsum = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) lam[s] = 0.0;
+        const double gs = a.inv_n;
+        int hi = n_out;                            // observations [hi, n_out) are already accounted for
+        int n_max = n_acc;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
+#pragma unroll 1
+        for (int n = n_max - 1; n >= 0; n--) {
+            // a lane with fewer accepted steps idles on its last entry with zero adjoints until its own steps come up
+            const bool on = n < n_acc;
+            const int src = on ? n : (n_acc > 0 ? n_acc - 1 : 0);
+            const double tn = TAPE(src, 0), h = TAPE(src, 1);
+#pragma unroll
+            for (int s = 0; s < NS; s++) y[s] = TAPE(src, 2 + s);
+            // ---- re-run the seven stages of the step: k_1 .. k_7 (k_1 = the previous step's k_7 bit for bit: same
+            // arguments), Y_7 = y_{n+1}
+#pragma unroll 1
+            for (int sq = 0; sq <= 6; sq++) {
+                double uu[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) uu[s] = 0.0;
+#pragma unroll 1
+                for (int j = 0; j < sq; j++) {
+                    const double aj = TS_A[sq][j];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) uu[s] = fma(aj, KROW(j, s), uu[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; s++) uu[s] = sq == 0 ? y[s] : fma(h, uu[s], y[s]);
+                if (M::NEED_Y) {
+#pragma unroll
+                    for (int s = 0; s < NS; s++) YROW(sq, s) = uu[s];
+                }
+                const double te = sq == 0 ? tn : (sq < 6 ? fma(TS_C[sq], h, tn) : tn + h);
+                double dd[NS];
+                if constexpr (IS_CPEP) {
+                    m.finish_rhs(m.production(m.forcing_input(te)), uu, dd);
+                } else {
+                    const double uh = M::Net::eval(m.p, m.c, uu);
+                    dd[0] = -0.4 * uu[0];
+                    dd[1] = fma(0.4, uu[0], -uh);
+                    dd[2] = fma(-0.3, uu[2], uh);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; s++) { KROW(sq, s) = dd[s]; BROW(sq, s) = 0.0; }
+            }
+            // ---- the observations that were saved from this step: adjoint of o = y_n + h sum_j w_j(theta) k_j
+            double yb[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) yb[s] = 0.0;
+            while (__any(on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12)) {
+                const bool mine = on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12;
+                if (mine) {
+                    const int oi = hi - 1;
+                    const double th = fmin(1.0, (tout[oi] - tn) / h);
+                    const bool at_end = fabs(th - 1.0) < 1e-12;
+                    double w[7], o[NS], ob[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) o[s] = 0.0;
+#pragma unroll 1
+                    for (int j = 0; j < 7; j++) {
+                        w[j] = at_end ? (j < 6 ? TS_A[6][j] : 0.0)
+                                      : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+#pragma unroll
+                        for (int s = 0; s < NS; s++) o[s] = fma(w[j], KROW(j, s), o[s]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; s++) o[s] = fma(h, o[s], y[s]);
+                    m.residual_bar(a, oi, i, o, ob);
+#pragma unroll
+                    for (int s = 0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
+#pragma unroll 1
+                    for (int j = 0; j < 7; j++) {
+#pragma unroll
+                        for (int s = 0; s < NS; s++) BROW(j, s) = fma(w[j], ob[s], BROW(j, s));
+                    }
+                    hi--;
+                }
+            }
+            // ---- stage VJPs, last stage first
+#pragma unroll 1
+            for (int sq = 6; sq >= 0; sq--) {
+                double kb[NS], ub[NS], uu[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    kb[s] = BROW(sq, s);
+                    ub[s] = sq == 6 ? lam[s] : 0.0;            // Y_7 = y_{n+1}
+                    uu[s] = M::NEED_Y ? YROW(sq, s) : 0.0;
+                }
+                const double te = sq == 0 ? tn : (sq < 6 ? fma(TS_C[sq], h, tn) : tn + h);
+                m.vjp(te, uu, kb, ub, acc, wsum);
+#pragma unroll
+                for (int s = 0; s < NS; s++) yb[s] += ub[s];
+#pragma unroll 1
+                for (int j = 0; j < sq; j++) {                 // Y_sq = y_n + h sum_{j<sq} a(sq, j) k_j
+                    const double aj = h * TS_A[sq][j];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) BROW(j, s) = fma(aj, ub[s], BROW(j, s));
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++) lam[s] = yb[s];
+        }
+        if (active && a.tape_n != nullptr) a.tape_n[set * a.N + i] = n_acc;
+        double cst[M::NCST];
+        m.finish_grad(a, i, set, acc, wsum, cst);
+        __syncthreads();                   // the reduction scratch aliases s_K
+        if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(m.p, acc, cst);
+        block_reduce_expand<Net, M::NCST>(acc, cst, active ? 1.0 : 0.0, active ? sse : 0.0, (active && bad) ? 1.0 : 0.0,
+                                          smem, out, lane);
+#undef BROW
+#undef YROW
+    }
+#undef KROW
+#undef TAPE
 }
 
 // ---------------------------------------------------------------------------------- dispatch
 template <class M, bool IS_CPEP>
-static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, hipStream_t s) {
-    constexpr int KROWS = 7 * M::NS > kRedRows ? 7 * M::NS : kRedRows;
+static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, bool grad, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
-    const size_t lds = sizeof(double) * (size_t)(KROWS + extra_rows) * kBlock;
+    const size_t lds = sizeof(double) * (size_t)(adaptive_rows<M>(grad) + extra_rows) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
-    hipLaunchKernelGGL((adaptive_kernel<M, IS_CPEP>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    if (grad) {
+        if (a.tape == nullptr || a.tape_cap < 1 || a.g_cond == nullptr) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((adaptive_kernel<M, IS_CPEP, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((adaptive_kernel<M, IS_CPEP, false>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    }
     return hipGetLastError();
 }
 
 #define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
 #define CUDE_SUPP_AD_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
 
-hipError_t launch_cpep_adaptive(const NetShape& net, const CpepArgs& a, hipStream_t s) {
+hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
     if (a.TG < 2 || a.TG > kMaxObs || a.T < 1) return hipErrorInvalidValue;
+    if (grad && a.obs == nullptr) return hipErrorInvalidValue;
     if (net.symbolic())
-        return a.cond_raw ? launch_adaptive<CpepAd<MmProd<true>>, true>(a, a.TG, s)
-                          : launch_adaptive<CpepAd<MmProd<false>>, true>(a, a.TG, s);
+        return a.cond_raw ? launch_adaptive<CpepAd<MmProd<true>>, true>(a, a.TG, grad, s)
+                          : launch_adaptive<CpepAd<MmProd<false>>, true>(a, a.TG, grad, s);
 #define X(NIN, W, D) \
-    if (net.nin == NIN && net.width == W && net.depth == D) return launch_adaptive<CpepAd<Mlp<NIN, W, D, 1>>, true>(a, a.TG, s);
+    if (net.nin == NIN && net.width == W && net.depth == D) return launch_adaptive<CpepAd<Mlp<NIN, W, D, 1>>, true>(a, a.TG, grad, s);
     CUDE_CPEP_AD_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_supp_adaptive(const NetShape& net, const SuppArgs& a, hipStream_t s) {
+hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
     if (net.nin != 4 || a.T < 1) return hipErrorInvalidValue;
-#define X(W, D) if (net.width == W && net.depth == D) return launch_adaptive<SuppAd<W, D>, false>(a, 0, s);
+#define X(W, D) if (net.width == W && net.depth == D) return launch_adaptive<SuppAd<W, D>, false>(a, 0, grad, s);
     CUDE_SUPP_AD_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

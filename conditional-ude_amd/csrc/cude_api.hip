@@ -248,6 +248,10 @@ struct cude_ctx {
     DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt, ms_act;
     DevBuf<double> ms_fsum, ms_wts, ms_gcp, ms_p2;   // time-split path with parameter sets (small populations)
     DevBuf<double> act;     // SUPP: kept network activations of the gradient launch (small populations only)
+    DevBuf<double> tape, ms_tape;   // adaptive mode: accepted steps of the forward sweep, walked back by the adjoint
+    DevBuf<int32_t> tape_n;
+    int tape_cap = 0;
+    bool have_tape = false;
     DevBuf<double> red_tmp; // staging of small host vectors reduced through the communicator
     std::vector<double> ms_host;
 #ifdef CUDE_WAVE_TIMING
@@ -289,6 +293,7 @@ cude::CpepArgs cpep_args(const cude_ctx* c) {
     a.tp = c->tp_dev.p; a.TG = c->T; a.out_times = c->tp_dev.p;
     a.t_begin = c->tp.front(); a.t_end = c->tp.back();
     a.abstol = c->abstol; a.reltol = c->reltol;
+    a.tape = c->tape.p; a.tape_cap = c->tape_cap; a.tape_n = c->tape_n.p;
     return a;
 }
 
@@ -310,6 +315,7 @@ cude::SuppArgs supp_args(const cude_ctx* c) {
     a.out_times = c->tp_dev.p;
     a.t_begin = c->tp.front(); a.t_end = c->tp.back();
     a.abstol = c->abstol; a.reltol = c->reltol;
+    a.tape = c->tape.p; a.tape_cap = c->tape_cap; a.tape_n = c->tape_n.p;
     return a;
 }
 
@@ -354,6 +360,19 @@ int32_t alloc_common(cude_ctx* c) {
     HIP_TRY(c->g_cond.resize(N));
     HIP_TRY(c->sse.resize(N));
     HIP_TRY(c->partials.resize((size_t)c->nblocks * (c->P + 2)));
+    if (adaptive(c)) {
+        // tape of the adaptive gradient: (2 + NS) doubles per accepted step and subject.  The reference's problems take
+        // 10-40 steps at its tolerances; the capacity is what ~4 GB hold, between 64 and 1024 steps (CUDE_TAPE_STEPS
+        // overrides).  A subject with more accepted steps fails its gradient evaluation (+Inf), not the process.
+        const int rows = cude::adaptive_tape_rows(c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2);
+        int64_t cap = (int64_t)(4e9 / (8.0 * rows * (double)N));
+        cap = std::max<int64_t>(64, std::min<int64_t>(1024, cap));
+        if (const char* env = getenv("CUDE_TAPE_STEPS")) cap = std::max(1, atoi(env));
+        c->tape_cap = (int)cap;
+        HIP_TRY(c->tape.resize((size_t)cap * rows * N));
+        HIP_TRY(c->tape_n.resize((size_t)N));
+        c->have_tape = false;
+    }
     HIP_TRY(c->m_cond.resize(N));
     HIP_TRY(c->v_cond.resize(N));
     HIP_TRY(hipMemsetAsync(c->cond.p, 0, N * sizeof(double), c->stream));
@@ -515,8 +534,6 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                      const double* cond_ov = nullptr, double* sse_ov = nullptr) {
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!c->have_nn || (!c->have_cond && !cond_ov)) return fail(CUDE_ERR_STATE, "parameters not set");
-    if (grad && adaptive(c))
-        return fail(CUDE_ERR_UNSUPPORTED, "adaptive mode (n_steps = 0) is forward-only: gradients need a fixed step count");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && !c->capturing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -557,6 +574,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         HIP_TRY(cude::launch_supp(c->net, grad, a, c->stream));
     }
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+    if (grad && adaptive(c)) c->have_tape = true;
     if (sse_ov) return CUDE_OK;
     const int P = c->P;
     if (grad && is_cpep(c) && c->chunks > 1) {
@@ -1101,8 +1119,6 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (n_sets < 1 || !nn_sets || !cond_sets || !losses || !g_nn_sets || !g_cond_sets)
         return fail(CUDE_ERR_ARG, "null/empty input");
-    if (adaptive(c))
-        return fail(CUDE_ERR_UNSUPPORTED, "adaptive mode (n_steps = 0) is forward-only: gradients need a fixed step count");
     const int P = c->P, S = c->cfg.n_steps;
     const int64_t N = c->N, nb = c->nblocks;
     const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
@@ -1113,7 +1129,9 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     const int L = c->chunks;
     const bool split = !supp && L > 1 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 && getenv("CUDE_NO_MS_SPLIT") == nullptr;
     // sets per launch: bounded by the grid's y / z dimension and ~512 MB of scratch
-    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (supp ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
+    const int64_t tape_rows = adaptive(c) ? (int64_t)c->tape_cap * cude::adaptive_tape_rows(supp ? 3 : 2) : 0;
+    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (double)tape_rows * N +
+                                  (supp && !adaptive(c) ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
                                   (split ? (double)L * (3 + c->T) * N + 5.0 * S * N + (double)L * N + (double)L * nb * P : 0.0));
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_sets, split ? 16384 : 32768), (int64_t)(512e6 / per_set)));
     if (split) {
@@ -1127,7 +1145,8 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     HIP_TRY(c->ms_gcond.reserve((size_t)chunk * N));
     HIP_TRY(c->ms_part.reserve((size_t)chunk * nb * (P + 2)));
     HIP_TRY(c->ms_out.reserve((size_t)chunk * (P + 2)));
-    if (supp) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * cude::supp_ckpt_rows(S, c->T) * N));
+    if (supp && !adaptive(c)) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * cude::supp_ckpt_rows(S, c->T) * N));
+    if (adaptive(c)) HIP_TRY(c->ms_tape.reserve((size_t)chunk * tape_rows * N));
     c->ms_host.resize((size_t)chunk * (P + 2));
     for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
         const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
@@ -1151,12 +1170,14 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
             a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
             a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
+            if (adaptive(c)) { a.tape = c->ms_tape.p; a.tape_n = nullptr; }
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));     // one-lane kernel: the sets fill the chip
         } else {
             cude::SuppArgs a = supp_args(c);
             a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
             a.ckpt = c->ms_ckpt.p; a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
-            if (!a.ckpt_steps_only && supp_keep_activations(c, kn)) {
+            if (adaptive(c)) { a.tape = c->ms_tape.p; a.tape_n = nullptr; }
+            if (!adaptive(c) && !a.ckpt_steps_only && supp_keep_activations(c, kn)) {
                 HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
                 a.act = c->ms_act.p;
             }
@@ -1197,6 +1218,29 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
                                                                     : sum / c->n_global;
         }
     }
+    return CUDE_OK;
+}
+
+int32_t cude_adaptive_steps(cude_ctx* c, int64_t subject, int32_t cap, double* t_out, double* dt_out, int32_t* n_steps) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!n_steps || cap < 0) return fail(CUDE_ERR_ARG, "null/negative argument");
+    if (!adaptive(c) || !c->have_tape) return fail(CUDE_ERR_STATE, "no adaptive gradient evaluation on this context yet");
+    if (subject < 0 || subject >= c->N) return fail(CUDE_ERR_ARG, "subject out of range");
+    int32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, c->tape_n.p + subject, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_steps = n;
+    const int rows = cude::adaptive_tape_rows(c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2);
+    const int m = std::min(std::min(n, cap), c->tape_cap);
+    for (int r = 0; r < 2 && m > 0; r++) {
+        double* dst = r == 0 ? t_out : dt_out;
+        if (!dst) continue;
+        // entry k, row r of the tape: one double every rows * N
+        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double), c->tape.p + (size_t)r * c->N + subject, (size_t)rows * c->N * sizeof(double),
+                                 sizeof(double), (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return CUDE_OK;
 }
 

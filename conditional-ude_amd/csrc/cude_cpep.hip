@@ -413,7 +413,7 @@ bool cpep_shape_supported(const NetShape& net, int n_state) {
 }
 
 hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepArgs& a, hipStream_t s) {
-    if (a.S == 0) return (grad || n_state != 2) ? hipErrorInvalidValue : launch_cpep_adaptive(net, a, s);
+    if (a.S == 0) return n_state != 2 ? hipErrorInvalidValue : launch_cpep_adaptive(net, grad, a, s);
     if (net.symbolic())
         return a.cond_raw ? launch_shape<MmProd<true>>(n_state, grad, a, s) : launch_shape<MmProd<false>>(n_state, grad, a, s);
 #define X(NIN, W, D) \

@@ -57,6 +57,9 @@ struct CpepArgs {
     const double* out_times; // [T]
     double t_begin, t_end;   // integration span = the population's time span
     double abstol, reltol;
+    double* tape;            // adaptive gradient: [n_sets][tape_cap][2 + NS][N] accepted steps (t_n, dt_n, y_n)
+    int32_t tape_cap;
+    int32_t* tape_n;         // [n_sets][N] accepted steps per subject, or nullptr
 #ifdef CUDE_WAVE_TIMING
     long long* dbg;          // development builds only: [nblocks][4] = {start, end of forward, end, hw id} per wave
 #endif
@@ -134,6 +137,9 @@ struct SuppArgs {
     const double* out_times; // adaptive mode (S == 0): [T] observation times
     double t_begin, t_end;
     double abstol, reltol;
+    double* tape;            // adaptive gradient, as CpepArgs
+    int32_t tape_cap;
+    int32_t* tape_n;
 };
 
 // returns hipSuccess, or hipErrorInvalidValue when the shape is not compiled in
@@ -141,9 +147,12 @@ hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepAr
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
 bool cpep_shape_supported(const NetShape& net, int n_state);
 bool supp_shape_supported(const NetShape& net);
-// adaptive Tsit5 (forward only); launch_cpep / launch_supp route here when args.S == 0
-hipError_t launch_cpep_adaptive(const NetShape& net, const CpepArgs& a, hipStream_t s);
-hipError_t launch_supp_adaptive(const NetShape& net, const SuppArgs& a, hipStream_t s);
+// adaptive Tsit5 (grad: + the adjoint of the accepted step sequence, needs args.tape); launch_cpep / launch_supp
+// route here when args.S == 0
+hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
+hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
+// rows of N doubles per accepted step on the adaptive gradient's tape: t_n, dt_n, y_n
+inline int adaptive_tape_rows(int n_state) { return 2 + n_state; }
 
 // common kernels
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1

@@ -399,7 +399,7 @@ bool supp_shape_supported(const NetShape& net) {
 
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
     if (net.nin != 4) return hipErrorInvalidValue;
-    if (a.S == 0) return grad ? hipErrorInvalidValue : launch_supp_adaptive(net, a, s);
+    if (a.S == 0) return launch_supp_adaptive(net, grad, a, s);
 #define X(W, D)                                                                                   \
     if (net.width == W && net.depth == D)                                                         \
         return !grad ? launch_one<W, D, false, false>(a, s)                                       \

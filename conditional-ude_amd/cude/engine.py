@@ -117,6 +117,14 @@ class Engine:
         """Tolerances of the adaptive mode (n_steps = 0)."""
         check(self._lib.cude_set_tolerances(self._h, float(abstol), float(reltol)))
 
+    def adaptive_steps(self, subject):
+        """(t_n, dt_n) of the steps `subject` accepted in the last gradient evaluation (adaptive mode): `sol.t`."""
+        n = C.c_int32(0)
+        check(self._lib.cude_adaptive_steps(self._h, int(subject), 0, None, None, C.byref(n)))
+        t, dt = np.empty(n.value), np.empty(n.value)
+        check(self._lib.cude_adaptive_steps(self._h, int(subject), n.value, _ptr(t), _ptr(dt), C.byref(n)))
+        return t, dt
+
     # -- population
     def set_population_cpep(self, timepoints, glucose, cpeptide, age, t2dm):
         """glucose, cpeptide: (N, T) arrays (any strides are honoured without a host copy when

@@ -61,6 +61,18 @@ end
 set_tolerances!(c::Ctx, abstol, reltol) =
     check(ccall((:cude_set_tolerances, LIB), Int32, (Ptr{Cvoid}, Float64, Float64), c.h, abstol, reltol))
 
+# accepted steps (t_n, dt_n) of `subject` (1-based) in the last gradient evaluation of the adaptive mode: `sol.t`
+function adaptive_steps(c::Ctx, subject::Integer)
+    n = Ref{Int32}(0)
+    check(ccall((:cude_adaptive_steps, LIB), Int32, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                c.h, subject - 1, 0, C_NULL, C_NULL, n))
+    t = Vector{Float64}(undef, n[]); dt = similar(t)
+    GC.@preserve t dt check(ccall((:cude_adaptive_steps, LIB), Int32,
+                                  (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                                  c.h, subject - 1, n[], t, dt, n))
+    return t, dt
+end
+
 # glucose / cpeptide as Julia column-major N×T matrices: ld_subject = 1, ld_time = N (no host copy)
 function set_population!(c::Ctx, timepoints::Vector{Float64}, glucose::Matrix{Float64}, cpeptide::Matrix{Float64},
                          ages::Vector{Float64}, t2dm::Vector{UInt8})

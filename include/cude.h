@@ -62,10 +62,10 @@ typedef struct cude_config {
     int32_t nn_width; /* hidden width (0 for CUDE_MODEL_CPEP_SYM) */
     int32_t nn_depth; /* number of tanh hidden layers; output layer is softplus, 1 unit (0 for CPEP_SYM) */
     int32_t n_steps;  /* fixed Tsit5 steps over the time span; 0 = ADAPTIVE Tsit5 as the reference runs it
-                         (OrdinaryDiffEq defaults abstol 1e-6 / reltol 1e-3, PI controller, cude_set_tolerances):
-                         forward-only -- cude_forward, cude_simulate, cude_profile_conditional,
-                         cude_multistart_forward, cude_fit_conditional, cude_mh_estep / cude_mh_chain; the gradient
-                         entry points return CUDE_ERR_UNSUPPORTED (differentiate the fixed-step map instead) */
+                         (OrdinaryDiffEq defaults abstol 1e-6 / reltol 1e-3, PI controller, cude_set_tolerances), in
+                         every entry point.  Gradients in this mode are those of the accepted step sequence taken as
+                         fixed arithmetic -- what AutoForwardDiff through `solve` yields, dt carrying no partials
+                         (src/parameter-estimation.jl:165, suppression_model.jl:155); CPEP: n_state = 2 only */
     int32_t device;   /* HIP device ordinal */
     int32_t cond_space; /* CUDE_COND_*; must be CUDE_COND_LOG (0) for the network models */
     double lambda;    /* L2 weight on the network parameters (suppression_loss :128); 0 for CPEP */
@@ -84,6 +84,11 @@ int32_t cude_destroy(cude_ctx* ctx);
  * are OrdinaryDiffEq's, which every solve call of the reference uses (src/parameter-estimation.jl:59, src/saem.jl:52,
  * suppression/src/suppression_model.jl:113,123). */
 int32_t cude_set_tolerances(cude_ctx* ctx, double abstol, double reltol);
+/* Adaptive mode: the accepted steps (t_n, dt_n) `subject` took in the last gradient evaluation of the context's own
+ * parameters (cude_loss_grad, cude_loss_grad_partial, cude_adam_step ...) -- `sol.t` of the reference's solve.
+ * *n_steps = number of accepted steps; at most `cap` of them are written to t_out / dt_out (either may be NULL).
+ * CUDE_ERR_STATE before the first such evaluation or outside the adaptive mode. */
+int32_t cude_adaptive_steps(cude_ctx* ctx, int64_t subject, int32_t cap, double* t_out, double* dt_out, int32_t* n_steps);
 
 /* --- population (replaces the CPeptideConditionalUDEModel constructor loop,
  * src/c-peptide-models.jl:170-194 incl. van_cauter_parameters :30-42, u0, tspan and the

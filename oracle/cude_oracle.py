@@ -284,9 +284,10 @@ def solve_fixed(rhs, u0, timepoints, n_steps):
     return out
 
 
-def solve_adaptive(rhs, u0, timepoints, abstol=1e-6, reltol=1e-3, max_steps=100000):
+def solve_adaptive(rhs, u0, timepoints, abstol=1e-6, reltol=1e-3, max_steps=100000, record=None):
     """Adaptive Tsit5 with OrdinaryDiffEq-style PI control for ONE trajectory (numpy scalars/
-    0-d arrays).  Used only for the soft pins against stored reference results."""
+    0-d arrays).  Used only for the soft pins against stored reference results.
+    record: a list that receives (t_n, dt_n) of every ACCEPTED step (for replay_steps)."""
     t0, t1 = float(timepoints[0]), float(timepoints[-1])
     y = [float(v) for v in u0]
     ns = len(y)
@@ -332,6 +333,8 @@ def solve_adaptive(rhs, u0, timepoints, abstol=1e-6, reltol=1e-3, max_steps=1000
             q11 = est ** beta1 if est > 0 else 1e-12
             q = q11 / (qold ** beta2)
             q = max(1 / qmax, min(1 / qmin, q / gamma))
+            if record is not None:
+                record.append((t, dt))
             t, y, k[0] = t + dt, ynew, k[6]
             qold = max(est, 1e-4)
             dt = dt / q
@@ -340,6 +343,48 @@ def solve_adaptive(rhs, u0, timepoints, abstol=1e-6, reltol=1e-3, max_steps=1000
             q = q11 / (qold ** beta2)
             q = max(1 / qmax, min(1 / qmin, q / gamma))
             dt = dt / min(1 / qmin, q11 / gamma)
+    if nxt < len(timepoints):
+        return None
+    return out
+
+
+def replay_steps(rhs, u0, timepoints, steps):
+    """Tsit5 over a GIVEN sequence of accepted steps [(t_n, dt_n)] with solve_adaptive's `saveat` rule -- the map the
+    reference's gradient differentiates: under ForwardDiff the solver's time variables stay Float64 (tspan and dt
+    carry no partials; src/parameter-estimation.jl:59 passes only p = theta as duals), so the derivative of an adaptive
+    solve is the derivative of this fixed sequence of arithmetic.  Generic in the number type (floats, complex
+    perturbation batches, torch tensors): no comparison touches a state.  u0 / rhs values: per-state scalars or arrays."""
+    y = list(u0)
+    ns = len(y)
+    out = [None] * len(timepoints)
+    out[0] = list(y)
+    nxt = 1
+    k = [None] * 7
+    k[0] = rhs(float(timepoints[0]), y)
+    for (t, dt) in steps:
+        for i in range(1, 7):
+            Y = []
+            for s in range(ns):
+                acc = A[i][0] * k[0][s]
+                for j in range(1, i):
+                    acc = acc + A[i][j] * k[j][s]
+                Y.append(y[s] + dt * acc)
+            if i < 6:
+                k[i] = rhs(t + C[i] * dt, Y)
+            else:
+                ynew = Y
+                k[6] = rhs(t + dt, ynew)
+        while nxt < len(timepoints) and timepoints[nxt] <= t + dt + 1e-12:
+            w = interp_weights(min(1.0, (timepoints[nxt] - t) / dt))
+            o = []
+            for s in range(ns):
+                acc = w[0] * k[0][s]
+                for j in range(1, 7):
+                    acc = acc + w[j] * k[j][s]
+                o.append(y[s] + dt * acc)
+            out[nxt] = o
+            nxt += 1
+        y, k[0] = ynew, k[6]
     if nxt < len(timepoints):
         return None
     return out
@@ -431,6 +476,81 @@ def supp_loss_grad_torch(nn, theta, data, timepoints, arch, n_steps, lam):
     loss.backward()
     return (float(loss.detach()), nn_t.grad.numpy().copy(), th_t.grad.numpy().copy(),
             sse.detach().numpy().copy())
+
+
+def _complex_step_batch(nn, cond_log, cond_space="log"):
+    """Parameter batch for complex-step differentiation: column b < P perturbs nn[b], column P the conditional
+    parameter, by i*1e-30 (the derivative is Im f / 1e-30 to machine precision: no subtraction)."""
+    P = len(nn)
+    p = np.asarray(nn, dtype=np.complex128)[:, None] + 1e-30j * np.eye(P, P + 1)
+    c = np.full(P + 1, complex(cond_log))
+    c[P] += 1e-30j
+    return p, (np.exp(c) if cond_space == "log" else c)
+
+
+def cpep_adaptive_loss_grad(nn, beta, pop, arch, abstol=1e-6, reltol=1e-3, cond_space="log"):
+    """Loss and gradient of the ADAPTIVE solve as the reference's AutoForwardDiff sees it
+    (src/parameter-estimation.jl:56-68,126-140,165): per subject, the accepted steps of the plain adaptive solve are
+    recorded and the fixed sequence is differentiated (replay_steps) -- here by the complex-step method over a batch of
+    P + 1 perturbations.  Returns (loss, g_nn, g_beta, sse); loss = +Inf and NaN gradients when a solve fails.
+    Checker for the device's adjoint of the adaptive solve (a different algorithm: reverse-mode, hand-written)."""
+    nn = np.asarray(nn, dtype=np.float64)
+    P, N = len(nn), pop.N
+    tpl = [float(v) for v in pop.timepoints]
+    g_nn, g_b, sse = np.zeros(P), np.zeros(N), np.zeros(N)
+    for i in range(N):
+        cond = float(np.exp(beta[i])) if cond_space == "log" else float(beta[i])
+        c0 = float(pop.c0[i])
+        u0 = [c0, float(pop.k2[i] / pop.k1[i]) * c0]
+        rec = []
+        if solve_adaptive(cpep_rhs_scalar(pop, i, nn, cond, arch), u0, tpl, abstol, reltol, record=rec) is None:
+            return float("inf"), np.full(P, np.nan), np.full(N, np.nan), sse
+        pb, cb = _complex_step_batch(nn, beta[i], cond_space)
+        G = [float(v) for v in pop.glucose[i]]
+        k0, k1, k2, age = float(pop.k0[i]), float(pop.k1[i]), float(pop.k2[i]), float(pop.age[i])
+
+        def rhs(t, u):
+            dG = linear_interp(tpl, G, t) - G[0]
+            if arch[1] == 0:
+                prod = (pb[0] * dG) / (dG + cb) if dG >= 0 else 0.0 * cb
+            elif pop.covariate:
+                prod = mlp(np, [dG, cb, age], pb, arch) - mlp(np, [0.0, cb, age], pb, arch)
+            else:
+                prod = mlp(np, [dG, cb], pb, arch) - mlp(np, [0.0, cb], pb, arch)
+            return [-(k0 + k2) * u[0] + k1 * u[1] + k0 * c0 + prod, -k1 * u[1] + k2 * u[0]]
+        out = replay_steps(rhs, [u0[0] + 0.0 * cb, u0[1] + 0.0 * cb], tpl, rec)
+        e = sum((out[ti][0] - pop.cpeptide[i, ti]) ** 2 for ti in range(1, pop.T)) + (u0[0] - pop.cpeptide[i, 0]) ** 2
+        sse[i] = e[0].real
+        g_nn += e.imag[:P] / 1e-30
+        g_b[i] = e.imag[P] / 1e-30
+    return sse.sum() / N, g_nn / N, g_b / N, sse
+
+
+def supp_adaptive_loss_grad(nn, theta, data, timepoints, arch, lam, abstol=1e-6, reltol=1e-3):
+    """The same for suppression_loss (suppression/src/suppression_model.jl:117-130 with its AutoForwardDiff gradient,
+    :155).  Returns (loss, g_nn, g_theta, sse)."""
+    nn = np.asarray(nn, dtype=np.float64)
+    P, N = len(nn), data.shape[2]
+    tpl = [float(v) for v in timepoints]
+    scale = supp_scale(data)
+    g_nn, g_t, sse = np.zeros(P), np.zeros(N), np.zeros(N)
+    for i in range(N):
+        et = math.exp(float(theta[i]))
+        u0 = [float(data[s, 0, i]) for s in range(3)]
+        rec = []
+        if solve_adaptive(lambda t, u: supp_rhs(math, [float(v) for v in nn], et, arch, t, u), u0, tpl, abstol, reltol,
+                          record=rec) is None:
+            return float("inf"), np.full(P, np.nan), np.full(N, np.nan), sse
+        pb, cb = _complex_step_batch(nn, theta[i])
+        out = replay_steps(lambda t, u: supp_rhs(np, pb, cb, arch, t, u), [v + 0.0 * cb for v in u0], tpl, rec)
+        e = 0.0 * cb
+        for ti in range(1, len(tpl)):
+            for s in range(3):
+                e = e + ((out[ti][s] - data[s, ti, i]) / scale[s]) ** 2
+        sse[i] = e[0].real
+        g_nn += e.imag[:P] / 1e-30
+        g_t[i] = e.imag[P] / 1e-30
+    return sse.sum() / N + lam * float(nn @ nn), g_nn / N + 2.0 * lam * nn, g_t / N, sse
 
 
 # ----------------------------------------------------------------------------- Adam / MH

@@ -69,3 +69,43 @@ def test_product_gradient_at_the_stored_optima(nn_key, beta_key, arch, bound):
     ratios, ratios_cond = np.array(ratios), np.array(ratios_cond)
     assert ratios.size >= 20 and np.median(ratios) < bound and ratios.max() < 0.25, (np.median(ratios), ratios.max())
     assert np.median(ratios_cond) < 0.05, np.median(ratios_cond)
+
+
+@pytest.mark.parametrize("nn_key,beta_key,arch,bound", RUNS)
+def test_adaptive_gradient_at_the_stored_optima(nn_key, beta_key, arch, bound):
+    """The same pin with the gradient of the reference's OWN loss: the adaptive solve differentiated as ForwardDiff
+    differentiates it (accepted steps as fixed arithmetic; n_steps = 0, csrc/cude_adaptive.hip).  This is the function
+    whose gradient the reference's L-BFGS drove towards zero, so the stored optima must be at least as stationary for
+    it as for the fixed-step discretisation above."""
+    import torch  # noqa: F401
+    from cude.engine import Engine
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    tp = g["timepoints"]
+    full = Engine("cpep", arch, n_steps=0, n_state=2)
+    full.set_population_cpep(tp, g["glucose"], g["cpeptide"], g["ages"], g["t2dm"])
+    ratios, ratios_cond, ratios_fixed = [], [], []
+    for k in range(g[nn_key].shape[0]):
+        nn, stored = g[nn_key][k], g[beta_key][k]
+        full.set_params(nn, None)
+        refit, _, _ = full.fit_conditional(-5.0, 3.0, 81, 48)
+        cost = np.abs(stored[:, None] - refit[None, :])
+        _, c = linear_sum_assignment(cost)
+        if np.median(cost[np.arange(57), c]) > 1e-2:
+            continue
+        for n_steps, dst in ((0, ratios), (32, ratios_fixed)):
+            eng = Engine("cpep", arch, n_steps=n_steps, n_state=2)
+            eng.set_population_cpep(tp, g["glucose"][c], g["cpeptide"][c], g["ages"][c], g["t2dm"][c])
+            eng.set_params(nn, stored)
+            _, gn0, gb0 = eng.loss_grad()
+            eng.set_params(nn * 1.1, stored + 0.2)
+            _, gn1, gb1 = eng.loss_grad()
+            eng.close()
+            dst.append(np.max(np.abs(gn0)) / np.max(np.abs(gn1)))
+            if n_steps == 0:
+                ratios_cond.append(np.median(np.abs(gb0)) / np.median(np.abs(gb1)))
+    full.close()
+    ratios, ratios_cond, ratios_fixed = np.array(ratios), np.array(ratios_cond), np.array(ratios_fixed)
+    # measured (2x4x4x1 runs): median 0.0058 adaptive / 0.0057 fixed-step -- what is left is where L-BFGS stopped
+    assert np.median(ratios) < 1.5 * np.median(ratios_fixed) + 1e-3
+    assert ratios.size >= 20 and np.median(ratios) < bound and ratios.max() < 0.25, (np.median(ratios), ratios.max())
+    assert np.median(ratios_cond) < 0.05, np.median(ratios_cond)
