@@ -42,6 +42,9 @@ __device__ __constant__ const double TS_R[7][4] = {{1.0, -2.763706197274826, 2.9
                                                    {0.0, 1.5, -4.0, 2.5}};
 
 constexpr int kAdaptiveMaxSteps = 100000;     // OrdinaryDiffEq's default maxiters
+#ifndef CUDE_ADAPT_2W_NACC
+#define CUDE_ADAPT_2W_NACC 64
+#endif
 
 // ---------------------------------------------------------------------------------- model policies
 // c-peptide cUDE / symbolic model: f(t, u) = A u + [k0 c0 + q(t); 0],  q(t) = P(dG(t)) - P(0)
@@ -124,23 +127,28 @@ struct CpepAd {
         ob[0] = 2.0 * (o[0] - a.obs[(int64_t)oi * a.N + i]);
         ob[1] = 0.0;
     }
-    // ub += J_f^T kb,  acc += kb . d f / d params  at time te (the baseline term is collected in wsum)
+    // acc += wgt * d production(te) / d params  (the baseline term is collected by the caller)
     template <class A>
-    __device__ __forceinline__ void vjp(double te, const double (&)[NS], const double (&kb)[NS], double (&ub)[NS], A& acc,
-                                        double& wsum) const {
-        ub[0] += fma(a11, kb[0], a21 * kb[1]);
-        ub[1] += fma(a12, kb[0], a22 * kb[1]);
+    __device__ __forceinline__ void vjp_net(double te, double wgt, A& acc) const {
         const double xx[1] = {forcing_input(te)};
         double dx[1] = {0.0};
-        Net::template eval_grad<false>(p, c, xx, kb[0], acc, dx);
-        wsum += kb[0];
+        Net::template eval_grad<false>(p, c, xx, wgt, acc, dx);
+    }
+    __device__ __forceinline__ void vjp_linear(const double (&kb)[NS], double (&ub)[NS]) const {
+        ub[0] += fma(a11, kb[0], a21 * kb[1]);
+        ub[1] += fma(a12, kb[0], a22 * kb[1]);
     }
     template <class A>
-    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A& acc, double wsum,
+    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A& acc, double wsum, double carry,
                                                 double (&cst)[NCST]) const {
-        const double xx[1] = {0.0};
         double dx[1] = {0.0};
-        Net::template eval_grad<false>(p, c, xx, -wsum, acc, dx);       // - sum(kb) * d NN([0; e^beta]) / d params
+        // one call site for the two closing evaluations: k_1 of the first step (time t_0, weight carry), then the
+        // baseline term  - sum(kb) * d NN([0; e^beta]) / d params
+#pragma unroll 1
+        for (int r = 0; r < 2; r++) {
+            const double xx[1] = {r == 0 ? forcing_input(a.t_begin) : 0.0};
+            Net::template eval_grad<false>(p, c, xx, r == 0 ? carry : -wsum, acc, dx);
+        }
         cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
         if (NCST > 1) cst[NCST - 1] = a.age[i];
     }
@@ -197,9 +205,11 @@ struct SuppAd {
         ub[2] += fma(-0.3, kb[2], dx[2]);
     }
     template <class A>
-    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A&, double, double (&cst)[NCST]) const {
+    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A&, double, double,
+                                                double (&cst)[NCST]) const {
         cst[0] = exp(a.cond[set * a.set_stride_cond + i]);
     }
+
 };
 
 __device__ __forceinline__ double rms(const double* v, int n) {
@@ -218,8 +228,16 @@ constexpr int adaptive_rows(bool grad) {
     return KROWS + (grad ? 7 * M::NS * (M::NEED_Y ? 2 : 1) : 0);
 }
 
+// waves per SIMD the register allocation aims at: the solve is a latency chain, so a second resident wave is worth more
+// than unrolling room, as long as the gradient accumulators (2 VGPRs each) leave space for it
+template <class M, bool GRAD>
+constexpr int adaptive_waves() {
+    return !GRAD ? 2 : (M::NetT::NACC <= (M::NEED_Y ? 48 : CUDE_ADAPT_2W_NACC) ? 2 : 1);
+}
+
 template <class M, bool IS_CPEP, bool GRAD>
-__global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(adaptive_waves<M, GRAD>())))
+void adaptive_kernel(typename M::Args a) {
     constexpr int NS = M::NS;
     constexpr int P = M::P;
     constexpr int KROWS = 7 * NS > kRedRows ? 7 * NS : kRedRows;
@@ -240,8 +258,9 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
     M m;
     double y[NS];
     const double chk = m.init(a, smem + adaptive_rows<M>(GRAD) * kBlock, lane, i, set, y);
-    double* const tape = GRAD ? a.tape + ((int64_t)set * a.tape_cap * TROWS) * a.N + i : nullptr;
+    double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + i : nullptr;
 #define TAPE(n, r) tape[((int64_t)(n) * TROWS + (r)) * a.N]
+#define OUTV(oi) tape[((int64_t)a.tape_cap * TROWS + (oi)) * a.N]     /* saved output (state 1) behind the steps */
     int n_acc = 0;
     if (GRAD) {                                    // entry 0 always holds finite numbers (parked lanes read it)
         TAPE(0, 0) = a.t_begin;
@@ -257,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
     double sk[NS], d0 = 0.0, d1 = 0.0;
     int nxt = 0;
     bool failed = false;
+    double prod_last = 0.0;
     // outputs at (or before) the initial time
     while (nxt < n_out && tout[nxt] <= t0 + 1e-12) {
         sse += m.residual2(a, nxt, i, y, active);
@@ -308,7 +328,9 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
         double du[NS];
         if constexpr (IS_CPEP) {
             if (st == -2) m.base = m.production(0.0);      // NN([0; e^beta]): time-invariant, evaluated once
-            m.finish_rhs(m.production(m.forcing_input(te)), Y, du);
+            // the forcing depends on time only and c_6 = c_7 = 1: stage 7 (st == 6, wave-uniform) reuses stage 6's value
+            if (st != 6) prod_last = m.production(m.forcing_input(te));
+            m.finish_rhs(prod_last, Y, du);
         } else {
             const double uh = M::Net::eval(m.p, m.c, Y);
             du[0] = -0.4 * Y[0];
@@ -375,6 +397,7 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
 #pragma unroll
                     for (int s = 0; s < NS; s++) o[s] = fma(dt, o[s], y[s]);
                     sse += m.residual2(a, nxt, i, o, active);
+                    if (GRAD && !M::NEED_Y) OUTV(nxt) = o[0];
                     nxt++;
                 }
             }
@@ -423,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
         double acc[Net::NACC];
 #pragma unroll
         for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
-        double lam[NS], wsum = 0.0;
+        double lam[NS], wsum = 0.0, carry = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; s++) lam[s] = 0.0;
         const double gs = a.inv_n;
@@ -437,6 +460,72 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
             const bool on = n < n_acc;
             const int src = on ? n : (n_acc > 0 ? n_acc - 1 : 0);
             const double tn = TAPE(src, 0), h = TAPE(src, 1);
+            if constexpr (!M::NEED_Y) {
+                // ---- linear kinetics + a forcing that depends on time only: J_f = A, nothing to re-run.  The outputs
+                // were saved by the forward sweep; stages 6 and 7 of this step and stage 1 of the next share one time,
+                // hence one network VJP: 5 per step (+ 1 at t_0), as in the fixed-step kernel.
+#pragma unroll 1
+                for (int j = 0; j < 7; j++) {
+#pragma unroll
+                    for (int s = 0; s < NS; s++) BROW(j, s) = 0.0;
+                }
+                double yb[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) yb[s] = 0.0;
+                while (__any(on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12)) {
+                    const bool mine = on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12;
+                    if (mine) {
+                        const int oi = hi - 1;
+                        const double th = fmin(1.0, (tout[oi] - tn) / h);
+                        const bool at_end = fabs(th - 1.0) < 1e-12;
+                        double o[NS], ob[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; s++) o[s] = 0.0;
+                        o[0] = OUTV(oi);
+                        m.residual_bar(a, oi, i, o, ob);
+#pragma unroll
+                        for (int s = 0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
+#pragma unroll 1
+                        for (int j = 0; j < 7; j++) {
+                            const double w = at_end ? (j < 6 ? TS_A[6][j] : 0.0)
+                                                    : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+#pragma unroll
+                            for (int s = 0; s < NS; s++) BROW(j, s) = fma(w, ob[s], BROW(j, s));
+                        }
+                        hi--;
+                    }
+                }
+                double wacc = carry;                            // weight of the evaluation at t_n + h
+#pragma unroll 1
+                for (int sq = 6; sq >= 0; sq--) {
+                    double kb[NS], ub[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) { kb[s] = BROW(sq, s); ub[s] = sq == 6 ? lam[s] : 0.0; }
+                    if (sq == 6) {
+                        m.vjp_linear(kb, ub);
+                        wacc += kb[0];
+                        wsum += kb[0];
+                    } else if (sq == 0) {
+                        m.vjp_linear(kb, ub);
+                        carry = kb[0];                          // evaluated with the previous step's stages 6 and 7
+                        wsum += kb[0];
+                    } else {
+                        m.vjp_linear(kb, ub);
+                        m.vjp_net(sq == 5 ? tn + h : fma(TS_C[sq], h, tn), sq == 5 ? wacc + kb[0] : kb[0], acc);
+                        wsum += kb[0];
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; s++) yb[s] += ub[s];
+#pragma unroll 1
+                    for (int j = 0; j < sq; j++) {
+                        const double aj = h * TS_A[sq][j];
+#pragma unroll
+                        for (int s = 0; s < NS; s++) BROW(j, s) = fma(aj, ub[s], BROW(j, s));
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; s++) lam[s] = yb[s];
+            } else {
 #pragma unroll
             for (int s = 0; s < NS; s++) y[s] = TAPE(src, 2 + s);
             // ---- re-run the seven stages of the step: k_1 .. k_7 (k_1 = the previous step's k_7 bit for bit: same
@@ -527,10 +616,11 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
             }
 #pragma unroll
             for (int s = 0; s < NS; s++) lam[s] = yb[s];
+            }
         }
         if (active && a.tape_n != nullptr) a.tape_n[set * a.N + i] = n_acc;
         double cst[M::NCST];
-        m.finish_grad(a, i, set, acc, wsum, cst);
+        m.finish_grad(a, i, set, acc, wsum, carry, cst);
         __syncthreads();                   // the reduction scratch aliases s_K
         if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(m.p, acc, cst);
         block_reduce_expand<Net, M::NCST>(acc, cst, active ? 1.0 : 0.0, active ? sse : 0.0, (active && bad) ? 1.0 : 0.0,
@@ -540,6 +630,7 @@ __global__ __launch_bounds__(kBlock) void adaptive_kernel(typename M::Args a) {
     }
 #undef KROW
 #undef TAPE
+#undef OUTV
 }
 
 // ---------------------------------------------------------------------------------- dispatch

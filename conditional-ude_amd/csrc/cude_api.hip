@@ -369,7 +369,7 @@ int32_t alloc_common(cude_ctx* c) {
         cap = std::max<int64_t>(64, std::min<int64_t>(1024, cap));
         if (const char* env = getenv("CUDE_TAPE_STEPS")) cap = std::max(1, atoi(env));
         c->tape_cap = (int)cap;
-        HIP_TRY(c->tape.resize((size_t)cap * rows * N));
+        HIP_TRY(c->tape.resize((size_t)cude::adaptive_tape_rows(rows - 2, (int)cap, c->T) * N));
         HIP_TRY(c->tape_n.resize((size_t)N));
         c->have_tape = false;
     }
@@ -1129,7 +1129,7 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     const int L = c->chunks;
     const bool split = !supp && L > 1 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 && getenv("CUDE_NO_MS_SPLIT") == nullptr;
     // sets per launch: bounded by the grid's y / z dimension and ~512 MB of scratch
-    const int64_t tape_rows = adaptive(c) ? (int64_t)c->tape_cap * cude::adaptive_tape_rows(supp ? 3 : 2) : 0;
+    const int64_t tape_rows = adaptive(c) ? cude::adaptive_tape_rows(supp ? 3 : 2, c->tape_cap, c->T) : 0;
     const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (double)tape_rows * N +
                                   (supp && !adaptive(c) ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
                                   (split ? (double)L * (3 + c->T) * N + 5.0 * S * N + (double)L * N + (double)L * nb * P : 0.0));

@@ -152,7 +152,9 @@ bool supp_shape_supported(const NetShape& net);
 hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
 hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
 // rows of N doubles per accepted step on the adaptive gradient's tape: t_n, dt_n, y_n
-inline int adaptive_tape_rows(int n_state) { return 2 + n_state; }
+inline __host__ __device__ int adaptive_tape_rows(int n_state) { return 2 + n_state; }
+// ... and of one parameter set's tape: the steps, then T saved outputs
+inline __host__ __device__ int64_t adaptive_tape_rows(int n_state, int cap, int T) { return (int64_t)cap * (2 + n_state) + T; }
 
 // common kernels
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1

@@ -21,10 +21,11 @@ Reference items mirrored (paths relative to the reference repo):
   SAEM_symbolic                            src/saem-symreg.jl:31-66,86-131,134-229
 Differences that are deliberate and documented in DESIGN.md: by default the ODE is solved with FIXED-step Tsit5
 (`n_steps`; default for the c-peptide model: 8 steps per observation interval, see default_steps; 30 for the
-suppression model) so that the loss has an exact discrete adjoint; `n_steps=ADAPTIVE` (0) runs the reference's own
-adaptive Tsit5 on the device for everything that needs no gradient (loss values, simulations, profiles, per-subject
-fits, Metropolis steps).  Gradients are a discrete adjoint instead of ForwardDiff; the per-subject 1-D fits use a
-bracketing search instead of Fminbox(LBFGS).
+suppression model): a smooth loss with an exact discrete adjoint and the fastest kernels; `n_steps=ADAPTIVE` (0) runs
+the reference's own adaptive Tsit5 on the device in every function of this module, training included -- its gradient
+is that of the accepted step sequence taken as fixed arithmetic, which is what ForwardDiff through `solve` yields.
+Gradients are a discrete adjoint instead of ForwardDiff; the per-subject 1-D fits use a bracketing search instead of
+Fminbox(LBFGS).
 """
 import hashlib
 import math
@@ -37,7 +38,7 @@ from .engine import Engine
 from .lbfgs import lbfgs, lbfgs_batched
 
 DEFAULT_STEPS = 30
-ADAPTIVE = 0      # n_steps = ADAPTIVE: the reference's own adaptive Tsit5 (abstol 1e-6, reltol 1e-3) -- forward-only calls
+ADAPTIVE = 0      # n_steps = ADAPTIVE: the reference's own adaptive Tsit5 (abstol 1e-6, reltol 1e-3)
 
 
 def default_steps(timepoints, per_interval=8):

@@ -116,7 +116,8 @@ def test_symbolic_model_adaptive_matches_the_oracle():
     eng.close()
 
 
-def test_gradients_are_refused_and_failures_follow_the_reference_convention():
+def test_failures_follow_the_reference_convention():
+    """(gradients in this mode: tests/test_gpu_adaptive_grad.py)"""
     import torch  # noqa: F401
     from cude.engine import CudeError, Engine
     arch = (2, 4, 2)
@@ -125,10 +126,8 @@ def test_gradients_are_refused_and_failures_follow_the_reference_convention():
     eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
     eng.set_params(c["nn"], c["beta"])
     with pytest.raises(CudeError) as e:
-        eng.loss_grad()
-    assert e.value.status == -4
-    with pytest.raises(CudeError):
-        eng.multistart_loss_grad(c["nn"][None, :], c["beta"][None, :])
+        eng.adaptive_steps(0)                                         # no gradient evaluation yet
+    assert e.value.status == -3
     beta = c["beta"].copy()
     beta[7] = np.nan
     eng.set_params(c["nn"], beta)

@@ -12,12 +12,15 @@ the oracle's own adaptive sequence (same accept / reject decisions, step sizes t
 is asserted separately, and the oracle's end-to-end adaptive gradient (cude_oracle.*_adaptive_loss_grad) is compared at
 the solver's own tolerance.
 Tolerances: loss / SSE 1e-10 relative, gradients 1e-8 of the largest entry."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import make_cpep_case, make_supp_case
 
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _cpep_replay_grad(o, c, pop, arch, steps):
@@ -177,3 +180,36 @@ def test_adaptive_gradient_everywhere_the_fixed_step_one_goes():
     assert abs(loss - ol) <= 1e-3 * ol and abs(g_p[0] - og[0]) <= 2e-2 * abs(og[0])
     assert np.median(np.abs(g_k - ok)) <= 1e-3 * np.max(np.abs(ok))
     eng.close()
+
+
+def test_training_on_the_reference_objective_through_the_api():
+    """train / fit_suppression_model with n_steps = ADAPTIVE: screening, Adam and L-BFGS (inside the library) on the
+    adaptive-solve loss -- the function the reference's own optimisers see (parameter-estimation.jl:340-386,
+    suppression_model.jl:140-177)."""
+    from cude import api
+    g = dict(np.load(os.path.join(GOLD, "ohashi_cude.npz")))
+    net = api.chain(4, 2, "tanh")
+    n = 40
+    models = [api.CPeptideCUDEModel(g["glucose"][i], g["timepoints"], g["ages"][i], net, g["cpeptide"][i], bool(g["t2dm"][i]))
+              for i in range(n)]
+    sols = api.train(models, g["timepoints"], g["cpeptide"][:n], np.random.default_rng(5), initial_guesses=200,
+                     selected_initials=2, number_of_iterations_adam=150, number_of_iterations_lbfgs=40, n_steps=api.ADAPTIVE)
+    for s in sols:
+        assert np.isfinite(s.objective) and s.objective < 1.5
+        assert abs(api.loss(s.u, (models, g["timepoints"], g["cpeptide"][:n]), n_steps=api.ADAPTIVE) - s.objective) < 1e-9
+        # the fixed-step loss at the same point differs by the solver's own error, no more
+        assert abs(api.loss(s.u, (models, g["timepoints"], g["cpeptide"][:n])) - s.objective) < 2e-2 * s.objective
+    api.clear_cache()
+    gs = dict(np.load(os.path.join(GOLD, "suppression_lambda0.npz")))
+    prob = api.SuppressionProblem(api.neural_network_model(5, 3, input_dims=4))
+    rng = np.random.default_rng(2)
+    p0 = [api.ComponentArray(theta=rng.uniform(-1.0, 1.0, gs["group_data"].shape[2]), neural=api.init_params(prob.network, rng))
+          for _ in range(3)]
+    fits, _ = api.fit_suppression_model(p0, prob, gs["group_data"], gs["timepoints"], 0.0, select_best_n=3, adam_iters=150,
+                                        lbfgs_iters=60, n_steps=api.ADAPTIVE)
+    start = [api.suppression_loss(p, (prob, gs["group_data"], gs["timepoints"], 0.0), n_steps=api.ADAPTIVE) for p in p0]
+    assert len(fits) == 3
+    for f, l0 in zip(fits, sorted(start)):                 # best initial guess first
+        assert np.isfinite(f.objective) and f.objective < 0.95 * l0
+        assert abs(api.suppression_loss(f.u, (prob, gs["group_data"], gs["timepoints"], 0.0), n_steps=api.ADAPTIVE) - f.objective) < 1e-9
+    api.clear_cache()
