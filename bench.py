@@ -349,6 +349,25 @@ def extras(Engine, device, steps=20, warm=40):
                           "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
                           "roofline": hbm, "roofline_valu": valu}
     eng.close()
+    # ---- the same instance as the reference itself solves and differentiates it: adaptive Tsit5 (abstol 1e-6, reltol
+    # 1e-3) + the adjoint of the accepted step sequence (= AutoForwardDiff through solve) + Adam
+    eng = Engine("cpep", arch, n_steps=0, n_state=2, device=device)
+    eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+    eng.set_params(nn4, pop["beta0"])
+    eng.adam_init(1e-2)
+    dt, ms, launches = timed_adam(eng, n, steps, warm)
+    acc_steps = np.array([len(eng.adaptive_steps(i)[0]) for i in range(0, n, n // 500)])
+    out["cpep2_4_1e5_adaptive"] = {
+        "config": "reference c-peptide cUDE, 2x4x4x1, 2 states, 1e5 subjects, ADAPTIVE Tsit5 forward (the reference's "
+                  "solver settings) + adjoint of the accepted steps + Adam",
+        "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
+        "kernel": "adaptive_kernel<CpepAd<Mlp<2,4,2,1>>,grad>", "kernel_ms": ms, "launches": launches,
+        "accepted_steps_per_subject": {"min": int(acc_steps.min()), "median": float(np.median(acc_steps)),
+                                       "max": int(acc_steps.max())},
+        "note": "work per subject is data-dependent (a wave runs as long as its slowest lane): no fixed algorithmic "
+                "flop count, hence no roofline fraction; 5 network evaluations per trial step forward, 5 VJPs per "
+                "accepted step in reverse, 40 B/subject/step of tape"}
+    eng.close()
     # ---- suppression instance: 4->3x5->1, 3 states, T = 8, 1e5 subjects, fwd + adjoint + Adam
     n, arch = 100000, (4, 3, 5)
     tp, data, theta = synthetic_suppression(n, 779)

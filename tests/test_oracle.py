@@ -1,5 +1,7 @@
 """The CPU oracle checked against itself three ways (numpy values, torch reverse-mode autograd, C forward-mode
 duals), against finite differences, and for the properties of the discretisation it restates."""
+import math
+
 import numpy as np
 import pytest
 
@@ -189,6 +191,69 @@ def test_c_adaptive_mode_is_the_python_adaptive_mode():
             ref = o.solve_adaptive(o.cpep_rhs_scalar(pop, i, nn, cond[i], arch), [c0, float(pop.k2[i] / pop.k1[i]) * c0],
                                    list(times))
             assert np.max(np.abs(got[i] - np.array([r[0] for r in ref]))) < 1e-11
+
+
+def test_adaptive_gradient_checker_replay_and_complex_step():
+    """The checker of the device's adaptive gradient (tests/test_gpu_adaptive_grad.py): (i) replaying the recorded
+    accepted steps reproduces the adaptive solution exactly -- same arithmetic; (ii) its complex-step derivative equals
+    torch's reverse-mode derivative of the same replay (a third algorithm) and central differences of it."""
+    import torch
+    import cude_oracle as o
+    arch = (2, 4, 2)
+    c = make_cpep_case(4, arch)
+    pop = o.CPepPopulation(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    loss, g_nn, g_b, sse = o.cpep_adaptive_loss_grad(c["nn"], c["beta"], pop, arch)
+    tl = torch.zeros((), dtype=torch.float64)
+    nn_t = torch.tensor(c["nn"], requires_grad=True)
+    b_t = torch.tensor(c["beta"], requires_grad=True)
+    for i in range(pop.N):
+        c0 = float(pop.c0[i])
+        u0 = [c0, float(pop.k2[i] / pop.k1[i]) * c0]
+        rec = []
+        ref = o.solve_adaptive(o.cpep_rhs_scalar(pop, i, c["nn"], float(np.exp(c["beta"][i])), arch), u0, pop.timepoints,
+                               record=rec)
+        assert 8 <= len(rec) <= 60 and abs(rec[-1][0] + rec[-1][1] - pop.timepoints[-1]) < 1e-12
+        again = o.replay_steps(o.cpep_rhs_scalar(pop, i, c["nn"], float(np.exp(c["beta"][i])), arch), u0, pop.timepoints, rec)
+        assert np.max(np.abs(np.array(again) - np.array(ref))) == 0.0
+        assert abs(sum((again[t][0] - pop.cpeptide[i, t]) ** 2 for t in range(pop.T)) - sse[i]) <= 1e-11 * sse[i]
+        G = [float(v) for v in pop.glucose[i]]
+        k0, k1, k2 = float(pop.k0[i]), float(pop.k1[i]), float(pop.k2[i])
+        eb = torch.exp(b_t[i])
+
+        def rhs(t, u, G=G, k0=k0, k1=k1, k2=k2, c0=c0, eb=eb):
+            dG = o.linear_interp(pop.timepoints, G, t) - G[0]
+            prod = o.mlp(torch, [dG + 0.0 * eb, eb], nn_t, arch) - o.mlp(torch, [0.0 * eb, eb], nn_t, arch)
+            return [-(k0 + k2) * u[0] + k1 * u[1] + k0 * c0 + prod, -k1 * u[1] + k2 * u[0]]
+        out = o.replay_steps(rhs, [torch.tensor(u0[0], dtype=torch.float64), torch.tensor(u0[1], dtype=torch.float64)],
+                             pop.timepoints, rec)
+        for t in range(1, pop.T):
+            tl = tl + (out[t][0] - pop.cpeptide[i, t]) ** 2
+    (tl / pop.N).backward()
+    assert np.max(np.abs(nn_t.grad.numpy() - g_nn)) <= 1e-11 * np.max(np.abs(g_nn))
+    assert np.max(np.abs(b_t.grad.numpy() - g_b)) <= 1e-11 * np.max(np.abs(g_b))
+    # suppression model: complex step against central differences of the replayed loss in one direction
+    s = make_supp_case(3)
+    l0, gn, gt, _ = o.supp_adaptive_loss_grad(s["nn"], s["theta"], s["data"], s["tp"], s["arch"], 0.01)
+    scale, tpl = o.supp_scale(s["data"]), [float(v) for v in s["tp"]]
+    recs = []
+    for i in range(3):
+        rec = []
+        o.solve_adaptive(lambda t, u: o.supp_rhs(math, [float(v) for v in s["nn"]], math.exp(float(s["theta"][i])), s["arch"], t, u),
+                         [float(v) for v in s["data"][:, 0, i]], tpl, record=rec)
+        recs.append(rec)
+
+    def replayed(nn, theta):
+        tot = 0.0
+        for i in range(3):
+            out = o.replay_steps(lambda t, u: o.supp_rhs(np, nn, float(np.exp(theta[i])), s["arch"], t, u),
+                                 [float(v) for v in s["data"][:, 0, i]], tpl, recs[i])
+            tot += sum(((out[t][k] - s["data"][k, t, i]) / scale[k]) ** 2 for t in range(1, len(tpl)) for k in range(3))
+        return tot / 3 + 0.01 * float(nn @ nn)
+    assert abs(replayed(s["nn"], s["theta"]) - l0) <= 1e-12 * l0
+    rng = np.random.default_rng(0)
+    dn, dth, h = rng.standard_normal(s["nn"].size), rng.standard_normal(3), 1e-6
+    fd = (replayed(s["nn"] + h * dn, s["theta"] + h * dth) - replayed(s["nn"] - h * dn, s["theta"] - h * dth)) / (2 * h)
+    assert abs(fd - (gn @ dn + gt @ dth)) <= 1e-7 * abs(fd)
 
 
 def test_failure_convention_and_adam():

@@ -4,7 +4,8 @@ the reference's own recipe -- 25 000 screened initial guesses (network init + La
 the best K trained with Adam(1e-2) x 1000 then L-BFGS x 1000 -- and compare the final objective with the
 objective of the reference's STORED optimum (model k=0 weights + its betas) evaluated by the same loss.
 
-usage: python tools/e2e_cpeptide.py [K=5]
+usage: python tools/e2e_cpeptide.py [K=5] [adaptive]      adaptive: train on the reference's own objective (adaptive
+Tsit5, abstol 1e-6 / reltol 1e-3, gradient = adjoint of the accepted steps) instead of the fixed-step discretisation
 """
 import os
 import sys
@@ -19,6 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "conditional-ude_amd"))
 from cude import api  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+N_STEPS = api.ADAPTIVE if len(sys.argv) > 2 and sys.argv[2] == "adaptive" else None
 g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ohashi_cude.npz")))
 net = api.chain(4, 2, "tanh")
 all_models = [api.CPeptideConditionalUDEModel(g["glucose"][i], g["timepoints"], g["ages"][i], net, g["cpeptide"][i],
@@ -31,12 +33,14 @@ rows, cols = linear_sum_assignment(np.abs(betas0[:, None] - beta_hat[None, :]))
 sel = cols[np.argsort(rows)]
 models = [all_models[i] for i in sel]
 data = g["cpeptide"][sel]
-stored = api.loss(api.ComponentArray(neural=nn0, conditional=betas0[:, None]), (models, g["timepoints"], data))
-print(f"objective of the reference's stored optimum (model 0) on its 57 subjects: {stored:.4f}")
+stored = api.loss(api.ComponentArray(neural=nn0, conditional=betas0[:, None]), (models, g["timepoints"], data),
+                  n_steps=N_STEPS)
+print(f"objective of the reference's stored optimum (model 0) on its 57 subjects"
+      f"{' (adaptive solve)' if N_STEPS == api.ADAPTIVE else ''}: {stored:.4f}")
 
 t0 = time.perf_counter()
 sols = api.train(models, g["timepoints"], data, np.random.default_rng(232705), initial_guesses=25_000,
-                 selected_initials=K)
+                 selected_initials=K, n_steps=N_STEPS)
 dt = time.perf_counter() - t0
 obj = np.array(sorted(s.objective for s in sols))
 print(f"{len(sols)} runs (25 000 screened + Adam x1000 + L-BFGS x1000 each) in {dt:.1f} s; objectives {np.round(obj, 4).tolist()}")
