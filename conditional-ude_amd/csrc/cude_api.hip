@@ -352,6 +352,25 @@ int32_t lbfgs_comm_reduce(double* values, int32_t count, int32_t op, void* user)
 
 void drop_graph(cude_ctx* c);
 
+// Tape of the adaptive gradient: (2 + NS) doubles per accepted step and subject + T saved outputs.  The reference's
+// problems take 10-40 steps at its tolerances; the capacity is what ~4 GB hold, between 64 and 1024 steps
+// (CUDE_TAPE_STEPS overrides).  A subject with more accepted steps fails its gradient evaluation (+Inf), not the
+// process.  Allocated by the first gradient evaluation (forward-only users of the adaptive mode never pay for it), never
+// under stream capture.
+int32_t ensure_tape(cude_ctx* c) {
+    if (!adaptive(c) || c->tape.p) return CUDE_OK;
+    if (c->capturing) return fail(CUDE_ERR_STATE, "adaptive gradient tape not allocated before stream capture");
+    const int64_t N = c->N;
+    const int rows = cude::adaptive_tape_rows(c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2);
+    int64_t cap = (int64_t)(4e9 / (8.0 * rows * (double)N));
+    cap = std::max<int64_t>(64, std::min<int64_t>(1024, cap));
+    if (const char* env = getenv("CUDE_TAPE_STEPS")) cap = std::max(1, atoi(env));
+    c->tape_cap = (int)cap;
+    HIP_TRY(c->tape.resize((size_t)cude::adaptive_tape_rows(rows - 2, (int)cap, c->T) * N));
+    HIP_TRY(c->tape_n.resize((size_t)N));
+    return CUDE_OK;
+}
+
 int32_t alloc_common(cude_ctx* c) {
     const int64_t N = c->N;
     drop_graph(c);
@@ -360,19 +379,9 @@ int32_t alloc_common(cude_ctx* c) {
     HIP_TRY(c->g_cond.resize(N));
     HIP_TRY(c->sse.resize(N));
     HIP_TRY(c->partials.resize((size_t)c->nblocks * (c->P + 2)));
-    if (adaptive(c)) {
-        // tape of the adaptive gradient: (2 + NS) doubles per accepted step and subject.  The reference's problems take
-        // 10-40 steps at its tolerances; the capacity is what ~4 GB hold, between 64 and 1024 steps (CUDE_TAPE_STEPS
-        // overrides).  A subject with more accepted steps fails its gradient evaluation (+Inf), not the process.
-        const int rows = cude::adaptive_tape_rows(c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2);
-        int64_t cap = (int64_t)(4e9 / (8.0 * rows * (double)N));
-        cap = std::max<int64_t>(64, std::min<int64_t>(1024, cap));
-        if (const char* env = getenv("CUDE_TAPE_STEPS")) cap = std::max(1, atoi(env));
-        c->tape_cap = (int)cap;
-        HIP_TRY(c->tape.resize((size_t)cude::adaptive_tape_rows(rows - 2, (int)cap, c->T) * N));
-        HIP_TRY(c->tape_n.resize((size_t)N));
-        c->have_tape = false;
-    }
+    HIP_TRY(c->tape.resize(0));          // adaptive gradient tape: allocated by the first gradient evaluation
+    c->tape_cap = 0;
+    c->have_tape = false;
     HIP_TRY(c->m_cond.resize(N));
     HIP_TRY(c->v_cond.resize(N));
     HIP_TRY(hipMemsetAsync(c->cond.p, 0, N * sizeof(double), c->stream));
@@ -534,6 +543,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                      const double* cond_ov = nullptr, double* sse_ov = nullptr) {
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!c->have_nn || (!c->have_cond && !cond_ov)) return fail(CUDE_ERR_STATE, "parameters not set");
+    if (grad) { int32_t rc = ensure_tape(c); if (rc) return rc; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && !c->capturing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -948,6 +958,7 @@ int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
     if (n_iters < 1) return fail(CUDE_ERR_ARG, "n_iters must be >= 1");
     if (!c->have_pop || !c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "population / parameters not set");
     if ((rc = ensure_trace(c, n_iters))) return rc;
+    if ((rc = ensure_tape(c))) return rc;
     HIP_TRY(hipMemsetAsync(c->adam_state.p + 3, 0, sizeof(double), c->stream));     // trace position = 0
     const bool use_graph = (c->comm == nullptr) && !c->timing && getenv("CUDE_NO_GRAPH") == nullptr;
     if (use_graph && !c->graph_exec) {
@@ -1129,6 +1140,7 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     const int L = c->chunks;
     const bool split = !supp && L > 1 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 && getenv("CUDE_NO_MS_SPLIT") == nullptr;
     // sets per launch: bounded by the grid's y / z dimension and ~512 MB of scratch
+    if ((rc = ensure_tape(c))) return rc;                 // (fixes the capacity the per-set tapes share)
     const int64_t tape_rows = adaptive(c) ? cude::adaptive_tape_rows(supp ? 3 : 2, c->tape_cap, c->T) : 0;
     const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (double)tape_rows * N +
                                   (supp && !adaptive(c) ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
