@@ -28,6 +28,12 @@ for mode in stage_inputs steps; do
   echo "supp $mode rc=$?"
 done
 unset CUDE_SUPP_CKPT
+# adaptive mode: forward and gradient launches of the reference's c-peptide instance at 1e5 subjects
+ADAPT="python3 $ROOT/tools/bench_adaptive.py 100000 4"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/adaptive_stats -o stats -- $ADAPT > $OUT/adaptive.log 2> $OUT/adaptive.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/adaptive_fetch -o fetch -- $ADAPT > /dev/null 2>> $OUT/adaptive.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/adaptive_write -o write -- $ADAPT > /dev/null 2>> $OUT/adaptive.err
+echo "adaptive rc=$?"
 cd $ROOT
 python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
