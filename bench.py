@@ -366,7 +366,7 @@ def extras(Engine, device, steps=20, warm=40):
                                        "max": int(acc_steps.max())},
         "note": "work per subject is data-dependent (a wave runs as long as its slowest lane): no fixed algorithmic "
                 "flop count, hence no roofline fraction; 5 network evaluations per trial step forward, 5 VJPs per "
-                "accepted step in reverse, 40 B/subject/step of tape"}
+                "accepted step in reverse, 32 B/subject/step of tape (PMC: profiles/pmc_traffic.json)"}
     eng.close()
     # ---- suppression instance: 4->3x5->1, 3 states, T = 8, 1e5 subjects, fwd + adjoint + Adam
     n, arch = 100000, (4, 3, 5)

@@ -90,7 +90,7 @@ for mode in ("stage_inputs", "steps"):
     except Exception:
         pass
 kernel_stats("adaptive_stats")
-AGRAD = "true, true>(cude::CpepArgs)"          # adaptive_kernel<CpepAd<...>, IS_CPEP, GRAD>
+AGRAD = "> >, true, true>("                   # adaptive_kernel<CpepAd<...>, IS_CPEP, GRAD>
 f, nf = mean_ctr("adaptive_fetch", AGRAD, "FETCH_SIZE", skip=3)
 w, nw = mean_ctr("adaptive_write", AGRAD, "WRITE_SIZE", skip=3)
 if f is not None and w is not None:
@@ -98,8 +98,8 @@ if f is not None and w is not None:
                                        "launches": nf, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                                        "source_sha": rec["source_sha"],
                                        "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024,
-                                       "note": "tape: 40 B per accepted step and subject written and read once "
-                                               "(20 steps typical => ~1.6 KB/subject) + 5 saved outputs"}
+                                       "note": "tape: 32 B per accepted step and subject written, its 16 B of "
+                                               "(t, dt) read back (20 steps typical) + 5 saved outputs"}
 try:
     print(open(os.path.join(out, "adaptive.log")).read().strip())
 except Exception:
