@@ -52,3 +52,55 @@ def test_one_million_subjects_equals_sum_of_eight_shards():
     assert abs(part_sum[P] / N - loss) < 1e-12 * loss
     assert np.max(np.abs(part_sum[:P] - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
     assert np.array_equal(np.concatenate(g_parts), g_cond)      # per-subject gradients are local: bitwise equal
+
+
+def test_adaptive_gradient_at_1e5_subjects_properties():
+    """BASELINE configs[2] size in the reference's own solver mode (adaptive Tsit5 + adjoint of the accepted steps,
+    csrc/cude_adaptive.hip): size-independent properties -- repeatable bit for bit, per-subject results independent of
+    how the population is sharded or ordered, loss / network gradient additive over shards, one failing subject fails
+    the evaluation and nothing else."""
+    import cude_oracle as o
+    from cude.engine import Engine
+    arch, N = (2, 4, 2), 100_000
+    tp, G, obs, age, t2, beta = _population(N, 7)
+    nn = o.glorot_params(arch, 5)
+    whole = Engine("cpep", arch, n_steps=0, n_state=2)
+    whole.set_population_cpep(tp, G, obs, age, t2)
+    whole.set_params(nn, beta)
+    loss, g_nn, g_cond = whole.loss_grad()
+    again = whole.loss_grad()
+    assert np.isfinite(loss) and again[0] == loss and np.array_equal(again[1], g_nn) and np.array_equal(again[2], g_cond)
+    fwd = whole.forward(want_sse=True)
+    assert abs(fwd["loss"] - loss) <= 1e-14 * loss
+    n_steps = np.array([len(whole.adaptive_steps(i)[0]) for i in range(0, N, 997)])
+    assert 5 <= n_steps.min() and n_steps.max() <= 64
+    P = g_nn.size
+    part_sum, g_parts = np.zeros(P + 2), []
+    for s in (slice(0, 37_003), slice(37_003, N)):                # ragged shards: neither a multiple of the wave size
+        eng = Engine("cpep", arch, n_steps=0, n_state=2)
+        eng.set_population_cpep(tp, G[s], obs[s], age[s], t2[s])
+        eng.set_global_subjects(N)
+        eng.set_params(nn, beta[s])
+        part, gc = eng.loss_grad_partial(want_cond_grad=True)
+        eng.close()
+        part_sum += part
+        g_parts.append(gc)
+    assert part_sum[P + 1] == 0 and abs(part_sum[P] / N - loss) < 1e-12 * loss
+    assert np.max(np.abs(part_sum[:P] - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
+    assert np.array_equal(np.concatenate(g_parts), g_cond)
+    rev = Engine("cpep", arch, n_steps=0, n_state=2)              # reversed subject order: lanes meet other neighbours
+    rev.set_population_cpep(tp, G[::-1], obs[::-1], age[::-1], t2[::-1])
+    rev.set_params(nn, beta[::-1])
+    l2, gn2, gc2 = rev.loss_grad()
+    rev.close()
+    assert np.array_equal(gc2[::-1], g_cond) and abs(l2 - loss) < 1e-12 * loss
+    assert np.max(np.abs(gn2 - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
+    bad = beta.copy()
+    bad[54_321] = np.inf
+    whole.set_params(nn, bad)
+    l3, _, gc3 = whole.loss_grad()
+    assert np.isinf(l3) and whole.n_failed() == 1
+    ok = np.ones(N, bool)
+    ok[54_321] = False
+    assert np.array_equal(gc3[ok], g_cond[ok])
+    whole.close()
