@@ -488,23 +488,15 @@ def _complex_step_batch(nn, cond_log, cond_space="log"):
     return p, (np.exp(c) if cond_space == "log" else c)
 
 
-def cpep_adaptive_loss_grad(nn, beta, pop, arch, abstol=1e-6, reltol=1e-3, cond_space="log"):
-    """Loss and gradient of the ADAPTIVE solve as the reference's AutoForwardDiff sees it
-    (src/parameter-estimation.jl:56-68,126-140,165): per subject, the accepted steps of the plain adaptive solve are
-    recorded and the fixed sequence is differentiated (replay_steps) -- here by the complex-step method over a batch of
-    P + 1 perturbations.  Returns (loss, g_nn, g_beta, sse); loss = +Inf and NaN gradients when a solve fails.
-    Checker for the device's adjoint of the adaptive solve (a different algorithm: reverse-mode, hand-written)."""
+def cpep_replay_loss_grad(nn, beta, pop, arch, steps, cond_space="log"):
+    """Loss and gradient of the c-peptide population loss over GIVEN accepted-step sequences, steps[i] = [(t_n, dt_n)]
+    (replay_steps), by the complex-step method over a batch of P + 1 perturbations.  Returns (loss, g_nn, g_beta, sse)."""
     nn = np.asarray(nn, dtype=np.float64)
     P, N = len(nn), pop.N
     tpl = [float(v) for v in pop.timepoints]
     g_nn, g_b, sse = np.zeros(P), np.zeros(N), np.zeros(N)
     for i in range(N):
-        cond = float(np.exp(beta[i])) if cond_space == "log" else float(beta[i])
         c0 = float(pop.c0[i])
-        u0 = [c0, float(pop.k2[i] / pop.k1[i]) * c0]
-        rec = []
-        if solve_adaptive(cpep_rhs_scalar(pop, i, nn, cond, arch), u0, tpl, abstol, reltol, record=rec) is None:
-            return float("inf"), np.full(P, np.nan), np.full(N, np.nan), sse
         pb, cb = _complex_step_batch(nn, beta[i], cond_space)
         G = [float(v) for v in pop.glucose[i]]
         k0, k1, k2, age = float(pop.k0[i]), float(pop.k1[i]), float(pop.k2[i]), float(pop.age[i])
@@ -518,31 +510,48 @@ def cpep_adaptive_loss_grad(nn, beta, pop, arch, abstol=1e-6, reltol=1e-3, cond_
             else:
                 prod = mlp(np, [dG, cb], pb, arch) - mlp(np, [0.0, cb], pb, arch)
             return [-(k0 + k2) * u[0] + k1 * u[1] + k0 * c0 + prod, -k1 * u[1] + k2 * u[0]]
-        out = replay_steps(rhs, [u0[0] + 0.0 * cb, u0[1] + 0.0 * cb], tpl, rec)
-        e = sum((out[ti][0] - pop.cpeptide[i, ti]) ** 2 for ti in range(1, pop.T)) + (u0[0] - pop.cpeptide[i, 0]) ** 2
+        out = replay_steps(rhs, [c0 + 0.0 * cb, (k2 / k1) * c0 + 0.0 * cb], tpl, steps[i])
+        if out is None:
+            return float("inf"), np.full(P, np.nan), np.full(N, np.nan), sse
+        e = sum((out[ti][0] - pop.cpeptide[i, ti]) ** 2 for ti in range(1, pop.T)) + (c0 - pop.cpeptide[i, 0]) ** 2
         sse[i] = e[0].real
         g_nn += e.imag[:P] / 1e-30
         g_b[i] = e.imag[P] / 1e-30
     return sse.sum() / N, g_nn / N, g_b / N, sse
 
 
-def supp_adaptive_loss_grad(nn, theta, data, timepoints, arch, lam, abstol=1e-6, reltol=1e-3):
-    """The same for suppression_loss (suppression/src/suppression_model.jl:117-130 with its AutoForwardDiff gradient,
-    :155).  Returns (loss, g_nn, g_theta, sse)."""
+def cpep_adaptive_loss_grad(nn, beta, pop, arch, abstol=1e-6, reltol=1e-3, cond_space="log"):
+    """Loss and gradient of the ADAPTIVE solve as the reference's AutoForwardDiff sees it
+    (src/parameter-estimation.jl:56-68,126-140,165): per subject, the accepted steps of the plain adaptive solve are
+    recorded and the fixed sequence is differentiated (cpep_replay_loss_grad).  Returns (loss, g_nn, g_beta, sse);
+    loss = +Inf and NaN gradients when a solve fails.  Checker for the device's adjoint of the adaptive solve (a
+    different algorithm: reverse-mode, hand-written)."""
+    nn = np.asarray(nn, dtype=np.float64)
+    steps = []
+    for i in range(pop.N):
+        cond = float(np.exp(beta[i])) if cond_space == "log" else float(beta[i])
+        c0 = float(pop.c0[i])
+        rec = []
+        if solve_adaptive(cpep_rhs_scalar(pop, i, nn, cond, arch), [c0, float(pop.k2[i] / pop.k1[i]) * c0],
+                          [float(v) for v in pop.timepoints], abstol, reltol, record=rec) is None:
+            return float("inf"), np.full(len(nn), np.nan), np.full(pop.N, np.nan), np.zeros(pop.N)
+        steps.append(rec)
+    return cpep_replay_loss_grad(nn, beta, pop, arch, steps, cond_space)
+
+
+def supp_replay_loss_grad(nn, theta, data, timepoints, arch, lam, steps):
+    """The same for suppression_loss over given step sequences.  Returns (loss, g_nn, g_theta, sse)."""
     nn = np.asarray(nn, dtype=np.float64)
     P, N = len(nn), data.shape[2]
     tpl = [float(v) for v in timepoints]
     scale = supp_scale(data)
     g_nn, g_t, sse = np.zeros(P), np.zeros(N), np.zeros(N)
     for i in range(N):
-        et = math.exp(float(theta[i]))
-        u0 = [float(data[s, 0, i]) for s in range(3)]
-        rec = []
-        if solve_adaptive(lambda t, u: supp_rhs(math, [float(v) for v in nn], et, arch, t, u), u0, tpl, abstol, reltol,
-                          record=rec) is None:
-            return float("inf"), np.full(P, np.nan), np.full(N, np.nan), sse
         pb, cb = _complex_step_batch(nn, theta[i])
-        out = replay_steps(lambda t, u: supp_rhs(np, pb, cb, arch, t, u), [v + 0.0 * cb for v in u0], tpl, rec)
+        out = replay_steps(lambda t, u: supp_rhs(np, pb, cb, arch, t, u), [float(data[s, 0, i]) + 0.0 * cb for s in range(3)],
+                           tpl, steps[i])
+        if out is None:
+            return float("inf"), np.full(P, np.nan), np.full(N, np.nan), sse
         e = 0.0 * cb
         for ti in range(1, len(tpl)):
             for s in range(3):
@@ -551,6 +560,22 @@ def supp_adaptive_loss_grad(nn, theta, data, timepoints, arch, lam, abstol=1e-6,
         g_nn += e.imag[:P] / 1e-30
         g_t[i] = e.imag[P] / 1e-30
     return sse.sum() / N + lam * float(nn @ nn), g_nn / N + 2.0 * lam * nn, g_t / N, sse
+
+
+def supp_adaptive_loss_grad(nn, theta, data, timepoints, arch, lam, abstol=1e-6, reltol=1e-3):
+    """suppression_loss with the reference's AutoForwardDiff gradient (suppression/src/suppression_model.jl:117-130,
+    :155): adaptive solve, accepted steps recorded, sequence differentiated.  Returns (loss, g_nn, g_theta, sse)."""
+    nn = np.asarray(nn, dtype=np.float64)
+    steps = []
+    for i in range(data.shape[2]):
+        et = math.exp(float(theta[i]))
+        rec = []
+        if solve_adaptive(lambda t, u: supp_rhs(math, [float(v) for v in nn], et, arch, t, u),
+                          [float(data[s, 0, i]) for s in range(3)], [float(v) for v in timepoints], abstol, reltol,
+                          record=rec) is None:
+            return float("inf"), np.full(len(nn), np.nan), np.full(data.shape[2], np.nan), np.zeros(data.shape[2])
+        steps.append(rec)
+    return supp_replay_loss_grad(nn, theta, data, timepoints, arch, lam, steps)
 
 
 # ----------------------------------------------------------------------------- Adam / MH

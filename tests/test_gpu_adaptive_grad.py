@@ -23,31 +23,6 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _cpep_replay_grad(o, c, pop, arch, steps):
-    """Loss and gradient of the replayed sequences `steps[i] = (t, dt)` (complex step), cude_oracle-style."""
-    nn, beta = c["nn"], c["beta"]
-    P, N = nn.size, pop.N
-    tpl = [float(v) for v in pop.timepoints]
-    g_nn, g_b, sse = np.zeros(P), np.zeros(N), np.zeros(N)
-    for i in range(N):
-        pb, cb = o._complex_step_batch(nn, beta[i])
-        G = [float(v) for v in pop.glucose[i]]
-        k0, k1, k2, age, c0 = (float(pop.k0[i]), float(pop.k1[i]), float(pop.k2[i]), float(pop.age[i]), float(pop.c0[i]))
-
-        def rhs(t, u):
-            dG = o.linear_interp(tpl, G, t) - G[0]
-            ins = [dG, cb, age] if pop.covariate else [dG, cb]
-            ins0 = [0.0, cb, age] if pop.covariate else [0.0, cb]
-            prod = o.mlp(np, ins, pb, arch) - o.mlp(np, ins0, pb, arch)
-            return [-(k0 + k2) * u[0] + k1 * u[1] + k0 * c0 + prod, -k1 * u[1] + k2 * u[0]]
-        out = o.replay_steps(rhs, [c0 + 0.0 * cb, (k2 / k1) * c0 + 0.0 * cb], tpl, list(zip(*steps[i])))
-        e = sum((out[ti][0] - pop.cpeptide[i, ti]) ** 2 for ti in range(1, pop.T)) + (c0 - pop.cpeptide[i, 0]) ** 2
-        sse[i] = e[0].real
-        g_nn += e.imag[:P] / 1e-30
-        g_b[i] = e.imag[P] / 1e-30
-    return sse.sum() / N, g_nn / N, g_b / N, sse
-
-
 @pytest.mark.parametrize("arch,N", [((2, 4, 2), 70), ((2, 6, 2), 131), ((3, 4, 2), 64), ((2, 8, 2), 30), ((2, 4, 3), 30),
                                     ((2, 5, 1), 20), ((2, 8, 3), 20)])
 def test_cpep_adaptive_gradient(arch, N):
@@ -66,7 +41,7 @@ def test_cpep_adaptive_gradient(arch, N):
     for t, dt in steps:                                          # a partition of the time span
         assert t[0] == c["tp"][0] and np.all(t[1:] == t[:-1] + dt[:-1]) and abs(t[-1] + dt[-1] - c["tp"][-1]) < 1e-12
     # (1) the adjoint of the device's own sequence
-    rl, rg, rb, rsse = _cpep_replay_grad(o, c, pop, arch, steps)
+    rl, rg, rb, rsse = o.cpep_replay_loss_grad(c["nn"], c["beta"], pop, arch, [list(zip(t, dt)) for t, dt in steps])
     assert abs(loss - rl) <= 1e-10 * rl
     assert np.max(np.abs(g_nn - rg)) <= 1e-8 * np.max(np.abs(rg))
     assert np.max(np.abs(g_b - rb)) <= 1e-8 * np.max(np.abs(rb))
@@ -102,20 +77,11 @@ def test_supp_adaptive_gradient():
         eng.set_params(s["nn"], s["theta"])
         loss, g_nn, g_t = eng.loss_grad()
         # (1) the adjoint of the device's own sequences
-        scale, tpl = o.supp_scale(s["data"]), [float(v) for v in s["tp"]]
-        rg, rt, rs = np.zeros(s["nn"].size), np.zeros(N), 0.0
-        for i in range(N):
-            pb, cb = o._complex_step_batch(s["nn"], s["theta"][i])
-            out = o.replay_steps(lambda t, u: o.supp_rhs(np, pb, cb, arch, t, u), [s["data"][k, 0, i] + 0.0 * cb for k in range(3)],
-                                 tpl, list(zip(*eng.adaptive_steps(i))))
-            e = sum(((out[ti][k] - s["data"][k, ti, i]) / scale[k]) ** 2 for ti in range(1, len(tpl)) for k in range(3))
-            rs += e[0].real
-            rg += e.imag[:-1] / 1e-30
-            rt[i] = e.imag[-1] / 1e-30
-        rl = rs / N + 0.01 * float(s["nn"] @ s["nn"])
+        rl, rg, rt, _ = o.supp_replay_loss_grad(s["nn"], s["theta"], s["data"], s["tp"], arch, 0.01,
+                                                [list(zip(*eng.adaptive_steps(i))) for i in range(N)])
         assert abs(loss - rl) <= 1e-10 * rl
-        assert np.max(np.abs(g_nn - (rg / N + 0.02 * s["nn"]))) <= 1e-8 * np.max(np.abs(rg / N))
-        assert np.max(np.abs(g_t - rt / N)) <= 1e-8 * np.max(np.abs(rt / N))
+        assert np.max(np.abs(g_nn - rg)) <= 1e-8 * np.max(np.abs(rg))
+        assert np.max(np.abs(g_t - rt)) <= 1e-8 * np.max(np.abs(rt))
         # (2) end to end against the oracle's own adaptive solve + gradient (its own accepted steps)
         ol, og, ot, _ = o.supp_adaptive_loss_grad(s["nn"], s["theta"], s["data"], s["tp"], arch, 0.01)
         assert abs(loss - ol) <= 1e-8 * ol
