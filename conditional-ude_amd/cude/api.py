@@ -755,7 +755,115 @@ def validate_suppression_model(p_init, prob, data, timepoints, network_params, *
     return theta, float(best.sum() / N)
 
 
+def validate_suppression_model_sigma(p_init, prob, data, timepoints, network_params, *, n_steps=None, lower=-8.0,
+                                     upper=5.0, n_grid=261, iters=50):
+    """validate_suppression_model_sigma(p_init, prob, data, timepoints, network_params) (:224-275, used by
+    suppression/figures.jl:46): theta and one noise level per state for a test subject, minimising
+    sum_s (n/2) log sigma_s^2 + SSE_s(theta) / (2 sigma_s^2) on the UNSCALED residuals with the network frozen.
+    `data` is one subject (3 x T, as in the reference) or many (3 x T x N: all of them at once).  For given theta the
+    optimal sigma_s^2 is SSE_s / n, so the problem is 1-D per subject in theta: a grid over [lower, upper] and
+    golden-section refinements, all subjects in lock step, one forward launch (trajectories) per probe.  Returns
+    (ComponentArray(ode=theta, sigma=(3,) or (N, 3)), objective) -- the global minimum per subject, hence <= what the
+    reference's L-BFGS run from the best of `p_init` reaches; p_init only widens the bracket."""
+    data = np.asarray(data, dtype=np.float64)
+    single = data.ndim == 2
+    if single:
+        data = data[:, :, None]
+    pop = _supp_population(prob, data, timepoints, 0.0, n_steps)
+    eng, N, n = pop.engine, data.shape[2], data.shape[1]
+    if p_init is not None and len(p_init):
+        lower = min(lower, float(np.min(p_init)))
+        upper = max(upper, float(np.max(p_init)))
+
+    def nll(theta):
+        eng.set_params(network_params, theta)
+        traj = eng.forward(want_traj=True)["traj"]                       # (3, T, N)
+        sse = np.sum((traj - data) ** 2, axis=1)                         # (3, N)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = np.sum(0.5 * n * (np.log(sse / n) + 1.0), axis=0)
+        return np.where(np.isfinite(v), v, np.inf), sse
+
+    # sum_s log SSE_s(theta) has a narrow dip wherever one state is fitted well: a fine grid, then the three deepest
+    # local minima of every subject are refined and the best kept
+    grid = np.linspace(lower, upper, n_grid)
+    vals = np.stack([nll(np.full(N, g))[0] for g in grid])              # (n_grid, N)
+    pad = np.concatenate([np.full((1, N), np.inf), vals, np.full((1, N), np.inf)])
+    is_min = (vals <= pad[:-2]) & (vals <= pad[2:])                      # the ends of the bracket count
+    score = np.where(is_min & np.isfinite(vals), vals, np.inf)
+    r = (math.sqrt(5.0) - 1.0) / 2.0
+    theta, best = np.full(N, grid[0]), np.full(N, np.inf)
+    for rank in range(3):
+        k = np.argsort(score, axis=0, kind="stable")[rank]              # (N,) grid index of the rank-th deepest minimum
+        k = np.where(np.isfinite(score[k, np.arange(N)]), k, np.argmin(vals, axis=0))
+        a, b = grid[np.maximum(k - 1, 0)], grid[np.minimum(k + 1, n_grid - 1)]
+        x1, x2 = b - r * (b - a), a + r * (b - a)
+        f1, f2 = nll(x1)[0], nll(x2)[0]
+        for _ in range(iters):
+            left = f1 < f2
+            b = np.where(left, x2, b)
+            a = np.where(left, a, x1)
+            probe = np.where(left, b - r * (b - a), a + r * (b - a))    # the surviving interior point is reused
+            fp = nll(probe)[0]
+            x1, f1, x2, f2 = (np.where(left, probe, x2), np.where(left, fp, f2), np.where(left, x1, probe),
+                              np.where(left, f1, fp))
+        cand, fc = np.where(f1 < f2, x1, x2), np.minimum(f1, f2)
+        gk = vals[k, np.arange(N)]                                       # (a minimum AT an end of the bracket)
+        cand, fc = np.where(gk < fc, grid[k], cand), np.minimum(gk, fc)
+        theta, best = np.where(fc < best, cand, theta), np.minimum(fc, best)
+    best, sse = nll(theta)
+    sigma = np.sqrt(sse / n).T                                           # (N, 3)
+    if single:
+        return ComponentArray(ode=float(theta[0]), sigma=sigma[0]), float(best[0])
+    return ComponentArray(ode=theta, sigma=sigma), best
+
+
+# ----------------------------------------------------------------------------- utilities of the scripts (src/utils.jl)
+def stratified_split(rng, types, f_train):
+    """stratified_split(rng, types, f_train) (src/utils.jl:15-31): per type, round(f_train * count) subjects sampled
+    without replacement for training; returns (sorted training indices, the complement), 0-based.  `rng` is a
+    numpy Generator (the reference's StableRNG stream is not reproducible here: the split is of the same
+    distribution, not the same subjects)."""
+    types = np.asarray(types)
+    train = []
+    for ty in dict.fromkeys(types.tolist()):                              # unique(), first-occurrence order
+        idx = np.flatnonzero(types == ty)
+        n_train = int(round(f_train * idx.size))                          # round half to even, as Julia's round
+        train.extend(rng.choice(idx, size=n_train, replace=False).tolist())
+    train = np.sort(np.asarray(train, dtype=np.int64))
+    return train, np.setdiff1d(np.arange(types.size), train)
+
+
+def argmedian(x):
+    """argmin(abs.(x .- median(x))) (src/utils.jl:43-45)."""
+    x = np.asarray(x, dtype=np.float64)
+    return int(np.argmin(np.abs(x - np.median(x))))
+
+
 # ----------------------------------------------------------------------------- SAEM
+def map_objective(p_individual, sse, n_obs, sigma, omega, *, prior_individual=0.0):
+    """map_objective (src/saem.jl:68-72): -(log-likelihood + log N(p; prior_individual, omega)) given the subject's SSE."""
+    return -(individual_log_likelihood(sse, n_obs, sigma) + _log_normal(p_individual, prior_individual, omega))
+
+
+def compute_individual_maps(p_individuals, p_neural, models, timepoints, cpeptide_data, sigma, omega, *,
+                            prior_individual=0.0, lower=-6.0, upper=4.0, n_steps=None):
+    """compute_individual_maps (src/saem.jl:74-84): every subject's maximum-a-posteriori conditional parameter with
+    the network frozen.  argmin_x -(ll + logprior) = argmin_x SSE(x) + (sigma / omega)^2 (x - prior)^2: one penalised
+    per-subject search on the device for all subjects (cude_fit_conditional) instead of an L-BFGS run per subject;
+    p_individuals (the reference's starting points) only widen the bracket."""
+    models = [models] if _is_model(models) else list(models)
+    data = np.asarray(cpeptide_data, dtype=np.float64)
+    data = data[None, :] if data.ndim == 1 else data
+    pop = _population(models, timepoints, data, n_steps)
+    if p_individuals is not None and np.size(p_individuals):
+        lower = min(lower, float(np.min(p_individuals)))
+        upper = max(upper, float(np.max(p_individuals)))
+    pop.engine.set_params(p_neural, None)
+    x, _, _ = pop.engine.fit_conditional(lower, upper, 81, 48, penalty_weight=(sigma / omega) ** 2,
+                                         penalty_center=prior_individual)
+    return x
+
+
 def individual_log_likelihood(sse, n_obs, sigma):
     """-(n/2) log sigma^2 - SSE/(2 sigma^2), -Inf on solver failure (src/saem.jl:55-66)."""
     ll = -(n_obs / 2) * math.log(sigma ** 2) - sse / (2 * sigma ** 2)

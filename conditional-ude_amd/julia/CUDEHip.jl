@@ -606,6 +606,50 @@ function fit_suppression_model(p_init, prob::SuppressionProblem, data, timepoint
     optsols, loss_traces
 end
 
+# validate_suppression_model_sigma(p_init, prob, data, timepoints, network_params) (suppression_model.jl:224-275): θ and one
+# noise level per state for a test subject (data: 3 × T), minimising Σ_s (n/2) log σ_s² + SSE_s / (2σ_s²) on the unscaled
+# residuals with the network frozen.  For given θ the optimal σ_s² is SSE_s / n: a 1-D search in θ (fine grid, then a
+# golden-section refinement around the three deepest local minima), one forward launch per probe.
+function validate_suppression_model_sigma(p_init, prob::SuppressionProblem, data::AbstractMatrix{<:Real}, timepoints,
+                                          network_params; lower = -8.0, upper = 5.0, n_grid = 261, iters = 50)
+    d3 = reshape(Array{Float64}(data), 3, :, 1)
+    c = supp_population(prob, d3, timepoints, 0.0)
+    n = size(d3, 2)
+    lo = isempty(p_init) ? lower : min(lower, minimum(p_init)); hi = isempty(p_init) ? upper : max(upper, maximum(p_init))
+    function nll(θ)
+        set_params!(c, network_params, [θ])
+        traj = forward(c; want_traj = true)[3]                       # 3 × T × 1
+        sse = [sum(abs2, traj[s, :, 1] .- d3[s, :, 1]) for s in 1:3]
+        v = sum(0.5 * n * (log(x / n) + 1) for x in sse)
+        (isfinite(v) ? v : Inf), sse
+    end
+    grid = collect(range(lo, hi; length = n_grid))
+    vals = [nll(g)[1] for g in grid]
+    mins = [k for k in 1:n_grid if isfinite(vals[k]) && (k == 1 || vals[k] <= vals[k-1]) && (k == n_grid || vals[k] <= vals[k+1])]
+    sort!(mins; by = k -> vals[k])
+    r = (sqrt(5) - 1) / 2
+    best_θ, best_v = grid[argmin(vals)], minimum(vals)
+    for k in mins[1:min(3, length(mins))]
+        a, b = grid[max(k - 1, 1)], grid[min(k + 1, n_grid)]
+        x1, x2 = b - r * (b - a), a + r * (b - a)
+        f1, f2 = nll(x1)[1], nll(x2)[1]
+        for _ in 1:iters
+            if f1 < f2
+                b, x2, f2 = x2, x1, f1
+                x1 = b - r * (b - a); f1 = nll(x1)[1]
+            else
+                a, x1, f1 = x1, x2, f2
+                x2 = a + r * (b - a); f2 = nll(x2)[1]
+            end
+        end
+        θc, vc = f1 < f2 ? (x1, f1) : (x2, f2)
+        vals[k] < vc && ((θc, vc) = (grid[k], vals[k]))
+        vc < best_v && ((best_θ, best_v) = (θc, vc))
+    end
+    v, sse = nll(best_θ)
+    (ode = best_θ, sigma = sqrt.(sse ./ n)), v
+end
+
 # ----------------------------------------------------------------------------------------------- SAEM
 # individuals: NamedTuples with glucose, timepoints, cpeptide, age, condition ("T2DM" or not), as c-peptide/06-saem.jl builds
 function individuals_population(individuals, network::Chain; n_steps = nothing)
@@ -628,6 +672,22 @@ function individual_log_likelihood(p_individual, p_neural, individual, network::
     set_params!(c, p_neural, [p_individual[1]])
     sse = forward(c; want_sse = true)[2][1]
     isfinite(sse) ? -(length(individual.timepoints) / 2) * log(σ^2) - sse / (2 * σ^2) : -Inf
+end
+
+# map_objective / compute_individual_maps (src/saem.jl:68-84): -(ll + log N(p; prior, Ω)); the MAPs of all individuals are one
+# penalised per-subject search on the device: argmin SSE(x) + (σ/Ω)² (x - prior)²  (cude_fit_conditional)
+function map_objective(p_individual, p_neural, individual, σ, Ω, network::Chain; prior_individual = 0.0)
+    ll = individual_log_likelihood(p_individual, p_neural, individual, network, σ)
+    prior = -0.5 * ((p_individual - prior_individual) / Ω)^2 - log(Ω) - 0.5 * log(2π)
+    -(ll + prior)
+end
+function compute_individual_maps(p_individuals, p_neural, individuals, σ, Ω, network::Chain; prior_individual = 0.0,
+                                 lower = -6.0, upper = 4.0)
+    c = individuals_population(individuals, network)
+    set_params!(c, p_neural, Vector{Float64}(p_individuals))
+    x, _, _ = fit_conditional(c, min(lower, minimum(p_individuals)), max(upper, maximum(p_individuals)); n_grid = 81,
+                              penalty_weight = (σ / Ω)^2, penalty_center = prior_individual)
+    x
 end
 
 # SAEM(individuals, initial_neural_params, network; ...) (:134-237): the E-step of all individuals is one call

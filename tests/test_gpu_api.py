@@ -522,3 +522,54 @@ def test_two_rank_sharded_saem_matches_single_engine(tmp_path):
     assert np.allclose(r0["nn"], one.p_neural, rtol=0, atol=1e-9)
     assert np.allclose(r0["nll"], one.total_nll_values, rtol=1e-10)
     assert abs(r0["sigma"] - one.sigma) < 1e-10 and abs(r0["omega"] - one.Omega) < 1e-11
+
+
+def test_validate_suppression_model_sigma_and_individual_maps():
+    """validate_suppression_model_sigma (suppression_model.jl:224-275; suppression/figures.jl:46) and
+    compute_individual_maps (src/saem.jl:68-84) through the GPU path, against scalar minimisations of the oracle's
+    own objectives (scipy Brent on a bracket from a grid)."""
+    import cude_oracle as o
+    from scipy.optimize import minimize_scalar
+    from cude import api
+    g = dict(np.load(os.path.join(GOLD, "suppression_lambda0.npz")))
+    prob = api.SuppressionProblem(api.neural_network_model(5, 3, input_dims=4))
+    nn, tp, arch = g["nn_4x3x5x1"][0], g["timepoints"], (4, 3, 5)
+    data = g["validation_data"][:, :, :6]
+    res, obj = api.validate_suppression_model_sigma([0.0, 1.0], prob, data, tp, nn)
+    assert res.ode.shape == (6,) and res.sigma.shape == (6, 3) and obj.shape == (6,)
+    n = len(tp)
+    for i in range(6):
+        def nll(th, i=i):
+            traj = o.supp_forward(np, nn, np.array([th]), data[:, :, i:i + 1], tp, arch, 30)
+            sse = np.array([sum((traj[t][s][0] - data[s, t, i]) ** 2 for t in range(n)) for s in range(3)])
+            return float(np.sum(0.5 * n * (np.log(sse / n) + 1.0))), sse
+        grid = np.linspace(-8.0, 5.0, 53)
+        k = int(np.argmin([nll(t)[0] for t in grid]))
+        ref = minimize_scalar(lambda t: nll(t)[0], bounds=(grid[max(k - 1, 0)], grid[min(k + 1, 52)]), method="bounded",
+                              options={"xatol": 1e-10})
+        assert obj[i] <= ref.fun + 1e-7 * max(1.0, abs(ref.fun))             # the global minimum over the bracket
+        assert abs(nll(res.ode[i])[0] - obj[i]) <= 1e-8 * max(1.0, abs(obj[i]))   # ... of the same function
+        assert np.allclose(res.sigma[i], np.sqrt(nll(res.ode[i])[1] / n), rtol=1e-8)
+    one, obj1 = api.validate_suppression_model_sigma([0.0], prob, data[:, :, 2], tp, nn)     # the reference's call shape
+    assert abs(one.ode - res.ode[2]) < 1e-6 and one.sigma.shape == (3,) and abs(obj1 - obj[2]) < 1e-9
+    api.clear_cache()
+    # MAP estimates of the conditional parameters, c-peptide model
+    net = api.chain(4, 2, "tanh")
+    gc, models = _ohashi_models(api, net, n=12)
+    nn4, sigma, omega, prior = gc["nn_2x4x4x1"][0], 0.35, 0.8, -0.7
+    maps = api.compute_individual_maps(np.zeros(12), nn4, models, gc["timepoints"], gc["cpeptide"][:12], sigma, omega,
+                                       prior_individual=prior)
+    import c_oracle as co
+    for i in range(12):
+        def objective(x, i=i):
+            r = co.cpep(gc["timepoints"], gc["glucose"][i:i + 1], gc["cpeptide"][i:i + 1], gc["ages"][i:i + 1],
+                        gc["t2dm"][i:i + 1], (2, 4, 2), nn4, np.array([x]), api.default_steps(gc["timepoints"]), 2,
+                        want_grad=False)
+            return api.map_objective(x, r["sse"][0], 5, sigma, omega, prior_individual=prior)
+        grid = np.linspace(-6.0, 4.0, 41)
+        k = int(np.argmin([objective(t) for t in grid]))
+        ref = minimize_scalar(objective, bounds=(grid[max(k - 1, 0)], grid[min(k + 1, 40)]), method="bounded",
+                              options={"xatol": 1e-10})
+        assert objective(maps[i]) <= ref.fun + 1e-8 * max(1.0, abs(ref.fun))
+        assert abs(maps[i] - ref.x) < 1e-4
+    api.clear_cache()

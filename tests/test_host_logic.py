@@ -468,3 +468,22 @@ def test_unequal_widths_are_the_zero_padded_equal_width_network():
     assert api.chain([4, 4], "tanh").mask is None and api.chain(4, 2, "tanh").widths is None
     with pytest.raises(NotImplementedError):
         api.chain([6, 3], "relu")
+
+
+def test_script_utilities_stratified_split_and_argmedian():
+    """src/utils.jl:15-31,43-45 as the reference's scripts use them (02-conditional.jl:19,463)."""
+    from cude import api
+    types = np.array(["NGT"] * 37 + ["IGT"] * 25 + ["T2DM"] * 20)
+    np.random.default_rng(0).shuffle(types)
+    train, test = api.stratified_split(np.random.default_rng(1), types, 0.7)
+    assert np.all(np.diff(train) > 0) and np.array_equal(np.sort(np.concatenate([train, test])), np.arange(82))
+    for ty, n in (("NGT", 26), ("IGT", 18), ("T2DM", 14)):         # round(0.7 * count): 25.9 -> 26, 17.5 -> 18 (half to even), 14
+        assert np.sum(types[train] == ty) == n
+    again, _ = api.stratified_split(np.random.default_rng(1), types, 0.7)
+    assert np.array_equal(again, train)
+    assert api.argmedian([3.0, 9.0, 1.0, 4.0, 7.0]) == 3 and api.argmedian([2.0, 8.0]) == 0     # even length: first of the two nearest
+    # map_objective = -(ll + log prior), src/saem.jl:68-72
+    v = api.map_objective(0.3, 1.7, 5, 0.6, 0.9, prior_individual=-0.2)
+    ll = -2.5 * np.log(0.36) - 1.7 / 0.72
+    lp = -0.5 * (0.5 / 0.9) ** 2 - np.log(0.9) - 0.5 * np.log(2 * np.pi)
+    assert abs(v + ll + lp) < 1e-14
