@@ -675,6 +675,56 @@ def _supp_population(prob, data, timepoints, lam, n_steps=None):
     return _cached(key, lambda: _SuppPop(data, timepoints, prob.network, lam, n_steps, _DEVICE))
 
 
+def lsup(u, p):
+    """lsup! (suppression_model.jl:16-20): the ground-truth model that generates the suppression data; u, p: arrays whose
+    first axis is the state / parameter index."""
+    a = p[1] * u[1] / (1.0 + p[3] * u[2])
+    return np.stack([-p[0] * u[0], p[0] * u[0] - a, a - p[2] * u[2]])
+
+
+def get_group_parameters(mu_sup, n_samples, *, rng):
+    """get_group_parameters (:33-37): max(mu + std * randn(4, n), 0.05), mu = [0.4, 0.9, 0.3, mu_sup],
+    std = [0.1, 0.1, 0.1, mu_sup / 8].  `rng`: numpy Generator (the reference's StableRNG stream is not reproducible
+    here: same distribution, other numbers)."""
+    mu = np.array([0.4, 0.9, 0.3, mu_sup])[:, None]
+    sd = np.array([0.1, 0.1, 0.1, mu_sup / 8.0])[:, None]
+    return np.maximum(mu + sd * rng.standard_normal((4, int(n_samples))), 0.05)
+
+
+def generate_data(group_means, group_sizes, timepoints, *, noise_additive=0.0, noise_multiplicative=0.0, rng=None,
+                  substeps=200):
+    """generate_data (:39-63): per group the parameters of get_group_parameters, per subject the solution of lsup! from
+    u0 = (10, 0, 0) at `timepoints` plus additive and multiplicative Gaussian noise, clamped at 0.  Returns
+    (data 3 x T x N, ground-truth suppression parameters).  Data generation is not on the device path: a classical RK4
+    solve with `substeps` steps per observation interval on the host (error ~1e-8 for the reference's grid), draws
+    in the reference's order (group parameters, then per subject the additive and the multiplicative field)."""
+    rng = np.random.default_rng(232705) if rng is None else rng
+    tp = np.asarray(timepoints, dtype=np.float64)
+    T, N = tp.size, int(np.sum(group_sizes))
+    data, gt, col = np.zeros((3, T, N)), [], 0
+    for mean, size in zip(group_means, group_sizes):
+        p = get_group_parameters(mean, size, rng=rng)
+        u = np.stack([np.full(size, 10.0), np.zeros(size), np.zeros(size)])
+        sol = np.empty((3, T, size))
+        sol[:, 0] = u
+        for k in range(1, T):
+            h = (tp[k] - tp[k - 1]) / substeps
+            for _ in range(substeps):
+                k1 = lsup(u, p)
+                k2 = lsup(u + 0.5 * h * k1, p)
+                k3 = lsup(u + 0.5 * h * k2, p)
+                k4 = lsup(u + h * k3, p)
+                u = u + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+            sol[:, k] = u
+        for j in range(size):
+            s = sol[:, :, j]
+            s = s + noise_additive * rng.standard_normal(s.shape) + noise_multiplicative * s * rng.standard_normal(s.shape)
+            data[:, :, col] = np.maximum(s, 0.0)
+            col += 1
+        gt.extend(p[3].tolist())
+    return data, np.asarray(gt)
+
+
 def SuppressionProblem(network):
     """Stand-in for `ODEProblem(ude_lsup!, [10,0,0], (0,30))` with the network closed over
     (suppression/suppression.jl:18-20): carries the network shape; u0 comes from the data (:119)."""

@@ -487,3 +487,31 @@ def test_script_utilities_stratified_split_and_argmedian():
     ll = -2.5 * np.log(0.36) - 1.7 / 0.72
     lp = -0.5 * (0.5 / 0.9) ** 2 - np.log(0.9) - 0.5 * np.log(2 * np.pi)
     assert abs(v + ll + lp) < 1e-14
+
+
+def test_generate_data_mirrors_the_reference_generator():
+    """generate_data / get_group_parameters / lsup! (suppression/src/suppression_model.jl:16-20,33-63; suppression.jl:27-36):
+    noise-free output solves the ground-truth model (scipy DOP853 at 1e-12), the noise enters as the reference writes it,
+    and the oracle's independent restatement gives the same noise-free trajectories for the same parameters."""
+    from scipy.integrate import solve_ivp
+    from cude import api
+    tp = np.linspace(0.0, 30.0, 8)
+    means, sizes = [0.5, 2.5, 5.0, 7.5, 10.0, 12.5], [3, 2, 2, 1, 2, 3]
+    data, gt = api.generate_data(means, sizes, tp, rng=np.random.default_rng(4))
+    assert data.shape == (3, 8, 13) and gt.shape == (13,) and np.all(data[:, 0] == np.array([10.0, 0.0, 0.0])[:, None])
+    # the same draws again: group parameters are the first thing drawn in every group
+    rng = np.random.default_rng(4)
+    col = 0
+    for mean, size in zip(means, sizes):
+        p = api.get_group_parameters(mean, size, rng=rng)
+        assert np.all(p >= 0.05) and np.array_equal(p[3], gt[col:col + size])
+        for j in range(size):
+            rng.standard_normal((3, 8)); rng.standard_normal((3, 8))          # the two noise fields of this subject
+            sol = solve_ivp(lambda t, u: api.lsup(u, p[:, j]), (0.0, 30.0), [10.0, 0.0, 0.0], method="DOP853", t_eval=tp,
+                            rtol=1e-12, atol=1e-14).y
+            assert np.max(np.abs(sol - data[:, :, col])) < 1e-7
+            col += 1
+    noisy, gt2 = api.generate_data(means, sizes, tp, noise_multiplicative=0.1, rng=np.random.default_rng(4))
+    assert np.array_equal(gt2, gt) and np.all(noisy >= 0.0)
+    ratio = noisy[:, 1:] / data[:, 1:] - 1.0                                   # = 0.1 * randn wherever nothing was clamped
+    assert 0.07 < np.std(ratio) < 0.13 and abs(np.mean(ratio)) < 0.03
