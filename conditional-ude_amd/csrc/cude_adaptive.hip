@@ -232,7 +232,7 @@ constexpr int adaptive_rows(bool grad) {
 // than unrolling room, as long as the gradient accumulators (2 VGPRs each) leave space for it
 template <class M, bool GRAD>
 constexpr int adaptive_waves() {
-    return !GRAD ? 2 : (M::NetT::NACC <= (M::NEED_Y ? 48 : CUDE_ADAPT_2W_NACC) ? 2 : 1);
+    return !GRAD ? 2 : (M::NetT::NACC <= (M::NEED_Y ? 24 : CUDE_ADAPT_2W_NACC) ? 2 : 1);
 }
 
 template <class M, bool IS_CPEP, bool GRAD>
@@ -447,6 +447,9 @@ void adaptive_kernel(typename M::Args a) {
 #pragma unroll
         for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
         double lam[NS], wsum = 0.0, carry = 0.0;
+        double k1_next[NS], kcar[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) { k1_next[s] = 0.0; kcar[s] = 0.0; }
 #pragma unroll
         for (int s = 0; s < NS; s++) lam[s] = 0.0;
         const double gs = a.inv_n;
@@ -528,8 +531,13 @@ void adaptive_kernel(typename M::Args a) {
             } else {
 #pragma unroll
             for (int s = 0; s < NS; s++) y[s] = TAPE(src, 2 + s);
-            // ---- re-run the seven stages of the step: k_1 .. k_7 (k_1 = the previous step's k_7 bit for bit: same
-            // arguments), Y_7 = y_{n+1}
+            // ---- re-run the stages of the step: k_1 .. k_6 and Y_7 = y_{n+1}.  k_7 = f(y_{n+1}) is k_1 of the step after
+            // this one (FSAL), which the sweep has just re-run: it is carried over (k1_next), and so is the adjoint of
+            // that k_1 (kcar), which is applied together with k_7's at the shared linearisation point -- six network
+            // evaluations and six VJPs per step instead of seven.  A lane's LAST step (and an idling lane) has no
+            // later step: the seventh evaluation is made whenever some lane of the wave needs it.
+            const bool last = !(n + 1 < n_acc);
+            const bool need7 = __any(last);
 #pragma unroll 1
             for (int sq = 0; sq <= 6; sq++) {
                 double uu[NS];
@@ -549,17 +557,25 @@ void adaptive_kernel(typename M::Args a) {
                 }
                 const double te = sq == 0 ? tn : (sq < 6 ? fma(TS_C[sq], h, tn) : tn + h);
                 double dd[NS];
-                if constexpr (IS_CPEP) {
-                    m.finish_rhs(m.production(m.forcing_input(te)), uu, dd);
-                } else {
-                    const double uh = M::Net::eval(m.p, m.c, uu);
-                    dd[0] = -0.4 * uu[0];
-                    dd[1] = fma(0.4, uu[0], -uh);
-                    dd[2] = fma(-0.3, uu[2], uh);
+                if (sq < 6 || need7) {
+                    if constexpr (IS_CPEP) {
+                        m.finish_rhs(m.production(m.forcing_input(te)), uu, dd);
+                    } else {
+                        const double uh = M::Net::eval(m.p, m.c, uu);
+                        dd[0] = -0.4 * uu[0];
+                        dd[1] = fma(0.4, uu[0], -uh);
+                        dd[2] = fma(-0.3, uu[2], uh);
+                    }
+                }
+                if (sq == 6 && !last) {
+#pragma unroll
+                    for (int s = 0; s < NS; s++) dd[s] = k1_next[s];
                 }
 #pragma unroll
                 for (int s = 0; s < NS; s++) { KROW(sq, s) = dd[s]; BROW(sq, s) = 0.0; }
             }
+#pragma unroll
+            for (int s = 0; s < NS; s++) k1_next[s] = KROW(0, s);
             // ---- the observations that were saved from this step: adjoint of o = y_n + h sum_j w_j(theta) k_j
             double yb[NS];
 #pragma unroll
@@ -599,11 +615,16 @@ void adaptive_kernel(typename M::Args a) {
                 double kb[NS], ub[NS], uu[NS];
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
-                    kb[s] = BROW(sq, s);
+                    kb[s] = BROW(sq, s) + (sq == 6 ? kcar[s] : 0.0);
                     ub[s] = sq == 6 ? lam[s] : 0.0;            // Y_7 = y_{n+1}
                     uu[s] = M::NEED_Y ? YROW(sq, s) : 0.0;
                 }
-                const double te = sq == 0 ? tn : (sq < 6 ? fma(TS_C[sq], h, tn) : tn + h);
+                if (sq == 0) {                                 // applied with k_7 of the step before (finish_grad for step 0)
+#pragma unroll
+                    for (int s = 0; s < NS; s++) kcar[s] = kb[s];
+                    break;
+                }
+                const double te = sq < 6 ? fma(TS_C[sq], h, tn) : tn + h;
                 m.vjp(te, uu, kb, ub, acc, wsum);
 #pragma unroll
                 for (int s = 0; s < NS; s++) yb[s] += ub[s];
@@ -619,6 +640,12 @@ void adaptive_kernel(typename M::Args a) {
             }
         }
         if (active && a.tape_n != nullptr) a.tape_n[set * a.N + i] = n_acc;
+        if constexpr (M::NEED_Y) {                 // k_1 of the first step: linearisation point y_0 (entry 0 of the tape)
+            double y0[NS], ub0[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) { y0[s] = TAPE(0, 2 + s); ub0[s] = 0.0; }
+            m.vjp(a.t_begin, y0, kcar, ub0, acc, wsum);
+        }
         double cst[M::NCST];
         m.finish_grad(a, i, set, acc, wsum, carry, cst);
         __syncthreads();                   // the reduction scratch aliases s_K
