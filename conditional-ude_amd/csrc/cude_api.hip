@@ -218,6 +218,7 @@ struct cude_ctx {
     DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;
     // chunked gradient path (cude_cpep2.hip)
     int chunks = 1;
+    int64_t blk0 = 0;       // > 0: mixed gradient launch -- blocks [0, blk0) on the one-lane kernel, the rest time-split
     DevBuf<double> param_mask;                      // frozen shared parameters (cude_set_param_mask); empty = none
     std::vector<double> mask_host;
     DevBuf<int32_t> chunk_start;
@@ -469,6 +470,7 @@ cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base) {
     a2.chunk_start = c->chunk_start.p;
     a2.hom_M = c->hom_M.p; a2.hom_obs = c->hom_obs.p; a2.fsum = c->fsum.p; a2.wts = c->res.p;
     a2.g_cond_part = c->g_cond_part.p; a2.partials2 = c->partials2.p;
+    a2.base.blk0 = c->blk0; a2.base.blk_count = 0;
     return a2;
 }
 
@@ -494,6 +496,7 @@ double launch_cost(double waves, double slots, double evals) {
 // stays at L = 1 (0.654 vs 0.683 for L = 2).
 int32_t setup_chunks(cude_ctx* c) {
     c->chunks = 1;
+    c->blk0 = 0;
     if (adaptive(c)) return CUDE_OK;
     const char* env = getenv("CUDE_CPEP_PATH");
     if (env && env[0] == '1') return CUDE_OK;
@@ -510,10 +513,34 @@ int32_t setup_chunks(cude_ctx* c) {
         const double cost = launch_cost((double)c->nblocks * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
         if (cost < best * (1.0 - 1e-3)) { best = cost; L = d; }
     }
+    // Mixed launch (more than one machine-fill of subjects): whole rounds of the one-lane kernel, the remainder --
+    // which would otherwise be a second, mostly idle round -- time-split on its own.  Cost = the two parts one after
+    // the other (they do overlap at the seam; not counted).
+    int64_t blk0 = 0;
+    const int64_t slots_one = (int64_t)n_cu * occ_one;
+    if (c->nblocks > slots_one && getenv("CUDE_NO_MIXED") == nullptr) {
+        const int64_t bulk = (c->nblocks / slots_one) * slots_one, rem = c->nblocks - bulk;
+        if (rem > 0) {
+            const double cost_bulk = launch_cost((double)bulk, (double)slots_one, 5.0 * S + 1.0);
+            int Lm = 0;
+            double best_m = best;
+            for (int d = 2; d <= S; d++) {
+                if (S % d) continue;
+                const double cost = cost_bulk + launch_cost((double)rem * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
+                if (cost < best_m * (1.0 - 3e-2)) { best_m = cost; Lm = d; }
+            }
+            if (Lm > 0) { L = Lm; blk0 = bulk; best = best_m; }
+        }
+    }
     if (getenv("CUDE_DEBUG_SELECTOR"))
-        fprintf(stderr, "[cude] chunk selector: nblocks=%lld CUs=%d waves/CU one-lane=%d reverse=%d -> L=%d\n",
-                (long long)c->nblocks, n_cu, occ_one, occ_rev, L);
-    if (env && env[0] == '2' && env[1] == ':') L = atoi(env + 2);
+        fprintf(stderr, "[cude] chunk selector: nblocks=%lld CUs=%d waves/CU one-lane=%d reverse=%d -> L=%d, one-lane blocks %lld\n",
+                (long long)c->nblocks, n_cu, occ_one, occ_rev, L, (long long)blk0);
+    if (env && env[0] == '2' && env[1] == ':') { L = atoi(env + 2); blk0 = 0; }
+    if (env && env[0] == '3' && env[1] == ':') {              // CUDE_CPEP_PATH=3:<one-lane blocks>:<L> (tests)
+        blk0 = std::min<int64_t>(std::max<int64_t>(atoll(env + 2), 0), c->nblocks - 1);
+        const char* q = std::strchr(env + 2, ':');
+        L = q ? atoi(q + 1) : 2;
+    }
     if (L > S) L = S;
     if (L < 2) return CUDE_OK;
     std::vector<int32_t> cs(L + 1);
@@ -529,6 +556,7 @@ int32_t setup_chunks(cude_ctx* c) {
     HIP_TRY(c->partials2.resize((size_t)L * c->nblocks * c->P));
     HIP_TRY(hipMemcpyAsync(c->chunk_start.p, cs.data(), (L + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     c->chunks = L;
+    c->blk0 = blk0;
     cude::CpepArgs a = cpep_args(c);
     cude::Cpep2Args a2 = chunk_args(c, a);
     HIP_TRY(cude::launch_cpep2_homog(a2, c->stream));
@@ -568,7 +596,13 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
         a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
-        if (c->chunks > 1 && (grad || traj_dev == nullptr)) {
+        if (c->chunks > 1 && c->blk0 > 0 && grad) {
+            a.blk_count = c->blk0;                                  // whole rounds: one lane per subject
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));
+            a.blk_count = 0;
+            cude::Cpep2Args a2 = chunk_args(c, a);                  // the remainder: time-split
+            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, true, a2, c->stream));
+        } else if (c->chunks > 1 && c->blk0 == 0 && (grad || traj_dev == nullptr)) {
             cude::Cpep2Args a2 = chunk_args(c, a);
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
         } else {
@@ -587,7 +621,12 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     if (grad && adaptive(c)) c->have_tape = true;
     if (sse_ov) return CUDE_OK;
     const int P = c->P;
-    if (grad && is_cpep(c) && c->chunks > 1) {
+    if (grad && is_cpep(c) && c->chunks > 1 && c->blk0 > 0) {
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->blk0, P + 2, 0, P, c->g_nn.p, c->stream, 1, c->param_mask.p, P));
+        HIP_TRY(cude::launch_reduce_cols(c->partials2.p, (c->nblocks - c->blk0) * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
+                                         c->param_mask.p, P, 0, /*accumulate=*/true));
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+    } else if (grad && is_cpep(c) && c->chunks > 1) {
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
                                          c->param_mask.p, P));
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
@@ -1138,7 +1177,8 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     // the sets do not fill the chip either, the time-split kernels take the set index as a third grid dimension: K x L
     // short waves instead.  Same kernels as cude_loss_grad on this context, so a set's result is bit-identical to it.
     const int L = c->chunks;
-    const bool split = !supp && L > 1 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 && getenv("CUDE_NO_MS_SPLIT") == nullptr;
+    const bool split = !supp && L > 1 && c->blk0 == 0 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 &&
+                       getenv("CUDE_NO_MS_SPLIT") == nullptr;
     // sets per launch: bounded by the grid's y / z dimension and ~512 MB of scratch
     if ((rc = ensure_tape(c))) return rc;                 // (fixes the capacity the per-set tapes share)
     const int64_t tape_rows = adaptive(c) ? cude::adaptive_tape_rows(supp ? 3 : 2, c->tape_cap, c->T) : 0;
@@ -1515,7 +1555,8 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     if (m.carry_sse && (rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;
     // Time-split forward path + carried SSE: the proposal is formed inside the forward chunks and accepted inside the
     // scan (Cpep2Args::mh_fused) -- two launches per Metropolis step instead of four, same bits.
-    const bool fused = m.carry_sse && is_cpep(c) && !adaptive(c) && c->chunks > 1 && getenv("CUDE_NO_MH_FUSE") == nullptr;
+    const bool fused = m.carry_sse && is_cpep(c) && !adaptive(c) && c->chunks > 1 && c->blk0 == 0 &&
+                       getenv("CUDE_NO_MH_FUSE") == nullptr;
     for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
         m.key = cude::RngKey{c->rng_seed, c->rng_offset, c->rng_step + k};
         if (fused) {

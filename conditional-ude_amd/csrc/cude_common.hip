@@ -47,7 +47,8 @@ hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const
 // mask (optional, n_mask entries): frozen shared parameters (cude_set_param_mask) -- column q < n_mask is scaled by mask[q]
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
                                                               int stride, int col0, double* __restrict__ out,
-                                                              const double* __restrict__ mask, int n_mask, int out_stride) {
+                                                              const double* __restrict__ mask, int n_mask, int out_stride,
+                                                              int accumulate) {
     __shared__ double s[256];
     const int q = col0 + blockIdx.x;
     partials += (int64_t)blockIdx.y * nblocks * stride;      // multi-start: one row of the grid per parameter set
@@ -60,14 +61,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
         if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[q] = (mask != nullptr && q < n_mask) ? s[0] * mask[q] : s[0];
+    if (threadIdx.x == 0) {
+        const double v0 = (mask != nullptr && q < n_mask) ? s[0] * mask[q] : s[0];
+        out[q] = accumulate ? out[q] + v0 : v0;         // accumulate: a second group of rows of the same launch
+    }
 }
 
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s, int n_sets, const double* mask, int n_mask, int out_stride) {
+                              hipStream_t s, int n_sets, const double* mask, int n_mask, int out_stride, bool accumulate) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol, n_sets), dim3(256), 0, s, partials, nblocks, stride, col0,
-                       out, mask, n_mask, out_stride > 0 ? out_stride : stride);
+                       out, mask, n_mask, out_stride > 0 ? out_stride : stride, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
 
 template <class Net, int NS, bool GRAD>
 static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
-    const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
+    const int64_t nblocks = a.blk_count > 0 ? a.blk_count : (a.N + kBlock - 1) / kBlock;   // (mixed launch: the first blocks)
     constexpr int TABROWS = Net::HAS_TAB ? 5 * Net::NCST : 0;
     constexpr int REDROWS = TABROWS > kRedRows ? TABROWS : kRedRows;
     const size_t lds = sizeof(double) * (size_t)(5 + REDROWS + (GRAD ? a.T : 0)) * kBlock;

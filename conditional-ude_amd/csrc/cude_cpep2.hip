@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     double* s_q = smem;                         // [5][kBlock]
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x;
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const int64_t gid = ((int64_t)blockIdx.x + b.blk0) * kBlock + lane;      // (blk0: mixed launch, see CpepArgs)
     const bool active = gid < b.N;
     const int64_t i = active ? gid : b.N - 1;
     const int64_t N = b.N;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     extern __shared__ double smem[];
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x;
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const int64_t gid = ((int64_t)blockIdx.x + b.blk0) * kBlock + lane;      // (blk0: mixed launch, see CpepArgs)
     const bool active = gid < b.N;
     const int64_t i = active ? gid : b.N - 1;
     const int64_t N = b.N;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
         }
     }
     const double v2[2] = {active ? sse : 0.0, (active && failed) ? 1.0 : 0.0};
-    block_reduce_store<2>(v2, smem, b.partials + (set * gridDim.x + blockIdx.x) * (P + 2) + P, lane);
+    block_reduce_store<2>(v2, smem, b.partials + (set * gridDim.x + blockIdx.x + b.blk0) * (P + 2) + P, lane);
 }
 
 // ---------------------------------------------------------------------------------- reverse sweep
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     double* s_tab = smem;                       // ... [5][W][kBlock] layer-1 factor table during it (Net::HAS_TAB)
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x;
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const int64_t gid = ((int64_t)blockIdx.x + b.blk0) * kBlock + lane;      // (blk0: mixed launch, see CpepArgs)
     const bool active = gid < b.N;
     const int64_t i = active ? gid : b.N - 1;
     const int64_t N = b.N;
@@ -487,8 +487,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
 
 // g_cond[i] = sum_c part[c][i]
 __global__ void cpep2_sum_chunks_kernel(const double* __restrict__ part, int L, int64_t N, double* __restrict__ out,
-                                        int64_t out_set_stride) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                        int64_t out_set_stride, int64_t i0) {
+    const int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     part += (int64_t)blockIdx.y * L * N;        // parameter set
     double s = 0.0;
@@ -500,8 +500,9 @@ __global__ void cpep2_sum_chunks_kernel(const double* __restrict__ part, int L, 
 template <int NIN, int W, int D>
 static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStream_t s) {
     using Net = Mlp<NIN, W, D, 1>;
-    const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
+    const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock - a.base.blk0;             // blocks [blk0, end)
     const unsigned n_sets = a.base.n_sets > 0 ? (unsigned)a.base.n_sets : 1u;
+    if (nblocks < 1 || (a.base.blk0 > 0 && n_sets > 1)) return hipErrorInvalidValue;
     const dim3 grid2((unsigned)nblocks, (unsigned)a.L, n_sets);
     const size_t lds_f = sizeof(double) * 5 * kBlock;
     static const bool no_vw = getenv("CUDE_NO_VW2") != nullptr;
@@ -525,8 +526,9 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;
     hipLaunchKernelGGL((cpep2_rev_kernel<NIN, W, D>), grid2, dim3(kBlock), lds_r, s, a);
     const int bs = 256;
-    hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N + bs - 1) / bs), n_sets), dim3(bs), 0, s,
-                       a.g_cond_part, a.L, a.base.N, a.base.g_cond, a.base.set_stride_cond);
+    const int64_t i0 = a.base.blk0 * kBlock;
+    hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N - i0 + bs - 1) / bs), n_sets), dim3(bs), 0, s,
+                       a.g_cond_part, a.L, a.base.N, a.base.g_cond, a.base.set_stride_cond, i0);
     return hipGetLastError();
 }
 

@@ -57,6 +57,9 @@ struct CpepArgs {
     const double* out_times; // [T]
     double t_begin, t_end;   // integration span = the population's time span
     double abstol, reltol;
+    // mixed launch of a large population (single parameter set): the one-lane kernel takes blocks [0, blk_count)
+    // (0 = all of them), the time-split kernels blocks [blk0, nblocks)
+    int64_t blk0, blk_count;
     double* tape;            // adaptive gradient: [n_sets][tape_cap][2 + NS][N] accepted steps (t_n, dt_n, y_n)
     int32_t tape_cap;
     int32_t* tape_n;         // [n_sets][N] accepted steps per subject, or nullptr
@@ -161,7 +164,8 @@ inline __host__ __device__ int64_t adaptive_tape_rows(int n_state, int cap, int 
 // the same for every set k: partials + k*nblocks*stride -> out + k*stride
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
                               hipStream_t s, int n_sets = 1, const double* mask = nullptr, int n_mask = 0,
-                              int out_stride = 0 /* doubles between the sets' output rows; 0 = stride */);
+                              int out_stride = 0 /* doubles between the sets' output rows; 0 = stride */,
+                              bool accumulate = false /* add to out instead of overwriting it */);
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s);

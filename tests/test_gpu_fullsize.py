@@ -51,7 +51,12 @@ def test_one_million_subjects_equals_sum_of_eight_shards():
     assert part_sum[P + 1] == 0
     assert abs(part_sum[P] / N - loss) < 1e-12 * loss
     assert np.max(np.abs(part_sum[:P] - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
-    assert np.array_equal(np.concatenate(g_parts), g_cond)      # per-subject gradients are local: bitwise equal
+    # per-subject gradients are local.  The whole population runs as a mixed launch (7 machine-fills on the one-lane
+    # kernel -- bitwise equal to the shards, which run on it entirely -- and the remainder time-split: rounding)
+    gp = np.concatenate(g_parts)
+    n_bulk = 7 * 2048 * 64
+    assert np.array_equal(gp[:n_bulk], g_cond[:n_bulk]) or np.array_equal(gp, g_cond)
+    assert np.max(np.abs(gp - g_cond)) <= 1e-12 * np.max(np.abs(g_cond))
 
 
 def test_adaptive_gradient_at_1e5_subjects_properties():
@@ -104,3 +109,43 @@ def test_adaptive_gradient_at_1e5_subjects_properties():
     ok[54_321] = False
     assert np.array_equal(gc3[ok], g_cond[ok])
     whole.close()
+
+
+def test_mixed_launch_above_one_machine_fill():
+    """More than one machine-fill of subjects (> 131 072 on 256 CUs x 2 waves x 4 SIMDs): whole rounds run on the
+    one-lane kernel, the remainder time-split (cude_api.hip: setup_chunks).  Same loss and gradient as the one-lane
+    kernel alone to rounding (and NOT bit-identical: it is a different path), per-subject gradients included; against
+    the CPU oracle (reverse-mode port) at the test-suite tolerances."""
+    import os
+    import c_oracle as co
+    import cude_oracle as o
+    from cude.engine import Engine
+    arch, N = (2, 6, 2), 200_003
+    tp, G, obs, age, t2, beta = _population(N, 11)
+    nn = o.glorot_params(arch, 5)
+    out = {}
+    for tag, env in (("mixed", None), ("one", "1")):
+        if env:
+            os.environ["CUDE_CPEP_PATH"] = env                         # the one-lane kernel for every block
+        try:
+            eng = Engine("cpep", arch, n_steps=30, n_state=3)
+            eng.set_population_cpep(tp, G, obs, age, t2)
+        finally:
+            os.environ.pop("CUDE_CPEP_PATH", None)
+        eng.set_params(nn, beta)
+        out[tag] = eng.loss_grad()
+        fwd = eng.forward()["loss"]
+        assert abs(fwd - out[tag][0]) <= 1e-13 * fwd
+        eng.adam_init(1e-2)
+        out[tag + "_trace"] = eng.adam_run(3)
+        eng.close()
+    (l1, g1, c1), (l0, g0, c0) = out["mixed"], out["one"]
+    assert abs(l1 - l0) <= 1e-13 * l0 and np.max(np.abs(g1 - g0)) <= 1e-12 * np.max(np.abs(g0))
+    assert np.max(np.abs(c1 - c0)) <= 1e-12 * np.max(np.abs(c0))
+    assert not np.array_equal(c1, c0)                                  # the remainder really took the other path
+    assert np.array_equal(c1[:131072], c0[:131072])                    # ... and the whole rounds the same one
+    assert np.allclose(out["mixed_trace"], out["one_trace"], rtol=1e-12)
+    ref = co.cpep(tp, G, obs, age, t2, arch, nn, beta, 30, 3, method="reverse")
+    assert abs(l1 - ref["loss"]) <= 1e-10 * ref["loss"]
+    assert np.max(np.abs(g1 - ref["g_nn"])) <= 1e-9 * np.max(np.abs(ref["g_nn"]))
+    assert np.max(np.abs(c1 - ref["g_beta"])) <= 1e-9 * np.max(np.abs(ref["g_beta"]))

@@ -42,7 +42,9 @@ def test_paths_agree_with_oracle_and_each_other(arch, n_state, n_steps, N):
     c = make_cpep_case(N, arch, n_steps=n_steps)
     ref = co.cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], arch, c["nn"], c["beta"], n_steps, n_state,
                   covariate=(arch[0] == 3))
-    results = {p: _run(p, c, arch, n_state, n_steps) for p in ("1", "2:2", "2:3", "2:7", f"2:{n_steps}")}
+    nb = (N + 63) // 64
+    mixed = [f"3:{nb - 1}:2", f"3:{max(nb // 2, 1)}:{n_steps}"] if nb > 1 else []     # one-lane blocks + time-split remainder
+    results = {p: _run(p, c, arch, n_state, n_steps) for p in ["1", "2:2", "2:3", "2:7", f"2:{n_steps}"] + mixed}
     for p, r in results.items():
         assert abs(r["fwd"] - ref["loss"]) < 1e-10 * ref["loss"], p
         assert abs(r["loss"] - ref["loss"]) < 1e-10 * ref["loss"], p
