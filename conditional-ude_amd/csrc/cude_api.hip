@@ -219,6 +219,8 @@ struct cude_ctx {
     // chunked gradient path (cude_cpep2.hip)
     int chunks = 1;
     int64_t blk0 = 0;       // > 0: mixed gradient launch -- blocks [0, blk0) on the one-lane kernel, the rest time-split
+    hipStream_t stream2 = nullptr;                  // mixed launch: the time-split remainder runs beside the whole rounds
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf<double> param_mask;                      // frozen shared parameters (cude_set_param_mask); empty = none
     std::vector<double> mask_host;
     DevBuf<int32_t> chunk_start;
@@ -557,6 +559,11 @@ int32_t setup_chunks(cude_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->chunk_start.p, cs.data(), (L + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     c->chunks = L;
     c->blk0 = blk0;
+    if (blk0 > 0 && !c->stream2 && getenv("CUDE_MIXED_ONE_STREAM") == nullptr) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
     cude::CpepArgs a = cpep_args(c);
     cude::Cpep2Args a2 = chunk_args(c, a);
     HIP_TRY(cude::launch_cpep2_homog(a2, c->stream));
@@ -597,11 +604,22 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         if (c->chunks > 1 && c->blk0 > 0 && grad) {
-            a.blk_count = c->blk0;                                  // whole rounds: one lane per subject
+            // whole rounds: one lane per subject; the remainder: time-split, on a second stream so that its short waves
+            // fill the SIMDs the long ones leave one by one (fork / join by events: capturable)
+            hipStream_t s2 = c->stream2 ? c->stream2 : c->stream;
+            if (c->stream2) {
+                HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            }
+            a.blk_count = c->blk0;
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));
             a.blk_count = 0;
-            cude::Cpep2Args a2 = chunk_args(c, a);                  // the remainder: time-split
-            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, true, a2, c->stream));
+            cude::Cpep2Args a2 = chunk_args(c, a);
+            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, true, a2, s2));
+            if (c->stream2) {
+                HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            }
         } else if (c->chunks > 1 && c->blk0 == 0 && (grad || traj_dev == nullptr)) {
             cude::Cpep2Args a2 = chunk_args(c, a);
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
@@ -742,6 +760,9 @@ int32_t cude_destroy(cude_ctx* c) {
     drop_graph(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return CUDE_OK;
