@@ -328,7 +328,9 @@ def extras(Engine, device, steps=20, warm=40):
     eng.set_params(nn6, pop["beta0"])
     eng.adam_init(1e-2)
     dt, ms, launches = timed_adam(eng, n, steps, warm)
-    hbm, valu = rooflines("cpep2_fwd + cpep2_scan + cpep2_rev <2,6,2,3> (time-split gradient launch)", ms, launches, n,
+    hbm, valu = rooflines("mixed gradient launch: cpep_kernel<Mlp<2,6,2,1>,3,grad> on 1024 workgroups (one long wave per "
+                          "SIMD) beside cpep2_fwd / scan / rev <2,6,2,3> on the other 539 (library's path selector)", ms,
+                          launches, n,
                           cpep_algo_bytes(T_OBS, N_STATE, True), cpep_flops())
     out["train_step_1e5"] = {"config": "BASELINE configs[2]: CPEP3 2x6x6x1, exactly 1e5 subjects, fwd + adjoint + Adam",
                              "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,

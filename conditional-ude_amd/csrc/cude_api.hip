@@ -534,6 +534,25 @@ int32_t setup_chunks(cude_ctx* c) {
             if (Lm > 0) { L = Lm; blk0 = bulk; best = best_m; }
         }
     }
+    // Mixed launch below one machine-fill (between one and two waves per SIMD, register-limited one-lane kernel): one
+    // long wave on every SIMD and the remainder as short waves in the second slot, side by side.  Measured on the
+    // headline instance (profiles/r02/mixed_launch.txt): 1e5 subjects 0.549 -> 0.485 ms, 8e4 0.448 -> 0.402 ms, no gain
+    // at 125 000 (0.610 vs 0.580) or at <= 65 536.  Model: the longer of the lone long wave (0.69 of its co-resident
+    // time) and the whole work at two waves per SIMD, + 6 %; chunks of ~6 steps, ~3 for a small remainder.
+    const int64_t half = (int64_t)n_cu * 4;
+    if (blk0 == 0 && occ_one == 8 && c->nblocks > half && c->nblocks < slots_one && getenv("CUDE_NO_MIXED") == nullptr) {
+        const int64_t rem = c->nblocks - half;
+        const double target = S / (rem >= 300 ? 6.0 : 3.0);
+        int Lm = 0;
+        for (int d = 2; d <= S; d++)
+            if (S % d == 0 && (Lm == 0 || std::fabs(d - target) < std::fabs(Lm - target))) Lm = d;
+        if (Lm > 0) {
+            const double e1 = 5.0 * S + 1.0;
+            const double cost = std::max(0.69 * e1, 1.06 * ((double)half * e1 + (double)rem * (5.0 * S + 3.0 * Lm)) / (double)slots_one);
+            // (the time-split launches measure 8-10 % above their modelled cost in this range, the one-lane launch on it)
+            if (cost <= best * (L >= 2 ? 1.08 : 1.0)) { L = Lm; blk0 = half; best = cost; }
+        }
+    }
     if (getenv("CUDE_DEBUG_SELECTOR"))
         fprintf(stderr, "[cude] chunk selector: nblocks=%lld CUs=%d waves/CU one-lane=%d reverse=%d -> L=%d, one-lane blocks %lld\n",
                 (long long)c->nblocks, n_cu, occ_one, occ_rev, L, (long long)blk0);
