@@ -465,14 +465,16 @@ int32_t enqueue_adam(cude_ctx* c) {
     return CUDE_OK;
 }
 
-cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base) {
+// all_blocks: the time-split kernels for every workgroup (forward-only launches, also when the gradient launch is mixed:
+// the chunk tables cover all subjects); otherwise from the mixed launch's first time-split block on
+cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base, bool all_blocks = false) {
     cude::Cpep2Args a2{};
     a2.base = base;
     a2.L = c->chunks;
     a2.chunk_start = c->chunk_start.p;
     a2.hom_M = c->hom_M.p; a2.hom_obs = c->hom_obs.p; a2.fsum = c->fsum.p; a2.wts = c->res.p;
     a2.g_cond_part = c->g_cond_part.p; a2.partials2 = c->partials2.p;
-    a2.base.blk0 = c->blk0; a2.base.blk_count = 0;
+    a2.base.blk0 = all_blocks ? 0 : c->blk0; a2.base.blk_count = 0;
     return a2;
 }
 
@@ -639,8 +641,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                 HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
                 HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             }
-        } else if (c->chunks > 1 && c->blk0 == 0 && (grad || traj_dev == nullptr)) {
-            cude::Cpep2Args a2 = chunk_args(c, a);
+        } else if (c->chunks > 1 && (grad || traj_dev == nullptr)) {
+            cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true);
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
         } else {
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, grad, a, c->stream));
@@ -1595,8 +1597,7 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     if (m.carry_sse && (rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;
     // Time-split forward path + carried SSE: the proposal is formed inside the forward chunks and accepted inside the
     // scan (Cpep2Args::mh_fused) -- two launches per Metropolis step instead of four, same bits.
-    const bool fused = m.carry_sse && is_cpep(c) && !adaptive(c) && c->chunks > 1 && c->blk0 == 0 &&
-                       getenv("CUDE_NO_MH_FUSE") == nullptr;
+    const bool fused = m.carry_sse && is_cpep(c) && !adaptive(c) && c->chunks > 1 && getenv("CUDE_NO_MH_FUSE") == nullptr;
     for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
         m.key = cude::RngKey{c->rng_seed, c->rng_offset, c->rng_step + k};
         if (fused) {
@@ -1605,7 +1606,7 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
             cude::CpepArgs a = cpep_args(c);
             a.cond = c->cond.p; a.nn = c->nn.p; a.sse = d_sn.p; a.traj = nullptr; a.auc = c->auc.p;
             a.g_cond = c->g_cond.p; a.partials = c->partials.p;
-            cude::Cpep2Args a2 = chunk_args(c, a);
+            cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true);
             a2.mh_fused = 1;
             a2.mh_z = device_rng ? nullptr : d_z.p + (size_t)k * N;
             a2.mh_std = proposal_std;
