@@ -18,7 +18,7 @@
  *     cude_n_failed() tells how many subjects failed.
  *   - discretisation: fixed-step Tsit5, n_steps uniform steps over [t[0], t[T-1]],
  *     observations by the Tsit5 dense-output interpolant (DESIGN.md "numerical contract"); n_steps = 0 selects the
- *     reference's own adaptive Tsit5 for the forward-only entry points.
+ *     reference's own adaptive Tsit5 (every entry point; gradients = adjoint of the accepted steps).
  */
 #ifndef CUDE_H
 #define CUDE_H
