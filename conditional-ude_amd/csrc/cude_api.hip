@@ -219,6 +219,7 @@ struct cude_ctx {
     // chunked gradient path (cude_cpep2.hip)
     int chunks = 1;
     int64_t blk0 = 0;       // > 0: mixed gradient launch -- blocks [0, blk0) on the one-lane kernel, the rest time-split
+    int64_t slots_one = 0, half_slots = 0;          // resident-wave slots of the one-lane gradient kernel; one per SIMD
     hipStream_t stream2 = nullptr;                  // mixed launch: the time-split remainder runs beside the whole rounds
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf<double> param_mask;                      // frozen shared parameters (cude_set_param_mask); empty = none
@@ -501,13 +502,16 @@ double launch_cost(double waves, double slots, double evals) {
 int32_t setup_chunks(cude_ctx* c) {
     c->chunks = 1;
     c->blk0 = 0;
+    c->slots_one = c->half_slots = 0;
     if (adaptive(c)) return CUDE_OK;
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device);
+    c->slots_one = (int64_t)n_cu * std::max(1, cude::cpep_grad_waves_per_cu(c->net, c->cfg.n_state, c->T));
+    c->half_slots = (int64_t)n_cu * 4;
     const char* env = getenv("CUDE_CPEP_PATH");
     if (env && env[0] == '1') return CUDE_OK;
     if (!cude::cpep2_shape_supported(c->net, c->cfg.n_state)) return CUDE_OK;
     const int S = c->cfg.n_steps;
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device);
     const int occ_rev = std::max(1, cude::cpep2_rev_waves_per_cu(c->net));
     const int occ_one = std::max(1, cude::cpep_grad_waves_per_cu(c->net, c->cfg.n_state, c->T));
     int L = 1;
@@ -592,6 +596,14 @@ int32_t setup_chunks(cude_ctx* c) {
     return CUDE_OK;
 }
 
+// Alternating issue priority in the one-lane gradient kernel (CpepArgs::prio_shift): for a launch of `blocks` workgroups
+// that is a single round with two waves on (some of) the SIMDs.  CUDE_PRIO_SHIFT=k overrides (0 = never).
+int prio_shift_for(const cude_ctx* c, int64_t blocks) {
+    static const char* env = getenv("CUDE_PRIO_SHIFT");
+    if (env) return atoi(env);
+    return (c->slots_one == 2 * c->half_slots && blocks > c->half_slots && blocks <= c->slots_one) ? 5 : 0;
+}
+
 // launches the ensemble kernel + second-stage reduction (+ all-reduce, + L2 term)
 // cond_ov / sse_ov: evaluate at other conditional parameters / write the per-subject SSE elsewhere and stop
 // after the ensemble kernels (used by the Metropolis E-step, which needs neither loss nor gradient).
@@ -632,7 +644,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                 HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
                 HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             }
-            a.blk_count = c->blk0;
+            a.blk_count = c->blk0;          // (no alternating issue priority here: it starves the short waves -- measured)
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));
             a.blk_count = 0;
             cude::Cpep2Args a2 = chunk_args(c, a);
@@ -645,6 +657,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
             cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true);
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
         } else {
+            if (grad) a.prio_shift = prio_shift_for(c, c->nblocks);
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, grad, a, c->stream));
         }
     } else {

@@ -89,8 +89,19 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
 #endif
     typename Net::VW vw;
     if constexpr (kVW) Net::load_vw(p, vw);
+    // Issue priority (CpepArgs::prio_shift > 0; single-round launches with two waves per SIMD): the arbiter serves the
+    // OLDEST ready wave first, so of two co-resident waves one runs ahead, finishes at ~0.7 of the launch and leaves the
+    // other alone on the SIMD at the poor single-wave issue rate.  The two take turns at the higher priority instead --
+    // by the parity of their hardware wave slot, every 2^prio_shift evaluations -- and finish together
+    // (125 000 subjects: 0.582 -> 0.554 ms; no effect with one wave per SIMD, -2 % over many rounds: off there).
+    const unsigned prio_par = GRAD ? (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u) : 0u;   // HW_ID.wave_id
+    const int prio_shift = GRAD ? a.prio_shift : 0;
 #pragma unroll 1
     for (int e = -1; e < 5 * S; e++) {
+        if (GRAD && prio_shift > 0) {
+            if ((((unsigned)(e + 1) >> prio_shift) ^ prio_par) & 1u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         double xv = 0.0;
         bool tab = false;
         if (e >= 0) {
@@ -234,6 +245,10 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         // evaluations in reverse order; e = -1 is the baseline with weight -sum(w)
 #pragma unroll 1
         for (int e = 5 * S - 1; e >= -1; e--) {
+            if (prio_shift > 0) {
+                if ((((unsigned)(e + 1) >> prio_shift) ^ prio_par) & 1u) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(0);
+            }
                 if (e >= 0 && s == 4) {
                 // ---- adjoint algebra of step n (J_f = A, no forward state needed)
                 double kb[7][2];

@@ -60,6 +60,8 @@ struct CpepArgs {
     // mixed launch of a large population (single parameter set): the one-lane kernel takes blocks [0, blk_count)
     // (0 = all of them), the time-split kernels blocks [blk0, nblocks)
     int64_t blk0, blk_count;
+    int32_t prio_shift;      // one-lane gradient kernel: co-resident waves alternate issue priority every 2^prio_shift
+                             // evaluations (0 = off); set by the host for single-round launches with two waves per SIMD
     double* tape;            // adaptive gradient: [n_sets][tape_cap][2 + NS][N] accepted steps (t_n, dt_n, y_n)
     int32_t tape_cap;
     int32_t* tape_n;         // [n_sets][N] accepted steps per subject, or nullptr
