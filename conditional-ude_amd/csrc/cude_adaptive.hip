@@ -287,8 +287,19 @@ void adaptive_kernel(typename M::Args a) {
     // phase -2: k1 = f(t0, y0); -1: f1 probe of the initial-step heuristic; 1..6: stages 2..7 of the current step
     int st = -2;
     double Y[NS], ynew[NS];
+    // alternating issue priority of co-resident waves (see cpep_kernel): every 2^prio_shift evaluations
+    int prio_shift = 0;
+    unsigned prio_par = 0, it = 0;
+    if constexpr (GRAD && IS_CPEP) {
+        prio_shift = a.prio_shift;
+        prio_par = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u;       // HW_ID.wave_id
+    }
 #pragma unroll 1
     while (true) {
+        if (GRAD && IS_CPEP && prio_shift > 0) {
+            if ((((it++) >> prio_shift) ^ prio_par) & 1u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         double te;
         if (st == -2) {
             te = t0;
@@ -460,6 +471,10 @@ void adaptive_kernel(typename M::Args a) {
 #pragma unroll 1
         for (int n = n_max - 1; n >= 0; n--) {
             // a lane with fewer accepted steps idles on its last entry with zero adjoints until its own steps come up
+            if (IS_CPEP && prio_shift > 0) {               // (5 VJPs per step: switch every 2^(prio_shift - 2) steps)
+                if ((((unsigned)n >> (prio_shift > 2 ? prio_shift - 2 : 0)) ^ prio_par) & 1u) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             const bool on = n < n_acc;
             const int src = on ? n : (n_acc > 0 ? n_acc - 1 : 0);
             const double tn = TAPE(src, 0), h = TAPE(src, 1);

@@ -503,9 +503,10 @@ int32_t setup_chunks(cude_ctx* c) {
     c->chunks = 1;
     c->blk0 = 0;
     c->slots_one = c->half_slots = 0;
-    if (adaptive(c)) return CUDE_OK;
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device);
+    c->half_slots = (int64_t)n_cu * 4;
+    if (adaptive(c)) return CUDE_OK;
     c->slots_one = (int64_t)n_cu * std::max(1, cude::cpep_grad_waves_per_cu(c->net, c->cfg.n_state, c->T));
     c->half_slots = (int64_t)n_cu * 4;
     const char* env = getenv("CUDE_CPEP_PATH");
@@ -657,7 +658,12 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
             cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true);
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
         } else {
-            if (grad) a.prio_shift = prio_shift_for(c, c->nblocks);
+            if (grad && !adaptive(c)) a.prio_shift = prio_shift_for(c, c->nblocks);
+            if (grad && adaptive(c)) {      // adaptive gradient kernel: at most two waves per SIMD (measured -4.8 %)
+                static const char* env_ps = getenv("CUDE_PRIO_SHIFT");
+                a.prio_shift = env_ps ? atoi(env_ps)
+                                      : ((c->nblocks > c->half_slots && c->nblocks <= 2 * c->half_slots) ? 5 : 0);
+            }
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, grad, a, c->stream));
         }
     } else {
