@@ -431,16 +431,17 @@ def _type_block(out):
     Array{Float64,1} DataType object), both relative to the end of the file header."""
     t0 = len(out) - HEADER_BYTES
     # sizes are fixed, so the addresses of everything that follows are known up front
-    committed_len = 6 + (4 + len(_DT_DATATYPE)) + (4 + 65) + 4
-    heap = (t0 + committed_len + 7) // 8 * 8
+    def committed(heap_rel):
+        shared = b"\x03\x02" + struct.pack("<Q", t0)
+        attr = (bytes.fromhex("02010b000a000400") + b"julia_type\x00" + shared + bytes([2, 0, 0, 0]) +
+                _vlen(13, heap_rel, 1) + _vlen(0, 0, 0))
+        return _ohdr([_msg(0x03, _DT_DATATYPE, 0x40), _msg(0x0C, attr)])
+    heap = (t0 + len(committed(0)) + 7) // 8 * 8
     array_obj = heap + _HEAP_BYTES + 16
     dt_obj_len = len(_datatype_object(0, 0, 0, 0, (0, 0)))
     float_obj = array_obj + dt_obj_len
     one_obj = float_obj + dt_obj_len
-    shared = b"\x03\x02" + struct.pack("<Q", t0)
-    attr = (bytes.fromhex("02010b000a000400") + b"julia_type\x00" + shared + bytes([2, 0, 0, 0]) +
-            _vlen(13, heap, 1) + _vlen(0, 0, 0))
-    out += _ohdr([_msg(0x03, _DT_DATATYPE, 0x40), _msg(0x0C, attr)])
+    out += committed(heap)
     _pad8(out)
     assert len(out) - HEADER_BYTES == heap
     objects = [b"Core.DataType", b"Core.Array", b"Core.Float64", struct.pack("<QQ", float_obj, one_obj)]
