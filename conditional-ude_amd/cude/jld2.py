@@ -513,6 +513,8 @@ def save(path, entries, julia_version="1.11.1", vectors_as_matrix=False):
     links = []
     types = None                                                # (committed datatype, Array{Float64,1} description)
     for name, value in entries.items():
+        if name == "_types":
+            raise ValueError("'_types' is JLD2's own group of committed datatypes: not available as a dataset name")
         if isinstance(value, (list, tuple)) and len(value) and isinstance(value[0], np.ndarray):
             if vectors_as_matrix:
                 value = np.stack(value, axis=1)
