@@ -519,7 +519,9 @@ int32_t setup_chunks(cude_ctx* c) {
     double best = launch_cost((double)c->nblocks, (double)n_cu * occ_one, 5.0 * S + 1.0);
     for (int d = 2; d <= S; d++) {
         if (S % d) continue;
-        const double cost = launch_cost((double)c->nblocks * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
+        // (x 1.10: time-split launches of a whole population measure 8-10 % above this model, the one-lane launch on it --
+        // 300 000 subjects: L = 3 modelled 9 % faster than one lane per subject, measured 7 % slower)
+        const double cost = 1.10 * launch_cost((double)c->nblocks * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
         if (cost < best * (1.0 - 1e-3)) { best = cost; L = d; }
     }
     // Mixed launch (more than one machine-fill of subjects): whole rounds of the one-lane kernel, the remainder --
@@ -527,18 +529,20 @@ int32_t setup_chunks(cude_ctx* c) {
     // the other (they do overlap at the seam; not counted).
     int64_t blk0 = 0;
     const int64_t slots_one = (int64_t)n_cu * occ_one;
-    if (c->nblocks > slots_one && getenv("CUDE_NO_MIXED") == nullptr) {
+    // Only between one and two machine-fills: with two or more whole rounds the one-lane launch's own tail is amortised
+    // and the mixed launch measured slower (300 000 subjects 1.461 against 1.366 ms, 1e6 4.415 against 4.183 ms).
+    if (c->nblocks > slots_one && c->nblocks < 2 * slots_one && getenv("CUDE_NO_MIXED") == nullptr) {
         const int64_t bulk = (c->nblocks / slots_one) * slots_one, rem = c->nblocks - bulk;
         if (rem > 0) {
             const double cost_bulk = launch_cost((double)bulk, (double)slots_one, 5.0 * S + 1.0);
+            // chunks of ~6 steps for the remainder (measured best at 140 000 ... 200 000 subjects: L = 5 or 6 of S = 30)
             int Lm = 0;
-            double best_m = best;
-            for (int d = 2; d <= S; d++) {
-                if (S % d) continue;
-                const double cost = cost_bulk + launch_cost((double)rem * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
-                if (cost < best_m * (1.0 - 3e-2)) { best_m = cost; Lm = d; }
+            for (int d = 2; d <= S; d++)
+                if (S % d == 0 && (Lm == 0 || std::fabs(d - S / 6.0) < std::fabs(Lm - S / 6.0))) Lm = d;
+            if (Lm > 0) {
+                const double cost = cost_bulk + launch_cost((double)rem * Lm, (double)n_cu * occ_rev, 5.0 * S / Lm + 3.0);
+                if (cost < best * (1.0 - 3e-2)) { L = Lm; blk0 = bulk; best = cost; }
             }
-            if (Lm > 0) { L = Lm; blk0 = bulk; best = best_m; }
         }
     }
     // Mixed launch below one machine-fill (between one and two waves per SIMD, register-limited one-lane kernel): one
@@ -556,8 +560,7 @@ int32_t setup_chunks(cude_ctx* c) {
         if (Lm > 0) {
             const double e1 = 5.0 * S + 1.0;
             const double cost = std::max(0.69 * e1, 1.06 * ((double)half * e1 + (double)rem * (5.0 * S + 3.0 * Lm)) / (double)slots_one);
-            // (the time-split launches measure 8-10 % above their modelled cost in this range, the one-lane launch on it)
-            if (cost <= best * (L >= 2 ? 1.08 : 1.0)) { L = Lm; blk0 = half; best = cost; }
+            if (cost <= best) { L = Lm; blk0 = half; best = cost; }
         }
     }
     if (getenv("CUDE_DEBUG_SELECTOR"))
