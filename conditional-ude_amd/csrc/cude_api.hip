@@ -248,6 +248,7 @@ struct cude_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double host_red[3];
+    double* pinned = nullptr;       // page-locked staging of the small result vectors ([g_nn; loss sum; n_failed])
     // scratch of cude_multistart_loss_grad (kept between calls: it is called once per optimiser iteration)
     DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt, ms_act;
     DevBuf<double> ms_fsum, ms_wts, ms_gcp, ms_p2;   // time-split path with parameter sets (small populations)
@@ -712,15 +713,17 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
 // copies [loss_sum, n_failed] (and optionally g_nn) back and forms the reference's loss value
 int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
     const int P = c->P;
-    std::vector<double> tmp(P + 2);
+    std::vector<double> pageable;
+    if (!c->pinned) pageable.resize(P + 2);
+    double* const tmp = c->pinned ? c->pinned : pageable.data();      // page-locked: no staging copy behind the sync
     if (g_nn_host) {
-        HIP_TRY(hipMemcpyAsync(tmp.data(), c->g_nn.p, (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(tmp, c->g_nn.p, (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     } else {
-        HIP_TRY(hipMemcpyAsync(tmp.data() + P, c->g_nn.p + P, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(tmp + P, c->g_nn.p + P, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->last_failed = (int64_t)std::llround(tmp[P + 1]);
-    if (g_nn_host) std::memcpy(g_nn_host, tmp.data(), P * sizeof(double));
+    if (g_nn_host) std::memcpy(g_nn_host, tmp, P * sizeof(double));
     if (loss) *loss = (c->last_failed > 0 || !std::isfinite(tmp[P])) ? std::numeric_limits<double>::infinity()
                                                                      : tmp[P] / c->n_global;
     return CUDE_OK;
@@ -785,6 +788,7 @@ int32_t cude_create(const cude_config* cfg, cude_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(CUDE_ERR_HIP, hipGetErrorString(e)); }
     const int P = c->P;
+    if (hipHostMalloc((void**)&c->pinned, (size_t)(P + 2) * sizeof(double), hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;
     if (c->nn.resize(P) || c->g_nn.resize(P + 2) || c->m_nn.resize(P) || c->v_nn.resize(P)) {
         cude_destroy(c);
         return fail(CUDE_ERR_HIP, "hipMalloc failed");
@@ -803,6 +807,7 @@ int32_t cude_destroy(cude_ctx* c) {
     drop_graph(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
