@@ -149,3 +149,45 @@ def test_mixed_launch_above_one_machine_fill():
     assert abs(l1 - ref["loss"]) <= 1e-10 * ref["loss"]
     assert np.max(np.abs(g1 - ref["g_nn"])) <= 1e-9 * np.max(np.abs(ref["g_nn"]))
     assert np.max(np.abs(c1 - ref["g_beta"])) <= 1e-9 * np.max(np.abs(ref["g_beta"]))
+
+
+def test_mixed_launch_below_one_fill_failures_and_small_remainder():
+    """66 000 subjects: the selector pairs 1024 workgroups on the one-lane kernel with a remainder of 8 (the last one
+    ragged) time-split beside them.  Against the one-lane kernel alone; a failing subject in either part fails the
+    evaluation and is counted, everybody else's gradient is untouched."""
+    import os
+    import cude_oracle as o
+    from cude.engine import Engine
+    arch, N = (2, 6, 2), 66_000
+    tp, G, obs, age, t2, beta = _population(N, 3)
+    nn = o.glorot_params(arch, 5)
+    res = {}
+    for tag in ("auto", "one"):
+        if tag == "one":
+            os.environ["CUDE_CPEP_PATH"] = "1"
+        try:
+            eng = Engine("cpep", arch, n_steps=30, n_state=3)
+            eng.set_population_cpep(tp, G, obs, age, t2)
+        finally:
+            os.environ.pop("CUDE_CPEP_PATH", None)
+        eng.set_params(nn, beta)
+        res[tag] = eng.loss_grad()
+        if tag == "auto":
+            bad = beta.copy()
+            bad[100] = np.nan                       # in the one-lane part
+            bad[65_990] = np.inf                    # in the time-split remainder
+            eng.set_params(nn, bad)
+            lb, _, gcb = eng.loss_grad()
+            assert np.isinf(lb) and eng.n_failed() == 2
+            ok = np.ones(N, bool)
+            ok[[100, 65_990]] = False
+            # (the two waves that hold a failing lane leave the layer-1 exponent table -- a wave-uniform choice -- so
+            # their other lanes agree to rounding; every other wave bit for bit)
+            same = gcb == res["auto"][2]
+            assert np.count_nonzero(~same[ok]) <= 2 * 63
+            assert np.max(np.abs(gcb[ok] - res["auto"][2][ok])) <= 1e-12 * np.max(np.abs(res["auto"][2]))
+        eng.close()
+    (l1, g1, c1), (l0, g0, c0) = res["auto"], res["one"]
+    assert abs(l1 - l0) <= 1e-13 * l0 and np.max(np.abs(g1 - g0)) <= 1e-12 * np.max(np.abs(g0))
+    assert np.array_equal(c1[:65_536], c0[:65_536]) and not np.array_equal(c1[65_536:], c0[65_536:])
+    assert np.max(np.abs(c1 - c0)) <= 1e-12 * np.max(np.abs(c0))
