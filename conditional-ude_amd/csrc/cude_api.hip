@@ -606,7 +606,9 @@ int32_t setup_chunks(cude_ctx* c) {
 int prio_shift_for(const cude_ctx* c, int64_t blocks) {
     static const char* env = getenv("CUDE_PRIO_SHIFT");
     if (env) return atoi(env);
-    return (c->slots_one == 2 * c->half_slots && blocks > c->half_slots && blocks <= c->slots_one) ? 5 : 0;
+    // two waves on (some of) the SIMDs and no third: also the kernels that could hold three (2-4-4-1 / 2 states at
+    // 120 000 ... 131 072 subjects: 0.451 -> 0.426 ms); not the one-wave kernels (2-7-7-1: +2 %)
+    return (c->slots_one >= 2 * c->half_slots && blocks > c->half_slots && blocks <= 2 * c->half_slots) ? 5 : 0;
 }
 
 // launches the ensemble kernel + second-stage reduction (+ all-reduce, + L2 term)
