@@ -564,6 +564,26 @@ int32_t setup_chunks(cude_ctx* c) {
             if (cost <= best) { L = Lm; blk0 = half; best = cost; }
         }
     }
+    // Kernels that could hold three waves per SIMD (the reference's 2-4-4-1 / 2-state instance): a third resident wave
+    // adds no throughput to the one-lane launch (0.45 ms with one or two waves per SIMD, 0.83 ms with three), which the
+    // slot-count model above does not know.  Measured rule (profiles/r02/mixed_launch.txt, second table): from ~1.2
+    // waves per SIMD up to two, one long wave per SIMD + the rest in chunks of ~3 steps (1e5 subjects 0.387 -> 0.369 ms);
+    // between two and three, two long waves per SIMD + the rest in chunks of ~6 steps (150 000: 0.549 -> 0.494 ms,
+    // 196 608: 0.834 -> 0.629 ms).
+    if (blk0 == 0 && occ_one >= 12 && getenv("CUDE_NO_MIXED") == nullptr) {
+        int64_t bulk = 0;
+        double target = 0.0;
+        if (c->nblocks >= half + half / 6 && c->nblocks <= half + 3 * half / 4) { bulk = half; target = S / 3.0; }
+        else if (c->nblocks > half + 3 * half / 4 && c->nblocks <= 2 * half) L = 1;   // two waves per SIMD, taking turns at
+                                                                                     // the issue priority: 0.428 ms up to 131 072
+        else if (c->nblocks > 2 * half && c->nblocks <= 3 * half) { bulk = 2 * half; target = S / 6.0; }
+        if (bulk > 0) {
+            int Lm = 0;
+            for (int d = 2; d <= S; d++)
+                if (S % d == 0 && (Lm == 0 || std::fabs(d - target) < std::fabs(Lm - target))) Lm = d;
+            if (Lm > 0) { L = Lm; blk0 = bulk; }
+        }
+    }
     if (getenv("CUDE_DEBUG_SELECTOR"))
         fprintf(stderr, "[cude] chunk selector: nblocks=%lld CUs=%d waves/CU one-lane=%d reverse=%d -> L=%d, one-lane blocks %lld\n",
                 (long long)c->nblocks, n_cu, occ_one, occ_rev, L, (long long)blk0);
