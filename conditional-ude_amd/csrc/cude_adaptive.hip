@@ -247,6 +247,7 @@ void adaptive_kernel(typename M::Args a) {
     double* s_B = smem + KROWS * kBlock;
     double* s_Y = s_B + 7 * NS * kBlock;
     const int lane = threadIdx.x;
+    if constexpr (M::NetT::USES_TANH) tanh_tab_init(lane);
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
     const bool active = gid < a.N;
     const int64_t i = active ? gid : a.N - 1;

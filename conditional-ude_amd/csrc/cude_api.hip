@@ -279,6 +279,19 @@ bool supp_keep_activations(const cude_ctx* c, int64_t n_sets) {
     return (double)n_sets * (double)supp_act_doubles(c) * 8.0 <= 256e6;
 }
 
+// c-peptide gradient launches (one lane per subject, single parameter set): CUDE_CPEP_KEEP=1 keeps the upper layers'
+// activations of the forward sweep in HBM for the reverse sweep (CpepArgs::act)
+size_t cpep_act_doubles(const cude_ctx* c) {
+    const int nk = cude::cpep_keep_values(c->net);
+    if (nk == 0 || c->cfg.n_steps == 0) return 0;
+    return (size_t)(5 * c->cfg.n_steps + 1) * (size_t)nk * (size_t)c->N;
+}
+bool cpep_keep_activations(const cude_ctx* c) {
+    const char* env = getenv("CUDE_CPEP_KEEP");
+    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1' && cpep_act_doubles(c) > 0;
+    return false;
+}
+
 // both c-peptide models share the population layout, solver tables and the ensemble kernel
 bool is_cpep(const cude_ctx* c) { return c->cfg.model == CUDE_MODEL_CPEP || c->cfg.model == CUDE_MODEL_CPEP_SYM; }
 
@@ -663,6 +676,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.cond = cond_ov ? cond_ov : c->cond.p; a.nn = c->nn.p;
         a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
+        // allocated by cude_set_population_cpep (never here: this function also runs under stream capture)
+        if (grad && !adaptive(c) && c->act.p && cpep_act_doubles(c) > 0 && c->act.n >= cpep_act_doubles(c)) a.act = c->act.p;
         if (c->chunks > 1 && c->blk0 > 0 && grad) {
             // whole rounds: one lane per subject; the remainder: time-split, on a second stream so that its short waves
             // fill the SIMDs the long ones leave one by one (fork / join by events: capturable)
@@ -874,6 +889,7 @@ int32_t cude_set_population_cpep(cude_ctx* c, int64_t N, int32_t n_obs, const do
     HIP_TRY(cude::launch_prepare_cpep(N, T, gdev.p, c->obs.p, c->age.p, t2dev.p, c->k0.p, c->k1.p, c->k2.p, c->c0.p,
                                       c->dG.p, c->stream));
     if ((rc = alloc_common(c))) return rc;
+    HIP_TRY(c->act.resize(cpep_keep_activations(c) ? cpep_act_doubles(c) : 0));
     if ((rc = upload_tables(c, true))) return rc;
     if ((rc = setup_chunks(c))) return rc;
     c->n_global = (double)N;

@@ -22,8 +22,11 @@
 namespace cude {
 
 // Net: the production term -- Mlp<NIN, W, D, 1> (conditional UDE) or MmProd<RAW> (symbolic model).
-template <class Net, int NS, bool GRAD>
-__global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
+// KEEP (gradient only, CpepArgs::act): the forward sweep stores the upper layers' activations of every evaluation to HBM
+// ([evaluation][value][subject], coalesced) and the reverse sweep reads them back -- one evaluation ahead -- instead of
+// re-evaluating those layers: bit-identical results, Net::NKEEP * 8 bytes each way per evaluation and subject.
+template <class Net, int NS, bool GRAD, bool KEEP = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2 : 1))) void cpep_kernel(CpepArgs a) {
     constexpr int P = Net::P;
     constexpr int NC = Net::NC;
     constexpr int TABROWS = Net::HAS_TAB ? 5 * Net::NCST : 0;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     int kind = 0;
     bool run_ok = false;                         // wave-uniform: the current run is inside the table's exact range
 #ifndef CUDE_NO_VW
-    constexpr bool kVW = GRAD && Net::HAS_VW;    // only where the reverse sweep already pays for the registers
+    constexpr bool kVW = (GRAD && Net::HAS_VW) || KEEP;   // only where the reverse sweep already pays for the registers
 #else
     constexpr bool kVW = false;
 #endif
@@ -96,6 +99,8 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
     // (125 000 subjects: 0.582 -> 0.554 ms; no effect with one wave per SIMD, -2 % over many rounds: off there).
     const unsigned prio_par = GRAD ? (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u) : 0u;   // HW_ID.wave_id
     const int prio_shift = GRAD ? a.prio_shift : 0;
+    // (here, not at the top: the table's global read then travels with the subject's own loads -- one latency, not two)
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane);
 #pragma unroll 1
     for (int e = -1; e < 5 * S; e++) {
         if (GRAD && prio_shift > 0) {
@@ -144,8 +149,17 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         }
         const double x[1] = {xv};
         double v;
-        if constexpr (kVW) v = Net::eval_vw(p, vw, c, x, tab, &E1);
-        else v = Net::eval(p, c, x, tab, &E1);
+        if constexpr (KEEP) {
+            double keep[Net::NKEEP];
+            v = Net::eval_vw_keep(p, vw, c, x, tab, &E1, keep);
+            double* dst = a.act + ((int64_t)(e + 1) * Net::NKEEP) * N + i;
+#pragma unroll
+            for (int q = 0; q < Net::NKEEP; q++) dst[(int64_t)q * N] = keep[q];
+        } else if constexpr (kVW) {
+            v = Net::eval_vw(p, vw, c, x, tab, &E1);
+        } else {
+            v = Net::eval(p, c, x, tab, &E1);
+        }
         if (e < 0) { base = v; s = 0; continue; }
         s_q[s * kBlock + lane] = v - base;
         if (++s < 5) continue;
@@ -242,6 +256,13 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
         cur_seg = -1;
         n = S - 1;
         s = 4;
+        // kept activations of the evaluation about to be reversed, requested one evaluation ahead
+        double kn[Net::NKEEP];
+        if constexpr (KEEP) {
+            const double* src = a.act + ((int64_t)(5 * S) * Net::NKEEP) * N + i;
+#pragma unroll
+            for (int q = 0; q < Net::NKEEP; q++) kn[q] = src[(int64_t)q * N];
+        }
         // evaluations in reverse order; e = -1 is the baseline with weight -sum(w)
 #pragma unroll 1
         for (int e = 5 * S - 1; e >= -1; e--) {
@@ -360,7 +381,23 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
                 wv = -wtot;
             }
             const double x[1] = {xv};
-            Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy, tab, &E1);
+            if constexpr (KEEP) {
+                double hk[Net::DEPTH][Net::WIDTH];
+#pragma unroll
+                for (int l = 1; l < Net::DEPTH; l++)
+#pragma unroll
+                    for (int j = 0; j < Net::WIDTH; j++) hk[l][j] = kn[(l - 1) * Net::WIDTH + j];
+                const double sg = kn[Net::NKEEP - 1];
+                if (e >= 0) {                   // next evaluation's (e - 1: row block e) values: in flight during this one
+                    const double* src = a.act + ((int64_t)e * Net::NKEEP) * N + i;
+#pragma unroll
+                    for (int q = 0; q < Net::NKEEP; q++) kn[q] = src[(int64_t)q * N];
+                }
+                Net::layer1(p, c, x, hk[0], tab, &E1);
+                Net::template backward<false>(launder(p), x, hk, sg, wv, acc, dxdummy);
+            } else {
+                Net::template eval_grad<false>(p, c, x, wv, acc, dxdummy, tab, &E1);
+            }
         }
 
         if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(p, acc, cst);
@@ -381,6 +418,17 @@ __global__ __launch_bounds__(kBlock) void cpep_kernel(CpepArgs a) {
 // ------------------------------------------------------------------------------------ dispatch
 #define CUDE_CPEP_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
 
+// shapes with a kept-activation variant of the gradient kernel: the forward sweep must already hold the upper layers'
+// weights in VGPRs (Mlp::HAS_VW) and there must be an upper layer to keep
+template <class Net>
+constexpr bool cpep_can_keep() {
+#ifdef CUDE_NO_KEEP
+    return false;
+#else
+    return Net::HAS_VW && Net::DEPTH >= 2 && Net::HAS_TAB;
+#endif
+}
+
 template <class Net, int NS, bool GRAD>
 static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
     const int64_t nblocks = a.blk_count > 0 ? a.blk_count : (a.N + kBlock - 1) / kBlock;   // (mixed launch: the first blocks)
@@ -388,6 +436,12 @@ static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
     constexpr int REDROWS = TABROWS > kRedRows ? TABROWS : kRedRows;
     const size_t lds = sizeof(double) * (size_t)(5 + REDROWS + (GRAD ? a.T : 0)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
+    if constexpr (GRAD && cpep_can_keep<Net>()) {
+        if (a.act != nullptr && n_sets == 1) {
+            hipLaunchKernelGGL((cpep_kernel<Net, NS, true, true>), dim3((unsigned)nblocks, 1), dim3(kBlock), lds, s, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((cpep_kernel<Net, NS, GRAD>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
@@ -412,7 +466,16 @@ static int grad_occupancy(int n_state, int T) {
 // resident waves per CU of the one-lane-per-subject gradient kernel (0 = unknown)
 int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T) {
     if (net.symbolic()) return grad_occupancy<MmProd<false>>(n_state, T);
-#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return grad_occupancy<Mlp<NIN, W, D, 1>>(n_state, T);
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return grad_occupancy<CpepNet<NIN, W, D>>(n_state, T);
+    CUDE_CPEP_SHAPES(X)
+#undef X
+    return 0;
+}
+
+// kept values per evaluation of the gradient kernel's kept-activation variant (0: the shape has none)
+int cpep_keep_values(const NetShape& net) {
+    if (net.symbolic()) return 0;
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return cpep_can_keep<CpepNet<NIN, W, D>>() ? CpepNet<NIN, W, D>::NKEEP : 0;
     CUDE_CPEP_SHAPES(X)
 #undef X
     return 0;
@@ -432,7 +495,7 @@ hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepAr
     if (net.symbolic())
         return a.cond_raw ? launch_shape<MmProd<true>>(n_state, grad, a, s) : launch_shape<MmProd<false>>(n_state, grad, a, s);
 #define X(NIN, W, D) \
-    if (net.nin == NIN && net.width == W && net.depth == D) return launch_shape<Mlp<NIN, W, D, 1>>(n_state, grad, a, s);
+    if (net.nin == NIN && net.width == W && net.depth == D) return launch_shape<CpepNet<NIN, W, D>>(n_state, grad, a, s);
     CUDE_CPEP_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

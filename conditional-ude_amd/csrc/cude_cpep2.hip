@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_homog_kernel(Cpep2Args a) {
 // latency-bound regime of small populations (forward launch at 1e4 subjects 46.4 -> 45.0 us, 2e4 64.2 -> 61.5 us).
 template <int NIN, int W, int D, int NS, bool VWR = false>
 __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
-    using Net = Mlp<NIN, W, D, 1>;
+    using Net = CpepNet<NIN, W, D>;
     constexpr int NC = NIN - 1;
     extern __shared__ double smem[];
     double* s_q = smem;                         // [5][kBlock]
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     // (= last stage time of the previous step; exactly 0 for the first chunk); idx >= 0 own stage times.
     int n = n0, s = 0;
     const int n_own = 5 * (n1 - n0);
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane);    // (here: its global read travels with the subject's own loads)
 #pragma unroll 1
     for (int idx = -2; idx < n_own; idx++) {
         double xv = 0.0;
@@ -356,7 +357,7 @@ __device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, 
 
 template <int NIN, int W, int D>
 __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
-    using Net = Mlp<NIN, W, D, 1>;
+    using Net = CpepNet<NIN, W, D>;
     constexpr int P = Net::P;
     constexpr int NC = NIN - 1;
     extern __shared__ double smem[];
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     int kind = 0, s = 4, n = n1 - 1;
     bool run_ok = false, have_anchor = false;
     // own stage times in reverse order; e = 5 n0 - 1 stands for the baseline with weight -sum(own w)
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane);
 #pragma unroll 1
     for (int e = 5 * n1 - 1; e >= 5 * n0 - 1; e--) {
         const bool own = e >= 5 * n0;
@@ -499,7 +501,7 @@ __global__ void cpep2_sum_chunks_kernel(const double* __restrict__ part, int L, 
 // ---------------------------------------------------------------------------------- dispatch
 template <int NIN, int W, int D>
 static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStream_t s) {
-    using Net = Mlp<NIN, W, D, 1>;
+    using Net = CpepNet<NIN, W, D>;
     const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock - a.base.blk0;             // blocks [blk0, end)
     const unsigned n_sets = a.base.n_sets > 0 ? (unsigned)a.base.n_sets : 1u;
     if (nblocks < 1 || (a.base.blk0 > 0 && n_sets > 1)) return hipErrorInvalidValue;
@@ -546,7 +548,7 @@ bool cpep2_shape_supported(const NetShape& net, int n_state) {
 template <int NIN, int W, int D>
 static int rev_occupancy() {
     int n = 0;
-    constexpr int TABROWS = Mlp<NIN, W, D, 1>::HAS_TAB ? 5 * W : 0;
+    constexpr int TABROWS = CpepNet<NIN, W, D>::HAS_TAB ? 5 * W : 0;
     const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpep2_rev_kernel<NIN, W, D>, kBlock, lds_r) != hipSuccess) return 0;
     return n;

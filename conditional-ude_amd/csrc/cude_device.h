@@ -66,7 +66,46 @@ __device__ __forceinline__ cptr_t launder(cptr_t p) {
     return p;
 }
 
-__device__ __forceinline__ double act_tanh(double x) { return m_tanh(x); }
+// tanh of a layer (cude_math.h): two forms.
+//  * table + addition theorem (round 3): 5 issue slots fewer per tanh than the exponential form, but ~35 more live
+//    VGPRs per layer (numerator, denominator and the table read of every unit are in flight together).  The table of
+//    tanh(k/8) sits in LDS -- per-lane index, 161 doubles = 3 rows of every workgroup's static allocation; a kernel that
+//    evaluates such a network calls tanh_tab_init() first.
+//  * exponential form: sign(x) (1 - 2/(exp(2|x|) + 1)).
+// Chosen per kernel family through Mlp's TT parameter (CpepNet / SuppNet below), the same in every kernel a family's
+// results are compared across bit for bit (one-lane and time-split c-peptide kernels; the suppression kernel's modes).
+// Measured on MI355X (tools/abl_run.sh, same box): suppression 4-3x5-1 gradient launch at 1e5 subjects 1.012 -> 0.958 ms;
+// 2-4-4-1 forward call at 125 000 subjects 0.245 -> 0.223 ms, its gradient launch unchanged (0.430 / 0.433 ms: three
+// waves per SIMD become two); but the width-6 gradient kernels sit at the 256-register line of two waves per SIMD and
+// pay for the extra live values with scratch traffic (2-6-6-1 0.564 -> 0.603 ms), and the adaptive kernels -- latency
+// chains that want resident waves more than short instruction streams -- would drop from three waves per SIMD to two.
+// Hence: fixed-step c-peptide kernels up to width CUDE_TANH_TAB_MAXW, the fixed-step suppression kernel always, the
+// adaptive kernels never.
+#ifndef CUDE_TANH_TAB_MAXW
+#define CUDE_TANH_TAB_MAXW 4
+#endif
+#ifdef CUDE_TANH_EXP
+constexpr int kTanhTabMaxW = 0;
+#else
+constexpr int kTanhTabMaxW = CUDE_TANH_TAB_MAXW;
+#endif
+__device__ const double TANH_TAB_G[kTanhEntries] = {CUDE_TANH_TABLE_VALUES};
+constexpr int kTanhRows = (kTanhEntries + 63) / 64;
+__shared__ double s_tanh_tab[kTanhRows * 64];
+__device__ __forceinline__ void tanh_tab_init(int lane) {
+#pragma unroll
+    for (int r = 0; r < kTanhRows; r++) {
+        const int k = lane + 64 * r;
+        s_tanh_tab[k] = TANH_TAB_G[k < kTanhEntries ? k : kTanhEntries - 1];
+    }
+    __syncthreads();
+}
+template <int W, bool TT>
+__device__ __forceinline__ void act_tanh_vec(const double (&z)[W], double (&t)[W]) {
+    if constexpr (TT) m_tanh_vec_tab<W>(z, t, s_tanh_tab);
+    else m_tanh_vec<W>(z, t);
+}
+
 // softplus(x) = log(1+exp(x)) (reference form, evaluated stably); *sig receives the logistic derivative.
 __device__ __forceinline__ double act_softplus(double x, double* sig) { return m_softplus(x, sig); }
 __device__ __forceinline__ double act_softplus_val(double x) { return m_softplus_val(x); }
@@ -112,10 +151,28 @@ __device__ __forceinline__ void touch(const SCol<W>& c) {
 #define CUDE_COLGROUP 3       // three columns per scalar load + wait: -1 % (125 000 subjects) ... -1.7 % (1e6) on 2-6-6-1
 #endif
 
-template <int NIN, int W, int D, int NV>
+// Pins an accumulator right behind its update.  An accumulator feeds nothing inside the time loop, so LLVM sinks the
+// whole outer-product update of every layer into the loop latch and keeps the operands (d, h of every layer) alive until
+// there: ~100 VGPRs of the suppression gradient kernel (275 -> one wave per SIMD).  An empty volatile asm that reads and
+// writes the register holds the FMA where it was written.
+template <class A>
+struct AccPin {
+    __device__ static __forceinline__ void pin(A& acc, int q) { acc.pin(q); }
+};
+template <int N>
+struct AccPin<double[N]> {
+    __device__ static __forceinline__ void pin(double (&a)[N], int q) {
+#ifndef CUDE_NO_ACC_PIN
+        asm volatile("" : "+v"(a[q]));
+#endif
+    }
+};
+
+template <int NIN, int W, int D, int NV, bool TT = false>      // TT: tanh by table (act_tanh_vec)
 struct Mlp {
     // weight columns fetched per scalar load (a column = W doubles); W must be a multiple of it
     static constexpr int CG = (W % CUDE_COLGROUP == 0) ? CUDE_COLGROUP : 1;
+    static constexpr bool USES_TANH = TT;           // kernels then call tanh_tab_init() before the first evaluation
     static constexpr int NC = NIN - NV;
     static constexpr int NCST = W;                  // per-subject constants kept in registers (first-layer offsets)
     // the conditional parameter enters the network as exp(beta) (src/c-peptide-models.jl:90)
@@ -224,7 +281,7 @@ struct Mlp {
 #pragma unroll
                 for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
             }
-            m_tanh_vec<W>(z, h[0]);
+            act_tanh_vec<W, TT>(z, h[0]);
         }
 #pragma unroll
         for (int l = 1; l < D; l++) {
@@ -247,7 +304,7 @@ struct Mlp {
                         if (i0 + g < W) z[j] = fma(col.v[g * W + j], h[l - 1][i0 + g], z[j]);
             }
             CUDE_FENCE();
-            m_tanh_vec<W>(z, h[l]);
+            act_tanh_vec<W, TT>(z, h[l]);
         }
         CUDE_FENCE();
         const SCol<W> wo = ld_col<W>(p, OUT);
@@ -293,7 +350,7 @@ struct Mlp {
 #pragma unroll
                 for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
             }
-            m_tanh_vec<W>(z, h);
+            act_tanh_vec<W, TT>(z, h);
         }
 #pragma unroll
         for (int l = 1; l < D; l++) {
@@ -304,7 +361,7 @@ struct Mlp {
             for (int i = 0; i < W; i++)
 #pragma unroll
                 for (int j = 0; j < W; j++) z[j] = fma(v.w[o + W * i + j], h[i], z[j]);
-            m_tanh_vec<W>(z, h);
+            act_tanh_vec<W, TT>(z, h);
         }
         constexpr int oo = (D - 1) * LH;
         double z0 = v.w[oo + W], z1 = 0.0;
@@ -314,6 +371,67 @@ struct Mlp {
             else z0 = fma(v.w[oo + i], h[i], z0);
         }
         return act_softplus_val(z0 + z1);
+    }
+
+    // ---- kept activations (c-peptide gradient kernel, CpepArgs::act): the forward sweep hands out the tanh outputs of
+    // the hidden layers 2..D and the output unit's logistic derivative, the reverse sweep forms layer 1 again (one
+    // multiply per unit on the exponent-table path) and runs `backward` on them
+    static constexpr int DEPTH = D, WIDTH = W;
+    static constexpr int NKEEP = (D - 1) * W + 1;
+    __device__ static __forceinline__ double eval_vw_keep(cptr_t p, const VW& v, const double (&c)[W],
+                                                          const double (&x)[NV], bool use_tab, const Exps* E1,
+                                                          double (&keep)[NKEEP]) {
+        double h[W], z[W];
+        if (use_tab) {
+            m_tanh_from_exp<W>(E1->v, h);
+        } else {
+            p = launder(p);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const SCol<W> col = ld_col<W>(p, W * i);
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
+            }
+            act_tanh_vec<W, TT>(z, h);
+        }
+#pragma unroll
+        for (int l = 1; l < D; l++) {
+            const int o = (l - 1) * LH;
+#pragma unroll
+            for (int j = 0; j < W; j++) z[j] = v.w[o + W * W + j];
+#pragma unroll
+            for (int i = 0; i < W; i++)
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = fma(v.w[o + W * i + j], h[i], z[j]);
+            act_tanh_vec<W, TT>(z, h);
+#pragma unroll
+            for (int j = 0; j < W; j++) keep[(l - 1) * W + j] = h[j];
+        }
+        constexpr int oo = (D - 1) * LH;
+        double z0 = v.w[oo + W], z1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (i & 1) z1 = fma(v.w[oo + i], h[i], z1);
+            else z0 = fma(v.w[oo + i], h[i], z0);
+        }
+        return act_softplus(z0 + z1, &keep[NKEEP - 1]);
+    }
+    // layer 1 alone
+    __device__ static __forceinline__ void layer1(cptr_t p, const double (&c)[W], const double (&x)[NV], double (&h0)[W],
+                                                  bool use_tab, const Exps* E1) {
+        if (use_tab) {
+            m_tanh_from_exp<W>(E1->v, h0);
+        } else {
+            p = launder(p);
+            double z[W];
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const SCol<W> col = ld_col<W>(p, W * i);
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
+            }
+            act_tanh_vec<W, TT>(z, h0);
+        }
     }
 
     // value only
@@ -345,6 +463,13 @@ struct Mlp {
     static constexpr int CGP = (W == 3) ? 3 : (W % 2 == 0) ? 2 : 1;  // columns per group of the pipelined stream
 #endif
     static constexpr int NG = W / CGP;                // column groups per hidden layer
+    // hidden-layer accumulators pinned behind their update (AccPin): where the network's input is the ODE state, the
+    // evaluation is followed by stage-adjoint algebra the updates would otherwise be sunk behind
+#ifdef CUDE_PIN_LAYERS
+    static constexpr bool kPinLayers = CUDE_PIN_LAYERS;
+#else
+    static constexpr bool kPinLayers = (NV > 1);
+#endif
     static constexpr bool HAS_PF = (D >= 2);
     // forward half: hidden activations h, output pre-activation returned; wo and (KEEP) the last hidden layer's last
     // column group stay loaded for the backward half
@@ -368,7 +493,7 @@ struct Mlp {
 #pragma unroll
                 for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
             }
-            m_tanh_vec<W>(z, h[0]);
+            act_tanh_vec<W, TT>(z, h[0]);
         }
 #pragma unroll
         for (int l = 1; l < D; l++) {
@@ -395,7 +520,7 @@ struct Mlp {
                     for (int j = 0; j < W; j++) z[j] = fma(grp[l][g].v[k * W + j], h[l - 1][g * CGP + k], z[j]);
             }
             CUDE_FENCE();
-            m_tanh_vec<W>(z, h[l]);
+            act_tanh_vec<W, TT>(z, h[l]);
         }
         CUDE_FENCE();
         // the last hidden layer's last column group is needed again right after the output unit
@@ -459,6 +584,16 @@ struct Mlp {
                     }
                     dh[i] = s0 + s1;
                 }
+                if (kPinLayers) {
+#pragma unroll
+                    for (int k = 0; k < CGP; k++)
+#pragma unroll
+                        for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + j + W * (g * CGP + k));
+                }
+            }
+            if (kPinLayers) {
+#pragma unroll
+                for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + W * W + j);
             }
             CUDE_FENCE();
         }
@@ -557,8 +692,16 @@ struct Mlp {
                             else s0 = fma(col.v[g * W + j], d[j], s0);
                         }
                         dh[i] = s0 + s1;
+                        if (kPinLayers) {
+#pragma unroll
+                            for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + j + W * i);
+                        }
                     }
                 }
+            }
+            if (kPinLayers) {
+#pragma unroll
+                for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + W * W + j);
             }
             CUDE_FENCE();
         }
@@ -635,6 +778,17 @@ struct Mlp {
     }
 };
 
+// the networks of the fixed-step kernel families with their tanh form (see act_tanh_vec)
+template <int NIN, int W, int D>
+using CpepNet = Mlp<NIN, W, D, 1, (W <= kTanhTabMaxW)>;
+#ifdef CUDE_TANH_EXP
+template <int W, int D>
+using SuppNet = Mlp<4, W, D, 3, false>;
+#else
+template <int W, int D>
+using SuppNet = Mlp<4, W, D, 3, true>;
+#endif
+
 // ------------------------------------------------------------------------------------ analytic production
 // Drop-in for Mlp<2, W, D, 1> in the c-peptide kernel: the production term found by symbolic regression,
 //   production(dG, k) = dG >= 0 ? p0*dG/(dG + k) : 0,   p0 = 1.78 in the reference
@@ -643,10 +797,12 @@ struct Mlp {
 // parameter itself (RAW, 03-symreg.jl:99-106) or its exponential (saem-symreg.jl:57-59 km_pop*exp(eta)).
 template <bool RAW>
 struct MmProd {
+    static constexpr bool USES_TANH = false;
     static constexpr int NC = 1, NCST = 1, P = 1;
     static constexpr int NACC = 2;                  // [d/dp0, d/dk]
     static constexpr bool HAS_TAB = false;          // one division per evaluation: nothing to tabulate
     static constexpr bool HAS_VW = false;
+    static constexpr int DEPTH = 0, WIDTH = 1, NKEEP = 1;
     struct VW {};
     struct Exps {
         double v[1];
@@ -705,6 +861,11 @@ struct SplitAcc {
     }
     __device__ __forceinline__ const double& operator[](int q) const {
         return q < Net::G_H ? lds[q * 64] : (q >= HI ? lds[(q - NREG) * 64] : r[q - Net::G_H]);
+    }
+    __device__ __forceinline__ void pin(int q) {
+#ifndef CUDE_NO_ACC_PIN
+        if (q >= Net::G_H && q < HI) asm volatile("" : "+v"(r[q - Net::G_H]));
+#endif
     }
 };
 

@@ -45,6 +45,9 @@ struct CpepArgs {
     double* auc;             // [N] or nullptr (NS == 3: cumulative secretion at t_end)
     double* g_cond;          // [n_sets][N] (grad)
     double* partials;        // [n_sets][nblocks][P+2]
+    double* act;             // one-lane gradient kernel: [5S+1][(D-1)W+1][N] kept activations of the forward sweep (tanh
+                             // outputs of the hidden layers 2..D + the output unit's logistic derivative per evaluation),
+                             // read back by the reverse sweep instead of re-evaluating those layers; nullptr = recompute
     // multi-start evaluation: n_sets parameter sets in the grid's y dimension, set k reads nn + k*set_stride_nn and
     // cond + k*set_stride_cond (and writes sse / g_cond + k*set_stride_cond); 0/0/0 for the single-set path
     int32_t n_sets;
@@ -111,6 +114,7 @@ struct Cpep2Args {
 bool cpep2_shape_supported(const NetShape& net, int n_state);
 int cpep2_rev_waves_per_cu(const NetShape& net);
 int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T);
+int cpep_keep_values(const NetShape& net);
 hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s);
 // forward (+ scan) only when !grad: per-subject SSE and the loss partials, no trajectory output
 hipError_t launch_cpep2(const NetShape& net, int n_state, bool grad, const Cpep2Args& a, hipStream_t s);

@@ -9,14 +9,21 @@
 //   exp(2s) : Cody-Waite reduction to |s| <= ln2/4 + degree-10 near-minimax polynomial
 //             (tools/fit_exp_poly.py, max rel err 3.8e-16) + v_ldexp_f64           (16 slots)
 //   1/d     : v_rcp_f64 + one cubic Newton step r0*(1+e+e^2)                          (7 slots)
-//   tanh    : sign(x)*(1 - 2/(exp(2|x|)+1)); the W reciprocals of a layer share ONE v_rcp_f64
-//             through prefix products (3(W-1) multiplies)
+//   tanh    : addition theorem on a grid, tanh(a+b) = (T_a + tanh b)/(1 + T_a tanh b) with a = k/8 the nearest grid
+//             point (T_a from a 161-entry table, one LDS read on the device), |b| <= 1/16 and tanh b replaced by its
+//             [3/4] Pade approximant n/d (continued fraction cut at 7: error b^9/99225 <= 1.5e-16):
+//             tanh|x| = (T d + n)/(d + T n) -- 13 slots for numerator and denominator (the exponential it replaces
+//             took 18: round 3, -5 slots of 24 per tanh); the W quotients of a layer share ONE v_rcp_f64 through
+//             prefix products (3(W-1) multiplies).  -DCUDE_TANH_EXP selects the previous form,
+//             sign(x)*(1 - 2/(exp(2|x|)+1)).
 //   softplus(x) = max(x,0) + log1p(exp(-|x|)); logistic derivative from the same exponential
 // Reference semantics: softplus(x) = log(1+exp(x)) (src/neural-network.jl:13-15); the stable form
 // differs from it by rounding only (and does not overflow for x > 709).
 // Max abs error vs libm is asserted in tests/test_math_host.py.
 #pragma once
 #include <math.h>
+
+#include "cude_tanh_table.h"
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define CUDE_HD __host__ __device__ __forceinline__
@@ -92,6 +99,93 @@ CUDE_HD double m_tanh_den(double z) { return m_exp2x(fmin(fabs(z), 20.0)) + 1.0;
 CUDE_HD double m_tanh(double x) {
     const double r = m_rcp(m_tanh_den(x));
     return copysign(fma(-2.0, r, 1.0), x);
+}
+
+// ---- tanh by table + addition theorem (see the header comment)
+constexpr int kTanhEntries = CUDE_TANH_KMAX + 1;
+// 1.5 * 2^(52 - log2 grid): adding it rounds |x| to the grid, leaving k = round(|x| * grid) in the low mantissa bits
+constexpr double kTanhMagic = 6755399441055744.0 / CUDE_TANH_GRID;
+#if !defined(__HIP_DEVICE_COMPILE__)
+static const double kTanhTableHost[kTanhEntries] = {CUDE_TANH_TABLE_VALUES};
+#endif
+// Rational part of tanh b on the grid cell: tanh b ~ n / d with n = b (105 + 10 u) / 10, d = (105 + 45 u + u^2) / 10,
+// u = b^2.  Written so that no instruction needs two non-inline constants (gfx950's VOP3 reads one SGPR pair per
+// instruction: a second constant would be moved into VGPRs first, two v_mov_b32 each).  Returns the table index.
+CUDE_HD int m_tanh_cell(double x, double& n, double& d) {
+    const double xa = fmin(fabs(x), (double)CUDE_TANH_KMAX / CUDE_TANH_GRID);
+    const double t = xa + kTanhMagic;                                 // low mantissa bits = k = round(|x| * grid)
+    const double b = xa - (t - kTanhMagic);                           // exact, |b| <= 1/(2 grid)
+    const double u = b * b;
+    n = b * (u + 10.5);
+    d = fma(u, u + 45.0, 105.0) * 0.1;                                // in [10.5, 10.52]
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2loint(t);
+#else
+    unsigned long long tb;
+    __builtin_memcpy(&tb, &t, 8);
+    return (int)(unsigned)tb;
+#endif
+}
+// numerator and denominator of tanh|x|;  tab[k] = tanh(k / CUDE_TANH_GRID)
+CUDE_HD void m_tanh_nd(double x, const double* tab, double& num, double& den) {
+    double n, d;
+    const double T = tab[m_tanh_cell(x, n, d)];
+    num = fma(T, d, n);
+    den = fma(T, n, d);                                               // in [10.5, 11.2]
+}
+CUDE_HD double m_tanh_tab(double x, const double* tab) {
+    double num, den;
+    m_tanh_nd(x, tab, num, den);
+    return copysign(num * m_rcp(den), x);
+}
+// A whole layer with ONE reciprocal.  Source order = the order that keeps the fewest values alive: per unit, the table
+// read is requested first and the rational part (which does not need it) is formed while it is in flight -- three
+// doubles per unit (n, d, T) until all units are through, then two (numerator with the sign, denominator), the same
+// footprint as the exponential form's (denominator, prefix product, sign).
+template <int W>
+CUDE_HD void m_tanh_vec_tab(const double (&z)[W], double (&t)[W], const double* tab) {
+    static_assert(W <= 8, "batched reciprocal: product of denominators must stay below 1e308");
+    double n[W], d[W], T[W];
+    int zh[W];                                       // high words of z: all that the final copysign needs of it
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const int k = m_tanh_cell(z[j], n[j], d[j]);
+        T[j] = tab[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+        zh[j] = __double2hiint(z[j]);
+#else
+        unsigned long long zb;
+        __builtin_memcpy(&zb, &z[j], 8);
+        zh[j] = (int)(zb >> 32);
+#endif
+    }
+    double pre[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const double nj = n[j];
+        n[j] = fma(T[j], d[j], nj);                  // numerator of tanh|z|
+        d[j] = fma(T[j], nj, d[j]);                  // denominator
+        pre[j] = j == 0 ? d[0] : pre[j - 1] * d[j];
+    }
+    double r = m_rcp(pre[W - 1]);
+#pragma unroll
+    for (int j = W - 1; j >= 0; j--) {
+        double v;
+        if (j > 0) {
+            v = n[j] * (r * pre[j - 1]);
+            r = r * d[j];
+        } else {
+            v = n[0] * r;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        t[j] = __hiloint2double((__double2hiint(v) & 0x7fffffff) | (zh[j] & (int)0x80000000), __double2loint(v));
+#else
+        unsigned long long vb;
+        __builtin_memcpy(&vb, &v, 8);
+        vb = (vb & 0x7fffffffffffffffull) | ((unsigned long long)(unsigned)(zh[j] & (int)0x80000000) << 32);
+        __builtin_memcpy(&t[j], &vb, 8);
+#endif
+    }
 }
 
 // t[j] = tanh(z[j]) for a whole layer with ONE reciprocal (prefix-product trick).

@@ -18,7 +18,7 @@ namespace cude {
 
 template <int W, int D>
 struct SuppRhs {
-    using Net = Mlp<4, W, D, 3>;
+    using Net = SuppNet<W, D>;
     __device__ static __forceinline__ void f(cptr_t p, const double (&c)[W], const double (&u)[3], double (&du)[3]) {
         const double uh = Net::eval(p, c, u);
         du[0] = -0.4 * u[0];
@@ -65,12 +65,19 @@ struct SuppRhs {
 constexpr int kSuppRowsK = 21;
 
 // accumulator container per network shape: registers while they fit next to two resident waves, split otherwise
-template <class Net, bool SPLIT = (Net::NACC > 48)>
+// (round 3: with the accumulator updates pinned behind their FMAs -- AccPin, cude_device.h -- the reference's 4-3x5-1
+// network keeps all 64 accumulators in registers at 229-256 VGPRs = two waves per SIMD; the split container is for
+// larger networks only)
+#ifndef CUDE_SUPP_SPLIT_ABOVE
+#define CUDE_SUPP_SPLIT_ABOVE 64
+#endif
+template <class Net, bool SPLIT = (Net::NACC > CUDE_SUPP_SPLIT_ABOVE)>
 struct SuppAcc {
     struct type {
         double a[Net::NACC];
         __device__ __forceinline__ double& operator[](int q) { return a[q]; }
         __device__ __forceinline__ const double& operator[](int q) const { return a[q]; }
+        __device__ __forceinline__ void pin(int q) { AccPin<double[Net::NACC]>::pin(a, q); }
     };
     static constexpr int rows = 0;
     __device__ static __forceinline__ void init(type&, double*) {}
@@ -90,11 +97,18 @@ struct SuppAcc<Net, true> {
 // YONLY (gradient only, SuppArgs::ckpt_steps_only): the forward sweep keeps only the step states y_0 ... y_S (744 B per
 // subject at S = 30 instead of 4.3 KB of stage inputs) and the reverse sweep re-runs the six stage evaluations of the
 // step it is reversing: the low-traffic / high-arithmetic end of the trade (profiles/r02/supp_scratch_tradeoff.txt).
-#ifndef CUDE_SUPP_WAVES
-#define CUDE_SUPP_WAVES 1
+// resident waves per SIMD the register allocator aims at: two for the gradient kernels of networks with up to 64
+// accumulators (4-3x5-1: 256 VGPRs, 5 dwords spilled outside the time loops), otherwise no constraint
+template <int W, int D, bool GRAD>
+constexpr int supp_waves() {
+#ifdef CUDE_SUPP_WAVES
+    return CUDE_SUPP_WAVES;
+#else
+    return (GRAD && SuppNet<W, D>::NACC <= 64) ? 2 : 1;
 #endif
+}
 template <int W, int D, bool GRAD, bool STORE, bool YONLY>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUPP_WAVES))) void supp_kernel(SuppArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_waves<W, D, GRAD>()))) void supp_kernel(SuppArgs a) {
     using R = SuppRhs<W, D>;
     using Net = typename R::Net;
     constexpr int P = Net::P;
@@ -143,6 +157,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CUDE_SUP
     // st+1 of step n (st = 6: k_7 = f(y_{n+1}), reused as k_1 of the next step).
     double sse = fma(cst[0], 0.0, Net::param_check(p));   // NaN iff a parameter / theta is non-finite
     int oi = 0, n = 0, st = 0;
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane);    // (here: its global read travels with the subject's own loads)
 #pragma unroll 1
     for (int e = 0; e <= 6 * S; e++) {
         double u[3];
@@ -381,7 +396,7 @@ template <int W, int D, bool GRAD, bool STORE, bool YONLY = false>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(kSuppRowsK * (YONLY ? 2 : 1) +
-                                                 (GRAD ? 9 + SuppAcc<Mlp<4, W, D, 3>>::rows : 0)) * kBlock;
+                                                 (GRAD ? 9 + SuppAcc<SuppNet<W, D>>::rows : 0)) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE, YONLY>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();

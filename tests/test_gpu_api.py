@@ -372,8 +372,11 @@ def test_unequal_width_network_through_zero_padding():
     assert eng.forward()["loss"] < 0.9 * loss
     # the library's own optimisers work on the padded vector: without a mask Adam's scale invariance amplifies the
     # ~1e-17 gradients of the padding until it comes alive; with the mask (cude_set_param_mask) it stays exactly zero
+    # (round 3: the table tanh returns tanh(0) = 0 exactly, so in a hidden layer >= 2 -- this case -- the padding now
+    # survives even without the mask; a padded FIRST-layer unit on the exponent-table path still sees ~1e-17, so the
+    # mask remains what guarantees it)
     nn_t, _, obj, _ = eng.train_restarts(P[None, :], c["beta"][None, :], 30, 1e-2, 0, want_trace=True)
-    assert obj[0] < loss and np.max(np.abs(nn_t[0][pad])) > 1e-12
+    assert obj[0] < loss
     eng.set_param_mask((~pad).astype(float))
     eng.set_params(P, c["beta"])
     _, g_m, _ = eng.loss_grad()

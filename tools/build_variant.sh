@@ -1,10 +1,11 @@
 #!/bin/bash
 # Builds a variant of libcude_hip.so with extra compiler flags into tools/abl_so/<name>.so (A/B runs on the GPU box:
 # tools/abl_bench.py <name> ...).  usage: tools/build_variant.sh <name> [extra hipcc flags...]
+# CUDE_SRC_ROOT=<checkout> builds another checkout's sources (e.g. a `git worktree` of the previous round's HEAD).
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-SRC=$ROOT/conditional-ude_amd/csrc
+SRC=${CUDE_SRC_ROOT:-$ROOT}/conditional-ude_amd/csrc
 OUT=$ROOT/tools/abl_so
 TMP=$(mktemp -d)
 mkdir -p $OUT
