@@ -427,6 +427,41 @@ def extras(Engine, device, steps=20, warm=40):
     return out
 
 
+def saem_estep_sharded(Engine, device, world, rank, dist, torch, n_total=10000, n_mc=100, reps=5):
+    """BASELINE configs[4] on N GPUs: the SAEM E-step (src/saem.jl:86-108,177-186) of n_total subjects x n_mc Metropolis
+    steps, subjects sharded over the ranks (the E-step itself needs no communication), followed by the one exchange a
+    SAEM iteration makes: the sum over ranks of [accepted, sum p, sum p^2, n] (acceptance rate, eta <- mean(p), Omega <-
+    var(p), saem.jl:196-205), timed inside the same region.  Returns this rank's view; the caller takes the max time."""
+    arch = (2, 4, 2)
+    n = n_total // world + (1 if rank < n_total % world else 0)
+    first = rank * (n_total // world) + min(rank, n_total % world)
+    nn4 = glorot(arch, 4321)
+    eng, pop = cpep_engine(Engine, arch, 2, n, 780 + rank, device, nn4)
+    eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+    eng.set_params(nn4, pop["beta0"])
+    eng.set_rng(20250905, first)               # one global stream of draws: the chain does not depend on the sharding
+    eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
+    stats = torch.zeros(4, dtype=torch.float64, device=torch.device("cuda", device))
+    dist.all_reduce(stats)                     # warm the collective
+    torch.cuda.synchronize()
+    dist.barrier()
+    t_red = 0.0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        acc = eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=n_mc)
+        _, p = eng.get_params()
+        t1 = time.perf_counter()
+        stats = torch.tensor([float(acc.sum()), float(p.sum()), float(p @ p), float(n)], dtype=torch.float64,
+                             device=torch.device("cuda", device))
+        dist.all_reduce(stats)
+        tot = stats.cpu().numpy()
+        t_red += time.perf_counter() - t1
+    dt = (time.perf_counter() - t0) / reps
+    eng.close()
+    return dict(dt=dt, dt_allreduce=t_red / reps, acceptance=float(tot[0]) / (tot[3] * n_mc), n_seen=float(tot[3]),
+                mean_p=float(tot[1] / tot[3]), subjects_per_gpu=n)
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -457,7 +492,12 @@ def main():
         local_rank %= torch.cuda.device_count()
     ctl = "cpu" if rehearsal else "cuda"          # device of the small control tensors handed to torch.distributed
     torch.cuda.set_device(local_rank)
+    rccl_log = None
     if world > 1:
+        # RCCL's own account of a failure (WARN level: silent when all is well), per process, for `rccl_error` below
+        rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cude_rccl_{os.getpid()}.log")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -470,6 +510,7 @@ def main():
     eng, pop = cpep_engine(Engine, ARCH, N_STATE, n_local, 20250905 + rank, local_rank, nn)
     transport = "rccl"          # all-reduce of the P+2 doubles inside libcude_hip.so (RCCL on the context's stream)
     rccl_info = None
+    rccl_error = None           # why the built-in communicator was not used (this rank's view), for the JSON line
     if world > 1:
         # Every rank issues the same sequence of collectives whatever fails locally: first agree that librccl
         # is loadable everywhere (each rank draws an id; only rank 0's is used), then build the communicator.
@@ -481,6 +522,7 @@ def main():
             try:
                 my_id = Engine.comm_unique_id()
             except Exception as exc:  # e.g. librccl not loadable: fall back to the host-collective transport
+                rccl_error = f"cude_comm_unique_id: {exc}"
                 print(f"[rank {rank}] built-in RCCL communicator unavailable ({exc}); using torch.distributed",
                       file=sys.stderr)
                 ok.zero_()
@@ -494,25 +536,44 @@ def main():
                 if rccl_info[0] != world or rccl_info[1] != rank:
                     raise RuntimeError(f"communicator reports {rccl_info}, expected ({world}, {rank})")
             except Exception as exc:
+                rccl_error = f"cude_comm_init: {exc}"
                 print(f"[rank {rank}] cude_comm_init failed ({exc}); using torch.distributed", file=sys.stderr)
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
-            transport = "host"  # cude_loss_grad_partial -> dist.all_reduce (RCCL via PyTorch) -> cude_adam_apply
+            # cude_loss_grad_partial_device -> dist.all_reduce on a tensor ALIASING the context's P+2 doubles (RCCL via
+            # PyTorch, in place on the device) -> cude_adam_apply_device: no host copy in the step.  Under rehearsal
+            # (gloo, CPU tensors) the vector goes through the host as before.
+            transport = "torch" if not rehearsal else "host"
             rccl_info = None
+            if rccl_error is None:
+                rccl_error = "another rank could not build the communicator" if os.environ.get(
+                    "CUDE_BENCH_TRANSPORT", "rccl") == "rccl" else "CUDE_BENCH_TRANSPORT asked for torch.distributed"
+            if rccl_log and os.path.exists(rccl_log):
+                tail = open(rccl_log, errors="replace").read()[-1500:].strip()
+                if tail:
+                    rccl_error += " | RCCL: " + tail
             eng.close()
             eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
     eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])   # global count all-reduced here
-    if transport == "host":
+    if transport != "rccl":
         eng.set_global_subjects(n_local * world)
     eng.set_params(nn, pop["beta0"])
     eng.adam_init(1e-2)
+    alias = {}                 # engine -> tensor aliasing its partial vector (device-resident torch transport)
 
     def host_step(e):
-        part, _ = e.loss_grad_partial()
-        t = torch.from_numpy(part).to(ctl)
-        dist.all_reduce(t)
-        return e.adam_apply(t.cpu().numpy())
+        if rehearsal:          # gloo on CPU tensors: through the host
+            part, _ = e.loss_grad_partial()
+            t = torch.from_numpy(part)
+            dist.all_reduce(t)
+            return e.adam_apply(t.numpy())
+        if e not in alias:
+            alias[e] = e.partial_tensor(torch, torch.device("cuda", local_rank))
+        e.loss_grad_partial_device()          # (synchronises the context's stream)
+        dist.all_reduce(alias[e])             # in place, on PyTorch's stream
+        torch.cuda.current_stream().synchronize()
+        return e.adam_apply_device()
 
     def train_step(want_loss=True):
         """One optimiser iteration over ALL ranks' subjects; returns the global loss."""
@@ -580,6 +641,15 @@ def main():
     barrier()
     dt_sync = time.perf_counter() - t1
 
+    saem = None
+    if world > 1 and not rehearsal and not args.no_extra:
+        eng.close()
+        eng = None
+        saem = saem_estep_sharded(Engine, local_rank, world, rank, dist, torch)
+        t = torch.tensor([saem["dt"], saem["dt_allreduce"]], dtype=torch.float64, device=ctl)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        saem["dt"], saem["dt_allreduce"] = float(t[0]), float(t[1])
+
     kern_min = kern_max = kern_ms
     if world > 1:
         t = torch.tensor([dt, dt_sync, kern_ms, -kern_ms], dtype=torch.float64, device=ctl)
@@ -613,6 +683,15 @@ def main():
             out["rccl_ranks"] = rccl_info[0] if rccl_info else None
             out["rccl_version"] = rccl_info[2] if rccl_info else None
             out["allreduce_check"] = allreduce_check
+            out["rccl_error"] = rccl_error
+            if saem is not None:
+                out["saem_estep_1e4x100_sharded"] = {
+                    "config": f"BASELINE configs[4]: SAEM E-step, 1e4 subjects x 100 Metropolis steps sharded over "
+                              f"{world} GPUs ({saem['subjects_per_gpu']} subjects on rank 0), 2x4x4x1, device-side draws, "
+                              f"+ the 4-double all-reduce of a SAEM iteration (RCCL through torch.distributed)",
+                    "value": 10000 * 100 / saem["dt"], "unit": "Metropolis draws/s", "ms_per_estep": saem["dt"] * 1e3,
+                    "ms_allreduce_and_readback": saem["dt_allreduce"] * 1e3, "acceptance_rate": saem["acceptance"],
+                    "subjects_seen": saem["n_seen"]}
             out["kernel_ms_per_rank"] = {"min": kern_min, "max": kern_max}
             out["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
         if world == 1:

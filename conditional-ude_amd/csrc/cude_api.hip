@@ -136,6 +136,7 @@ struct Rccl {
     int (*CommCount)(void*, int*) = nullptr;
     int (*CommUserRank)(void*, int*) = nullptr;
     int (*GetVersion)(int*) = nullptr;
+    const char* (*GetLastError)(void*) = nullptr;      // NCCL >= 2.13: the library's own description of what went wrong
 };
 Rccl g_rccl;
 
@@ -162,18 +163,25 @@ int32_t load_rccl() {
     g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
     g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
     g_rccl.GetVersion = (int (*)(int*))dlsym(h, "ncclGetVersion");
+    g_rccl.GetLastError = (const char* (*)(void*))dlsym(h, "ncclGetLastError");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(CUDE_ERR_COMM, "librccl lacks a required symbol");
     g_rccl.handle = h;
     return CUDE_OK;
 }
 
+inline std::string rccl_diagnosis(int r) {
+    std::string m = g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error";
+    if (g_rccl.GetLastError) {
+        const char* last = g_rccl.GetLastError(nullptr);
+        if (last && last[0]) m += std::string(" [") + last + "]";
+    }
+    return m;
+}
 #define RCCL_TRY(expr)                                                                             \
     do {                                                                                           \
         int _r = (expr);                                                                           \
-        if (_r != 0)                                                                               \
-            return fail(CUDE_ERR_COMM, std::string(#expr) + ": " +                                 \
-                                           (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
+        if (_r != 0) return fail(CUDE_ERR_COMM, std::string(#expr) + ": " + rccl_diagnosis(_r));   \
     } while (0)
 
 template <class T>
@@ -280,16 +288,17 @@ bool supp_keep_activations(const cude_ctx* c, int64_t n_sets) {
 }
 
 // c-peptide gradient launches (one lane per subject, single parameter set): CUDE_CPEP_KEEP=1 keeps the upper layers'
-// activations of the forward sweep in HBM for the reverse sweep (CpepArgs::act)
+// activations of the forward sweep in HBM for the reverse sweep (CpepArgs::act; measured slower at the benchmark sizes,
+// see cpep_kernel -- off unless asked for)
 size_t cpep_act_doubles(const cude_ctx* c) {
     const int nk = cude::cpep_keep_values(c->net);
     if (nk == 0 || c->cfg.n_steps == 0) return 0;
-    return (size_t)(5 * c->cfg.n_steps + 1) * (size_t)nk * (size_t)c->N;
+    const size_t nblocks = (size_t)((c->N + cude::kBlock - 1) / cude::kBlock);
+    return (size_t)(5 * c->cfg.n_steps + 1) * (size_t)nk * nblocks * cude::kBlock;
 }
 bool cpep_keep_activations(const cude_ctx* c) {
     const char* env = getenv("CUDE_CPEP_KEEP");
-    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1' && cpep_act_doubles(c) > 0;
-    return false;
+    return env && env[0] == '1' && cpep_act_doubles(c) > 0;
 }
 
 // both c-peptide models share the population layout, solver tables and the ensemble kernel
@@ -343,11 +352,14 @@ int32_t bind(cude_ctx* c) {
     return CUDE_OK;
 }
 
-// op: 0 = sum, 1 = max (ncclSum = 0, ncclMax = 2)
+// The enumerators of nccl.h this file needs (librccl is dlopen'ed: its header is not compiled against).  They are not
+// trusted: cude_comm_init runs comm_self_test(), which fails unless a sum and a max of known doubles come back right.
+constexpr int kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2;
+
+// op: 0 = sum, 1 = max
 int32_t allreduce_dev(cude_ctx* c, double* buf, size_t count, int op = 0) {
     if (!c->comm) return CUDE_OK;
-    RCCL_TRY(g_rccl.AllReduce(buf, buf, count, /*ncclFloat64*/ 8, op == 1 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, c->comm,
-                              c->stream));
+    RCCL_TRY(g_rccl.AllReduce(buf, buf, count, kNcclFloat64, op == 1 ? kNcclMax : kNcclSum, c->comm, c->stream));
     return CUDE_OK;
 }
 
@@ -360,6 +372,22 @@ int32_t comm_reduce_host(cude_ctx* c, double* values, int32_t count, int op) {
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(values, c->red_tmp.p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return CUDE_OK;
+}
+
+// Every rank contributes [1, 2, rank + 1]: the sum must be [n, 2n, n(n+1)/2] and the max [1, 2, n].  A wrong datatype
+// or operator enumerator (or a communicator that silently spans fewer ranks) cannot produce both.
+int32_t comm_self_test(cude_ctx* c) {
+    const double n = (double)c->n_ranks;
+    double v[3] = {1.0, 2.0, (double)c->rank + 1.0};
+    int32_t rc = comm_reduce_host(c, v, 3, 0);
+    if (rc) return rc;
+    if (v[0] != n || v[1] != 2.0 * n || v[2] != 0.5 * n * (n + 1.0))
+        return fail(CUDE_ERR_COMM, "RCCL self-test: sum all-reduce of doubles returned a wrong result");
+    double w[3] = {1.0, 2.0, (double)c->rank + 1.0};
+    if ((rc = comm_reduce_host(c, w, 3, 1))) return rc;
+    if (w[0] != 1.0 || w[1] != 2.0 || w[2] != n)
+        return fail(CUDE_ERR_COMM, "RCCL self-test: max all-reduce of doubles returned a wrong result");
     return CUDE_OK;
 }
 
@@ -1065,9 +1093,9 @@ int32_t cude_adam_init(cude_ctx* c, double lr, double beta1, double beta2, doubl
     c->lr = lr; c->b1 = beta1; c->b2 = beta2; c->eps = eps;
     c->adam_t = 0;
     drop_graph(c);                              // hyper-parameters are baked into the captured launches
-    HIP_TRY(c->adam_state.resize(4));
+    HIP_TRY(c->adam_state.resize(5));
     if ((rc = ensure_trace(c, 1))) return rc;
-    const double st0[4] = {1.0, 1.0, 0.0, 0.0};
+    const double st0[5] = {1.0, 1.0, 0.0, 0.0, 0.0};     // (the last: the update kernel's arrival counter, all bits 0)
     HIP_TRY(hipMemcpyAsync(c->adam_state.p, st0, sizeof(st0), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));   // st0 is a stack buffer
     HIP_TRY(hipMemsetAsync(c->m_nn.p, 0, c->P * sizeof(double), c->stream));
@@ -1727,6 +1755,17 @@ int32_t cude_set_param_mask(cude_ctx* c, const double* mask) {
     c->mask_host.assign(mask, mask + c->P);
     HIP_TRY(c->param_mask.resize((size_t)c->P));
     HIP_TRY(hipMemcpyAsync(c->param_mask.p, c->mask_host.data(), c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // Adam moments gathered before the mask was set would keep moving a frozen entry (lr * m_hat / (sqrt(v_hat) + eps)
+    // while m decays): they are multiplied by the mask as well
+    if (c->adam_ready && c->m_nn.p && c->v_nn.p) {
+        std::vector<double> mv(2 * (size_t)c->P);
+        HIP_TRY(hipMemcpyAsync(mv.data(), c->m_nn.p, c->P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(mv.data() + c->P, c->v_nn.p, c->P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int q = 0; q < c->P; q++) { mv[q] *= mask[q]; mv[c->P + q] *= mask[q] * mask[q]; }
+        HIP_TRY(hipMemcpyAsync(c->m_nn.p, mv.data(), c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->v_nn.p, mv.data() + c->P, c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CUDE_OK;
 }
@@ -1794,6 +1833,36 @@ int32_t cude_loss_grad_partial(cude_ctx* c, double* partial, double* g_cond) {
     return CUDE_OK;
 }
 
+int32_t cude_partial_buffer(cude_ctx* c, double** device_ptr, int32_t* count) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!device_ptr || !count) return fail(CUDE_ERR_ARG, "null output");
+    if (!c->g_nn.p) return fail(CUDE_ERR_STATE, "context has no parameters yet");
+    *device_ptr = c->g_nn.p;
+    *count = c->P + 2;
+    return CUDE_OK;
+}
+
+int32_t cude_loss_grad_partial_device(cude_ctx* c) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if ((rc = run_ensemble(c, true, nullptr, /*local_only=*/true))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));     // the caller's collective runs on a stream this library does not know
+    return CUDE_OK;
+}
+
+int32_t cude_adam_apply_device(cude_ctx* c, double* loss) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
+    const int P = c->P;
+    if (c->cfg.lambda != 0.0)
+        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream, c->param_mask.p));
+    c->adam_t += 1;
+    if ((rc = finish_loss(c, loss, nullptr))) return rc;
+    return enqueue_adam(c);
+}
+
 int32_t cude_adam_apply(cude_ctx* c, const double* reduced, double* loss) {
     int32_t rc = bind(c);
     if (rc) return rc;
@@ -1821,9 +1890,11 @@ int32_t cude_debug_wave_timing(cude_ctx* c, long long* out, int64_t n_waves) {
 #endif
 
 int32_t cude_set_tolerances(cude_ctx* c, double abstol, double reltol) {
-    if (!c) return fail(CUDE_ERR_ARG, "null context");
     if (!(abstol > 0) || !(reltol > 0) || !std::isfinite(abstol) || !std::isfinite(reltol))
         return fail(CUDE_ERR_ARG, "tolerances must be positive");
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    drop_graph(c);      // a captured optimiser iteration carries the tolerances by value in its kernel arguments
     c->abstol = abstol;
     c->reltol = reltol;
     return CUDE_OK;
@@ -1890,6 +1961,13 @@ int32_t cude_comm_init(cude_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t
     RCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
     c->n_ranks = n_ranks;
     c->rank = rank;
+    if ((rc = comm_self_test(c))) {          // (collective: every rank runs it, every rank sees the same verdict)
+        (void)g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+        c->n_ranks = 1;
+        c->rank = 0;
+        return rc;
+    }
     return CUDE_OK;
 }
 

@@ -23,8 +23,11 @@ namespace cude {
 
 // Net: the production term -- Mlp<NIN, W, D, 1> (conditional UDE) or MmProd<RAW> (symbolic model).
 // KEEP (gradient only, CpepArgs::act): the forward sweep stores the upper layers' activations of every evaluation to HBM
-// ([evaluation][value][subject], coalesced) and the reverse sweep reads them back -- one evaluation ahead -- instead of
-// re-evaluating those layers: bit-identical results, Net::NKEEP * 8 bytes each way per evaluation and subject.
+// and the reverse sweep reads them back -- one evaluation ahead -- instead of re-evaluating those layers: bit-identical
+// results, Net::NKEEP * 8 bytes each way per evaluation and subject.  The trade the round-2 review asked to be measured
+// (2-6-6-1, 8.5 KB per subject each way): the reverse evaluation drops from 375 to ~215 VALU instructions, but the launch
+// becomes HBM-bound at ~3.7 TB/s of mixed streaming -- 125 000 subjects 0.564 -> 0.578 ms, 1e6 4.18 -> 4.64 ms, 1e5 (mixed
+// launch) 0.492 -> 0.476 ms, 65 536 unchanged (profiles/r03/keep_activations.txt).  Not enabled: CUDE_CPEP_KEEP=1 selects it.
 template <class Net, int NS, bool GRAD, bool KEEP = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2 : 1))) void cpep_kernel(CpepArgs a) {
     constexpr int P = Net::P;
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
 
     const double k0 = a.k0[i], k1 = a.k1[i], k2 = a.k2[i], c0 = a.c0[i];
     const double a11 = -(k0 + k2), a12 = k1, a21 = k2, a22 = -k1, f0 = k0 * c0;
+    // kept activations: one contiguous stretch per workgroup, [evaluation][value][lane] -- the wave streams through it
+    // forwards, then backwards (the population-wide [value][subject] rows of the other buffers would scatter every
+    // evaluation's 512-byte pieces a megabyte apart: measured 3.6 TB/s)
+    double* const act = KEEP ? a.act + (int64_t)blockIdx.x * ((int64_t)(5 * a.S + 1) * Net::NKEEP * kBlock) + lane : nullptr;
     double cst[NC];
     cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
     if (NC > 1) cst[1] = a.age[i];
@@ -152,9 +159,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
         if constexpr (KEEP) {
             double keep[Net::NKEEP];
             v = Net::eval_vw_keep(p, vw, c, x, tab, &E1, keep);
-            double* dst = a.act + ((int64_t)(e + 1) * Net::NKEEP) * N + i;
+            double* dst = act + (int64_t)(e + 1) * (Net::NKEEP * kBlock);
 #pragma unroll
-            for (int q = 0; q < Net::NKEEP; q++) dst[(int64_t)q * N] = keep[q];
+            for (int q = 0; q < Net::NKEEP; q++) dst[q * kBlock] = keep[q];
         } else if constexpr (kVW) {
             v = Net::eval_vw(p, vw, c, x, tab, &E1);
         } else {
@@ -259,9 +266,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
         // kept activations of the evaluation about to be reversed, requested one evaluation ahead
         double kn[Net::NKEEP];
         if constexpr (KEEP) {
-            const double* src = a.act + ((int64_t)(5 * S) * Net::NKEEP) * N + i;
+            const double* src = act + (int64_t)(5 * S) * (Net::NKEEP * kBlock);
 #pragma unroll
-            for (int q = 0; q < Net::NKEEP; q++) kn[q] = src[(int64_t)q * N];
+            for (int q = 0; q < Net::NKEEP; q++) kn[q] = src[q * kBlock];
         }
         // evaluations in reverse order; e = -1 is the baseline with weight -sum(w)
 #pragma unroll 1
@@ -389,9 +396,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
                     for (int j = 0; j < Net::WIDTH; j++) hk[l][j] = kn[(l - 1) * Net::WIDTH + j];
                 const double sg = kn[Net::NKEEP - 1];
                 if (e >= 0) {                   // next evaluation's (e - 1: row block e) values: in flight during this one
-                    const double* src = a.act + ((int64_t)e * Net::NKEEP) * N + i;
+                    const double* src = act + (int64_t)e * (Net::NKEEP * kBlock);
 #pragma unroll
-                    for (int q = 0; q < Net::NKEEP; q++) kn[q] = src[(int64_t)q * N];
+                    for (int q = 0; q < Net::NKEEP; q++) kn[q] = src[q * kBlock];
                 }
                 Net::layer1(p, c, x, hk[0], tab, &E1);
                 Net::template backward<false>(launder(p), x, hk, sg, wv, acc, dxdummy);

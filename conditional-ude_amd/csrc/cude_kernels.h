@@ -45,9 +45,10 @@ struct CpepArgs {
     double* auc;             // [N] or nullptr (NS == 3: cumulative secretion at t_end)
     double* g_cond;          // [n_sets][N] (grad)
     double* partials;        // [n_sets][nblocks][P+2]
-    double* act;             // one-lane gradient kernel: [5S+1][(D-1)W+1][N] kept activations of the forward sweep (tanh
-                             // outputs of the hidden layers 2..D + the output unit's logistic derivative per evaluation),
-                             // read back by the reverse sweep instead of re-evaluating those layers; nullptr = recompute
+    double* act;             // one-lane gradient kernel: [nblocks][5S+1][(D-1)W+1][64] kept activations of the forward
+                             // sweep (tanh outputs of the hidden layers 2..D + the output unit's logistic derivative per
+                             // evaluation), read back by the reverse sweep instead of re-evaluating those layers;
+                             // nullptr = recompute.  Off by default: measured slower (see cude_api.hip)
     // multi-start evaluation: n_sets parameter sets in the grid's y dimension, set k reads nn + k*set_stride_nn and
     // cond + k*set_stride_cond (and writes sse / g_cond + k*set_stride_cond); 0/0/0 for the single-set path
     int32_t n_sets;
@@ -197,7 +198,7 @@ struct AdamArgs {
     double* cond; double* m_cond; double* v_cond; const double* g_cond;
     double* nn; double* m_nn; double* v_nn; const double* g_nn;   // g_nn[P+1] = n_failed
     double lr, b1, b2, eps, c1, c2;   // c1 = 1-b1^t, c2 = 1-b2^t (filled on the device from `state`)
-    double* state;                    // device: {b1^(t-1), b2^(t-1), steps done, trace position}
+    double* state;                    // device: {b1^(t-1), b2^(t-1), steps done, trace position, arrival counter (u64)}
     double* trace;                    // device: [trace_cap][2] = (sum loss, n_failed) per iteration
     int64_t trace_cap;
 };

@@ -164,8 +164,11 @@ private:
     void armijo(double f, const double* g) {
         if (f > f0_ + kC1 * a2_ * dphi0_) {       // (NaN compares false: accepted, the main loop then stops)
             ls_it_++;
-            if (ls_it_ > kMaxLs) {                // LineSearchException: Optim stops the optimisation here
-                calls_ += n_eval_;
+            if (ls_it_ > kMaxLs) {                // LineSearchException(alpha = the last step tried): Optim's
+                calls_ += n_eval_;                // perform_linesearch! takes that step (state.x += alpha s), then
+                x_ = trial_;                      // update_state! reports failure and the main loop breaks: the
+                f_ = f;                           // result is the last TRIAL point and its value, not the iterate
+                std::copy(g, g + n_, g_.begin()); // the search started from
                 it_++;
                 finish();
                 return;

@@ -77,6 +77,9 @@ _SIGNATURES = {
     "cude_get_scale": (C.c_int32, [C.c_void_p, C.c_void_p, _dp]),
     "cude_loss_grad_partial": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cude_adam_apply": (C.c_int32, [C.c_void_p, C.c_void_p, _dp]),
+    "cude_partial_buffer": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    "cude_loss_grad_partial_device": (C.c_int32, [C.c_void_p]),
+    "cude_adam_apply_device": (C.c_int32, [C.c_void_p, _dp]),
     "cude_kernel_time_ms": (C.c_int32, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
     "cude_set_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cude_comm_unique_id": (C.c_int32, [C.c_void_p]),

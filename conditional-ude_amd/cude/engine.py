@@ -32,16 +32,25 @@ def lbfgs_minimize(fg, x0, maxiters=1000):
     x0 = _f64(x0).reshape(-1)
     n = x0.size
 
+    err = []
+
     def thunk(xp, nn, fp, gp, _user):
-        f, g = fg(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
-        fp[0] = float(f)
-        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
-        return 0
+        try:
+            f, g = fg(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+            fp[0] = float(f)
+            np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+            return 0
+        except BaseException as e:      # a ctypes callback must not raise: hand the error back through the status
+            err.append(e)
+            return -1
     cb = _OBJECTIVE(thunk)
     x = np.empty(n)
     f, it, calls, conv = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
-    check(_lib.load().cude_lbfgs_minimize(n, _ptr(x0), int(maxiters), C.cast(cb, C.c_void_p), None, _ptr(x),
-                                          C.byref(f), C.byref(it), C.byref(calls), C.byref(conv)))
+    rc = _lib.load().cude_lbfgs_minimize(n, _ptr(x0), int(maxiters), C.cast(cb, C.c_void_p), None, _ptr(x),
+                                         C.byref(f), C.byref(it), C.byref(calls), C.byref(conv))
+    if err:
+        raise err[0]
+    check(rc)
     return dict(x=x, f=f.value, iterations=it.value, f_calls=calls.value, converged=bool(conv.value))
 
 
@@ -55,22 +64,38 @@ def lbfgs_minimize_sharded(fg, x0, n_shared, reduce, maxiters=1000):
     x0 = _f64(x0).reshape(-1)
     n = x0.size
 
+    err = []
+
+    # A callback that raised would leave this rank on a different L-BFGS path from its peers, which then block in the
+    # next collective: the error goes back through the status (rc < 0 -> CUDE_ERR_ARG / CUDE_ERR_COMM) and is re-raised
+    # here once the library has returned.
     def thunk(xp, nn, fp, gp, _user):
-        f, g = fg(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
-        fp[0] = float(f)
-        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
-        return 0
+        try:
+            f, g = fg(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+            fp[0] = float(f)
+            np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+            return 0
+        except BaseException as e:
+            err.append(e)
+            return -1
 
     def red(vp, count, op, _user):
-        v = np.ctypeslib.as_array(vp, shape=(count,))
-        v[:] = reduce(v.copy(), int(op))
-        return 0
+        try:
+            v = np.ctypeslib.as_array(vp, shape=(count,))
+            v[:] = reduce(v.copy(), int(op))
+            return 0
+        except BaseException as e:
+            err.append(e)
+            return -1
     cb, rcb = _OBJECTIVE(thunk), _REDUCE(red)
     x = np.empty(n)
     f, it, calls, conv = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
-    check(_lib.load().cude_lbfgs_minimize_sharded(n, int(n_shared), _ptr(x0), int(maxiters), C.cast(cb, C.c_void_p),
-                                                  C.cast(rcb, C.c_void_p), None, _ptr(x), C.byref(f), C.byref(it),
-                                                  C.byref(calls), C.byref(conv)))
+    rc = _lib.load().cude_lbfgs_minimize_sharded(n, int(n_shared), _ptr(x0), int(maxiters), C.cast(cb, C.c_void_p),
+                                                 C.cast(rcb, C.c_void_p), None, _ptr(x), C.byref(f), C.byref(it),
+                                                 C.byref(calls), C.byref(conv))
+    if err:
+        raise err[0]
+    check(rc)
     return dict(x=x, f=f.value, iterations=it.value, f_calls=calls.value, converged=bool(conv.value))
 
 
@@ -97,6 +122,7 @@ class Engine:
         check(self._lib.cude_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self.n_state = n_state
+        self.lam = float(lam)
         self.P = n_params(*self.arch)
         self.N = 0
         self.T = 0
@@ -390,6 +416,30 @@ class Engine:
         r = _f64(reduced)
         loss = C.c_double()
         check(self._lib.cude_adam_apply(self._h, _ptr(r), C.byref(loss)))
+        return loss.value
+
+    # -- the same exchange without the host round trip (a collective that reduces device memory in place)
+    def partial_buffer(self):
+        """(device address, count = P + 2) of the context's [g_nn; sum sse; n_failed] vector."""
+        ptr, n = C.c_void_p(), C.c_int32()
+        check(self._lib.cude_partial_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def partial_tensor(self, torch, device):
+        """A torch tensor ALIASING that vector (no copy): torch.distributed.all_reduce on it reduces in place."""
+        ptr, n = self.partial_buffer()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3,
+                                        "strides": None}
+        return torch.as_tensor(_Alias(), device=device)
+
+    def loss_grad_partial_device(self):
+        check(self._lib.cude_loss_grad_partial_device(self._h))
+
+    def adam_apply_device(self):
+        loss = C.c_double()
+        check(self._lib.cude_adam_apply_device(self._h, C.byref(loss)))
         return loss.value
 
     def synchronize(self):

@@ -16,7 +16,9 @@ import numpy as np
 
 
 class LineSearchFailed(Exception):
-    """LineSearches.LineSearchException: BackTracking ran out of shrinks; Optim stops the optimisation."""
+    """LineSearches.LineSearchException: BackTracking ran out of shrinks.  Carries (alpha, f, g, n_eval) of the last
+    step tried: Optim's perform_linesearch! takes that step (state.alpha = ex.alpha; state.x += alpha s) and the main
+    loop then stops."""
 
 
 def _backtracking(x, f0, dphi0, d, alpha0=1.0, c1=1e-4, rho_hi=0.5, rho_lo=0.1, max_iter=1000, max_finite=52):
@@ -37,7 +39,7 @@ def _backtracking(x, f0, dphi0, d, alpha0=1.0, c1=1e-4, rho_hi=0.5, rho_lo=0.1, 
     while f > f0 + c1 * a2 * dphi0:
         it += 1
         if it > max_iter:
-            raise LineSearchFailed(n_eval)
+            raise LineSearchFailed(a2, f, g, n_eval)
         if it == 1:
             a_tmp = -(dphi0 * a2 ** 2) / (2.0 * (f - f0 - dphi0 * a2))
         else:
@@ -113,7 +115,9 @@ def lbfgs_steps(x0, maxiters=1000, m=10, g_tol=1e-8, callback=None, n_shared=Non
         try:
             alpha, f_new, g_new, n_eval = yield from _backtracking(x, f, dphi0, d)
         except LineSearchFailed as e:
-            calls += e.args[0]
+            alpha, f, g, n_eval = e.args
+            calls += n_eval
+            x = x + alpha * d
             it += 1
             break
         calls += n_eval

@@ -101,7 +101,7 @@ class ShardedTrainer:
             self.engine.set_global_subjects(tot[3], tot[:3] / tot[3])
             self.n_global = float(tot[3])
 
-    def lbfgs(self, maxiters, lam=0.0):
+    def lbfgs(self, maxiters, lam=None):
         """Second stage of `_optimize` (src/parameter-estimation.jl:179-180: L-BFGS + BackTracking after Adam) on the
         sharded population, starting from the engine's current parameters; leaves the result in the engine and
         returns dict(f, iterations, f_calls, converged) -- identical on every rank.
@@ -109,14 +109,18 @@ class ShardedTrainer:
         rccl: cude_train_restarts (one restart) reduces losses, network gradients and the conditional part of every
         inner product over its communicator.  host: the library's L-BFGS state machine
         (cude_lbfgs_minimize_sharded) with this trainer's collective as the reducer; every evaluation is
-        cude_loss_grad_partial + one sum of P+2 doubles.  `lam` is the context's L2 weight (host transport adds the
-        term here, as cude_adam_apply does on the device)."""
+        cude_loss_grad_partial + one sum of P+2 doubles.  `lam` defaults to the engine's configured L2 weight (the host
+        transport adds the term here, as cude_adam_apply does on the device), so both transports optimise the same
+        objective.  On the rccl transport the library does not hand out its counters: iterations, f_calls and converged
+        are None there."""
+        if lam is None:
+            lam = getattr(self.engine, "lam", 0.0)
         nn, cond = self.engine.get_params()
         P = nn.size
         if self.transport == "rccl":
             nn_o, cond_o, obj = self.engine.train_restarts(nn[None, :], cond[None, :], 0, 1e-3, int(maxiters))
             self.engine.set_params(nn_o[0], cond_o[0])
-            return dict(f=float(obj[0]))
+            return dict(f=float(obj[0]), iterations=None, f_calls=None, converged=None)
         from .engine import lbfgs_minimize_sharded
         n_glob = self.n_global
 

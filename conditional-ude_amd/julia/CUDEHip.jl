@@ -345,6 +345,20 @@ function adam_apply!(c::Ctx, reduced::Vector{Float64})
     l[]
 end
 
+# the same exchange without the host round trip: the P+2 doubles stay on the device, a GPU-aware collective (RCCL through
+# another binding, MPI.jl built against a ROCm-aware MPI) reduces them in place between the two calls
+function partial_buffer(c::Ctx)
+    p = Ref{Ptr{Float64}}(C_NULL); n = Ref{Int32}(0)
+    check(ccall((:cude_partial_buffer, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Int32}), c.h, p, n))
+    p[], Int(n[])
+end
+loss_grad_partial_device!(c::Ctx) = check(ccall((:cude_loss_grad_partial_device, LIB), Int32, (Ptr{Cvoid},), c.h))
+function adam_apply_device!(c::Ctx)
+    l = Ref{Float64}()
+    check(ccall((:cude_adam_apply_device, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}), c.h, l))
+    l[]
+end
+
 set_kernel_timing!(c::Ctx, on::Bool) = check(ccall((:cude_set_kernel_timing, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on ? 1 : 0))
 
 function kernel_time_ms(c::Ctx)

@@ -299,6 +299,15 @@ int32_t cude_set_global_subjects(cude_ctx* ctx, double n_global, const double* s
 int32_t cude_get_scale(cude_ctx* ctx, double* scale3, double* n_global);
 int32_t cude_loss_grad_partial(cude_ctx* ctx, double* partial /* P+2 */, double* g_cond /* N or NULL */);
 int32_t cude_adam_apply(cude_ctx* ctx, const double* reduced /* P+2 */, double* loss);
+/* The same exchange WITHOUT the host round trip, for a collective that reduces device memory in place (RCCL through
+ * another binding, GPU-aware MPI): cude_partial_buffer hands out the device address of the context's P+2 doubles,
+ * cude_loss_grad_partial_device fills them with this rank's un-reduced vector and synchronises the context's stream,
+ * the caller all-reduces them in place on a stream of its own and waits for that, cude_adam_apply_device continues as
+ * cude_adam_apply does.  (No reference line: the reference has no collective; this is the sharded form of
+ * ForwardDiff.gradient + Optimisers.update, src/parameter-estimation.jl:170-176.) */
+int32_t cude_partial_buffer(cude_ctx* ctx, double** device_ptr, int32_t* count /* P+2 */);
+int32_t cude_loss_grad_partial_device(cude_ctx* ctx);
+int32_t cude_adam_apply_device(cude_ctx* ctx, double* loss);
 
 /* Average device time (ms) of the ensemble launches (forward, or forward+adjoint: whatever the calls since the last
  * query ran) measured with HIP events on the context's stream; resets the accumulator. */

@@ -287,7 +287,11 @@ int cude_oracle_cpep_rev(int N, int T, const double* tp, const double* glucose, 
 #else
     nthreads = 1;
 #endif
-    double* gacc = (double*)calloc((size_t)nthreads * (P + 2), sizeof(double));
+    /* one accumulator row per thread, padded to whole cache lines and line-aligned: adjacent rows of P + 2 = 69 doubles
+     * shared a line at every boundary, and every subject's update of that line bounced it between two cores */
+    const size_t grow = ((size_t)(P + 2) + 7) / 8 * 8;
+    double* gacc = (double*)aligned_alloc(64, (size_t)nthreads * grow * sizeof(double));
+    memset(gacc, 0, (size_t)nthreads * grow * sizeof(double));
     int nfail = 0;
 #pragma omp parallel num_threads(nthreads) reduction(+ : nfail)
     {
@@ -296,7 +300,7 @@ int cude_oracle_cpep_rev(int N, int T, const double* tp, const double* glucose, 
 #else
         const int tid = 0;
 #endif
-        double* ga = gacc + (size_t)tid * (P + 2);
+        double* ga = gacc + (size_t)tid * grow;
         ract_t* acts = (ract_t*)malloc(sizeof(ract_t) * ((size_t)6 * n_steps + 1));
         double* work = (double*)malloc(sizeof(double) * (size_t)T * 3);
         double* obs = (double*)malloc(sizeof(double) * (size_t)T * 3);
@@ -326,8 +330,8 @@ int cude_oracle_cpep_rev(int N, int T, const double* tp, const double* glucose, 
     double tot = 0.0;
     if (want_grad) for (int q = 0; q < P; q++) g_nn[q] = 0.0;
     for (int t = 0; t < nthreads; t++) {
-        tot += gacc[(size_t)t * (P + 2) + P];
-        if (want_grad) for (int q = 0; q < P; q++) g_nn[q] += gacc[(size_t)t * (P + 2) + q];
+        tot += gacc[(size_t)t * grow + P];
+        if (want_grad) for (int q = 0; q < P; q++) g_nn[q] += gacc[(size_t)t * grow + q];
     }
     free(gacc);
     *loss = nfail ? INFINITY : tot / N;
@@ -354,7 +358,11 @@ int cude_oracle_supp_rev(int N, int T, const double* tp, const double* data, int
 #else
     nthreads = 1;
 #endif
-    double* gacc = (double*)calloc((size_t)nthreads * (P + 2), sizeof(double));
+    /* one accumulator row per thread, padded to whole cache lines and line-aligned: adjacent rows of P + 2 = 69 doubles
+     * shared a line at every boundary, and every subject's update of that line bounced it between two cores */
+    const size_t grow = ((size_t)(P + 2) + 7) / 8 * 8;
+    double* gacc = (double*)aligned_alloc(64, (size_t)nthreads * grow * sizeof(double));
+    memset(gacc, 0, (size_t)nthreads * grow * sizeof(double));
     int nfail = 0;
 #pragma omp parallel num_threads(nthreads) reduction(+ : nfail)
     {
@@ -363,7 +371,7 @@ int cude_oracle_supp_rev(int N, int T, const double* tp, const double* data, int
 #else
         const int tid = 0;
 #endif
-        double* ga = gacc + (size_t)tid * (P + 2);
+        double* ga = gacc + (size_t)tid * grow;
         ract_t* acts = (ract_t*)malloc(sizeof(ract_t) * ((size_t)6 * n_steps + 1));
         double* work = (double*)malloc(sizeof(double) * (size_t)T * 3);
 #pragma omp for schedule(static)
@@ -389,8 +397,8 @@ int cude_oracle_supp_rev(int N, int T, const double* tp, const double* data, int
     double tot = 0.0, reg = 0.0;
     if (want_grad) for (int q = 0; q < P; q++) g_nn[q] = 0.0;
     for (int t = 0; t < nthreads; t++) {
-        tot += gacc[(size_t)t * (P + 2) + P];
-        if (want_grad) for (int q = 0; q < P; q++) g_nn[q] += gacc[(size_t)t * (P + 2) + q];
+        tot += gacc[(size_t)t * grow + P];
+        if (want_grad) for (int q = 0; q < P; q++) g_nn[q] += gacc[(size_t)t * grow + q];
     }
     for (int q = 0; q < P; q++) reg += nn[q] * nn[q];
     if (want_grad) for (int q = 0; q < P; q++) g_nn[q] += 2.0 * lambda * nn[q];

@@ -354,7 +354,7 @@ def _profile_vertices(fig, i):
     return kr[keep].astype(int), (y_bot - c[keep, 1]) * 10.0 / (y_bot - y_top)
 
 
-def _recover_profile(sub, k, y, n_fine=1001, half_width=5e-3, edge_width=0.0, coarse_width=0.1):
+def _recover_profile(sub, k, y, n_fine=1001, half_width=5e-3, edge_width=0.0, coarse_width=0.1, stored=None):
     """The one free scalar of a plotted profile is the beta_i it is centred on (the reference's fitted value, not
     stored); sigma_i only scales it.  Locate beta_i with the smooth fixed-step loss, then scan its neighbourhood with
     the adaptive one (the profile resolves the ripple of the adaptive-step loss, so it matches at the figure's
@@ -390,6 +390,18 @@ def _recover_profile(sub, k, y, n_fine=1001, half_width=5e-3, edge_width=0.0, co
             for lo, hi, n in ((0.0, edge_width, n_fine), (-2e-5, 2e-5, 41)):
                 centre = best(np.clip(centre - edge * np.linspace(lo, hi, n), *sub.box), sub.adaptive_many, 0.75)
         found.append(centre)
+    if stored is not None:
+        # The curve does not always identify its centre (flat or multi-modal profiles).  For a subject of the reference's
+        # 57-subject training set the centre is, up to its L-BFGS's stopping error, one of the STORED fitted betas of the
+        # best model (source_data/cude_neural_parameters.jld2; which subject each belongs to is not stored): those near
+        # this subject's own optimum are scanned at the same 1e-5 / 1e-6 spacing as the curve-derived candidate.
+        near = [b for b in np.asarray(stored, dtype=np.float64) if abs(b - b_star) < 0.1 or
+                any(abs(b - f) < 0.1 for f in found)]
+        for b in near:
+            centre = b
+            for half, n in ((3e-3, 601), (2e-5, 41)):
+                centre = best(np.clip(centre + np.linspace(-half, half, n), *sub.box), sub.adaptive_many, 0.75)
+            found.append(centre)
     cand = np.array(found)
     s, res_all = score(cand, sub.adaptive_many, np.arange(k.size))
     j = int(np.argmin(np.median(res_all, axis=1)))

@@ -278,6 +278,7 @@ def test_product_reproduces_the_likelihood_profiles_of_all_subjects():
     from cude.engine import Engine
     d = F._Data()
     nn, arch, _ = d.network(False)
+    stored_betas = d.g["betas_train"][int(d.g["best_model_index"]) - 1]
     good, near, bad, n_vertices = 0, 0, [], 0
     for part, off, n in (("train", 0, 82), ("test", 82, 35)):
         for i in range(n):
@@ -285,7 +286,11 @@ def test_product_reproduces_the_likelihood_profiles_of_all_subjects():
             if k.size < 3:
                 continue
             sub = _GpuSubject(F._Subject(d, part, i, covariate=False))
-            beta, _, _ = F._recover_profile(sub, k, y, n_fine=4001, half_width=2e-2, edge_width=4e-2, coarse_width=0.6)
+            beta, _, res0 = F._recover_profile(sub, k, y, n_fine=4001, half_width=2e-2, edge_width=4e-2, coarse_width=0.6)
+            if part == "train" and np.median(res0) >= 1.5e-4:
+                # (round 3) the curve alone did not pin its centre: try the stored fitted betas of the best model too
+                beta, _, _ = F._recover_profile(sub, k, y, n_fine=4001, half_width=2e-2, edge_width=4e-2,
+                                                coarse_width=0.6, stored=stored_betas)
             # the reference's own call sequence for this subject: likelihood_profile(beta_i, ...; steps = 1000)
             eng = Engine("cpep", arch, n_steps=0, n_state=2)
             eng.set_population_cpep(d.tp, *(a for a in sub.row))

@@ -191,3 +191,36 @@ def test_mixed_launch_below_one_fill_failures_and_small_remainder():
     assert abs(l1 - l0) <= 1e-13 * l0 and np.max(np.abs(g1 - g0)) <= 1e-12 * np.max(np.abs(g0))
     assert np.array_equal(c1[:65_536], c0[:65_536]) and not np.array_equal(c1[65_536:], c0[65_536:])
     assert np.max(np.abs(c1 - c0)) <= 1e-12 * np.max(np.abs(c0))
+
+
+def test_baseline_config1_forward_only_at_its_own_size_and_launch_shape():
+    """BASELINE configs[1] as it is quoted: 1e4 subjects, CPEP3 (2x6x6x1, 3 states, 30 steps), forward-only, through
+    whatever path the library's selector takes at that size (time-split chunks: no CUDE_CPEP_PATH here).  Per-subject
+    SSE against the C oracle on 400 random subjects (1e-10), the loss against their mean, the quadrature state, and
+    bitwise repeatability of the whole call."""
+    import c_oracle as co
+    import cude_oracle as o
+    from cude.engine import Engine
+    arch, N = (2, 6, 2), 10_000
+    tp, G, obs, age, t2, beta = _population(N, 2024)
+    nn = o.glorot_params(arch, 5)
+    eng = Engine("cpep", arch, n_steps=30, n_state=3)
+    eng.set_population_cpep(tp, G, obs, age, t2)
+    eng.set_params(nn, beta)
+    f1 = eng.forward(want_sse=True)
+    f2 = eng.forward(want_sse=True)
+    assert np.isfinite(f1["loss"]) and eng.n_failed() == 0
+    assert f1["loss"] == f2["loss"] and np.array_equal(f1["sse"], f2["sse"])          # bitwise repeatable
+    assert abs(f1["loss"] - f1["sse"].mean()) <= 1e-13 * f1["loss"]
+    idx = np.sort(np.random.default_rng(7).choice(N, 400, replace=False))
+    ref = co.cpep(tp, G[idx], obs[idx], age[idx], t2[idx], arch, nn, beta[idx], 30, 3, want_grad=False)
+    assert ref["n_failed"] == 0
+    assert np.max(np.abs(f1["sse"][idx] - ref["sse"])) <= 1e-10 * max(1.0, float(np.max(ref["sse"])))
+    # the same subjects on their own (another launch shape: 7 workgroups): the same per-subject numbers to rounding
+    sub = Engine("cpep", arch, n_steps=30, n_state=3)
+    sub.set_population_cpep(tp, G[idx], obs[idx], age[idx], t2[idx])
+    sub.set_params(nn, beta[idx])
+    fs = sub.forward(want_sse=True)
+    assert np.max(np.abs(fs["sse"] - f1["sse"][idx])) <= 1e-12 * max(1.0, float(np.max(ref["sse"])))
+    sub.close()
+    eng.close()

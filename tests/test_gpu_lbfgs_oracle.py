@@ -1,0 +1,68 @@
+"""Second training stage on the device: the L-BFGS stage of cude_train_restarts -- the C++ state machine
+of csrc/cude_optim.h driving the HIP loss + gradient -- against oracle/lbfgs_oracle.py driving the C oracle's loss and
+gradient on the same problem (the reference's own sizes: 57 / 37 subjects).  Iterate k of the product = the run stopped
+at k iterations.  The bar follows the problem's own conditioning (tests/test_lbfgs_oracle.py: the oracle's iterates move
+by 1e-12 at iteration 21 and 1e-6 at iteration 50 when its start moves by one unit in the last place): a fixed 1e-8 for
+the first iterations, then 100 x the oracle's own sensitivity to a perturbation of the size by which the two objectives
+differ (device vs CPU gradient: ~1e-11 relative)."""
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+from test_lbfgs_oracle import _cpep_objective, _supp_objective
+
+pytestmark = pytest.mark.gpu
+
+
+def _sensitivity(fg, x0, ks, rel, n_probe=3):
+    from lbfgs_oracle import lbfgs_oracle
+    base = lbfgs_oracle(fg, x0, maxiters=max(ks))
+    sens = {k: 0.0 for k in ks}
+    rng = np.random.default_rng(5)
+    for _ in range(n_probe):
+        r = lbfgs_oracle(fg, x0 * (1.0 + rel * rng.standard_normal(x0.size)), maxiters=max(ks))
+        for k in ks:
+            sens[k] = max(sens[k], float(np.max(np.abs(r["trace"][k][0] - base["trace"][k][0]))))
+    return base, sens
+
+
+@pytest.mark.parametrize("problem", ["cpep", "supp"])
+def test_device_lbfgs_stage_follows_the_oracle(problem):
+    import os
+    from cude.engine import Engine
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if problem == "cpep":
+        fg, x0 = _cpep_objective(n_steps=40)
+        d = np.load(os.path.join(gold, "ohashi_cude.npz"))
+        idx = np.nonzero(np.isin(d["subject_no"], d["train_subject_numbers"]))[0][:57]
+        eng = Engine("cpep", (2, 4, 2), n_steps=40, n_state=2)
+        eng.set_population_cpep(d["timepoints"], d["glucose"][idx], d["cpeptide"][idx], d["ages"][idx], d["t2dm"][idx])
+        P, ks, k_fixed = 37, [1, 2, 3, 5, 8, 13, 21, 34], 8
+    else:
+        fg, x0 = _supp_objective(lam=0.0, n_steps=30)
+        d = np.load(os.path.join(gold, "suppression_lambda0.npz"))
+        eng = Engine("supp", (4, 3, 5), n_steps=30, lam=0.0)
+        eng.set_population_supp(d["timepoints"], d["group_data"])
+        P, ks, k_fixed = 67, [1, 2, 3, 5, 8], 3
+    # the two objectives at the start: the size of the perturbation the comparison lives with
+    eng.set_params(x0[:P], x0[P:])
+    l_dev, g_nn, g_c = eng.loss_grad()
+    f_o, g_o = fg(x0)
+    assert abs(l_dev - f_o) <= 1e-10 * f_o
+    rel = max(1e-13, float(np.max(np.abs(np.concatenate([g_nn, g_c]) - g_o)) / np.max(np.abs(g_o))))
+    assert rel <= 1e-9
+    ref, sens = _sensitivity(fg, x0, ks, rel)
+    for k in ks:
+        nn, cond, obj = eng.train_restarts(x0[None, :P], x0[None, P:], 0, 1e-3, k)
+        xk, fk = ref["trace"][k]
+        dx = float(np.max(np.abs(np.concatenate([nn[0], cond[0]]) - xk)))
+        assert dx <= 1e-10 + 100.0 * sens[k], (k, dx, sens[k])
+        if k <= k_fixed:
+            assert dx <= 1e-8 * max(1.0, float(np.max(np.abs(xk)))), (k, dx)
+            assert abs(obj[0] - fk) <= 1e-8 * max(1.0, abs(fk))
+    # the end of the stage: same quality of optimum as the oracle optimiser reaches from the same start
+    nn, cond, obj = eng.train_restarts(x0[None, :P], x0[None, P:], 0, 1e-3, 50)
+    from lbfgs_oracle import lbfgs_oracle
+    o50 = lbfgs_oracle(fg, x0, maxiters=50, keep_trace=False)
+    assert abs(obj[0] - o50["f"]) <= 0.05 * o50["f"]
+    eng.close()

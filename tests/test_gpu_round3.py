@@ -1,0 +1,108 @@
+"""Round-3 additions to the C ABI and fixes of the round-2 advisor findings, on the device."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_cpep_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(c, arch, n_steps=30, n_state=2, lam=0.0):
+    from cude.engine import Engine
+    eng = Engine("cpep", arch, n_steps=n_steps, n_state=n_state, lam=lam)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(c["nn"], c["beta"])
+    return eng
+
+
+def test_device_resident_partial_and_apply_match_the_host_round_trip():
+    """cude_partial_buffer / cude_loss_grad_partial_device / cude_adam_apply_device: the bring-your-own-collective step
+    with the P+2 doubles left on the device.  A torch tensor aliasing the buffer (what bench.py hands to
+    torch.distributed.all_reduce when the built-in communicator is unavailable) shows what cude_loss_grad_partial copies
+    to the host, an in-place change of it is what cude_adam_apply_device consumes, and the step equals the host one."""
+    arch, N = (2, 6, 2), 300
+    c = make_cpep_case(N, arch)
+    a, b = _engine(c, arch, lam=0.01), _engine(c, arch, lam=0.01)
+    for e in (a, b):
+        e.set_global_subjects(2 * N)             # as if a second rank held as many subjects again
+        e.adam_init(1e-2)
+    t = a.partial_tensor(torch, torch.device("cuda", 0))
+    assert t.dtype == torch.float64 and t.numel() == a.P + 2 and t.data_ptr() == a.partial_buffer()[0]
+    for _ in range(3):
+        part, _ = b.loss_grad_partial()
+        a.loss_grad_partial_device()
+        assert np.array_equal(t.cpu().numpy(), part)
+        t.mul_(2.0)                              # "all-reduce" over two identical ranks, in place on the device
+        torch.cuda.current_stream().synchronize()
+        la, lb = a.adam_apply_device(), b.adam_apply(2.0 * part)
+        assert la == lb
+    (nn_a, cond_a), (nn_b, cond_b) = a.get_params(), b.get_params()
+    assert np.array_equal(nn_a, nn_b) and np.array_equal(cond_a, cond_b)
+    a.close()
+    b.close()
+
+
+def test_set_tolerances_invalidates_a_captured_optimiser_iteration():
+    """in adaptive mode cude_adam_run replays a captured launch whose arguments hold the tolerances
+    by value; cude_set_tolerances must drop that graph, or training silently keeps the old tolerances."""
+    arch, N = (2, 4, 2), 200
+    c = make_cpep_case(N, arch)
+    runs = {}
+    for mode in ("run", "step"):
+        eng = _engine(c, arch, n_steps=0)
+        eng.adam_init(1e-2)
+        first = eng.adam_run(2) if mode == "run" else np.array([eng.adam_step() for _ in range(2)])
+        eng.set_tolerances(1e-9, 1e-7)
+        second = eng.adam_run(2) if mode == "run" else np.array([eng.adam_step() for _ in range(2)])
+        runs[mode] = (first, second, eng.get_params())
+        eng.close()
+    assert np.array_equal(runs["run"][0], runs["step"][0])
+    assert np.array_equal(runs["run"][1], runs["step"][1])                     # same losses AFTER the change ...
+    assert np.array_equal(runs["run"][2][0], runs["step"][2][0])               # ... and the same parameters
+    # and the change of tolerances is visible at all (the tight solve gives a different loss at the same parameters)
+    eng = _engine(c, arch, n_steps=0)
+    l_loose = eng.forward()["loss"]
+    eng.set_tolerances(1e-9, 1e-7)
+    assert eng.forward()["loss"] != l_loose
+    eng.close()
+
+
+def test_param_mask_set_after_adam_steps_freezes_entries_at_once():
+    """a mask set AFTER Adam has gathered moments must also silence those moments, otherwise a frozen
+    entry keeps drifting by lr * m_hat / (sqrt(v_hat) + eps) while m decays."""
+    arch, N = (2, 4, 2), 150
+    c = make_cpep_case(N, arch)
+    eng = _engine(c, arch)
+    eng.adam_init(1e-2)
+    for _ in range(5):
+        eng.adam_step()
+    nn_before, _ = eng.get_params()
+    mask = np.ones(eng.P)
+    mask[[0, 7, 20, eng.P - 1]] = 0.0
+    eng.set_param_mask(mask)
+    for _ in range(5):
+        eng.adam_step()
+    nn_after, _ = eng.get_params()
+    frozen = mask == 0.0
+    assert np.array_equal(nn_after[frozen], nn_before[frozen])
+    assert np.all(nn_after[~frozen] != nn_before[~frozen])
+    eng.close()
+
+
+def test_kept_activation_variant_of_the_gradient_kernel_is_bit_identical(monkeypatch):
+    """CUDE_CPEP_KEEP=1 (cude_cpep.hip: KEEP): upper-layer activations kept in HBM between the sweeps instead of
+    recomputed -- the same bits (measured slower at the benchmark sizes, hence off by default)."""
+    arch, N = (2, 6, 2), 700
+    c = make_cpep_case(N, arch)
+    out = {}
+    for keep in ("0", "1"):
+        monkeypatch.setenv("CUDE_CPEP_KEEP", keep)
+        monkeypatch.setenv("CUDE_CPEP_PATH", "1")             # the one-lane kernel (a small population would time-split)
+        eng = _engine(c, arch, n_state=3)
+        out[keep] = eng.loss_grad()
+        eng.close()
+    for x, y in zip(out["0"], out["1"]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))

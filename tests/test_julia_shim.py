@@ -103,7 +103,8 @@ def _jl_kind(t):
 
 
 _POINTEE = {"Float64": {"double"}, "Int64": {"int64_t"}, "Int32": {"int32_t"}, "UInt8": {"uint8_t"},
-            "Cvoid": {"cude_ctx", "void", "fn"}, "Config": {"cude_config"}, "Ptr{Cvoid}": {"cude_ctx*"}}
+            "Cvoid": {"cude_ctx", "void", "fn"}, "Config": {"cude_config"}, "Ptr{Cvoid}": {"cude_ctx*"},
+            "Ptr{Float64}": {"double*"}}
 
 
 def test_every_ccall_matches_its_prototype():
