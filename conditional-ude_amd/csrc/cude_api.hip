@@ -257,6 +257,9 @@ struct cude_ctx {
     size_t ev_used = 0;
     double host_red[3];
     double* pinned = nullptr;       // page-locked staging of the small result vectors ([g_nn; loss sum; n_failed])
+    double* pinned_pairs = nullptr; // page-locked [nblocks][2]: per-workgroup (sum SSE, failures) of a forward-only launch,
+    int64_t pinned_pairs_n = 0;     // written by the scan kernel itself and added up by the host (finish_loss)
+    bool loss_in_pinned = false;    // the last forward launch left its result there
     // scratch of cude_multistart_loss_grad (kept between calls: it is called once per optimiser iteration)
     DevBuf<double> ms_nn, ms_cond, ms_part, ms_out, ms_gcond, ms_ckpt, ms_act;
     DevBuf<double> ms_fsum, ms_wts, ms_gcp, ms_p2;   // time-split path with parameter sets (small populations)
@@ -425,6 +428,16 @@ int32_t alloc_common(cude_ctx* c) {
     HIP_TRY(c->g_cond.resize(N));
     HIP_TRY(c->sse.resize(N));
     HIP_TRY(c->partials.resize((size_t)c->nblocks * (c->P + 2)));
+    if (c->pinned_pairs_n < c->nblocks && c->nblocks <= 8192) {      // (bigger populations are not launch-bound)
+        if (c->pinned_pairs) (void)hipHostFree(c->pinned_pairs);
+        c->pinned_pairs = nullptr;
+        c->pinned_pairs_n = 0;
+        if (hipHostMalloc((void**)&c->pinned_pairs, (size_t)c->nblocks * 2 * sizeof(double), hipHostMallocDefault) ==
+            hipSuccess)
+            c->pinned_pairs_n = c->nblocks;
+        else
+            c->pinned_pairs = nullptr;
+    }
     HIP_TRY(c->tape.resize(0));          // adaptive gradient tape: allocated by the first gradient evaluation
     c->tape_cap = 0;
     c->have_tape = false;
@@ -681,6 +694,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     if (!c->have_nn || (!c->have_cond && !cond_ov)) return fail(CUDE_ERR_STATE, "parameters not set");
     if (grad) { int32_t rc = ensure_tape(c); if (rc) return rc; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool fused_final = false;
+    c->loss_in_pinned = false;
     if (c->timing && !c->capturing) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
@@ -725,6 +740,14 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
             }
         } else if (c->chunks > 1 && (grad || traj_dev == nullptr)) {
             cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true);
+            // forward-only on one rank without an L2 term: the scan kernel's workgroups write their (sum SSE, failures)
+            // pairs straight into page-locked host memory, which finish_loss adds up (no reduction launch, no copy)
+            static const bool no_fuse = getenv("CUDE_NO_FUSED_FINAL") != nullptr;
+            if (!grad && !sse_ov && !c->comm && c->cfg.lambda == 0.0 && c->pinned_pairs &&
+                c->pinned_pairs_n >= c->nblocks && !c->capturing && !no_fuse) {
+                a2.final_host = c->pinned_pairs;
+                fused_final = true;
+            }
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
         } else {
             if (grad && !adaptive(c)) a.prio_shift = prio_shift_for(c, c->nblocks);
@@ -760,6 +783,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     } else if (grad) {
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream, 1,
                                          c->param_mask.p, P));
+    } else if (fused_final) {
+        c->loss_in_pinned = true;
     } else {
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
     }
@@ -783,10 +808,26 @@ int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
     double* const tmp = c->pinned ? c->pinned : pageable.data();      // page-locked: no staging copy behind the sync
     if (g_nn_host) {
         HIP_TRY(hipMemcpyAsync(tmp, c->g_nn.p, (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    } else {
+    } else if (!c->loss_in_pinned) {
         HIP_TRY(hipMemcpyAsync(tmp + P, c->g_nn.p + P, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->loss_in_pinned && !g_nn_host) {
+        // the scan kernel's per-workgroup pairs, added in the order of reduce_partials_kernel (256 strided partial sums,
+        // then the halving tree), so that the value does not depend on which of the two ways produced it
+        for (int col = 0; col < 2; col++) {
+            double part[256];
+            for (int t = 0; t < 256; t++) {
+                double v = 0.0;
+                for (int64_t b = t; b < c->nblocks; b += 256) v += c->pinned_pairs[2 * b + col];
+                part[t] = v;
+            }
+            for (int off = 128; off >= 1; off >>= 1)
+                for (int t = 0; t < off; t++) part[t] += part[t + off];
+            tmp[P + col] = part[0];
+        }
+    }
+    c->loss_in_pinned = false;
     c->last_failed = (int64_t)std::llround(tmp[P + 1]);
     if (g_nn_host) std::memcpy(g_nn_host, tmp, P * sizeof(double));
     if (loss) *loss = (c->last_failed > 0 || !std::isfinite(tmp[P])) ? std::numeric_limits<double>::infinity()
@@ -873,6 +914,7 @@ int32_t cude_destroy(cude_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_pairs) (void)hipHostFree(c->pinned_pairs);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);

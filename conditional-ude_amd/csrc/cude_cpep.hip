@@ -23,8 +23,8 @@ namespace cude {
 
 // Net: the production term -- Mlp<NIN, W, D, 1> (conditional UDE) or MmProd<RAW> (symbolic model).
 // KEEP (gradient only, CpepArgs::act): the forward sweep stores the upper layers' activations of every evaluation to HBM
-// and the reverse sweep reads them back -- one evaluation ahead -- instead of re-evaluating those layers: bit-identical
-// results, Net::NKEEP * 8 bytes each way per evaluation and subject.  The trade the round-2 review asked to be measured
+// and the reverse sweep reads them back -- one evaluation ahead -- instead of re-evaluating those layers: the same loss,
+// gradients equal to rounding, Net::NKEEP * 8 bytes each way per evaluation and subject.  The trade the round-2 review asked to be measured
 // (2-6-6-1, 8.5 KB per subject each way): the reverse evaluation drops from 375 to ~215 VALU instructions, but the launch
 // becomes HBM-bound at ~3.7 TB/s of mixed streaming -- 125 000 subjects 0.564 -> 0.578 ms, 1e6 4.18 -> 4.64 ms, 1e5 (mixed
 // launch) 0.492 -> 0.476 ms, 65 536 unchanged (profiles/r03/keep_activations.txt).  Not enabled: CUDE_CPEP_KEEP=1 selects it.

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
         }
     }
     const double v2[2] = {active ? sse : 0.0, (active && failed) ? 1.0 : 0.0};
-    block_reduce_store<2>(v2, smem, b.partials + (set * gridDim.x + blockIdx.x + b.blk0) * (P + 2) + P, lane);
+    block_reduce_store<2>(v2, smem, b.partials + (set * gridDim.x + blockIdx.x + b.blk0) * (P + 2) + P, lane,
+                          a.final_host != nullptr ? a.final_host + 2 * (int64_t)blockIdx.x : nullptr);
 }
 
 // ---------------------------------------------------------------------------------- reverse sweep

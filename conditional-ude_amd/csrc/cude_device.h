@@ -876,7 +876,8 @@ constexpr int kRedRows = 16;   // rows of the LDS transpose used by the wave red
 // Sum v[0..NV) over the 64 lanes of the (single-wave) workgroup and store the sums to out[0..NV).
 // Chunked LDS transpose: rolled code (small i-cache footprint), fixed order (deterministic).
 template <int NV>
-__device__ __forceinline__ void block_reduce_store(const double (&v)[NV], double* s_red, double* out, int lane) {
+__device__ __forceinline__ void block_reduce_store(const double (&v)[NV], double* s_red, double* out, int lane,
+                                                   double* out2 = nullptr /* second destination of the sums, or null */) {
 #pragma unroll
     for (int c0 = 0; c0 < NV; c0 += kRedRows) {
         __syncthreads();
@@ -889,6 +890,7 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], double
 #pragma unroll 8
             for (int l = 0; l < kBlockLanes; l++) acc += s_red[lane * kBlockLanes + ((l + lane) & (kBlockLanes - 1))];
             out[c0 + lane] = acc;
+            if (out2 != nullptr) out2[c0 + lane] = acc;
         }
     }
 }

@@ -107,6 +107,11 @@ struct Cpep2Args {
     // fused Metropolis step (forward-only launches): the forward chunks evaluate at the PROPOSAL state + std * draw
     // instead of base.cond, and the scan accepts / rejects it right where the SSE is formed -- two launches per
     // Metropolis step instead of four (propose, forward, scan, accept)
+    // forward-only calls on one parameter set and one rank: every scan workgroup also writes its (sum SSE, failures)
+    // pair straight into page-locked host memory mapped into the device, final_host[2 * workgroup + {0, 1}], and the
+    // host adds the pairs up in workgroup order behind the synchronisation it performs anyway: no reduction launch and
+    // no copy kernel behind the scan (two dispatches per forward call instead of four).  nullptr = off.
+    double* final_host;
     int32_t mh_fused;
     const double* mh_z;          // [N] normals of this step, or nullptr = device stream (mh.key)
     double mh_std;

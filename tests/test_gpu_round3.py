@@ -92,9 +92,11 @@ def test_param_mask_set_after_adam_steps_freezes_entries_at_once():
     eng.close()
 
 
-def test_kept_activation_variant_of_the_gradient_kernel_is_bit_identical(monkeypatch):
+def test_kept_activation_variant_of_the_gradient_kernel(monkeypatch):
     """CUDE_CPEP_KEEP=1 (cude_cpep.hip: KEEP): upper-layer activations kept in HBM between the sweeps instead of
-    recomputed -- the same bits (measured slower at the benchmark sizes, hence off by default)."""
+    recomputed (measured slower at the benchmark sizes, hence off by default).  Same forward sweep, so the same loss
+    bit for bit; the reverse sweep runs Mlp::backward on the kept values instead of the fused evaluation, whose
+    multiply-adds the compiler contracts differently: gradients equal to rounding."""
     arch, N = (2, 6, 2), 700
     c = make_cpep_case(N, arch)
     out = {}
@@ -104,5 +106,6 @@ def test_kept_activation_variant_of_the_gradient_kernel_is_bit_identical(monkeyp
         eng = _engine(c, arch, n_state=3)
         out[keep] = eng.loss_grad()
         eng.close()
-    for x, y in zip(out["0"], out["1"]):
-        assert np.array_equal(np.asarray(x), np.asarray(y))
+    (l0, g0, c0), (l1, g1, c1) = out["0"], out["1"]
+    assert l0 == l1
+    assert np.max(np.abs(g0 - g1)) <= 1e-13 * np.max(np.abs(g0)) and np.max(np.abs(c0 - c1)) <= 1e-13 * np.max(np.abs(c0))
