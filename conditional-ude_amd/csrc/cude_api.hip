@@ -293,16 +293,22 @@ bool supp_keep_activations(const cude_ctx* c, int64_t n_sets) {
 // c-peptide gradient launches (one lane per subject, single parameter set): CUDE_CPEP_KEEP=1 keeps the upper layers'
 // activations of the forward sweep in HBM for the reverse sweep (CpepArgs::act; measured slower at the benchmark sizes,
 // see cpep_kernel -- off unless asked for)
+#ifndef CUDE_CPEP_KEEP_DEFAULT
+#define CUDE_CPEP_KEEP_DEFAULT 0
+#endif
 size_t cpep_act_doubles(const cude_ctx* c) {
     const int nk = cude::cpep_keep_values(c->net);
     if (nk == 0 || c->cfg.n_steps == 0) return 0;
     const size_t nblocks = (size_t)((c->N + cude::kBlock - 1) / cude::kBlock);
     return (size_t)(5 * c->cfg.n_steps + 1) * (size_t)nk * nblocks * cude::kBlock;
 }
-bool cpep_keep_activations(const cude_ctx* c) {
+// CUDE_CPEP_KEEP = 0 (recompute everything) | 1 (keep the output unit's logistic derivative) | 2 (keep the upper layers)
+int cpep_keep_mode(const cude_ctx* c) {
     const char* env = getenv("CUDE_CPEP_KEEP");
-    return env && env[0] == '1' && cpep_act_doubles(c) > 0;
+    const int m = env ? atoi(env) : CUDE_CPEP_KEEP_DEFAULT;
+    return (m == 1 || m == 2) && cpep_act_doubles(c) > 0 ? m : 0;
 }
+bool cpep_keep_activations(const cude_ctx* c) { return cpep_keep_mode(c) != 0; }
 
 // both c-peptide models share the population layout, solver tables and the ensemble kernel
 bool is_cpep(const cude_ctx* c) { return c->cfg.model == CUDE_MODEL_CPEP || c->cfg.model == CUDE_MODEL_CPEP_SYM; }
@@ -720,7 +726,10 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
         a.sse = sse_ov ? sse_ov : c->sse.p; a.traj = traj_dev; a.auc = c->auc.p;
         a.g_cond = c->g_cond.p; a.partials = c->partials.p;
         // allocated by cude_set_population_cpep (never here: this function also runs under stream capture)
-        if (grad && !adaptive(c) && c->act.p && cpep_act_doubles(c) > 0 && c->act.n >= cpep_act_doubles(c)) a.act = c->act.p;
+        if (grad && !adaptive(c) && c->act.p && cpep_act_doubles(c) > 0 && c->act.n >= cpep_act_doubles(c)) {
+            a.act = c->act.p;
+            a.keep_mode = cpep_keep_mode(c);
+        }
         if (c->chunks > 1 && c->blk0 > 0 && grad) {
             // whole rounds: one lane per subject; the remainder: time-split, on a second stream so that its short waves
             // fill the SIMDs the long ones leave one by one (fork / join by events: capturable)

@@ -28,8 +28,8 @@ namespace cude {
 // (2-6-6-1, 8.5 KB per subject each way): the reverse evaluation drops from 375 to ~215 VALU instructions, but the launch
 // becomes HBM-bound at ~3.7 TB/s of mixed streaming -- 125 000 subjects 0.564 -> 0.578 ms, 1e6 4.18 -> 4.64 ms, 1e5 (mixed
 // launch) 0.492 -> 0.476 ms, 65 536 unchanged (profiles/r03/keep_activations.txt).  Not enabled: CUDE_CPEP_KEEP=1 selects it.
-template <class Net, int NS, bool GRAD, bool KEEP = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2 : 1))) void cpep_kernel(CpepArgs a) {
+template <class Net, int NS, bool GRAD, int KEEP = 0>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP != 0 ? 2 : 1))) void cpep_kernel(CpepArgs a) {
     constexpr int P = Net::P;
     constexpr int NC = Net::NC;
     constexpr int TABROWS = Net::HAS_TAB ? 5 * Net::NCST : 0;
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
     // kept activations: one contiguous stretch per workgroup, [evaluation][value][lane] -- the wave streams through it
     // forwards, then backwards (the population-wide [value][subject] rows of the other buffers would scatter every
     // evaluation's 512-byte pieces a megabyte apart: measured 3.6 TB/s)
-    double* const act = KEEP ? a.act + (int64_t)blockIdx.x * ((int64_t)(5 * a.S + 1) * Net::NKEEP * kBlock) + lane : nullptr;
+    constexpr int NK = KEEP == 2 ? Net::NKEEP : 1;            // kept values per evaluation (KEEP = 1: the logistic derivative)
+    double* const act = KEEP ? a.act + (int64_t)blockIdx.x * ((int64_t)(5 * a.S + 1) * NK * kBlock) + lane : nullptr;
     double cst[NC];
     cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
     if (NC > 1) cst[1] = a.age[i];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
     int kind = 0;
     bool run_ok = false;                         // wave-uniform: the current run is inside the table's exact range
 #ifndef CUDE_NO_VW
-    constexpr bool kVW = (GRAD && Net::HAS_VW) || KEEP;   // only where the reverse sweep already pays for the registers
+    constexpr bool kVW = (GRAD && Net::HAS_VW) || KEEP != 0;   // only where the reverse sweep already pays for the registers
 #else
     constexpr bool kVW = false;
 #endif
@@ -156,12 +157,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
         }
         const double x[1] = {xv};
         double v;
-        if constexpr (KEEP) {
+        if constexpr (KEEP == 2) {
             double keep[Net::NKEEP];
             v = Net::eval_vw_keep(p, vw, c, x, tab, &E1, keep);
             double* dst = act + (int64_t)(e + 1) * (Net::NKEEP * kBlock);
 #pragma unroll
             for (int q = 0; q < Net::NKEEP; q++) dst[q * kBlock] = keep[q];
+        } else if constexpr (KEEP == 1) {
+            double sg;
+            v = Net::eval_vw_sig(p, vw, c, x, tab, &E1, &sg);
+            act[(int64_t)(e + 1) * kBlock] = sg;
         } else if constexpr (kVW) {
             v = Net::eval_vw(p, vw, c, x, tab, &E1);
         } else {
@@ -264,11 +269,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
         n = S - 1;
         s = 4;
         // kept activations of the evaluation about to be reversed, requested one evaluation ahead
-        double kn[Net::NKEEP];
-        if constexpr (KEEP) {
-            const double* src = act + (int64_t)(5 * S) * (Net::NKEEP * kBlock);
+        double kn[NK];
+        if constexpr (KEEP != 0) {
+            const double* src = act + (int64_t)(5 * S) * (NK * kBlock);
 #pragma unroll
-            for (int q = 0; q < Net::NKEEP; q++) kn[q] = src[q * kBlock];
+            for (int q = 0; q < NK; q++) kn[q] = src[q * kBlock];
         }
         // evaluations in reverse order; e = -1 is the baseline with weight -sum(w)
 #pragma unroll 1
@@ -388,7 +393,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP ? 2
                 wv = -wtot;
             }
             const double x[1] = {xv};
-            if constexpr (KEEP) {
+            if constexpr (KEEP == 1) {
+                const double sg = kn[0];
+                if (e >= 0) kn[0] = act[(int64_t)e * kBlock];      // next evaluation's value: in flight during this one
+                Net::template eval_grad_pf<false, decltype(acc), true>(p, c, x, wv, acc, dxdummy, tab, &E1, sg);
+            } else if constexpr (KEEP == 2) {
                 double hk[Net::DEPTH][Net::WIDTH];
 #pragma unroll
                 for (int l = 1; l < Net::DEPTH; l++)
@@ -445,7 +454,10 @@ static hipError_t launch_one(const CpepArgs& a, hipStream_t s) {
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     if constexpr (GRAD && cpep_can_keep<Net>()) {
         if (a.act != nullptr && n_sets == 1) {
-            hipLaunchKernelGGL((cpep_kernel<Net, NS, true, true>), dim3((unsigned)nblocks, 1), dim3(kBlock), lds, s, a);
+            if (a.keep_mode == 2)
+                hipLaunchKernelGGL((cpep_kernel<Net, NS, true, 2>), dim3((unsigned)nblocks, 1), dim3(kBlock), lds, s, a);
+            else
+                hipLaunchKernelGGL((cpep_kernel<Net, NS, true, 1>), dim3((unsigned)nblocks, 1), dim3(kBlock), lds, s, a);
             return hipGetLastError();
         }
     }

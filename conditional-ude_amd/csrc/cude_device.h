@@ -416,6 +416,15 @@ struct Mlp {
         }
         return act_softplus(z0 + z1, &keep[NKEEP - 1]);
     }
+    // value and the output unit's logistic derivative (the only kept value of the KEEP = 1 gradient kernel)
+    __device__ static __forceinline__ double eval_vw_sig(cptr_t p, const VW& v, const double (&c)[W],
+                                                         const double (&x)[NV], bool use_tab, const Exps* E1,
+                                                         double* sig) {
+        double keep[NKEEP];
+        const double y = eval_vw_keep(p, v, c, x, use_tab, E1, keep);
+        *sig = keep[NKEEP - 1];
+        return y;
+    }
     // layer 1 alone
     __device__ static __forceinline__ void layer1(cptr_t p, const double (&c)[W], const double (&x)[NV], double (&h0)[W],
                                                   bool use_tab, const Exps* E1) {
@@ -473,7 +482,8 @@ struct Mlp {
     static constexpr bool HAS_PF = (D >= 2);
     // forward half: hidden activations h, output pre-activation returned; wo and (KEEP) the last hidden layer's last
     // column group stay loaded for the backward half
-    template <bool KEEP>
+    // SKIP_OUT: the output unit is not evaluated (its logistic derivative is supplied: eval_grad_pf with SIG_IN)
+    template <bool KEEP, bool SKIP_OUT = false>
     __device__ static __forceinline__ double forward_pf(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                         double (&h)[D][W], bool use_tab, const Exps* E1, SCol<W>& wo,
                                                         SCol<W * CGP>& glast) {
@@ -526,6 +536,7 @@ struct Mlp {
         // the last hidden layer's last column group is needed again right after the output unit
         if (KEEP) glast = ld_col<W * CGP>(p, L1 + (D - 2) * LH + W * CGP * (NG - 1));
         CUDE_FENCE();
+        if (SKIP_OUT) return 0.0;
         double z0 = bo, z1 = 0.0;
 #pragma unroll
         for (int i = 0; i < W; i++) {
@@ -535,17 +546,21 @@ struct Mlp {
         return z0 + z1;
     }
 
-    template <bool WANT_DX, class A>
+    // SIG_IN: the output unit's logistic derivative comes from the caller (kept by the forward sweep, CpepArgs::act);
+    // neither the output pre-activation nor the softplus is evaluated (52 of ~375 instructions of a 2-6-6-1 reverse
+    // evaluation) and the return value is 0
+    template <bool WANT_DX, class A, bool SIG_IN = false>
     __device__ static __forceinline__ double eval_grad_pf(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                           double wgt, A& acc, double (&dx)[NV],
-                                                          bool use_tab, const Exps* E1) {
+                                                          bool use_tab, const Exps* E1, double sig_in = 0.0) {
         p = launder(p);
         double h[D][W];
         SCol<W * CGP> grp[D][NG];        // grp[l][g]: column group g of hidden layer l (l >= 1), backward order
         SCol<W> wo;
-        const double zo = forward_pf<true>(p, c, x, h, use_tab, E1, wo, grp[D - 1][NG - 1]);
-        double sig;
-        const double y = act_softplus(zo, &sig);
+        const double zo = forward_pf<true, SIG_IN>(p, c, x, h, use_tab, E1, wo, grp[D - 1][NG - 1]);
+        double sig = sig_in;
+        double y = 0.0;
+        if (!SIG_IN) y = act_softplus(zo, &sig);
         // ------------------------------------------------ backward (column groups from the last to the first)
         const double dz = wgt * sig;
         acc[G_OUT + W] += dz;

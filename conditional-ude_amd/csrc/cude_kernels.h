@@ -48,7 +48,8 @@ struct CpepArgs {
     double* act;             // one-lane gradient kernel: [nblocks][5S+1][(D-1)W+1][64] kept activations of the forward
                              // sweep (tanh outputs of the hidden layers 2..D + the output unit's logistic derivative per
                              // evaluation), read back by the reverse sweep instead of re-evaluating those layers;
-                             // nullptr = recompute.  Off by default: measured slower (see cude_api.hip)
+                             // nullptr = recompute.
+    int32_t keep_mode;       // with act: 1 = only the logistic derivative is kept ([nblocks][5S+1][64]), 2 = all of the above
     // multi-start evaluation: n_sets parameter sets in the grid's y dimension, set k reads nn + k*set_stride_nn and
     // cond + k*set_stride_cond (and writes sse / g_cond + k*set_stride_cond); 0/0/0 for the single-set path
     int32_t n_sets;

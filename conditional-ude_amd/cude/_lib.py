@@ -89,6 +89,7 @@ _SIGNATURES = {
 }
 
 _lib = None
+STRICT = True        # every declared entry point must be there (tools/abl_*.py relax this for older library variants)
 
 
 def exported_symbols():
@@ -113,7 +114,11 @@ def load():
     except OSError as e:  # pragma: no cover
         raise CudeError(-2, f"cannot load {LIB_PATH}: {e}")
     for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if STRICT:
+                raise CudeError(-2, f"{LIB_PATH} does not export {name}: rebuild it (make -C conditional-ude_amd/csrc)")
+            continue            # development A/B runs against an older build (tools/abl_bench.py)
         fn.restype = res
         fn.argtypes = args
     _lib = lib
