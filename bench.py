@@ -454,12 +454,13 @@ def extras(Engine, device, steps=20, warm=40):
                                            "draws generated on the device (counter-based Philox4x32-10)",
                                  "ms_per_estep_with_host_supplied_draws": dt_host_draws * 1e3,
                                  "value": n * n_mc / dt, "unit": "Metropolis draws/s", "ms_per_estep": dt * 1e3,
-                                 "forward_solves_per_s": n * launches / dt,
+                                 "forward_solves_per_s": n * (n_mc + 1) / dt,
                                  "reference_equivalent_solves_per_s": 2 * n * n_mc / dt,
                                  "solves_note": "the reference solves the proposal AND the current state in every "
                                                 "step (2 x 1e6 solves); with gamma = 1 the current state's SSE is "
                                                 "carried over from the step that accepted it (identical bits), so "
-                                                f"{launches} ensemble launches do the work",
+                                                f"{n_mc + 1} ensemble launches do the work; HIP events time every 8th "
+                                                f"Metropolis step ({launches} launches timed)",
                                  "acceptance_rate": float(acc.sum()) / (n * n_mc),
                                  "roofline": hbm, "roofline_valu": valu}
     eng.close()

@@ -345,61 +345,59 @@ hipError_t launch_fill(int64_t N, double v, double* out, hipStream_t s) {
 }
 
 // Adam exactly as Optimisers.jl: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
-// x -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).  The update is skipped when any subject failed
+// x -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).  Skipped when any subject failed
 // (g_nn[P+1] > 0): the reference's optimiser would see an Inf objective there.
 __global__ void adam_kernel(AdamArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool failed = a.g_nn[a.P + 1] > 0.0;
+    if (a.g_nn[a.P + 1] > 0.0) return;
     // bias corrections of step t = (steps done) + 1 from the device-resident running powers b^(t-1), so that a
     // captured hipGraph of the iteration needs no per-iteration kernel arguments
     a.c1 = 1.0 - a.state[0] * a.b1;
     a.c2 = 1.0 - a.state[1] * a.b2;
-    if (!failed) {
-        double *x = nullptr, *m = nullptr, *v = nullptr;
-        double g = 0.0;
-        if (idx < a.N) {
-            x = a.cond + idx; m = a.m_cond + idx; v = a.v_cond + idx; g = a.g_cond[idx];
-        } else if (idx < a.N + a.P) {
-            const int64_t q = idx - a.N;
-            x = a.nn + q; m = a.m_nn + q; v = a.v_nn + q; g = a.g_nn[q];
-        }
-        if (x != nullptr) {
-            const double mm = fma(a.b1, *m, (1.0 - a.b1) * g);
-            const double vv = fma(a.b2, *v, (1.0 - a.b2) * g * g);
-            *m = mm;
-            *v = vv;
-            *x -= a.lr * (mm / a.c1) / (sqrt(vv / a.c2) + a.eps);
-        }
+    double *x, *m, *v;
+    double g;
+    if (idx < a.N) {
+        x = a.cond + idx; m = a.m_cond + idx; v = a.v_cond + idx; g = a.g_cond[idx];
+    } else if (idx < a.N + a.P) {
+        const int64_t q = idx - a.N;
+        x = a.nn + q; m = a.m_nn + q; v = a.v_nn + q; g = a.g_nn[q];
+    } else {
+        return;
     }
-    // The workgroup that finishes LAST advances the running powers / step counter (unless the step was skipped because
-    // a subject failed) and appends [sum loss, n_failed] of this iterate to the loss trace: every other workgroup has
-    // read the state by then.  state = {b1^t, b2^t, t, trace position, arrival counter}.  (Round 2 did this in a
-    // second, one-wave launch: ~4 us of every optimiser step.)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        unsigned long long* arrived = reinterpret_cast<unsigned long long*>(a.state + 4);
-        if (atomicAdd(arrived, 1ull) + 1ull == (unsigned long long)gridDim.x) {
-            *arrived = 0ull;
-            if (!failed) {
-                a.state[0] *= a.b1;
-                a.state[1] *= a.b2;
-                a.state[2] += 1.0;
-            }
-            const int64_t pos = (int64_t)a.state[3];
-            if (pos < a.trace_cap) {
-                a.trace[2 * pos] = a.g_nn[a.P];
-                a.trace[2 * pos + 1] = a.g_nn[a.P + 1];
-            }
-            a.state[3] = (double)(pos + 1);
-        }
+    const double mm = fma(a.b1, *m, (1.0 - a.b1) * g);
+    const double vv = fma(a.b2, *v, (1.0 - a.b2) * g * g);
+    *m = mm;
+    *v = vv;
+    *x -= a.lr * (mm / a.c1) / (sqrt(vv / a.c2) + a.eps);
+}
+
+// (Round 3 measured folding this into adam_kernel -- the workgroup that finishes last advances the state, found by an
+// arrival counter: the ~500 device-scope atomics on one address cost more than the launch they save, step tail 20 ->
+// 23 us with a relaxed atomic, 33 us with the fence a hand-over of data would need.  Two launches it stays.)
+// After the update: advance the running powers / step counter (unless the step was skipped because a subject
+// failed) and append [sum loss, n_failed] of this iterate to the loss trace.  state = {b1^t, b2^t, t, trace pos}.
+__global__ void adam_advance_kernel(double* state, double b1, double b2, const double* g_tail, double* trace,
+                                    int64_t cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!(g_tail[1] > 0.0)) {
+        state[0] *= b1;
+        state[1] *= b2;
+        state[2] += 1.0;
     }
+    const int64_t pos = (int64_t)state[3];
+    if (pos < cap) {
+        trace[2 * pos] = g_tail[0];
+        trace[2 * pos + 1] = g_tail[1];
+    }
+    state[3] = (double)(pos + 1);
 }
 
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
     const int bs = 256;
     const int64_t n = a.N + a.P;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, a);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, s, a.state, a.b1, a.b2, a.g_nn + a.P, a.trace,
+                       a.trace_cap);
     return hipGetLastError();
 }
 

@@ -204,7 +204,7 @@ struct AdamArgs {
     double* cond; double* m_cond; double* v_cond; const double* g_cond;
     double* nn; double* m_nn; double* v_nn; const double* g_nn;   // g_nn[P+1] = n_failed
     double lr, b1, b2, eps, c1, c2;   // c1 = 1-b1^t, c2 = 1-b2^t (filled on the device from `state`)
-    double* state;                    // device: {b1^(t-1), b2^(t-1), steps done, trace position, arrival counter (u64)}
+    double* state;                    // device: {b1^(t-1), b2^(t-1), steps done, trace position}
     double* trace;                    // device: [trace_cap][2] = (sum loss, n_failed) per iteration
     int64_t trace_cap;
 };
