@@ -1953,6 +1953,16 @@ int32_t cude_set_tolerances(cude_ctx* c, double abstol, double reltol) {
     return CUDE_OK;
 }
 
+int32_t cude_grad_occupancy(cude_ctx* c, int32_t* waves_per_cu) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!waves_per_cu) return fail(CUDE_ERR_ARG, "null output");
+    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
+    *waves_per_cu = is_cpep(c) ? cude::cpep_grad_waves_per_cu(c->net, c->cfg.n_state, c->T)
+                               : cude::supp_grad_waves_per_cu(c->net);
+    return CUDE_OK;
+}
+
 int32_t cude_synchronize(cude_ctx* c) {
     int32_t rc = bind(c);
     if (rc) return rc;

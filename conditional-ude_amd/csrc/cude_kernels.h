@@ -163,6 +163,7 @@ hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepAr
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
 bool cpep_shape_supported(const NetShape& net, int n_state);
 bool supp_shape_supported(const NetShape& net);
+int supp_grad_waves_per_cu(const NetShape& net);
 // adaptive Tsit5 (grad: + the adjoint of the accepted step sequence, needs args.tape); launch_cpep / launch_supp
 // route here when args.S == 0
 hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);

@@ -404,6 +404,22 @@ static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
 
 #define CUDE_SUPP_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
 
+// resident waves per CU of the gradient kernel (stage-input mode; 0 = unknown): what the launch actually gets
+template <int W, int D>
+static int supp_grad_occupancy() {
+    int n = 0;
+    const size_t lds = sizeof(double) * (size_t)(kSuppRowsK + 9 + SuppAcc<SuppNet<W, D>>::rows) * kBlock;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, supp_kernel<W, D, true, false, false>, kBlock, lds) != hipSuccess)
+        return 0;
+    return n;
+}
+int supp_grad_waves_per_cu(const NetShape& net) {
+#define X(W, D) if (net.width == W && net.depth == D) return supp_grad_occupancy<W, D>();
+    CUDE_SUPP_SHAPES(X)
+#undef X
+    return 0;
+}
+
 bool supp_shape_supported(const NetShape& net) {
     if (net.nin != 4) return false;
 #define X(W, D) if (net.width == W && net.depth == D) return true;

@@ -445,6 +445,12 @@ class Engine:
     def synchronize(self):
         check(self._lib.cude_synchronize(self._h))
 
+    def grad_occupancy(self):
+        """Resident waves per CU the runtime grants the one-lane gradient kernel of this context."""
+        n = C.c_int32()
+        check(self._lib.cude_grad_occupancy(self._h, C.byref(n)))
+        return n.value
+
     def set_kernel_timing(self, enabled):
         check(self._lib.cude_set_kernel_timing(self._h, int(bool(enabled))))
 

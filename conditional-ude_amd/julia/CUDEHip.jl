@@ -359,6 +359,12 @@ function adam_apply_device!(c::Ctx)
     l[]
 end
 
+function grad_occupancy(c::Ctx)
+    n = Ref{Int32}(0)
+    check(ccall((:cude_grad_occupancy, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}), c.h, n))
+    Int(n[])
+end
+
 set_kernel_timing!(c::Ctx, on::Bool) = check(ccall((:cude_set_kernel_timing, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on ? 1 : 0))
 
 function kernel_time_ms(c::Ctx)

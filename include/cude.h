@@ -284,6 +284,9 @@ int32_t cude_adam_init(cude_ctx* ctx, double lr, double beta1, double beta2, dou
  * synchronise (use cude_synchronize). The reported loss is the one BEFORE the update. */
 int32_t cude_adam_step(cude_ctx* ctx, double* loss);
 int32_t cude_synchronize(cude_ctx* ctx);
+/* Diagnostic: resident waves per compute unit (4 SIMDs) the one-lane gradient kernel of this context gets from the
+ * runtime (hipOccupancyMaxActiveBlocksPerMultiprocessor with the launch's LDS size) -- registers and LDS as compiled. */
+int32_t cude_grad_occupancy(cude_ctx* ctx, int32_t* waves_per_cu);
 /* n_iters optimiser iterations in one call (the `maxiters` loop of Optimization.solve(prob, Adam, maxiters),
  * src/parameter-estimation.jl:176): one iteration is captured into a hipGraph and replayed without host round
  * trips; losses[n_iters] (optional) receives the loss BEFORE each update, read back once at the end. */

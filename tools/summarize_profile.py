@@ -65,7 +65,7 @@ try:
     n = json.loads(open(os.path.join(out, "bench_stats.json")).read().strip().splitlines()[-1])["config"]["subjects_per_gpu"]
 except Exception as e:
     print("no bench line:", e)
-GRAD = "true>(cude::CpepArgs)"
+GRAD = "true, 0>(cude::CpepArgs)"      # cpep_kernel<Net, NS, GRAD = true, KEEP = 0>
 f, nf = mean_ctr("pmc_fetch", GRAD, "FETCH_SIZE")
 w, nw = mean_ctr("pmc_write", GRAD, "WRITE_SIZE")
 pf, _ = mean_ctr("pmc_fetch", "prepare_cpep_kernel", "FETCH_SIZE")
@@ -89,6 +89,15 @@ for mode in ("stage_inputs", "steps"):
         print(open(os.path.join(out, f"supp_{mode}.log")).read().strip())
     except Exception:
         pass
+print("== supp_sq")
+for k, d in counters("supp_sq").items():
+    if "supp_kernel" in k:
+        for c, v in sorted(d.items()):
+            print(f"{k[:70]:70s} {c:24s} n={len(v)} mean={sum(v)/len(v):.6g}")
+try:
+    print(open(os.path.join(out, "occupancy.txt")).read().strip())
+except Exception:
+    pass
 kernel_stats("adaptive_stats")
 AGRAD = "> >, true, true>("                   # adaptive_kernel<CpepAd<...>, IS_CPEP, GRAD>
 f, nf = mean_ctr("adaptive_fetch", AGRAD, "FETCH_SIZE", skip=3)
