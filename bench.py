@@ -521,6 +521,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # CUDE_BENCH_FORCE_DIST=1 (development only): run the N > 1 code path with ONE rank -- process group, communicator
+    # with its self-test, the cross-check of the two transports, the sharded SAEM E-step -- on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("CUDE_BENCH_FORCE_DIST") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
@@ -533,7 +541,7 @@ def main():
     ctl = "cpu" if rehearsal else "cuda"          # device of the small control tensors handed to torch.distributed
     torch.cuda.set_device(local_rank)
     rccl_log = None
-    if world > 1:
+    if dist_on:
         # RCCL's own account of a failure (WARN level: silent when all is well), per process, for `rccl_error` below
         rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cude_rccl_{os.getpid()}.log")
         os.environ.setdefault("NCCL_DEBUG", "WARN")
@@ -551,7 +559,7 @@ def main():
     transport = "rccl"          # all-reduce of the P+2 doubles inside libcude_hip.so (RCCL on the context's stream)
     rccl_info = None
     rccl_error = None           # why the built-in communicator was not used (this rank's view), for the JSON line
-    if world > 1:
+    if dist_on:
         # Every rank issues the same sequence of collectives whatever fails locally: first agree that librccl
         # is loadable everywhere (each rank draws an id; only rank 0's is used), then build the communicator.
         ok = torch.ones(1, device=ctl)
@@ -624,12 +632,12 @@ def main():
     def barrier():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     # ---- N > 1: the same optimiser step through both transports, from the same state (fresh Adam moments)
     allreduce_check = None
-    if world > 1 and transport == "rccl":
+    if dist_on and transport == "rccl":
         twin = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
         twin.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
         twin.set_global_subjects(n_local * world)
@@ -682,7 +690,7 @@ def main():
     dt_sync = time.perf_counter() - t1
 
     saem = None
-    if world > 1 and not rehearsal and not args.no_extra:
+    if dist_on and not rehearsal and not args.no_extra:
         eng.close()
         eng = None
         saem = saem_estep_sharded(Engine, local_rank, world, rank, dist, torch)
@@ -691,7 +699,7 @@ def main():
         saem["dt"], saem["dt_allreduce"] = float(t[0]), float(t[1])
 
     kern_min = kern_max = kern_ms
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt, dt_sync, kern_ms, -kern_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_sync, kern_max, kern_min = float(t[0]), float(t[1]), float(t[2]), -float(t[3])
@@ -714,12 +722,12 @@ def main():
                                    f"2x6x6x1 MLP, T={T_OBS}, {n_local} subjects/GPU "
                                    f"({n_total} total; BASELINE configs[2]/[3] shape)",
                        "subjects_per_gpu": n_local, "parallelism": f"subject-shard x{world}",
-                       "allreduce": transport if world > 1 else None},
+                       "allreduce": transport if dist_on else None},
             "roofline": hbm, "roofline_valu": valu,
             "value_with_loss_read_back_every_step": n_total * args.steps / dt_sync,
             "final_loss": loss, "prewarm_steps": PREWARM_STEPS, "kernel_source_sha": kernel_source_sha(),
         }
-        if world > 1:
+        if dist_on:
             out["rccl_ranks"] = rccl_info[0] if rccl_info else None
             out["rccl_version"] = rccl_info[2] if rccl_info else None
             out["allreduce_check"] = allreduce_check
@@ -734,7 +742,7 @@ def main():
                     "subjects_seen": saem["n_seen"]}
             out["kernel_ms_per_rank"] = {"min": kern_min, "max": kern_max}
             out["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
-        if world == 1:
+        if not dist_on:
             if not args.no_cpu_baseline:
                 out["cpu_baseline"], out["cpu_baseline_forward_mode"], parity = cpu_baseline(pop, nn, args.cpu_sample, eng)
                 if parity is not None:
@@ -746,7 +754,7 @@ def main():
         print(json.dumps(out), flush=True)
     if eng is not None:
         eng.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
