@@ -62,11 +62,20 @@ def supp_algo_bytes(n_obs, grad):
     return 8 + 3 * 8 * n_obs + 8 + (8 if grad else 0)
 
 
-def mlp_flops(nv, w, d, want_dx=False):
+TANH_TABLE_MAX_WIDTH_CPEP = 4   # csrc/cude_device.h CUDE_TANH_TAB_MAXW: fixed-step c-peptide kernels up to this width (and the
+                                # fixed-step suppression kernel always) evaluate tanh by table + addition theorem
+
+
+def mlp_flops(nv, w, d, want_dx=False, table_tanh=False):
     """(forward, backward) fp64 flops of one network evaluation as the kernels execute it (FMA = 2; cude_math.h)."""
-    # m_tanh_vec per neuron: min, mul, rndne, cvt, ldexp, add, bfi (7 x 1 flop) + 13 FMA (2 reduction, 10 Horner,
-    # 1 final); per layer: one reciprocal (rcp + 3 FMA) + 3(W-1) multiplies
-    tanh_layer = w * (7 + 13 * 2) + (1 + 3 * 2) + 3 * (w - 1)
+    if table_tanh:
+        # m_tanh_vec_tab per neuron: min, add, sub, sub, shift, mul, add, mul, add, mul (10 x 1) + 3 FMA (d, numerator,
+        # denominator) + the quotient's multiply and the sign (2); per layer: one reciprocal (rcp + 3 FMA) + 3(W-1)
+        tanh_layer = w * (10 + 3 * 2 + 2) + (1 + 3 * 2) + 3 * (w - 1)
+    else:
+        # m_tanh_vec per neuron: min, mul, rndne, cvt, ldexp, add, bfi (7 x 1 flop) + 13 FMA (2 reduction, 10 Horner,
+        # 1 final); per layer: one reciprocal (rcp + 3 FMA) + 3(W-1) multiplies
+        tanh_layer = w * (7 + 13 * 2) + (1 + 3 * 2) + 3 * (w - 1)
     softplus = 26 * 2 + 22      # exp (12 FMA) + shared reciprocal (3 FMA) + atanh series (11 FMA) + 22 other ops
     fwd = 2 * (w * nv + (d - 1) * w * w + w) + d * tanh_layer + softplus
     bwd = (2 * w + w + 2) + (d - 1) * w * (4 + 4 * w) + w * (4 + 2 * nv) + (2 * nv * w if want_dx else 0)
@@ -89,7 +98,7 @@ def cpep_flops(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS, n_state=N_STATE, grad=Tr
     """fp64 flops the one-lane-per-subject c-peptide kernel executes per subject (FMA = 2), counted from the kernel's
     structure (cude_cpep.hip): 5 S + 1 network evaluations per sweep, the Runge-Kutta algebra per step."""
     nin, w, d = arch
-    fwd_eval, bwd_eval = mlp_flops(1, w, d)
+    fwd_eval, bwd_eval = mlp_flops(1, w, d, table_tanh=w <= TANH_TABLE_MAX_WIDTH_CPEP)
     n_eval = 5 * n_steps + 1
     stage_fwd = 2 * (2 * 21 + 2 * 6 + 7 * 4) + (2 * 6 if n_state == 3 else 0)   # stage sums, Y, A*Y+g [, quadrature]
     stage_rev = 2 * (2 * 21 + 6 * 4 + 12) + 12
@@ -112,7 +121,7 @@ def supp_flops(arch, n_steps, n_obs, grad=True):
     """The same count for supp_kernel (cude_supp.hip): 6 S + 1 evaluations per sweep, all three inputs varying; the
     reverse sweep re-evaluates the network at the stored stage inputs (no kept activations at this size)."""
     nin, w, d = arch
-    fwd_eval, bwd_eval = mlp_flops(3, w, d, want_dx=True)
+    fwd_eval, bwd_eval = mlp_flops(3, w, d, want_dx=True, table_tanh=True)
     n_eval = 6 * n_steps + 1
     stage = 2 * 3 * 21 + 6 * 3 * 2 + 6 * 4            # stage sums + Y per stage + RHS algebra
     obs_fl = n_obs * (2 * 3 * 7 + 3 * 5)
