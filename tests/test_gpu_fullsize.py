@@ -224,3 +224,74 @@ def test_baseline_config1_forward_only_at_its_own_size_and_launch_shape():
     assert np.max(np.abs(fs["sse"] - f1["sse"][idx])) <= 1e-12 * max(1.0, float(np.max(ref["sse"])))
     sub.close()
     eng.close()
+
+
+def test_suppression_full_size_properties_1e5_subjects():
+    """The reference's EnsembleThreads workload (suppression cUDE 4-3x5-1, T = 8, 30 steps) at 1e5 subjects -- the size the
+    gradient kernel is measured at, where it runs two waves per SIMD (round 3) -- through properties that need no oracle
+    run at that size: bitwise determinism, loss = mean of the per-subject SSEs, additivity over two unequal shards (the
+    shards see the population's `scale` and 1/N through cude_set_global_subjects), the directional derivative against
+    central differences, and an oracle spot check of per-subject SSE and dL/dtheta on 300 subjects."""
+    import c_oracle as co
+    from conftest import make_supp_case
+    from cude.engine import Engine
+    N, lam = 100_000, 0.01
+    c = make_supp_case(N)
+    arch = c["arch"]
+    eng = Engine("supp", arch, n_steps=30, lam=lam)
+    eng.set_population_supp(c["tp"], c["data"])
+    eng.set_params(c["nn"], c["theta"])
+    assert eng.grad_occupancy() >= 8                                  # two waves per SIMD granted by the runtime
+    loss, g_nn, g_th = eng.loss_grad()
+    loss2, g_nn2, g_th2 = eng.loss_grad()
+    assert loss == loss2 and np.array_equal(g_nn, g_nn2) and np.array_equal(g_th, g_th2)
+    sse = eng.forward(want_sse=True)["sse"]
+    assert abs(sse.sum() / N + lam * float(c["nn"] @ c["nn"]) - loss) < 1e-12 * loss
+    scale, n_glob = eng.get_scale()
+    # two shards of unequal size with the whole population's scale and subject count
+    cut, parts = 41_007, []
+    for lo, hi in ((0, cut), (cut, N)):
+        e2 = Engine("supp", arch, n_steps=30, lam=lam)
+        e2.set_population_supp(c["tp"], c["data"][:, :, lo:hi])
+        e2.set_global_subjects(N, scale)
+        e2.set_params(c["nn"], c["theta"][lo:hi])
+        part, gt = e2.loss_grad_partial(want_cond_grad=True)
+        parts.append((part, gt))
+        e2.close()
+    P = g_nn.size
+    tot = parts[0][0] + parts[1][0]
+    assert tot[P + 1] == 0
+    assert abs(tot[P] / N + lam * float(c["nn"] @ c["nn"]) - loss) < 1e-12 * loss
+    assert np.max(np.abs(tot[:P] + 2 * lam * c["nn"] - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
+    assert np.max(np.abs(np.concatenate([parts[0][1], parts[1][1]]) - g_th)) <= 1e-15 * max(1.0, np.max(np.abs(g_th)) * N)
+    # directional derivative
+    rng = np.random.default_rng(3)
+    d_nn, d_t = rng.standard_normal(P), rng.standard_normal(N)
+    eps = 1e-6
+    eng.set_params(c["nn"] + eps * d_nn, c["theta"] + eps * d_t); lp = eng.forward()["loss"]
+    eng.set_params(c["nn"] - eps * d_nn, c["theta"] - eps * d_t); lm = eng.forward()["loss"]
+    dd = g_nn @ d_nn + g_th @ d_t
+    assert abs((lp - lm) / (2 * eps) - dd) < 2e-7 * abs(dd)
+    # oracle on 300 random subjects: per-subject quantities are local once the population's scale is used.  The C oracle
+    # takes its scale from the data it is given, so the subset is evaluated with the population's scale through the
+    # product (a 300-subject engine with set_global_subjects) AND the oracle is held to that engine at its own size.
+    idx = np.sort(rng.choice(N, 300, replace=False))
+    sub = Engine("supp", arch, n_steps=30, lam=0.0)
+    sub.set_population_supp(c["tp"], c["data"][:, :, idx])
+    sub.set_params(c["nn"], c["theta"][idx])
+    ls, gns, gts = sub.loss_grad()
+    ref = co.supp(c["tp"], c["data"][:, :, idx], arch, c["nn"], c["theta"][idx], 0.0, 30)
+    assert abs(ls - ref["loss"]) < 1e-10 * ref["loss"]
+    assert np.max(np.abs(gns - ref["g_nn"])) < 1e-9 * np.max(np.abs(ref["g_nn"]))
+    assert np.max(np.abs(gts - ref["g_theta"])) < 1e-9 * np.max(np.abs(ref["g_theta"]))
+    # ... and the same subjects inside the big population give the same per-subject SSE once rescaled by scale^2
+    s_sub, _ = sub.get_scale()
+    sse_sub = sub.forward(want_sse=True)["sse"]
+    # per-subject SSE is sum_s SSE_s / scale_s^2: not separable without the per-state parts, so compare through a third
+    # engine that holds the subset with the BIG population's scale
+    sub.set_global_subjects(300, scale)
+    sse_big_scale = sub.forward(want_sse=True)["sse"]
+    assert np.max(np.abs(sse_big_scale - sse[idx])) < 1e-11 * max(1.0, float(np.max(sse[idx])))
+    assert not np.array_equal(sse_sub, sse_big_scale) or np.allclose(s_sub, scale)
+    sub.close()
+    eng.close()
