@@ -234,6 +234,11 @@ struct cude_ctx {
     std::vector<double> mask_host;
     DevBuf<int32_t> chunk_start;
     DevBuf<double> hom_M, hom_obs, fsum, res, g_cond_part, partials2;
+    // forward-only launches of the time-split path have their own split (chunks_f, 0 = the gradient's): the scan's cost
+    // grows with the chunk count and there is no reverse kernel to feed, so fewer, longer chunks win there
+    int chunks_f = 0;
+    DevBuf<int32_t> chunk_start_f;
+    DevBuf<double> hom_M_f, hom_obs_f, fsum_f;
     DevBuf<double> m_nn, v_nn, m_cond, v_cond;
     int64_t nblocks = 0;
     double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-8;
@@ -529,12 +534,17 @@ int32_t enqueue_adam(cude_ctx* c) {
 
 // all_blocks: the time-split kernels for every workgroup (forward-only launches, also when the gradient launch is mixed:
 // the chunk tables cover all subjects); otherwise from the mixed launch's first time-split block on
-cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base, bool all_blocks = false) {
+cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base, bool all_blocks = false, bool forward_only = false) {
     cude::Cpep2Args a2{};
     a2.base = base;
     a2.L = c->chunks;
     a2.chunk_start = c->chunk_start.p;
     a2.hom_M = c->hom_M.p; a2.hom_obs = c->hom_obs.p; a2.fsum = c->fsum.p; a2.wts = c->res.p;
+    if (forward_only && all_blocks && c->chunks_f > 1) {     // the forward-only split and its own transfer matrices
+        a2.L = c->chunks_f;
+        a2.chunk_start = c->chunk_start_f.p;
+        a2.hom_M = c->hom_M_f.p; a2.hom_obs = c->hom_obs_f.p; a2.fsum = c->fsum_f.p; a2.wts = nullptr;
+    }
     a2.g_cond_part = c->g_cond_part.p; a2.partials2 = c->partials2.p;
     a2.base.blk0 = all_blocks ? 0 : c->blk0; a2.base.blk_count = 0;
     return a2;
@@ -562,6 +572,7 @@ double launch_cost(double waves, double slots, double evals) {
 // stays at L = 1 (0.654 vs 0.683 for L = 2).
 int32_t setup_chunks(cude_ctx* c) {
     c->chunks = 1;
+    c->chunks_f = 0;
     c->blk0 = 0;
     c->slots_one = c->half_slots = 0;
     int n_cu = 256;
@@ -678,6 +689,37 @@ int32_t setup_chunks(cude_ctx* c) {
     cude::Cpep2Args a2 = chunk_args(c, a);
     HIP_TRY(cude::launch_cpep2_homog(a2, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));   // cs (host vector) dies here
+    // ---- the forward-only split.  Model (fitted to profiles/r03/forward_chunks.txt): a SIMD that holds w waves of e
+    // evaluations each needs e * w / thr(w) evaluation times (thr = 1, 1.33, 1.36, 1.38 ... for 1, 2, 3, 4+ waves: the
+    // issue rates of profiles/r02/ubench_fma_latency.txt), e = 5S/L + 2, and the scan adds ~0.6 evaluation times per chunk.
+    c->chunks_f = 0;
+    if (getenv("CUDE_NO_FWD_SPLIT") == nullptr && !(env && (env[0] == '2' || env[0] == '3'))) {
+        const double simds = (double)n_cu * 4.0;
+        int Lf = 0;
+        double best_f = 0.0;
+        for (int d = 2; d <= S; d++) {
+            if (S % d) continue;
+            const double w = std::ceil((double)c->nblocks * d / simds);
+            const double thr = w <= 1.0 ? 1.0 : (w <= 2.0 ? 1.33 : (w <= 3.0 ? 1.36 : 1.38));
+            const double cost = (5.0 * S / d + 2.0) * w / thr + 0.6 * d;
+            if (Lf == 0 || cost < best_f) { best_f = cost; Lf = d; }
+        }
+        if (Lf >= 2 && Lf != L) {
+            std::vector<int32_t> csf(Lf + 1);
+            for (int k = 0; k <= Lf; k++) csf[k] = (int32_t)((int64_t)k * S / Lf);
+            HIP_TRY(c->chunk_start_f.resize(Lf + 1));
+            HIP_TRY(c->hom_M_f.resize((size_t)Lf * 4 * N));
+            HIP_TRY(c->hom_obs_f.resize((size_t)T * 2 * N));
+            HIP_TRY(c->fsum_f.resize((size_t)Lf * (3 + T) * N));
+            HIP_TRY(hipMemcpyAsync(c->chunk_start_f.p, csf.data(), (Lf + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            c->chunks_f = Lf;
+            cude::Cpep2Args af = chunk_args(c, a, /*all_blocks=*/true, /*forward_only=*/true);
+            HIP_TRY(cude::launch_cpep2_homog(af, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        if (getenv("CUDE_DEBUG_SELECTOR"))
+            fprintf(stderr, "[cude] forward-only split: L_f=%d (gradient L=%d)\n", Lf, L);
+    }
     return CUDE_OK;
 }
 
@@ -748,7 +790,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                 HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             }
         } else if (c->chunks > 1 && (grad || traj_dev == nullptr)) {
-            cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true);
+            cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true, /*forward_only=*/!grad);
             // forward-only on one rank without an L2 term: the scan kernel's workgroups write their (sum SSE, failures)
             // pairs straight into page-locked host memory, which finish_loss adds up (no reduction launch, no copy)
             static const bool no_fuse = getenv("CUDE_NO_FUSED_FINAL") != nullptr;
@@ -1750,7 +1792,7 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
             cude::CpepArgs a = cpep_args(c);
             a.cond = c->cond.p; a.nn = c->nn.p; a.sse = d_sn.p; a.traj = nullptr; a.auc = c->auc.p;
             a.g_cond = c->g_cond.p; a.partials = c->partials.p;
-            cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true);
+            cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true, /*forward_only=*/true);
             a2.mh_fused = 1;
             a2.mh_z = device_rng ? nullptr : d_z.p + (size_t)k * N;
             a2.mh_std = proposal_std;
