@@ -250,7 +250,8 @@ void adaptive_kernel(typename M::Args a) {
     if constexpr (M::NetT::USES_TANH) tanh_tab_init(lane);
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
     const bool active = gid < a.N;
-    const int64_t i = active ? gid : a.N - 1;
+    const int64_t slot = active ? gid : a.N - 1;                       // position in the launch (lane order) ...
+    const int64_t i = a.perm != nullptr ? (int64_t)a.perm[slot] : slot;  // ... and the subject that sits there
     const int64_t set = blockIdx.y;
     cptr_t tout = as_const(a.out_times);
     const int n_out = a.T;
@@ -259,7 +260,7 @@ void adaptive_kernel(typename M::Args a) {
     M m;
     double y[NS];
     const double chk = m.init(a, smem + adaptive_rows<M>(GRAD) * kBlock, lane, i, set, y);
-    double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + i : nullptr;
+    double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + slot : nullptr;
 #define TAPE(n, r) tape[((int64_t)(n) * TROWS + (r)) * a.N]
 #define OUTV(oi) tape[((int64_t)a.tape_cap * TROWS + (oi)) * a.N]     /* saved output (state 1) behind the steps */
     int n_acc = 0;

@@ -271,6 +271,8 @@ struct cude_ctx {
     DevBuf<double> act;     // SUPP: kept network activations of the gradient launch (small populations only)
     DevBuf<double> tape, ms_tape;   // adaptive mode: accepted steps of the forward sweep, walked back by the adjoint
     DevBuf<int32_t> tape_n;
+    DevBuf<int32_t> perm;                           // adaptive kernels: subject of every launch position (cude_adaptive_regroup)
+    std::vector<int32_t> slot_of;                   // its inverse on the host (empty = identity)
     int tape_cap = 0;
     bool have_tape = false;
     DevBuf<double> red_tmp; // staging of small host vectors reduced through the communicator
@@ -335,6 +337,7 @@ cude::CpepArgs cpep_args(const cude_ctx* c) {
     a.t_begin = c->tp.front(); a.t_end = c->tp.back();
     a.abstol = c->abstol; a.reltol = c->reltol;
     a.tape = c->tape.p; a.tape_cap = c->tape_cap; a.tape_n = c->tape_n.p;
+    a.perm = (adaptive(c) && !c->slot_of.empty()) ? c->perm.p : nullptr;
     return a;
 }
 
@@ -357,6 +360,7 @@ cude::SuppArgs supp_args(const cude_ctx* c) {
     a.t_begin = c->tp.front(); a.t_end = c->tp.back();
     a.abstol = c->abstol; a.reltol = c->reltol;
     a.tape = c->tape.p; a.tape_cap = c->tape_cap; a.tape_n = c->tape_n.p;
+    a.perm = (adaptive(c) && !c->slot_of.empty()) ? c->perm.p : nullptr;
     return a;
 }
 
@@ -449,6 +453,8 @@ int32_t alloc_common(cude_ctx* c) {
         else
             c->pinned_pairs = nullptr;
     }
+    HIP_TRY(c->perm.resize(0));          // a new population starts in its own order
+    c->slot_of.clear();
     HIP_TRY(c->tape.resize(0));          // adaptive gradient tape: allocated by the first gradient evaluation
     c->tape_cap = 0;
     c->have_tape = false;
@@ -1501,6 +1507,47 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     return CUDE_OK;
 }
 
+int32_t cude_adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!adaptive(c) || !c->have_tape) return fail(CUDE_ERR_STATE, "no adaptive gradient evaluation on this context yet");
+    const int64_t N = c->N;
+    std::vector<int32_t> n_acc((size_t)N);
+    HIP_TRY(hipMemcpyAsync(n_acc.data(), c->tape_n.p, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // mean over the waves of (largest - smallest accepted-step count among the wave's lanes), in the current order
+    auto spread = [&](const std::vector<int32_t>& order) {
+        int64_t tot = 0, waves = 0;
+        for (int64_t b = 0; b < N; b += cude::kBlock) {
+            int32_t lo = INT32_MAX, hi = 0;
+            for (int64_t k = b; k < std::min<int64_t>(b + cude::kBlock, N); k++) {
+                const int32_t v = n_acc[(size_t)(order.empty() ? k : order[(size_t)k])];
+                lo = std::min(lo, v); hi = std::max(hi, v);
+            }
+            tot += hi - lo; waves++;
+        }
+        return (int32_t)((tot + waves / 2) / std::max<int64_t>(waves, 1));
+    };
+    std::vector<int32_t> cur;
+    if (!c->slot_of.empty()) {
+        cur.resize((size_t)N);
+        for (int64_t sbj = 0; sbj < N; sbj++) cur[(size_t)c->slot_of[(size_t)sbj]] = (int32_t)sbj;
+    }
+    if (spread_before) *spread_before = spread(cur);
+    std::vector<int32_t> order((size_t)N);
+    for (int64_t k = 0; k < N; k++) order[(size_t)k] = (int32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return n_acc[(size_t)x] > n_acc[(size_t)y]; });
+    if (spread_after) *spread_after = spread(order);
+    drop_graph(c);                                  // (the buffer below may move)
+    HIP_TRY(c->perm.resize((size_t)N));
+    HIP_TRY(hipMemcpyAsync(c->perm.p, order.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->slot_of.assign((size_t)N, 0);
+    for (int64_t k = 0; k < N; k++) c->slot_of[(size_t)order[(size_t)k]] = (int32_t)k;
+    c->have_tape = false;                           // the tape on the device is in the OLD launch order
+    return CUDE_OK;
+}
+
 int32_t cude_adaptive_steps(cude_ctx* c, int64_t subject, int32_t cap, double* t_out, double* dt_out, int32_t* n_steps) {
     int32_t rc = bind(c);
     if (rc) return rc;
@@ -1513,11 +1560,12 @@ int32_t cude_adaptive_steps(cude_ctx* c, int64_t subject, int32_t cap, double* t
     *n_steps = n;
     const int rows = cude::adaptive_tape_rows(c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2);
     const int m = std::min(std::min(n, cap), c->tape_cap);
+    const int64_t slot = c->slot_of.empty() ? subject : c->slot_of[(size_t)subject];      // the tape is in launch order
     for (int r = 0; r < 2 && m > 0; r++) {
         double* dst = r == 0 ? t_out : dt_out;
         if (!dst) continue;
         // entry k, row r of the tape: one double every rows * N
-        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double), c->tape.p + (size_t)r * c->N + subject, (size_t)rows * c->N * sizeof(double),
+        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double), c->tape.p + (size_t)r * c->N + slot, (size_t)rows * c->N * sizeof(double),
                                  sizeof(double), (size_t)m, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));

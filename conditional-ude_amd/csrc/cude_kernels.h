@@ -70,6 +70,9 @@ struct CpepArgs {
     double* tape;            // adaptive gradient: [n_sets][tape_cap][2 + NS][N] accepted steps (t_n, dt_n, y_n)
     int32_t tape_cap;
     int32_t* tape_n;         // [n_sets][N] accepted steps per subject, or nullptr
+    const int32_t* perm;     // adaptive kernels: lane `gid` works on subject perm[gid] (nullptr = identity).  Lanes of a wave
+                             // run as long as the slowest of them: cude_adaptive_regroup orders the subjects by their
+                             // accepted-step counts so that a wave's lanes finish together.  The tape is kept in LANE order.
 #ifdef CUDE_WAVE_TIMING
     long long* dbg;          // development builds only: [nblocks][4] = {start, end of forward, end, hw id} per wave
 #endif
@@ -156,6 +159,7 @@ struct SuppArgs {
     double* tape;            // adaptive gradient, as CpepArgs
     int32_t tape_cap;
     int32_t* tape_n;
+    const int32_t* perm;     // as CpepArgs
 };
 
 // returns hipSuccess, or hipErrorInvalidValue when the shape is not compiled in

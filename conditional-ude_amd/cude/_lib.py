@@ -73,6 +73,7 @@ _SIGNATURES = {
     "cude_adam_step": (C.c_int32, [C.c_void_p, _dp]),
     "cude_synchronize": (C.c_int32, [C.c_void_p]),
     "cude_grad_occupancy": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "cude_adaptive_regroup": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cude_adam_run": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "cude_set_global_subjects": (C.c_int32, [C.c_void_p, C.c_double, C.c_void_p]),
     "cude_get_scale": (C.c_int32, [C.c_void_p, C.c_void_p, _dp]),

@@ -445,6 +445,13 @@ class Engine:
     def synchronize(self):
         check(self._lib.cude_synchronize(self._h))
 
+    def adaptive_regroup(self):
+        """Adaptive mode: order the launch by the accepted-step counts of the last gradient evaluation so that a wave's
+        lanes finish together.  Returns (mean max - min steps within a wave before, after)."""
+        b, a = C.c_int32(), C.c_int32()
+        check(self._lib.cude_adaptive_regroup(self._h, C.byref(b), C.byref(a)))
+        return b.value, a.value
+
     def grad_occupancy(self):
         """Resident waves per CU the runtime grants the one-lane gradient kernel of this context."""
         n = C.c_int32()

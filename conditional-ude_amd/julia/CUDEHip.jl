@@ -359,6 +359,12 @@ function adam_apply_device!(c::Ctx)
     l[]
 end
 
+function adaptive_regroup!(c::Ctx)
+    b = Ref{Int32}(0); a = Ref{Int32}(0)
+    check(ccall((:cude_adaptive_regroup, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), c.h, b, a))
+    Int(b[]), Int(a[])
+end
+
 function grad_occupancy(c::Ctx)
     n = Ref{Int32}(0)
     check(ccall((:cude_grad_occupancy, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}), c.h, n))

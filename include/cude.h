@@ -89,6 +89,14 @@ int32_t cude_set_tolerances(cude_ctx* ctx, double abstol, double reltol);
  * *n_steps = number of accepted steps; at most `cap` of them are written to t_out / dt_out (either may be NULL).
  * CUDE_ERR_STATE before the first such evaluation or outside the adaptive mode. */
 int32_t cude_adaptive_steps(cude_ctx* ctx, int64_t subject, int32_t cap, double* t_out, double* dt_out, int32_t* n_steps);
+/* Adaptive mode at large populations: a wave's 64 lanes run until the slowest of them has finished, and subjects differ
+ * in how many steps the controller lets them take (14 ... 23 at the reference's tolerances).  cude_adaptive_regroup
+ * orders the launch by the accepted-step counts of the LAST gradient evaluation (most steps first), so that lanes of a
+ * wave finish together; every later launch on this context uses that order (per-subject results are unchanged bit for
+ * bit -- only which lane computes which subject, and with it the order of the shared-gradient sum, changes).
+ * spread_* (optional): mean over the waves of (max - min accepted steps within the wave), before and after.  A new
+ * population resets the order.  (No reference line: EnsembleThreads has no lock-step lanes.) */
+int32_t cude_adaptive_regroup(cude_ctx* ctx, int32_t* spread_before, int32_t* spread_after);
 
 /* --- population (replaces the CPeptideConditionalUDEModel constructor loop,
  * src/c-peptide-models.jl:170-194 incl. van_cauter_parameters :30-42, u0, tspan and the

@@ -109,3 +109,61 @@ def test_kept_activation_variant_of_the_gradient_kernel(monkeypatch):
     (l0, g0, c0), (l1, g1, c1) = out["0"], out["1"]
     assert l0 == l1
     assert np.max(np.abs(g0 - g1)) <= 1e-13 * np.max(np.abs(g0)) and np.max(np.abs(c0 - c1)) <= 1e-13 * np.max(np.abs(c0))
+
+
+@pytest.mark.parametrize("model", ["cpep", "supp"])
+def test_adaptive_regroup_changes_the_launch_order_not_the_results(model):
+    """cude_adaptive_regroup: subjects ordered by the accepted-step counts of the last gradient evaluation, so that the
+    lanes of a wave finish together.  Every per-subject quantity (SSE, dL/dcond, the accepted steps themselves) is the
+    same bit for bit afterwards; the loss and the shared gradient -- sums over the subjects in a new order -- to rounding;
+    training continues; a new population starts in its own order again."""
+    from conftest import make_supp_case
+    from cude.engine import Engine
+    if model == "cpep":
+        arch, N = (2, 4, 2), 3000
+        c = make_cpep_case(N, arch)
+        eng = Engine("cpep", arch, n_steps=0, n_state=2)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], c["beta"])
+    else:
+        N = 1500
+        c = make_supp_case(N)
+        eng = Engine("supp", c["arch"], n_steps=0, lam=0.01)
+        eng.set_population_supp(c["tp"], c["data"])
+        eng.set_params(c["nn"], c["theta"])
+    l0, g0, c0 = eng.loss_grad()
+    sse0 = eng.forward(want_sse=True)["sse"]
+    eng.loss_grad()
+    probe = [0, 1, 63, 64, N // 2, N - 1]
+    steps0 = [eng.adaptive_steps(s) for s in probe]
+    before, after = eng.adaptive_regroup()
+    assert after <= 1 and after <= before                                # sorted: a wave holds (almost) one step count
+    if model == "cpep":
+        assert before >= 2                                                # (this population does vary; the synthetic
+                                                                          # suppression one takes the same steps everywhere)
+    with pytest.raises(Exception):
+        eng.adaptive_steps(0)                                             # the old tape is in the old order: invalidated
+    l1, g1, c1 = eng.loss_grad()
+    assert np.array_equal(c0, c1)
+    assert np.array_equal(sse0, eng.forward(want_sse=True)["sse"])
+    assert abs(l1 - l0) <= 1e-13 * abs(l0) and np.max(np.abs(g1 - g0)) <= 1e-12 * np.max(np.abs(g0))
+    eng.loss_grad()
+    for s, (t_a, dt_a) in zip(probe, steps0):
+        t_b, dt_b = eng.adaptive_steps(s)
+        assert np.array_equal(t_a, t_b) and np.array_equal(dt_a, dt_b)
+    eng.adam_init(1e-3)
+    losses = eng.adam_run(4)
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # a second regrouping (the counts have moved with the parameters) and a new population both work
+    eng.loss_grad()
+    eng.adaptive_regroup()
+    assert np.isfinite(eng.loss_grad()[0])
+    if model == "cpep":
+        eng.set_population_cpep(c["tp"], c["G"][:200], c["obs"][:200], c["age"][:200], c["t2dm"][:200])
+        eng.set_params(c["nn"], c["beta"][:200])
+    else:
+        eng.set_population_supp(c["tp"], c["data"][:, :, :200])
+        eng.set_params(c["nn"], c["theta"][:200])
+    l2, _, c2 = eng.loss_grad()
+    assert np.isfinite(l2) and c2.size == 200
+    eng.close()
