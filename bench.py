@@ -98,7 +98,7 @@ def cpep_flops(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS, n_state=N_STATE, grad=Tr
     """fp64 flops the one-lane-per-subject c-peptide kernel executes per subject (FMA = 2), counted from the kernel's
     structure (cude_cpep.hip): 5 S + 1 network evaluations per sweep, the Runge-Kutta algebra per step."""
     nin, w, d = arch
-    fwd_eval, bwd_eval = mlp_flops(1, w, d, table_tanh=w <= TANH_TABLE_MAX_WIDTH_CPEP)
+    fwd_eval, bwd_eval = mlp_flops(1, w, d, table_tanh=(w <= TANH_TABLE_MAX_WIDTH_CPEP and nin == 2))
     n_eval = 5 * n_steps + 1
     stage_fwd = 2 * (2 * 21 + 2 * 6 + 7 * 4) + (2 * 6 if n_state == 3 else 0)   # stage sums, Y, A*Y+g [, quadrature]
     stage_rev = 2 * (2 * 21 + 6 * 4 + 12) + 12

@@ -79,8 +79,8 @@ __device__ __forceinline__ cptr_t launder(cptr_t p) {
 // waves per SIMD become two); but the width-6 gradient kernels sit at the 256-register line of two waves per SIMD and
 // pay for the extra live values with scratch traffic (2-6-6-1 0.564 -> 0.603 ms), and the adaptive kernels -- latency
 // chains that want resident waves more than short instruction streams -- would drop from three waves per SIMD to two.
-// Hence: fixed-step c-peptide kernels up to width CUDE_TANH_TAB_MAXW, the fixed-step suppression kernel always, the
-// adaptive kernels never.
+// Hence: fixed-step c-peptide kernels (two inputs) up to width CUDE_TANH_TAB_MAXW, the fixed-step suppression kernel
+// always, the adaptive kernels and the covariate model never.
 #ifndef CUDE_TANH_TAB_MAXW
 #define CUDE_TANH_TAB_MAXW 4
 #endif
@@ -794,8 +794,11 @@ struct Mlp {
 };
 
 // the networks of the fixed-step kernel families with their tanh form (see act_tanh_vec)
+// (not the covariate model, NIN = 3: its raw-age input (20 ... 79) saturates first-layer units, and where tanh is within
+// 1e-8 of +-1 the quotient form's last-place errors show in 1 - h^2 -- gradients off by up to 2e-8 of their largest
+// entry in a randomised sweep, tools/fuzz_parity.py; the exponential form 1 - 2/(E + 1) rounds like libm there)
 template <int NIN, int W, int D>
-using CpepNet = Mlp<NIN, W, D, 1, (W <= kTanhTabMaxW)>;
+using CpepNet = Mlp<NIN, W, D, 1, (W <= kTanhTabMaxW && NIN == 2)>;
 #ifdef CUDE_TANH_EXP
 template <int W, int D>
 using SuppNet = Mlp<4, W, D, 3, false>;
