@@ -54,10 +54,7 @@ def test_paths_agree_with_oracle_and_each_other(arch, n_state, n_steps, N):
     base = results["1"]
     for p, r in results.items():
         assert np.allclose(r["steps"], base["steps"], rtol=1e-11), p
-        # parameters after three Adam steps: an entry whose gradient is below Adam's eps = 1e-8 moves by lr/eps = 1e6 times
-        # its gradient, so the paths' rounding-level gradient differences (1e-15 here: the covariate model's raw age
-        # input saturates units) show as 1e-9; the table tanh (round 3) has its rounding jumps at the grid cells
-        assert np.max(np.abs(r["nn"] - base["nn"])) < 5e-9 and np.max(np.abs(r["cond"] - base["cond"])) < 1e-10, p
+        assert np.max(np.abs(r["nn"] - base["nn"])) < 1e-10 and np.max(np.abs(r["cond"] - base["cond"])) < 1e-10, p
 
 
 def test_chunked_path_failure_convention():
