@@ -109,6 +109,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP != 
     const int prio_shift = GRAD ? a.prio_shift : 0;
     // (here, not at the top: the table's global read then travels with the subject's own loads -- one latency, not two)
     if constexpr (Net::USES_TANH) tanh_tab_init(lane);
+    Net::bias_init(a.nn + set * a.set_stride_nn, lane);
 #pragma unroll 1
     for (int e = -1; e < 5 * S; e++) {
         if (GRAD && prio_shift > 0) {

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     int n = n0, s = 0;
     const int n_own = 5 * (n1 - n0);
     if constexpr (Net::USES_TANH) tanh_tab_init(lane);    // (here: its global read travels with the subject's own loads)
+    Net::bias_init(b.nn + set * b.set_stride_nn, lane);
 #pragma unroll 1
     for (int idx = -2; idx < n_own; idx++) {
         double xv = 0.0;
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     bool run_ok = false, have_anchor = false;
     // own stage times in reverse order; e = 5 n0 - 1 stands for the baseline with weight -sum(own w)
     if constexpr (Net::USES_TANH) tanh_tab_init(lane);
+    Net::bias_init(b.nn + set * b.set_stride_nn, lane);
 #pragma unroll 1
     for (int e = 5 * n1 - 1; e >= 5 * n0 - 1; e--) {
         const bool own = e >= 5 * n0;

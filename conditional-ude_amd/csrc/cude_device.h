@@ -100,6 +100,18 @@ __device__ __forceinline__ void tanh_tab_init(int lane) {
     }
     __syncthreads();
 }
+// Hidden-layer biases in LDS (networks with LB set: the suppression kernel).  A bias seeds the accumulator of its unit
+// before the layer's FMAs; coming from the scalar unit it costs a v_mov_b64 -- a VALU slot -- per unit (fma(w, h, b) with w
+// AND b in SGPRs would need two constant-bus reads, gfx950 allows one), 15 per evaluation of a 4-3x5-1 network; read from LDS
+// (all lanes the same address: a broadcast) it lands in the VGPR pair without touching the VALU.
+__shared__ double s_bias[64];
+template <int W, int D, int L1, int LH>
+__device__ __forceinline__ void bias_lds_init(const double* p, int lane) {
+    static_assert((D - 1) * W <= 64, "bias row");
+    if (lane < (D - 1) * W) s_bias[lane] = p[L1 + (lane / W) * LH + W * W + lane % W];      // hidden layer 1 + lane / W
+    __syncthreads();
+}
+
 template <int W, bool TT>
 __device__ __forceinline__ void act_tanh_vec(const double (&z)[W], double (&t)[W]) {
     if constexpr (TT) m_tanh_vec_tab<W>(z, t, s_tanh_tab);
@@ -168,8 +180,13 @@ struct AccPin<double[N]> {
     }
 };
 
-template <int NIN, int W, int D, int NV, bool TT = false>      // TT: tanh by table (act_tanh_vec)
+template <int NIN, int W, int D, int NV, bool TT = false, bool LB = false>   // TT: tanh by table; LB: hidden biases from LDS
 struct Mlp {
+    static constexpr bool LDS_BIAS = LB && D >= 2;
+    // fills s_bias for this workgroup's network (call once, before the first evaluation, where LDS_BIAS)
+    __device__ static __forceinline__ void bias_init(const double* p, int lane) {
+        if constexpr (LDS_BIAS) bias_lds_init<W, D, W * NIN + W, W * W + W>(p, lane);
+    }
     // weight columns fetched per scalar load (a column = W doubles); W must be a multiple of it
     static constexpr int CG = (W % CUDE_COLGROUP == 0) ? CUDE_COLGROUP : 1;
     static constexpr bool USES_TANH = TT;           // kernels then call tanh_tab_init() before the first evaluation
@@ -287,7 +304,10 @@ struct Mlp {
         for (int l = 1; l < D; l++) {
             const int o = L1 + (l - 1) * LH;
             CUDE_FENCE();
-            {
+            if constexpr (LDS_BIAS) {
+#pragma unroll
+                for (int j = 0; j < W; j++) z[j] = s_bias[(l - 1) * W + j];
+            } else {
                 const SCol<W> b = ld_col<W>(p, o + W * W);
 #pragma unroll
                 for (int j = 0; j < W; j++) z[j] = b.v[j];
@@ -491,7 +511,7 @@ struct Mlp {
         SCol<W> bias[D];                 // bias[l]: hidden layer l (l >= 1)
         SCol<W * CGP> grp[D][NG];        // grp[l][g]: column group g of hidden layer l (l >= 1)
         double bo = 0.0;
-        bias[1] = ld_col<W>(p, L1 + W * W);
+        if constexpr (!LDS_BIAS) bias[1] = ld_col<W>(p, L1 + W * W);
         grp[1][0] = ld_col<W * CGP>(p, L1);
         CUDE_FENCE();
         if (use_tab) {
@@ -509,7 +529,7 @@ struct Mlp {
         for (int l = 1; l < D; l++) {
             const int o = L1 + (l - 1) * LH;
 #pragma unroll
-            for (int j = 0; j < W; j++) z[j] = bias[l].v[j];
+            for (int j = 0; j < W; j++) z[j] = LDS_BIAS ? s_bias[(l - 1) * W + j] : bias[l].v[j];
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 CUDE_FENCE();
@@ -517,7 +537,7 @@ struct Mlp {
                 if (g + 1 < NG) {
                     grp[l][g + 1] = ld_col<W * CGP>(p, o + W * CGP * (g + 1));
                 } else if (l + 1 < D) {
-                    bias[l + 1] = ld_col<W>(p, o + LH + W * W);
+                    if constexpr (!LDS_BIAS) bias[l + 1] = ld_col<W>(p, o + LH + W * W);
                     grp[l + 1][0] = ld_col<W * CGP>(p, o + LH);
                 } else {
                     wo = ld_col<W>(p, OUT);
@@ -797,14 +817,20 @@ struct Mlp {
 // (not the covariate model, NIN = 3: its raw-age input (20 ... 79) saturates first-layer units, and where tanh is within
 // 1e-8 of +-1 the quotient form's last-place errors show in 1 - h^2 -- gradients off by up to 2e-8 of their largest
 // entry in a randomised sweep, tools/fuzz_parity.py; the exponential form 1 - 2/(E + 1) rounds like libm there)
+#ifndef CUDE_CPEP_LDS_BIAS
+#define CUDE_CPEP_LDS_BIAS 1
+#endif
 template <int NIN, int W, int D>
-using CpepNet = Mlp<NIN, W, D, 1, (W <= kTanhTabMaxW && NIN == 2)>;
+using CpepNet = Mlp<NIN, W, D, 1, (W <= kTanhTabMaxW && NIN == 2), (W <= kTanhTabMaxW && NIN == 2 && CUDE_CPEP_LDS_BIAS != 0)>;
 #ifdef CUDE_TANH_EXP
 template <int W, int D>
 using SuppNet = Mlp<4, W, D, 3, false>;
 #else
+#ifndef CUDE_SUPP_LDS_BIAS
+#define CUDE_SUPP_LDS_BIAS 1
+#endif
 template <int W, int D>
-using SuppNet = Mlp<4, W, D, 3, true>;
+using SuppNet = Mlp<4, W, D, 3, true, (CUDE_SUPP_LDS_BIAS != 0)>;
 #endif
 
 // ------------------------------------------------------------------------------------ analytic production
@@ -816,6 +842,7 @@ using SuppNet = Mlp<4, W, D, 3, true>;
 template <bool RAW>
 struct MmProd {
     static constexpr bool USES_TANH = false;
+    __device__ static __forceinline__ void bias_init(const double*, int) {}
     static constexpr int NC = 1, NCST = 1, P = 1;
     static constexpr int NACC = 2;                  // [d/dp0, d/dk]
     static constexpr bool HAS_TAB = false;          // one division per evaluation: nothing to tabulate
