@@ -405,7 +405,9 @@ def extras(Engine, device, steps=20, warm=40):
     eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
     eng.set_params(nn4, pop["beta0"])
     eng.adam_init(1e-2)
+    os.environ["CUDE_NO_AUTO_REGROUP"] = "1"                                # (cude_adam_run would regroup by itself)
     dt_plain, ms_plain, _ = timed_adam(eng, n, steps, warm)                 # subjects in the caller's order
+    del os.environ["CUDE_NO_AUTO_REGROUP"]
     eng.loss_grad(want_cond_grad=False)
     spread = eng.adaptive_regroup()        # launch ordered by accepted-step count: a wave's lanes finish together
     dt, ms, launches = timed_adam(eng, n, steps, warm)
@@ -417,8 +419,9 @@ def extras(Engine, device, steps=20, warm=40):
         "kernel": "adaptive_kernel<CpepAd<Mlp<2,4,2,1>>,grad>", "kernel_ms": ms, "launches": launches,
         "accepted_steps_per_subject": {"min": int(acc_steps.min()), "median": float(np.median(acc_steps)),
                                        "max": int(acc_steps.max())},
-        "regrouped": {"note": "cude_adaptive_regroup after the warm-up: launch ordered by the accepted-step counts of "
-                              "the last evaluation (per-subject results unchanged bit for bit)",
+        "regrouped": {"note": "launch ordered by the accepted-step counts of the last evaluation (cude_adaptive_regroup; "
+                              "cude_adam_run does it by itself for populations >= 8192; per-subject results unchanged bit "
+                              "for bit)",
                       "mean_step_spread_within_a_wave": {"before": spread[0], "after": spread[1]},
                       "ms_per_step_in_the_callers_order": dt_plain * 1e3, "kernel_ms_in_the_callers_order": ms_plain},
         "note": "work per subject is data-dependent (a wave runs as long as its slowest lane): no fixed algorithmic "

@@ -273,6 +273,7 @@ struct cude_ctx {
     DevBuf<int32_t> tape_n;
     DevBuf<int32_t> perm;                           // adaptive kernels: subject of every launch position (cude_adaptive_regroup)
     std::vector<int32_t> slot_of;                   // its inverse on the host (empty = identity)
+    int64_t regroup_age = 0;                        // optimiser iterations since the launch order was last rebuilt
     int tape_cap = 0;
     bool have_tape = false;
     DevBuf<double> red_tmp; // staging of small host vectors reduced through the communicator
@@ -892,6 +893,47 @@ int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
     return CUDE_OK;
 }
 
+// (see cude_adaptive_regroup in include/cude.h)
+int32_t adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after) {
+    if (!adaptive(c) || !c->have_tape) return fail(CUDE_ERR_STATE, "no adaptive gradient evaluation on this context yet");
+    const int64_t N = c->N;
+    std::vector<int32_t> n_acc((size_t)N);
+    HIP_TRY(hipMemcpyAsync(n_acc.data(), c->tape_n.p, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // mean over the waves of (largest - smallest accepted-step count among the wave's lanes), in the current order
+    auto spread = [&](const std::vector<int32_t>& order) {
+        int64_t tot = 0, waves = 0;
+        for (int64_t b = 0; b < N; b += cude::kBlock) {
+            int32_t lo = INT32_MAX, hi = 0;
+            for (int64_t k = b; k < std::min<int64_t>(b + cude::kBlock, N); k++) {
+                const int32_t v = n_acc[(size_t)(order.empty() ? k : order[(size_t)k])];
+                lo = std::min(lo, v); hi = std::max(hi, v);
+            }
+            tot += hi - lo; waves++;
+        }
+        return (int32_t)((tot + waves / 2) / std::max<int64_t>(waves, 1));
+    };
+    std::vector<int32_t> cur;
+    if (!c->slot_of.empty()) {
+        cur.resize((size_t)N);
+        for (int64_t sbj = 0; sbj < N; sbj++) cur[(size_t)c->slot_of[(size_t)sbj]] = (int32_t)sbj;
+    }
+    if (spread_before) *spread_before = spread(cur);
+    std::vector<int32_t> order((size_t)N);
+    for (int64_t k = 0; k < N; k++) order[(size_t)k] = (int32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return n_acc[(size_t)x] > n_acc[(size_t)y]; });
+    if (spread_after) *spread_after = spread(order);
+    if (c->slot_of.empty() || c->perm.n != (size_t)N) drop_graph(c);   // the launches' `perm` argument changes (null -> buffer)
+    HIP_TRY(c->perm.resize((size_t)N));
+    HIP_TRY(hipMemcpyAsync(c->perm.p, order.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->slot_of.assign((size_t)N, 0);
+    for (int64_t k = 0; k < N; k++) c->slot_of[(size_t)order[(size_t)k]] = (int32_t)k;
+    c->have_tape = false;                           // the tape on the device is in the OLD launch order
+    c->regroup_age = 0;
+    return CUDE_OK;
+}
+
 }  // namespace
 
 // =============================================================================== exported ABI
@@ -1232,6 +1274,14 @@ int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
     if (!c->have_pop || !c->have_nn || !c->have_cond) return fail(CUDE_ERR_STATE, "population / parameters not set");
     if ((rc = ensure_trace(c, n_iters))) return rc;
     if ((rc = ensure_tape(c))) return rc;
+    // Large adaptive populations: keep the launch ordered by accepted-step count (cude_adaptive_regroup) -- once the
+    // first evaluation has told the counts, then every 200 iterations (they drift with the parameters).  Costs one
+    // read-back of N counters and a host sort, ~10 ms at 1e5 subjects; CUDE_NO_AUTO_REGROUP=1 leaves it to the caller.
+    if (adaptive(c) && c->N >= 8192 && c->have_tape && (c->slot_of.empty() || c->regroup_age >= 200) &&
+        getenv("CUDE_NO_AUTO_REGROUP") == nullptr) {
+        if ((rc = adaptive_regroup(c, nullptr, nullptr))) return rc;
+    }
+    c->regroup_age += n_iters;
     HIP_TRY(hipMemsetAsync(c->adam_state.p + 3, 0, sizeof(double), c->stream));     // trace position = 0
     const bool use_graph = (c->comm == nullptr) && !c->timing && getenv("CUDE_NO_GRAPH") == nullptr;
     if (use_graph && !c->graph_exec) {
@@ -1510,42 +1560,7 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
 int32_t cude_adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after) {
     int32_t rc = bind(c);
     if (rc) return rc;
-    if (!adaptive(c) || !c->have_tape) return fail(CUDE_ERR_STATE, "no adaptive gradient evaluation on this context yet");
-    const int64_t N = c->N;
-    std::vector<int32_t> n_acc((size_t)N);
-    HIP_TRY(hipMemcpyAsync(n_acc.data(), c->tape_n.p, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    // mean over the waves of (largest - smallest accepted-step count among the wave's lanes), in the current order
-    auto spread = [&](const std::vector<int32_t>& order) {
-        int64_t tot = 0, waves = 0;
-        for (int64_t b = 0; b < N; b += cude::kBlock) {
-            int32_t lo = INT32_MAX, hi = 0;
-            for (int64_t k = b; k < std::min<int64_t>(b + cude::kBlock, N); k++) {
-                const int32_t v = n_acc[(size_t)(order.empty() ? k : order[(size_t)k])];
-                lo = std::min(lo, v); hi = std::max(hi, v);
-            }
-            tot += hi - lo; waves++;
-        }
-        return (int32_t)((tot + waves / 2) / std::max<int64_t>(waves, 1));
-    };
-    std::vector<int32_t> cur;
-    if (!c->slot_of.empty()) {
-        cur.resize((size_t)N);
-        for (int64_t sbj = 0; sbj < N; sbj++) cur[(size_t)c->slot_of[(size_t)sbj]] = (int32_t)sbj;
-    }
-    if (spread_before) *spread_before = spread(cur);
-    std::vector<int32_t> order((size_t)N);
-    for (int64_t k = 0; k < N; k++) order[(size_t)k] = (int32_t)k;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return n_acc[(size_t)x] > n_acc[(size_t)y]; });
-    if (spread_after) *spread_after = spread(order);
-    drop_graph(c);                                  // (the buffer below may move)
-    HIP_TRY(c->perm.resize((size_t)N));
-    HIP_TRY(hipMemcpyAsync(c->perm.p, order.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->slot_of.assign((size_t)N, 0);
-    for (int64_t k = 0; k < N; k++) c->slot_of[(size_t)order[(size_t)k]] = (int32_t)k;
-    c->have_tape = false;                           // the tape on the device is in the OLD launch order
-    return CUDE_OK;
+    return adaptive_regroup(c, spread_before, spread_after);
 }
 
 int32_t cude_adaptive_steps(cude_ctx* c, int64_t subject, int32_t cap, double* t_out, double* dt_out, int32_t* n_steps) {

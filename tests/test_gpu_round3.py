@@ -167,3 +167,32 @@ def test_adaptive_regroup_changes_the_launch_order_not_the_results(model):
     l2, _, c2 = eng.loss_grad()
     assert np.isfinite(l2) and c2.size == 200
     eng.close()
+
+
+def test_adam_run_regroups_a_large_adaptive_population_by_itself(monkeypatch):
+    """cude_adam_run on an adaptive population of >= 8192 subjects orders the launch by accepted-step count once the first
+    evaluation has told the counts (CUDE_NO_AUTO_REGROUP=1 leaves it to the caller): same losses to rounding, the order
+    is in place afterwards (an explicit regroup finds nothing left to gain)."""
+    from cude.engine import Engine
+    arch, N = (2, 4, 2), 9000
+    c = make_cpep_case(N, arch)
+    traces, spread = {}, {}
+    for auto in (False, True):
+        if auto:
+            monkeypatch.delenv("CUDE_NO_AUTO_REGROUP", raising=False)
+        else:
+            monkeypatch.setenv("CUDE_NO_AUTO_REGROUP", "1")
+        eng = Engine("cpep", arch, n_steps=0, n_state=2)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], c["beta"])
+        eng.adam_init(1e-3)
+        eng.adam_step()                                   # tells the counts
+        traces[auto] = eng.adam_run(5)
+        eng.loss_grad()
+        spread[auto], _ = eng.adaptive_regroup()
+        eng.close()
+    # the shared gradient is summed in another order: parameters move by rounding, and the adaptive solve turns that
+    # into accept / reject flips for a few subjects (DESIGN.md 2: the map is discontinuous in its inputs): 1e-7 here
+    assert np.allclose(traces[True], traces[False], rtol=1e-5, atol=0) and traces[True][0] == traces[False][0]
+    # the launch order adam_run put in place is still (nearly) sorted six small steps later; the caller's order never was
+    assert spread[True] < spread[False] and spread[False] >= 2
