@@ -76,10 +76,15 @@ def mlp_flops(nv, w, d, want_dx=False, table_tanh=False):
         # m_tanh_vec per neuron: min, mul, rndne, cvt, ldexp, add, bfi (7 x 1 flop) + 13 FMA (2 reduction, 10 Horner,
         # 1 final); per layer: one reciprocal (rcp + 3 FMA) + 3(W-1) multiplies
         tanh_layer = w * (7 + 13 * 2) + (1 + 3 * 2) + 3 * (w - 1)
-    softplus = 26 * 2 + 22      # exp (12 FMA) + shared reciprocal (3 FMA) + atanh series (11 FMA) + 22 other ops
+    softplus = 23 * 2 + 22      # exp (12 FMA) + shared reciprocal (3 FMA) + atanh polynomial (8 FMA) + 22 other ops
     fwd = 2 * (w * nv + (d - 1) * w * w + w) + d * tanh_layer + softplus
     bwd = (2 * w + w + 2) + (d - 1) * w * (4 + 4 * w) + w * (4 + 2 * nv) + (2 * nv * w if want_dx else 0)
     return fwd, bwd
+
+
+# of a softplus evaluation, the part only the VALUE needs (atanh polynomial: 8 FMA; s, z, 2 s p, + ln 2, max(x, 0), the
+# final sum: 9 single ops): the reverse sweeps re-evaluate the network for its derivative and never execute it
+SOFTPLUS_VALUE_ONLY_FLOPS = 8 * 2 + 9
 
 
 def table_steps(n_steps, n_obs):
@@ -105,7 +110,7 @@ def cpep_flops(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS, n_state=N_STATE, grad=Tr
     obs_fl = n_obs * (2 * (3 if n_state == 3 else 2) * 7 + 8)
     total = n_eval * fwd_eval + n_steps * stage_fwd + obs_fl
     if grad:
-        total += n_eval * (fwd_eval + bwd_eval) + n_steps * stage_rev + obs_fl
+        total += n_eval * (fwd_eval - SOFTPLUS_VALUE_ONLY_FLOPS + bwd_eval) + n_steps * stage_rev + obs_fl
     if 6 <= w <= 7:
         # layer-1 exponent table (cude_device.h Mlp::HAS_TAB): inside a run of steps within one glucose piece the W
         # layer-1 exponentials (7 + 13 FMA each) and the W first-layer FMAs are replaced by one multiply + min + add
@@ -127,7 +132,7 @@ def supp_flops(arch, n_steps, n_obs, grad=True):
     obs_fl = n_obs * (2 * 3 * 7 + 3 * 5)
     total = n_eval * fwd_eval + n_steps * stage + obs_fl
     if grad:
-        total += n_eval * (fwd_eval + bwd_eval + 10) + n_steps * (2 * 3 * 21 + 6 * 3 * 2) + obs_fl
+        total += n_eval * (fwd_eval - SOFTPLUS_VALUE_ONLY_FLOPS + bwd_eval + 10) + n_steps * (2 * 3 * 21 + 6 * 3 * 2) + obs_fl
     return total
 
 

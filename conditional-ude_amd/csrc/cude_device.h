@@ -119,8 +119,14 @@ __device__ __forceinline__ void act_tanh_vec(const double (&z)[W], double (&t)[W
 }
 
 // softplus(x) = log(1+exp(x)) (reference form, evaluated stably); *sig receives the logistic derivative.
-__device__ __forceinline__ double act_softplus(double x, double* sig) { return m_softplus(x, sig); }
-__device__ __forceinline__ double act_softplus_val(double x) { return m_softplus_val(x); }
+// (LONE: no other exponential in the kernel -- networks with the table tanh; see m_exp2x_t)
+template <bool LONE>
+__device__ __forceinline__ double act_softplus(double x, double* sig) { return m_softplus_t<LONE>(x, sig); }
+template <bool LONE>
+__device__ __forceinline__ double act_softplus_val(double x) {
+    double sig;
+    return m_softplus_t<LONE>(x, &sig);
+}
 
 // ------------------------------------------------------------------------------------ MLP
 // Network NIN -> W (tanh) x D -> 1 (softplus).  The first NV inputs vary per evaluation; the
@@ -179,6 +185,18 @@ struct AccPin<double[N]> {
 #endif
     }
 };
+
+// A wave-uniform bias seeding its unit's accumulator: one v_mov_b64 (left alone, LLVM copies the SGPR pair with two
+// v_mov_b32 -- two VALU slots per unit and evaluation).
+__device__ __forceinline__ double seed_from_sgpr(double b) {
+#ifndef CUDE_NO_SEED_MOV64
+    double z;
+    asm("v_mov_b64 %0, %1" : "=v"(z) : "s"(b));
+    return z;
+#else
+    return b;
+#endif
+}
 
 template <int NIN, int W, int D, int NV, bool TT = false, bool LB = false>   // TT: tanh by table; LB: hidden biases from LDS
 struct Mlp {
@@ -310,7 +328,7 @@ struct Mlp {
             } else {
                 const SCol<W> b = ld_col<W>(p, o + W * W);
 #pragma unroll
-                for (int j = 0; j < W; j++) z[j] = b.v[j];
+                for (int j = 0; j < W; j++) z[j] = seed_from_sgpr(b.v[j]);
             }
 #pragma unroll
             for (int i0 = 0; i0 < W; i0 += CG) {               // CG weight columns per scalar load + wait
@@ -328,7 +346,7 @@ struct Mlp {
         }
         CUDE_FENCE();
         const SCol<W> wo = ld_col<W>(p, OUT);
-        double z0 = p[OUT + W], z1 = 0.0;
+        double z0 = seed_from_sgpr(p[OUT + W]), z1 = 0.0;
 #pragma unroll
         for (int i = 0; i < W; i++) {
             if (i & 1) z1 = fma(wo.v[i], h[D - 1][i], z1);
@@ -390,7 +408,7 @@ struct Mlp {
             if (i & 1) z1 = fma(v.w[oo + i], h[i], z1);
             else z0 = fma(v.w[oo + i], h[i], z0);
         }
-        return act_softplus_val(z0 + z1);
+        return act_softplus_val<TT>(z0 + z1);
     }
 
     // ---- kept activations (c-peptide gradient kernel, CpepArgs::act): the forward sweep hands out the tanh outputs of
@@ -434,7 +452,7 @@ struct Mlp {
             if (i & 1) z1 = fma(v.w[oo + i], h[i], z1);
             else z0 = fma(v.w[oo + i], h[i], z0);
         }
-        return act_softplus(z0 + z1, &keep[NKEEP - 1]);
+        return act_softplus<TT>(z0 + z1, &keep[NKEEP - 1]);
     }
     // value and the output unit's logistic derivative (the only kept value of the KEEP = 1 gradient kernel)
     __device__ static __forceinline__ double eval_vw_sig(cptr_t p, const VW& v, const double (&c)[W],
@@ -470,7 +488,7 @@ struct Mlp {
         double h[D][W];
         // (the pipelined weight stream of eval_grad_pf does not pay here: measured +1 ... +7 % on the forward-only
         // kernels, which run at 3-4 waves per SIMD and lose a wave or spill SGPRs to the extra groups in flight)
-        return act_softplus_val(forward(p, c, x, h, use_tab, E1));
+        return act_softplus_val<TT>(forward(p, c, x, h, use_tab, E1));
     }
 
     // ---- value + weighted reverse sweep with a SOFTWARE-PIPELINED weight stream.
@@ -529,7 +547,7 @@ struct Mlp {
         for (int l = 1; l < D; l++) {
             const int o = L1 + (l - 1) * LH;
 #pragma unroll
-            for (int j = 0; j < W; j++) z[j] = LDS_BIAS ? s_bias[(l - 1) * W + j] : bias[l].v[j];
+            for (int j = 0; j < W; j++) z[j] = LDS_BIAS ? s_bias[(l - 1) * W + j] : seed_from_sgpr(bias[l].v[j]);
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 CUDE_FENCE();
@@ -557,7 +575,7 @@ struct Mlp {
         if (KEEP) glast = ld_col<W * CGP>(p, L1 + (D - 2) * LH + W * CGP * (NG - 1));
         CUDE_FENCE();
         if (SKIP_OUT) return 0.0;
-        double z0 = bo, z1 = 0.0;
+        double z0 = seed_from_sgpr(bo), z1 = 0.0;
 #pragma unroll
         for (int i = 0; i < W; i++) {
             if (i & 1) z1 = fma(wo.v[i], h[D - 1][i], z1);
@@ -580,7 +598,7 @@ struct Mlp {
         const double zo = forward_pf<true, SIG_IN>(p, c, x, h, use_tab, E1, wo, grp[D - 1][NG - 1]);
         double sig = sig_in;
         double y = 0.0;
-        if (!SIG_IN) y = act_softplus(zo, &sig);
+        if (!SIG_IN) y = act_softplus<TT>(zo, &sig);
         // ------------------------------------------------ backward (column groups from the last to the first)
         const double dz = wgt * sig;
         acc[G_OUT + W] += dz;
@@ -670,7 +688,7 @@ struct Mlp {
         double h[D][W];
         const double zo = forward(p, c, x, h, use_tab, E1);
         double sig;
-        const double y = act_softplus(zo, &sig);
+        const double y = act_softplus<TT>(zo, &sig);
         backward<WANT_DX>(p, x, h, sig, wgt, acc, dx);
         return y;
     }
@@ -680,7 +698,7 @@ struct Mlp {
     __device__ static __forceinline__ double eval_keep(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                        double (&h)[D][W], double* sig) {
         p = launder(p);
-        return act_softplus(forward(p, c, x, h), sig);
+        return act_softplus<TT>(forward(p, c, x, h), sig);
     }
 
     // weighted reverse sweep from kept activations:  acc += wgt * d(out)/d(params);  if WANT_DX,
@@ -820,8 +838,12 @@ struct Mlp {
 #ifndef CUDE_CPEP_LDS_BIAS
 #define CUDE_CPEP_LDS_BIAS 1
 #endif
+#ifndef CUDE_LDS_BIAS_MAXW
+#define CUDE_LDS_BIAS_MAXW CUDE_TANH_TAB_MAXW
+#endif
 template <int NIN, int W, int D>
-using CpepNet = Mlp<NIN, W, D, 1, (W <= kTanhTabMaxW && NIN == 2), (W <= kTanhTabMaxW && NIN == 2 && CUDE_CPEP_LDS_BIAS != 0)>;
+using CpepNet = Mlp<NIN, W, D, 1, (W <= kTanhTabMaxW && NIN == 2),
+                    ((W <= kTanhTabMaxW || W <= CUDE_LDS_BIAS_MAXW) && NIN == 2 && CUDE_CPEP_LDS_BIAS != 0)>;
 #ifdef CUDE_TANH_EXP
 template <int W, int D>
 using SuppNet = Mlp<4, W, D, 3, false>;

@@ -31,6 +31,10 @@
 #define CUDE_HD inline
 #endif
 
+#ifndef CUDE_FMA_C_CONSTRAINT
+#define CUDE_FMA_C_CONSTRAINT "v"
+#endif
+
 namespace cude {
 
 // 1/d for d in [1, 1e290]
@@ -51,8 +55,41 @@ CUDE_HD double m_rcp(double d) {
     return fma(r0, t, r0);
 }
 
-// exp(2 x) for x in [-354, 354]
-CUDE_HD double m_exp2x(double x) {
+// fma(a, b, c) with a constant addend.  Left to itself LLVM forms the two-address v_fmac for a Horner step whose
+// addend it has hoisted into VGPRs and copies the constant into the accumulator first (a v_mov_b64 -- a VALU slot -- per
+// step, and two VGPRs per constant); written out, the addend is an SGPR pair of a three-address v_fma_f64.
+CUDE_HD double m_fma_c(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CUDE_NO_FMA_C)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), CUDE_FMA_C_CONSTRAINT(c));
+    return r;
+#else
+    return fma(a, b, c);
+#endif
+}
+// the same with the addend in an SGPR pair (no VGPRs held; the constant is rematerialised by the scalar unit)
+CUDE_HD double m_fma_cs(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CUDE_NO_FMA_CS)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return fma(a, b, c);
+#endif
+}
+
+template <bool CS>
+CUDE_HD double m_fma_sel(double a, double b, double c) {
+    if constexpr (CS) return m_fma_cs(a, b, c);
+    else return fma(a, b, c);
+}
+
+// exp(2 x) for x in [-354, 354].  CS: Horner steps written as three-address FMAs with SGPR addends (m_fma_cs) -- for the
+// kernels whose ONLY exponential is the output unit's (table tanh): there LLVM hoists the ten coefficients into VGPRs and
+// copies one into the accumulator per step; where the tanh layers evaluate exponentials too the coefficients already
+// live in SGPRs and the plain form schedules better (the asm statements are not interleaved with neighbouring chains).
+template <bool CS>
+CUDE_HD double m_exp2x_t(double x) {
 #ifdef CUDE_MAGIC_ROUND
     // round-to-nearest through the 1.5*2^52 trick: the integer lands in the low mantissa bits of t, so the
     // fp64-rate v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64 become one subtraction and one 32-bit shift-add
@@ -68,15 +105,15 @@ CUDE_HD double m_exp2x(double x) {
     double s = fma(n, -3.46573590184561908245e-01, x);                   // ln2/2 hi
     s = fma(n, -9.54107464635293850010e-11, s);                          // ln2/2 lo ; |s| <= ln2/4
     double p = 2.82893898152419560454e-04;
-    p = fma(p, s, 1.41517725676594432853e-03);
-    p = fma(p, s, 6.34918511283140765689e-03);
-    p = fma(p, s, 2.53966979461632859361e-02);
-    p = fma(p, s, 8.88888891679270320978e-02);
-    p = fma(p, s, 2.66666668341369039741e-01);
-    p = fma(p, s, 6.66666666665170271067e-01);
-    p = fma(p, s, 1.33333333332435244323e+00);
-    p = fma(p, s, 2.00000000000000222045e+00);
-    p = fma(p, s, 2.00000000000001332268e+00);
+    p = m_fma_sel<CS>(p, s, 1.41517725676594432853e-03);
+    p = m_fma_sel<CS>(p, s, 6.34918511283140765689e-03);
+    p = m_fma_sel<CS>(p, s, 2.53966979461632859361e-02);
+    p = m_fma_sel<CS>(p, s, 8.88888891679270320978e-02);
+    p = m_fma_sel<CS>(p, s, 2.66666668341369039741e-01);
+    p = m_fma_sel<CS>(p, s, 6.66666666665170271067e-01);
+    p = m_fma_sel<CS>(p, s, 1.33333333332435244323e+00);
+    p = m_fma_sel<CS>(p, s, 2.00000000000000222045e+00);
+    p = m_fma_sel<CS>(p, s, 2.00000000000001332268e+00);
     p = fma(p, s, 1.0);
 #ifdef CUDE_MAGIC_ROUND
     // p in [0.70, 1.42] and |n| <= 1022 for the argument range used (|x| <= 354): adding n to the exponent
@@ -90,6 +127,8 @@ CUDE_HD double m_exp2x(double x) {
     return ldexp(p, ni);
 #endif
 }
+
+CUDE_HD double m_exp2x(double x) { return m_exp2x_t<false>(x); }
 
 CUDE_HD double m_exp(double y) { return m_exp2x(0.5 * y); }
 
@@ -231,9 +270,10 @@ CUDE_HD void m_tanh_from_exp(const double (&E)[W], double (&t)[W]) {
     t[0] = fma(-2.0, r, 1.0);
 }
 
-// softplus value and logistic derivative
-CUDE_HD double m_softplus(double x, double* sig) {
-    const double e = m_exp2x(fmax(-0.5 * fabs(x), -350.0));     // exp(-|x|) in (0, 1]
+// softplus value and logistic derivative (LONE: this is the kernel's only exponential, see m_exp2x_t)
+template <bool LONE>
+CUDE_HD double m_softplus_t(double x, double* sig) {
+    const double e = m_exp2x_t<LONE>(fmax(-0.5 * fabs(x), -350.0));     // exp(-|x|) in (0, 1]
     const double d = 1.0 + e;                                    // in (1, 2]
     // log(d) = 2 atanh(s), s = (v-1)/(v+1), v = d or d/2 so that v in [1/sqrt2, sqrt2]
     const bool big = d > 1.41421356237309504880;
@@ -243,7 +283,8 @@ CUDE_HD double m_softplus(double x, double* sig) {
     const double inv_d = rp * den;
     const double s = num * (rp * d);
     *sig = x >= 0.0 ? inv_d : e * inv_d;
-    const double z = s * s;
+    const double z = s * s;                                      // <= 0.02944
+#ifdef CUDE_LOG_TAYLOR
     double p = 1.0 / 21.0;
     p = fma(p, z, 1.0 / 19.0);
     p = fma(p, z, 1.0 / 17.0);
@@ -255,9 +296,23 @@ CUDE_HD double m_softplus(double x, double* sig) {
     p = fma(p, z, 1.0 / 5.0);
     p = fma(p, z, 1.0 / 3.0);
     p = fma(p, z, 1.0);
+#else
+    // atanh(s)/s in z = s^2: degree-7 interpolant at the Chebyshev nodes of [0, 0.02944] (max relative error 1.2e-18;
+    // tools/fit_exp_poly.py), three steps shorter than the series cut at z^10
+    double p = 7.40485518032763800900e-02;
+    p = m_fma_c(p, z, 7.65626407418209531386e-02);
+    p = m_fma_c(p, z, 9.09181584011466425999e-02);
+    p = m_fma_c(p, z, 1.11110985283630239739e-01);
+    p = m_fma_c(p, z, 1.42857143803208408439e-01);
+    p = m_fma_c(p, z, 1.99999999996511690359e-01);
+    p = m_fma_c(p, z, 3.33333333333338255322e-01);
+    p = fma(p, z, 1.0);
+#endif
     const double l = 2.0 * s * p;
     return fmax(x, 0.0) + (big ? l + 0.693147180559945309417 : l);
 }
+
+CUDE_HD double m_softplus(double x, double* sig) { return m_softplus_t<false>(x, sig); }
 
 CUDE_HD double m_softplus_val(double x) {
     double sig;

@@ -31,20 +31,23 @@ def test_executed_flops_of_the_headline_kernel():
     b = _bench()
     w, d, S, T = 6, 2, 30, 5
     # one network evaluation as executed (cude_math.h): per tanh neuron 7 single-flop ops + 13 FMAs, per layer one shared
-    # reciprocal (rcp + 3 FMAs) and 3 (W - 1) prefix / back-substitution multiplies; softplus 26 FMAs + 22 other ops
+    # reciprocal (rcp + 3 FMAs) and 3 (W - 1) prefix / back-substitution multiplies; softplus 23 FMAs + 22 other ops
+    # (round 3: the atanh polynomial of the logarithm is a degree-7 interpolant, 8 FMAs instead of 11)
     tanh_layer = w * (7 + 26) + 7 + 3 * (w - 1)
-    fwd = 2 * (w * 1 + w * w + w) + d * tanh_layer + (26 * 2 + 22)
+    fwd = 2 * (w * 1 + w * w + w) + d * tanh_layer + (23 * 2 + 22)
     assert b.mlp_flops(1, w, d) == (fwd, (2 * w + w + 2) + w * (4 + 4 * w) + w * (4 + 2))
-    assert fwd == 610
+    assert fwd == 604
     # table bookkeeping of the headline grid: 30 steps over 4 glucose pieces of 7.5 steps: 2 straddle a knot (steps 7, 22),
     # step 15 starts exactly on one: 28 steps inside a piece, in 4 runs
     assert b.table_steps(S, T) == (28, 4)
-    assert b.cpep_flops() == 184560                                  # the figure quoted in DESIGN.md / profiles
+    assert b.cpep_flops() == 178973                                  # the figure quoted in DESIGN.md / profiles
     # without the layer-1 table the same kernel would execute the round-1 count
     n_eval = 5 * S + 1
-    plain = n_eval * (2 * fwd + b.mlp_flops(1, w, d)[1]) + S * (2 * (2 * 21 + 2 * 6 + 7 * 4) + 12 + 2 * (2 * 21 + 6 * 4 + 12) + 12) \
+    # (the reverse sweep's re-evaluation never executes the value-only part of the softplus: 8 FMAs + 9 single ops)
+    assert b.SOFTPLUS_VALUE_ONLY_FLOPS == 25
+    plain = n_eval * (2 * fwd - 25 + b.mlp_flops(1, w, d)[1]) + S * (2 * (2 * 21 + 2 * 6 + 7 * 4) + 12 + 2 * (2 * 21 + 6 * 4 + 12) + 12) \
         + 2 * T * (2 * 3 * 7 + 8)
-    assert plain == 228864                                          # "228.9 k per trajectory" before the table
+    assert plain == 223277                                          # (rounds 1 / 2 counted 228 864: longer series, value part twice)
     saved_per_eval, per_run = w * (7 + 26) + 2 * w - 3 * w, 6 * w * (6 + 24) + 10 * w
     assert plain - b.cpep_flops() == 2 * (5 * 28 * saved_per_eval - 4 * per_run - 28 * w)
     # forward-only and the 2-state / width-4 instances scale as their structure says
@@ -52,8 +55,9 @@ def test_executed_flops_of_the_headline_kernel():
     # round 3: the width-4 c-peptide kernels and the suppression kernel evaluate tanh by table + addition theorem
     # (18 flops per neuron instead of 33): 2 x 151 evaluations x 2 layers x 4 neurons x 15 fewer, resp. 2 x 181 x 5 x 3 x 15
     assert b.mlp_flops(1, 4, 2, table_tanh=True)[0] == b.mlp_flops(1, 4, 2)[0] - 2 * 4 * 15
-    assert b.cpep_flops((2, 4, 2), S, T, 2, True) == 154374 - 2 * 151 * 2 * 4 * 15 == 118134
-    assert b.supp_flops((4, 3, 5), S, 8, True) == 322853 - 2 * 181 * 5 * 3 * 15 == 241403
+    exp_form = b.cpep_flops((2, 4, 2), S, T, 2, True) + 2 * 151 * 2 * 4 * 15
+    assert b.cpep_flops((2, 4, 2), S, T, 2, True) == 112547 and exp_form == 154374 - 151 * (2 * 6 + 25)
+    assert b.supp_flops((4, 3, 5), S, 8, True) == 322853 - 2 * 181 * 5 * 3 * 15 - 181 * (2 * 6 + 25) == 234706
 
 
 def test_kernel_source_digest_matches_the_committed_pmc_record():

@@ -193,6 +193,8 @@ def test_adam_run_regroups_a_large_adaptive_population_by_itself(monkeypatch):
         eng.close()
     # the shared gradient is summed in another order: parameters move by rounding, and the adaptive solve turns that
     # into accept / reject flips for a few subjects (the map is discontinuous in its inputs): 1e-7 here
-    assert np.allclose(traces[True], traces[False], rtol=1e-5, atol=0) and traces[True][0] == traces[False][0]
+    assert np.allclose(traces[True], traces[False], rtol=1e-5, atol=0)
+    # the first step sees identical parameters: the same per-subject residuals, summed over workgroups in the new order
+    assert abs(traces[True][0] - traces[False][0]) <= 1e-13 * abs(traces[False][0])
     # the launch order adam_run put in place is still (nearly) sorted six small steps later; the caller's order never was
     assert spread[True] < spread[False] and spread[False] >= 2
