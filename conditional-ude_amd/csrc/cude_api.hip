@@ -246,9 +246,15 @@ struct cude_ctx {
     bool adam_ready = false;
     DevBuf<double> adam_state, adam_trace;   // device-resident step state and per-iteration loss trace
     int64_t trace_cap = 0;
-    hipGraph_t graph = nullptr;              // one captured optimiser iteration (cude_adam_run)
-    hipGraphExec_t graph_exec = nullptr;
+    // cude_adam_run: captured optimiser iterations -- [0] one iteration, [1] kGraphUnroll of them back to back (kernels of
+    // one graph follow each other without a gap; between two graph launches the GPU idles ~8 us, tools/step_gaps.py)
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     bool capturing = false;
+    // Adam state advance (running powers, step counter, loss trace): folded into the kernel that finishes an iteration's
+    // [sum loss, n_failed] when the iteration is run by cude_adam_step / cude_adam_run (fold_advance), otherwise -- and
+    // with a communicator but no L2 term, where the pair is final only after the all-reduce -- its own launch
+    bool fold_advance = false, advance_done = false;
     int64_t last_failed = 0;
     // comm
     void* comm = nullptr;
@@ -514,8 +520,10 @@ int32_t check_times(int32_t n_obs, const double* tp) {
 }
 
 void drop_graph(cude_ctx* c) {
-    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    for (int u = 0; u < 2; u++) {
+        if (c->graph_exec[u]) { (void)hipGraphExecDestroy(c->graph_exec[u]); c->graph_exec[u] = nullptr; }
+        if (c->graph[u]) { (void)hipGraphDestroy(c->graph[u]); c->graph[u] = nullptr; }
+    }
 }
 
 int32_t ensure_trace(cude_ctx* c, int64_t n) {
@@ -527,14 +535,22 @@ int32_t ensure_trace(cude_ctx* c, int64_t n) {
     return CUDE_OK;
 }
 
-// queues the Adam update (+ state advance / loss trace) behind the gradient already on the stream
+cude::TailAdvance tail_advance(cude_ctx* c) {
+    cude::TailAdvance t;
+    t.state = c->adam_state.p; t.b1 = c->b1; t.b2 = c->b2; t.trace = c->adam_trace.p; t.cap = c->trace_cap;
+    return t;
+}
+
+// queues the Adam update (+ state advance / loss trace unless run_ensemble folded it) behind the gradient already on the stream
 int32_t enqueue_adam(cude_ctx* c) {
+    if (!c->advance_done) HIP_TRY(cude::launch_adam_advance(tail_advance(c), c->g_nn.p + c->P, c->stream));
+    c->advance_done = false;
     cude::AdamArgs a{};
     a.N = c->N; a.P = c->P;
     a.cond = c->cond.p; a.m_cond = c->m_cond.p; a.v_cond = c->v_cond.p; a.g_cond = c->g_cond.p;
     a.nn = c->nn.p; a.m_nn = c->m_nn.p; a.v_nn = c->v_nn.p; a.g_nn = c->g_nn.p;
     a.lr = c->lr; a.b1 = c->b1; a.b2 = c->b2; a.eps = c->eps;
-    a.state = c->adam_state.p; a.trace = c->adam_trace.p; a.trace_cap = c->trace_cap;
+    a.state = c->adam_state.p;
     HIP_TRY(cude::launch_adam(a, c->stream));
     return CUDE_OK;
 }
@@ -829,18 +845,25 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     if (grad && adaptive(c)) c->have_tape = true;
     if (sse_ov) return CUDE_OK;
     const int P = c->P;
+    const bool fold = c->fold_advance && grad && !local_only;
+    const cude::TailAdvance adv_args = tail_advance(c);
+    const cude::TailAdvance* adv_red = (fold && c->comm == nullptr && c->cfg.lambda == 0.0) ? &adv_args : nullptr;
+    const cude::TailAdvance* adv_l2 = (fold && c->cfg.lambda != 0.0) ? &adv_args : nullptr;
+    c->advance_done = adv_red != nullptr || adv_l2 != nullptr;
     if (grad && is_cpep(c) && c->chunks > 1 && c->blk0 > 0) {
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->blk0, P + 2, 0, P, c->g_nn.p, c->stream, 1, c->param_mask.p, P));
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, (c->nblocks - c->blk0) * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
                                          c->param_mask.p, P, 0, /*accumulate=*/true));
-        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream, 1, nullptr, 0, 0, false,
+                                         adv_red));
     } else if (grad && is_cpep(c) && c->chunks > 1) {
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
                                          c->param_mask.p, P));
-        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream, 1, nullptr, 0, 0, false,
+                                         adv_red));
     } else if (grad) {
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream, 1,
-                                         c->param_mask.p, P));
+                                         c->param_mask.p, P, 0, false, adv_red));
     } else if (fused_final) {
         c->loss_in_pinned = true;
     } else {
@@ -853,7 +876,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     }
     if (c->cfg.lambda != 0.0) {
         if (!grad) HIP_TRY(hipMemsetAsync(c->g_nn.p, 0, P * sizeof(double), c->stream));
-        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream, c->param_mask.p));
+        HIP_TRY(cude::launch_l2_term(c->nn.p, P, c->cfg.lambda, c->n_global, c->g_nn.p, c->stream, c->param_mask.p, adv_l2));
     }
     return CUDE_OK;
 }
@@ -1253,7 +1276,10 @@ int32_t cude_adam_step(cude_ctx* c, double* loss) {
     int32_t rc = bind(c);
     if (rc) return rc;
     if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
-    if ((rc = run_ensemble(c, true, nullptr))) return rc;
+    c->fold_advance = true;
+    rc = run_ensemble(c, true, nullptr);
+    c->fold_advance = false;
+    if (rc) { c->advance_done = false; return rc; }
     c->adam_t += 1;
     // the update is queued BEFORE the host waits for the loss: the update kernel only reads g_nn (where the loss sum
     // and the failure count live), so the value read back is still the loss of the iterate the gradient was taken
@@ -1284,27 +1310,45 @@ int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
     c->regroup_age += n_iters;
     HIP_TRY(hipMemsetAsync(c->adam_state.p + 3, 0, sizeof(double), c->stream));     // trace position = 0
     const bool use_graph = (c->comm == nullptr) && !c->timing && getenv("CUDE_NO_GRAPH") == nullptr;
-    if (use_graph && !c->graph_exec) {
+    static const int kGraphUnroll = getenv("CUDE_GRAPH_UNROLL") ? std::max(1, atoi(getenv("CUDE_GRAPH_UNROLL"))) : 8;
+    for (int u = 0; u < 2 && use_graph; u++) {
+        const int reps = u == 0 ? 1 : kGraphUnroll;
+        const bool unrolled = kGraphUnroll >= 2 && n_iters >= kGraphUnroll;
+        if (c->graph_exec[u] || (u == 1 ? !unrolled : (unrolled && n_iters % kGraphUnroll == 0))) continue;
         c->capturing = true;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            rc = run_ensemble(c, true, nullptr);
-            if (!rc) rc = enqueue_adam(c);
-            hipError_t e2 = hipStreamEndCapture(c->stream, &c->graph);
-            if (!rc && e2 == hipSuccess) e2 = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
-            if (rc || e2 != hipSuccess) { drop_graph(c); c->capturing = false; if (rc) return rc; return fail(CUDE_ERR_HIP, hipGetErrorString(e2)); }
-        } else {
+        if (e != hipSuccess) {
             c->capturing = false;
             return fail(CUDE_ERR_HIP, hipGetErrorString(e));
         }
+        for (int r = 0; r < reps && !rc; r++) {
+            c->fold_advance = true;
+            rc = run_ensemble(c, true, nullptr);
+            c->fold_advance = false;
+            if (!rc) rc = enqueue_adam(c);
+            c->advance_done = false;
+        }
+        hipError_t e2 = hipStreamEndCapture(c->stream, &c->graph[u]);
+        if (!rc && e2 == hipSuccess) e2 = hipGraphInstantiate(&c->graph_exec[u], c->graph[u], nullptr, nullptr, 0);
         c->capturing = false;
+        if (rc || e2 != hipSuccess) {
+            drop_graph(c);
+            if (rc) return rc;
+            return fail(CUDE_ERR_HIP, hipGetErrorString(e2));
+        }
     }
-    for (int k = 0; k < n_iters; k++) {
+    for (int k = 0; k < n_iters;) {
         if (use_graph) {
-            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+            const bool many = c->graph_exec[1] != nullptr && n_iters - k >= kGraphUnroll;
+            HIP_TRY(hipGraphLaunch(c->graph_exec[many ? 1 : 0], c->stream));
+            k += many ? kGraphUnroll : 1;
         } else {
-            if ((rc = run_ensemble(c, true, nullptr))) return rc;
+            c->fold_advance = true;
+            rc = run_ensemble(c, true, nullptr);
+            c->fold_advance = false;
+            if (rc) { c->advance_done = false; return rc; }
             if ((rc = enqueue_adam(c))) return rc;
+            k++;
         }
     }
     c->adam_t += n_iters;

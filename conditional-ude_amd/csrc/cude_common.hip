@@ -43,35 +43,74 @@ hipError_t launch_prepare_cpep(int64_t N, int T, const double* glucose_tn, const
     return hipGetLastError();
 }
 
+// After an iteration's [sum loss, n_failed] is final: advance the running powers / step counter (unless the step is
+// skipped because a subject failed) and append the pair to the loss trace.  One thread.
+__device__ __forceinline__ void adam_advance(const TailAdvance& a, double loss_sum, double n_failed) {
+    if (!(n_failed > 0.0)) {
+        a.state[0] *= a.b1;
+        a.state[1] *= a.b2;
+        a.state[2] += 1.0;
+    }
+    const int64_t pos = (int64_t)a.state[3];
+    if (pos < a.cap) {
+        a.trace[2 * pos] = loss_sum;
+        a.trace[2 * pos + 1] = n_failed;
+    }
+    a.state[3] = (double)(pos + 1);
+}
+
 // One workgroup per column; fixed-shape tree => bitwise reproducible for a given nblocks.
 // mask (optional, n_mask entries): frozen shared parameters (cude_set_param_mask) -- column q < n_mask is scaled by mask[q]
+// adv.state != nullptr: the workgroup of the last column (the failure count) sums the column before it (the loss) as
+// well -- same tree, so the same bits as that column's own workgroup -- and advances the optimiser state: the update
+// kernel behind this launch then needs no third launch for it (round 2: 3 launches per step tail, 4.7 us the last).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
                                                               int stride, int col0, double* __restrict__ out,
                                                               const double* __restrict__ mask, int n_mask, int out_stride,
-                                                              int accumulate) {
+                                                              int accumulate, TailAdvance adv) {
     __shared__ double s[256];
+    __shared__ double s2[256];
     const int q = col0 + blockIdx.x;
+    const bool tail = adv.state != nullptr && q == stride - 1 && blockIdx.y == 0;      // wave-uniform
     partials += (int64_t)blockIdx.y * nblocks * stride;      // multi-start: one row of the grid per parameter set
     out += (int64_t)blockIdx.y * out_stride;
-    double v = 0.0;
-    for (int64_t b = threadIdx.x; b < nblocks; b += 256) v += partials[b * stride + q];
+    double v = 0.0, v2 = 0.0;
+    if (tail) {
+        for (int64_t b = threadIdx.x; b < nblocks; b += 256) {
+            v += partials[b * stride + q];
+            v2 += partials[b * stride + q - 1];
+        }
+    } else {
+        for (int64_t b = threadIdx.x; b < nblocks; b += 256) v += partials[b * stride + q];
+    }
     s[threadIdx.x] = v;
+    s2[threadIdx.x] = v2;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        if ((int)threadIdx.x < off) {
+            s[threadIdx.x] += s[threadIdx.x + off];
+            if (tail) s2[threadIdx.x] += s2[threadIdx.x + off];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         const double v0 = (mask != nullptr && q < n_mask) ? s[0] * mask[q] : s[0];
         out[q] = accumulate ? out[q] + v0 : v0;         // accumulate: a second group of rows of the same launch
+        if (tail) adam_advance(adv, s2[0], v0);
     }
 }
 
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
-                              hipStream_t s, int n_sets, const double* mask, int n_mask, int out_stride, bool accumulate) {
+                              hipStream_t s, int n_sets, const double* mask, int n_mask, int out_stride, bool accumulate,
+                              const TailAdvance* adv) {
+    TailAdvance a{};
+    if (adv != nullptr) {
+        if (accumulate || col0 + ncol != stride || ncol < 2) return hipErrorInvalidValue;
+        a = *adv;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol, n_sets), dim3(256), 0, s, partials, nblocks, stride, col0,
-                       out, mask, n_mask, out_stride > 0 ? out_stride : stride, accumulate ? 1 : 0);
+                       out, mask, n_mask, out_stride > 0 ? out_stride : stride, accumulate ? 1 : 0, a);
     return hipGetLastError();
 }
 
@@ -191,7 +230,7 @@ hipError_t launch_topk_merge(const TopkArgs& a, int P, int64_t N, const double* 
 }
 
 __global__ void l2_term_kernel(const double* __restrict__ nn, int P, double lambda, double n_global,
-                               double* __restrict__ out, const double* __restrict__ mask) {
+                               double* __restrict__ out, const double* __restrict__ mask, TailAdvance adv) {
     // single wave
     const int lane = threadIdx.x;
     double ss = 0.0;
@@ -201,12 +240,17 @@ __global__ void l2_term_kernel(const double* __restrict__ nn, int P, double lamb
         out[q] = fma(2.0 * lambda * (mask != nullptr ? mask[q] : 1.0), w, out[q]);
     }
     ss = wave_sum(ss);
-    if (lane == 0) out[P] = fma(lambda * n_global, ss, out[P]);
+    if (lane == 0) {
+        const double loss = fma(lambda * n_global, ss, out[P]);
+        out[P] = loss;
+        if (adv.state != nullptr) adam_advance(adv, loss, out[P + 1]);
+    }
 }
 
 hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s,
-                          const double* mask) {
-    hipLaunchKernelGGL(l2_term_kernel, dim3(1), dim3(64), 0, s, nn, P, lambda, n_global, out, mask);
+                          const double* mask, const TailAdvance* adv) {
+    hipLaunchKernelGGL(l2_term_kernel, dim3(1), dim3(64), 0, s, nn, P, lambda, n_global, out, mask,
+                       adv != nullptr ? *adv : TailAdvance{});
     return hipGetLastError();
 }
 
@@ -350,10 +394,11 @@ hipError_t launch_fill(int64_t N, double v, double* out, hipStream_t s) {
 __global__ void adam_kernel(AdamArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.g_nn[a.P + 1] > 0.0) return;
-    // bias corrections of step t = (steps done) + 1 from the device-resident running powers b^(t-1), so that a
-    // captured hipGraph of the iteration needs no per-iteration kernel arguments
-    a.c1 = 1.0 - a.state[0] * a.b1;
-    a.c2 = 1.0 - a.state[1] * a.b2;
+    // bias corrections of this step from the device-resident running powers b^t (advanced before this launch: by the
+    // reduction / L2 kernel that finished the iteration's loss, or by adam_advance_kernel), so that a captured hipGraph
+    // of the iteration needs no per-iteration kernel arguments
+    a.c1 = 1.0 - a.state[0];
+    a.c2 = 1.0 - a.state[1];
     double *x, *m, *v;
     double g;
     if (idx < a.N) {
@@ -371,33 +416,24 @@ __global__ void adam_kernel(AdamArgs a) {
     *x -= a.lr * (mm / a.c1) / (sqrt(vv / a.c2) + a.eps);
 }
 
-// (Round 3 measured folding this into adam_kernel -- the workgroup that finishes last advances the state, found by an
-// arrival counter: the ~500 device-scope atomics on one address cost more than the launch they save, step tail 20 ->
-// 23 us with a relaxed atomic, 33 us with the fence a hand-over of data would need.  Two launches it stays.)
-// After the update: advance the running powers / step counter (unless the step was skipped because a subject
-// failed) and append [sum loss, n_failed] of this iterate to the loss trace.  state = {b1^t, b2^t, t, trace pos}.
-__global__ void adam_advance_kernel(double* state, double b1, double b2, const double* g_tail, double* trace,
-                                    int64_t cap) {
+// The state advance on its own (bring-your-own-collective and RCCL flows without an L2 term: the pair is final only
+// after the all-reduce).  (Folding it into adam_kernel instead -- the workgroup that finishes last advances the state,
+// found by an arrival counter -- was measured: ~500 device-scope atomics on one address cost more than the launch they
+// save, step tail 20 -> 23 us with a relaxed atomic, 33 us with the fence a hand-over of data would need.)
+__global__ void adam_advance_kernel(TailAdvance adv, const double* g_tail) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (!(g_tail[1] > 0.0)) {
-        state[0] *= b1;
-        state[1] *= b2;
-        state[2] += 1.0;
-    }
-    const int64_t pos = (int64_t)state[3];
-    if (pos < cap) {
-        trace[2 * pos] = g_tail[0];
-        trace[2 * pos + 1] = g_tail[1];
-    }
-    state[3] = (double)(pos + 1);
+    adam_advance(adv, g_tail[0], g_tail[1]);
+}
+
+hipError_t launch_adam_advance(const TailAdvance& adv, const double* g_tail, hipStream_t s) {
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, s, adv, g_tail);
+    return hipGetLastError();
 }
 
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
     const int bs = 256;
     const int64_t n = a.N + a.P;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, a);
-    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, s, a.state, a.b1, a.b2, a.g_nn + a.P, a.trace,
-                       a.trace_cap);
     return hipGetLastError();
 }
 

@@ -180,10 +180,22 @@ inline __host__ __device__ int64_t adaptive_tape_rows(int n_state, int cap, int 
 // common kernels
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1
 // the same for every set k: partials + k*nblocks*stride -> out + k*stride
+// Adam state advance + loss-trace entry, folded into the kernel that produces an iteration's final [sum loss, n_failed]
+// (the reduction of the two tail columns, or the L2 term behind it) or run on its own before the update kernel.
+struct TailAdvance {
+    double* state = nullptr;   // {b1^t, b2^t, steps done, trace position}; nullptr: nothing to advance
+    double b1 = 0.0, b2 = 0.0;
+    double* trace = nullptr;   // [cap][2] = (sum loss, n_failed) per iteration
+    int64_t cap = 0;
+};
+// adv (optional; the launch must cover the tail columns stride-2, stride-1 and not accumulate): the workgroup of the
+// failure-count column also sums the loss column and advances the optimiser state with the pair
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
                               hipStream_t s, int n_sets = 1, const double* mask = nullptr, int n_mask = 0,
                               int out_stride = 0 /* doubles between the sets' output rows; 0 = stride */,
-                              bool accumulate = false /* add to out instead of overwriting it */);
+                              bool accumulate = false /* add to out instead of overwriting it */,
+                              const TailAdvance* adv = nullptr);
+hipError_t launch_adam_advance(const TailAdvance& adv, const double* g_tail, hipStream_t s);
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,
                               hipStream_t s);
@@ -203,15 +215,13 @@ hipError_t launch_topk_merge(const TopkArgs& a, int P, int64_t N, const double* 
                              hipStream_t s);
 // g_nn[q] += 2*lambda*nn[q];  out[P] += lambda*sum(nn^2)*n_global   (so that loss = out[P]/n_global)
 hipError_t launch_l2_term(const double* nn, int P, double lambda, double n_global, double* out, hipStream_t s,
-                          const double* mask = nullptr);
+                          const double* mask = nullptr, const TailAdvance* adv = nullptr);
 struct AdamArgs {
     int64_t N; int P;
     double* cond; double* m_cond; double* v_cond; const double* g_cond;
     double* nn; double* m_nn; double* v_nn; const double* g_nn;   // g_nn[P+1] = n_failed
     double lr, b1, b2, eps, c1, c2;   // c1 = 1-b1^t, c2 = 1-b2^t (filled on the device from `state`)
-    double* state;                    // device: {b1^(t-1), b2^(t-1), steps done, trace position}
-    double* trace;                    // device: [trace_cap][2] = (sum loss, n_failed) per iteration
-    int64_t trace_cap;
+    double* state;                    // device: {b1^t, b2^t, steps done, trace position}, ALREADY advanced to this step
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 // SAEM E-step (Metropolis-Hastings) helper kernels
