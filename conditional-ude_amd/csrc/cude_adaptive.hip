@@ -48,6 +48,12 @@ constexpr int kAdaptiveMaxSteps = 100000;     // OrdinaryDiffEq's default maxite
 
 // ---------------------------------------------------------------------------------- model policies
 // c-peptide cUDE / symbolic model: f(t, u) = A u + [k0 c0 + q(t); 0],  q(t) = P(dG(t)) - P(0)
+// accumulators pinned behind their updates in every network evaluation of the replay loop (Mlp::eval_grad, PIN)
+#ifndef CUDE_ADAPTIVE_PIN
+#define CUDE_ADAPTIVE_PIN 1
+#endif
+constexpr bool kAdaptivePin = CUDE_ADAPTIVE_PIN != 0;
+
 template <class Net>
 struct CpepAd {
     static constexpr int NS = 2;
@@ -132,7 +138,7 @@ struct CpepAd {
     __device__ __forceinline__ void vjp_net(double te, double wgt, A& acc) const {
         const double xx[1] = {forcing_input(te)};
         double dx[1] = {0.0};
-        Net::template eval_grad<false>(p, c, xx, wgt, acc, dx);
+        Net::template eval_grad<false, A, kAdaptivePin>(p, c, xx, wgt, acc, dx);
     }
     __device__ __forceinline__ void vjp_linear(const double (&kb)[NS], double (&ub)[NS]) const {
         ub[0] += fma(a11, kb[0], a21 * kb[1]);
@@ -147,7 +153,7 @@ struct CpepAd {
 #pragma unroll 1
         for (int r = 0; r < 2; r++) {
             const double xx[1] = {r == 0 ? forcing_input(a.t_begin) : 0.0};
-            Net::template eval_grad<false>(p, c, xx, r == 0 ? carry : -wsum, acc, dx);
+            Net::template eval_grad<false, A, kAdaptivePin>(p, c, xx, r == 0 ? carry : -wsum, acc, dx);
         }
         cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
         if (NCST > 1) cst[NCST - 1] = a.age[i];
@@ -199,7 +205,7 @@ struct SuppAd {
                                         double&) const {
         const double wgt = kb[2] - kb[1];
         double dx[3] = {0.0, 0.0, 0.0};
-        Net::template eval_grad<true>(p, c, u, wgt, acc, dx);
+        Net::template eval_grad<true, A, kAdaptivePin>(p, c, u, wgt, acc, dx);
         ub[0] += fma(-0.4, kb[0], fma(0.4, kb[1], dx[0]));
         ub[1] += dx[1];
         ub[2] += fma(-0.3, kb[2], dx[2]);

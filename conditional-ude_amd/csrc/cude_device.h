@@ -587,7 +587,7 @@ struct Mlp {
     // SIG_IN: the output unit's logistic derivative comes from the caller (kept by the forward sweep, CpepArgs::act);
     // neither the output pre-activation nor the softplus is evaluated (52 of ~375 instructions of a 2-6-6-1 reverse
     // evaluation) and the return value is 0
-    template <bool WANT_DX, class A, bool SIG_IN = false>
+    template <bool WANT_DX, class A, bool SIG_IN = false, bool PIN = kPinLayers>
     __device__ static __forceinline__ double eval_grad_pf(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                           double wgt, A& acc, double (&dx)[NV],
                                                           bool use_tab, const Exps* E1, double sig_in = 0.0) {
@@ -637,14 +637,14 @@ struct Mlp {
                     }
                     dh[i] = s0 + s1;
                 }
-                if (kPinLayers) {
+                if (PIN) {
 #pragma unroll
                     for (int k = 0; k < CGP; k++)
 #pragma unroll
                         for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + j + W * (g * CGP + k));
                 }
             }
-            if (kPinLayers) {
+            if (PIN) {
 #pragma unroll
                 for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + W * W + j);
             }
@@ -677,19 +677,22 @@ struct Mlp {
 
     // value + weighted reverse sweep:  acc += wgt * d(out)/d(params);  if WANT_DX,
     // dx[i] += wgt * d(out)/dx_i.  Returns the network output.
-    template <bool WANT_DX, class A>
+    // PIN: hidden-layer accumulators pinned behind their update (default: the network's own rule, kPinLayers; the adaptive
+    // kernels ask for it -- their evaluation sits inside a conditional of the replay loop and, unpinned, every
+    // accumulator is copied to another register at the end of it: 32 v_mov_b64 per evaluation of a 2-4-4-1 network)
+    template <bool WANT_DX, class A, bool PIN = kPinLayers>
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                        double wgt, A& acc, double (&dx)[NV],
                                                        bool use_tab = false, const Exps* E1 = nullptr) {
 #ifndef CUDE_NO_PREFETCH
-        if constexpr (HAS_PF) return eval_grad_pf<WANT_DX>(p, c, x, wgt, acc, dx, use_tab, E1);
+        if constexpr (HAS_PF) return eval_grad_pf<WANT_DX, A, false, PIN>(p, c, x, wgt, acc, dx, use_tab, E1);
 #endif
         p = launder(p);
         double h[D][W];
         const double zo = forward(p, c, x, h, use_tab, E1);
         double sig;
         const double y = act_softplus<TT>(zo, &sig);
-        backward<WANT_DX>(p, x, h, sig, wgt, acc, dx);
+        backward<WANT_DX, A, PIN>(p, x, h, sig, wgt, acc, dx);
         return y;
     }
 
@@ -703,7 +706,7 @@ struct Mlp {
 
     // weighted reverse sweep from kept activations:  acc += wgt * d(out)/d(params);  if WANT_DX,
     // dx[i] += wgt * d(out)/dx_i
-    template <bool WANT_DX, class A>
+    template <bool WANT_DX, class A, bool PIN = kPinLayers>
     __device__ static __forceinline__ void backward(cptr_t p, const double (&x)[NV], const double (&h)[D][W], double sig,
                                                     double wgt, A& acc, double (&dx)[NV]) {
         const double dz = wgt * sig;
@@ -745,14 +748,14 @@ struct Mlp {
                             else s0 = fma(col.v[g * W + j], d[j], s0);
                         }
                         dh[i] = s0 + s1;
-                        if (kPinLayers) {
+                        if (PIN) {
 #pragma unroll
                             for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + j + W * i);
                         }
                     }
                 }
             }
-            if (kPinLayers) {
+            if (PIN) {
 #pragma unroll
                 for (int j = 0; j < W; j++) AccPin<A>::pin(acc, go + W * W + j);
             }
@@ -884,7 +887,7 @@ struct MmProd {
         const double v = (p[0] * x[0]) / (x[0] + c[0]);
         return x[0] >= 0.0 ? v : 0.0;
     }
-    template <bool WANT_DX, class A>
+    template <bool WANT_DX, class A, bool PIN = false>
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[1], const double (&x)[1],
                                                        double wgt, A& acc, double (&dx)[1], bool = false,
                                                        const Exps* = nullptr) {
