@@ -7,6 +7,7 @@ Reference items mirrored (paths relative to the reference repo):
   chain / softplus                         src/neural-network.jl:13-15,42-58,85-87,105-107
   neural_network_model                     suppression/src/suppression_model.jl:78-85
   CPeptideConditionalUDEModel (+Covariate) src/c-peptide-models.jl:170-220, src/types.jl:16-19
+  CPeptideUDEModel, its loss and train     src/c-peptide-models.jl:76-84,144-168; src/parameter-estimation.jl:56-68,144-159,205-247
   loss / loss_sigma (3 methods each)       src/parameter-estimation.jl:56-75,93-109,126-140
   initial_parameters                       src/parameter-estimation.jl:22-24,36-38
   train (population / fixed-NN), train_with_sigma, evaluate_model
@@ -227,6 +228,55 @@ class CPeptideConditionalUDEModel:
 CPeptideCUDEModel = CPeptideConditionalUDEModel        # name used in the reference's docstrings / stale script
 
 
+def embed_single_input(width, params):
+    """Parameter (or mask) vector of a 1-input network -> that of its 2-input carrier: the first layer [vec(W1); b1]
+    with W1 of shape W x 1 becomes W x 2 with a zero second column (column-major: W zeros behind the first W entries)."""
+    q = np.asarray(params, dtype=np.float64).reshape(-1)
+    return np.concatenate([q[:width], np.zeros(width), q[width:]])
+
+
+def extract_single_input(width, carried):
+    """Inverse of embed_single_input (parameters or gradients of the carrier -> those of the 1-input network)."""
+    q = np.asarray(carried, dtype=np.float64).reshape(-1)
+    return np.concatenate([q[:width], q[2 * width:]])
+
+
+class CPeptideUDEModel:
+    """CPeptideUDEModel(glucose, timepoints, age, chain(...; input_dims = 1), cpeptide, t2dm) -- the non-conditional
+    UDE (src/c-peptide-models.jl:144-168): production = network([dG]) - network([0]) (neural_network_production,
+    :76-84), parameters = the network's alone.
+
+    On the device it IS the conditional model's kernel: the 1-input network is carried as the 2-input network whose
+    first-layer weights of the second input are zero and frozen by the library's parameter mask, so that
+    network([dG; e^beta]) == network([dG]) exactly (a product with an exact zero adds +0.0) and the conditional
+    parameter -- kept at 0 -- has a vanishing gradient.  Parameter vectors handed in and out have the 1-input
+    SimpleChains layout (embed_single_input / extract_single_input convert)."""
+
+    def __init__(self, glucose_data, glucose_timepoints, age, network, cpeptide_data, t2dm):
+        self.glucose = np.asarray(glucose_data, dtype=np.float64)
+        self.timepoints = np.asarray(glucose_timepoints, dtype=np.float64)
+        self.age = float(age)
+        self.chain = network
+        self.cpeptide = np.asarray(cpeptide_data, dtype=np.float64)
+        self.t2dm = bool(t2dm)
+        self.covariate = False
+        if self.glucose.shape != self.timepoints.shape or self.cpeptide.shape != self.timepoints.shape:
+            raise ValueError("glucose, cpeptide and timepoints must have the same length")
+        if network.input_dims != 1:
+            raise ValueError("network input_dims does not match the model (1: [dG])")
+        W = network.width
+        base = network.mask if network.mask is not None else np.ones(network.n_params)
+        mask = embed_single_input(W, base)                     # (zero where the second input's weights sit)
+        self._carrier = SimpleNamespace(arch=(2, W, network.depth), mask=mask, key=("ude",) + tuple(network.key))
+        self._key = _model_key(self, ("ude", network.key))
+
+    def embed(self, params):
+        return embed_single_input(self.chain.width, params)
+
+    def extract(self, carried):
+        return extract_single_input(self.chain.width, carried)
+
+
 def CPeptideConditionalCovariateUDEModel(glucose_data, glucose_timepoints, age, network, cpeptide_data, t2dm):
     return CPeptideConditionalUDEModel(glucose_data, glucose_timepoints, age, network, cpeptide_data, t2dm,
                                        covariate=True)
@@ -290,9 +340,10 @@ class _Pop:
             self.engine = Engine("cpep_sym", n_steps=n_steps, n_state=n_state, device=device, cond_space=cond_space)
             self.shared = np.array([models[0].production.vmax])
         else:
-            self.engine = Engine("cpep", models[0].chain.arch, n_steps=n_steps, n_state=n_state, device=device)
-            if models[0].chain.mask is not None:
-                self.engine.set_param_mask(models[0].chain.mask)
+            net = getattr(models[0], "_carrier", models[0].chain)      # (CPeptideUDEModel: its 2-input carrier)
+            self.engine = Engine("cpep", net.arch, n_steps=n_steps, n_state=n_state, device=device)
+            if net.mask is not None:
+                self.engine.set_param_mask(net.mask)
         G = np.stack([m.glucose for m in models])
         cp = np.asarray(cpeptide_data, dtype=np.float64).reshape(len(models), -1)
         self.engine.set_population_cpep(tp, G, cp, [m.age for m in models], [m.t2dm for m in models])
@@ -353,7 +404,7 @@ def _population(models, timepoints, cpeptide_data, n_steps=None, n_state=2, cond
 
 
 def _is_model(x):
-    return isinstance(x, (CPeptideConditionalUDEModel, CPeptideODEModel))
+    return isinstance(x, (CPeptideConditionalUDEModel, CPeptideODEModel, CPeptideUDEModel))
 
 
 def _first(theta):
@@ -373,6 +424,10 @@ def loss(theta, args, *, n_steps=None):
         out = pop.engine.forward(want_sse=True)
         return out["sse"][0] if np.isfinite(out["loss"]) else np.inf
     models, timepoints, data = args
+    if isinstance(models, CPeptideUDEModel):        # theta = the network's parameters (:56-68 with neural_network_production)
+        pop = _population([models], timepoints, np.asarray(data)[None, :], n_steps)
+        pop.engine.set_params(models.embed(theta), [0.0])
+        return pop.engine.forward()["loss"]           # N = 1: mean SSE == SSE
     if isinstance(models, CPeptideODEModel):        # p = theta, production(dG, p) reads p[1] (03-symreg.jl:38)
         pop = _population([models], timepoints, np.asarray(data)[None, :], n_steps, cond_space="raw")
         pop.engine.set_params(pop.shared, [_first(theta)])
@@ -397,8 +452,14 @@ def loss_sigma(theta, args, *, n_steps=None):
 
 
 def loss_and_gradient(theta, args, *, n_steps=None):
-    """Replaces ForwardDiff.gradient(loss, theta) (AutoForwardDiff, :370) for the population loss."""
+    """Replaces ForwardDiff.gradient(loss, theta) (AutoForwardDiff, :370) for the population loss (and, for a
+    CPeptideUDEModel, :232: value and gradient with respect to the network's parameters)."""
     models, timepoints, data = args
+    if isinstance(models, CPeptideUDEModel):
+        pop = _population([models], timepoints, np.asarray(data)[None, :], n_steps)
+        pop.engine.set_params(models.embed(theta), [0.0])
+        val, g_nn, _ = pop.engine.loss_grad()
+        return val, models.extract(g_nn)
     pop = _population(models, timepoints, data, n_steps)
     pop.engine.set_params(theta.neural, np.asarray(theta.conditional).reshape(-1)[:pop.N])
     val, g_nn, g_cond = pop.engine.loss_grad()
@@ -519,17 +580,28 @@ def _batched_adam_then_lbfgs(eng, nn_inits, cond_inits, adam_iters, lbfgs_iters,
     return out
 
 
-def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_000, selected_initials=25,
+def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=None, selected_initials=None,
           lhs_lower_bound=-2.0, lhs_upper_bound=0.0, n_conditional_parameters=1, number_of_iterations_adam=1000,
           number_of_iterations_lbfgs=1000, learning_rate_adam=1e-2, initial_beta=-2.0, lbfgs_lower_bound=-4.0,
           lbfgs_upper_bound=1.0, lbfgs_iterations=1000, n_steps=None, side_by_side=True):
-    """Two methods of the reference, selected by the 4th argument as Julia's dispatch does:
+    """Three methods of the reference, selected by the types of the 1st and 4th argument as Julia's dispatch does:
+    * a single CPeptideUDEModel + rng: the conventional UDE on one (mean) subject (:205-247): `initial_guesses`
+      (default 10 000) initialisations screened by their loss, the best `selected_initials` (10) -> Adam -> L-BFGS.
     * rng (numpy Generator): population training, unknown network (:340-386): LHS + init screening of
       `initial_guesses` candidates (forward-only), best `selected_initials` -> Adam -> L-BFGS; the selected
       restarts are trained side by side (one launch per optimiser iteration for all of them) unless
       side_by_side=False.
     * array of network parameters: per-subject estimation of the conditional parameter with the network
       frozen (:272-288)."""
+    if isinstance(models, CPeptideUDEModel):
+        return _train_ude(models, timepoints, cpeptide_data, rng_or_nn,
+                          initial_guesses=10_000 if initial_guesses is None else initial_guesses,
+                          selected_initials=10 if selected_initials is None else selected_initials,
+                          number_of_iterations_adam=number_of_iterations_adam,
+                          number_of_iterations_lbfgs=number_of_iterations_lbfgs, learning_rate_adam=learning_rate_adam,
+                          n_steps=n_steps, side_by_side=side_by_side)
+    initial_guesses = 25_000 if initial_guesses is None else initial_guesses
+    selected_initials = 25 if selected_initials is None else selected_initials
     if isinstance(rng_or_nn, np.random.Generator):
         rng = rng_or_nn
         pop = _population(models, timepoints, cpeptide_data, n_steps)
@@ -572,6 +644,40 @@ def train(models, timepoints, cpeptide_data, rng_or_nn, *, initial_guesses=25_00
     beta, sse = estimate_conditional(models, timepoints, cpeptide_data, nn, initial_beta=initial_beta,
                                      lower=lbfgs_lower_bound, upper=lbfgs_upper_bound, n_steps=n_steps)
     return [OptimizationSolution(u=np.array([b]), objective=s) for b, s in zip(beta, sse)]
+
+
+def _train_ude(model, timepoints, cpeptide_data, rng, *, initial_guesses, selected_initials, number_of_iterations_adam,
+               number_of_iterations_lbfgs, learning_rate_adam, n_steps, side_by_side):
+    """train(model::CPeptideUDEModel, timepoints, cpeptide_data, rng) (src/parameter-estimation.jl:205-247): the
+    screening loop, `partialsortperm(losses_initial, 1:selected_initials)` and the two optimiser stages of
+    `_optimize` (:144-159) run through the same device paths as the conditional model's (cude_screen_candidates,
+    cude_train_restarts) on a population of one subject; solutions carry the 1-input parameter vector."""
+    if not isinstance(rng, np.random.Generator):
+        raise TypeError("train(model::CPeptideUDEModel, timepoints, cpeptide_data, rng): rng must be a numpy Generator")
+    pop = _population([model], timepoints, np.asarray(cpeptide_data, dtype=np.float64)[None, :], n_steps)
+    eng, net = pop.engine, model.chain
+
+    def candidates(first, count):
+        return np.stack([model.embed(init_params(net, rng)) for _ in range(count)]), np.zeros((count, 1))
+    order, _, nn_sel, cond_sel = eng.screen_candidates(initial_guesses, selected_initials, candidates)
+    sols = []
+    if side_by_side and len(order) > 1:
+        fits = _batched_adam_then_lbfgs(eng, nn_sel, cond_sel, number_of_iterations_adam, number_of_iterations_lbfgs,
+                                        learning_rate_adam)
+    else:
+        fits = []
+        for k in range(len(order)):
+            try:
+                fits.append(_adam_then_lbfgs(eng, nn_sel[k], cond_sel[k], number_of_iterations_adam,
+                                             number_of_iterations_lbfgs, learning_rate_adam))
+            except FloatingPointError:
+                fits.append(None)
+    for fit in fits:
+        if fit is None:
+            print("Optimization failed... Skipping")
+            continue
+        sols.append(OptimizationSolution(u=model.extract(fit[0]), objective=fit[2]))
+    return sols
 
 
 def estimate_conditional(models, timepoints, cpeptide_data, nn, *, initial_beta=-2.0, lower=-4.0, upper=1.0,
@@ -1067,7 +1173,10 @@ def simulate(p_neural, p_individuals, models, timepoints, cpeptide_data, *, out_
     span of `timepoints`, e.g. the dense grids t0:0.1:tend of the model-fit figures -- as an (N, n_times) array."""
     sym = isinstance(models[0], CPeptideODEModel)
     pop = _population(models, timepoints, cpeptide_data, n_steps, cond_space="raw" if sym else "log")
-    pop.engine.set_params(pop.shared if sym else p_neural, np.asarray(p_individuals, dtype=np.float64).reshape(-1))
+    if isinstance(models[0], CPeptideUDEModel):      # `solve(model.problem, p = neural_network_parameters)` per subject
+        pop.engine.set_params(models[0].embed(p_neural), np.zeros(len(models)))   # (01-non-conditional.jl:64,74)
+    else:
+        pop.engine.set_params(pop.shared if sym else p_neural, np.asarray(p_individuals, dtype=np.float64).reshape(-1))
     times = np.asarray(timepoints if out_timepoints is None else out_timepoints, dtype=np.float64)
     return pop.engine.simulate(times)[save_idxs - 1].T
 

@@ -24,6 +24,7 @@ using Random: AbstractRNG, randn, rand, randperm
 using Statistics: mean, var
 
 export chain, neural_network_model, CPeptideConditionalUDEModel, CPeptideCUDEModel, CPeptideConditionalCovariateUDEModel,
+       CPeptideUDEModel,
        loss, loss_sigma, loss_and_gradient!, train, train_with_sigma, evaluate_model, likelihood_profile,
        SuppressionProblem, suppression_loss, simul, fit_suppression_model, simulate, individual_log_likelihood, SAEM
 
@@ -437,6 +438,27 @@ CPeptideConditionalCovariateUDEModel(g, t, age, network::Chain, c, t2dm) =
     network.input_dims == 3 ? CPeptideConditionalUDEModel(g, t, age, network, c, t2dm) :
     error("the covariate model takes a network with input_dims = 3")
 
+# CPeptideUDEModel (src/c-peptide-models.jl:144-168): the non-conditional UDE, production = network([ΔG]) - network([0])
+# (:76-84).  On the device it rides on the conditional model's kernels: the 1-input network is carried as the 2-input
+# network whose first-layer weights of the second input are zero and frozen (cude_set_param_mask), so that
+# network([ΔG; e^β]) == network([ΔG]) exactly; parameter vectors in and out have the 1-input SimpleChains layout.
+struct CPeptideUDEModel <: CPeptideModel
+    glucose::Vector{Float64}; timepoints::Vector{Float64}; age::Float64; chain::Chain
+    cpeptide::Vector{Float64}; t2dm::Bool
+end
+CPeptideUDEModel(glucose_data::AbstractVector{<:Real}, glucose_timepoints::AbstractVector{<:Real}, age::Real,
+                 network::Chain, cpeptide_data::AbstractVector{<:Real}, t2dm::Bool) =
+    network.input_dims == 1 ? CPeptideUDEModel(Vector{Float64}(glucose_data), Vector{Float64}(glucose_timepoints),
+                                               Float64(age), network, Vector{Float64}(cpeptide_data), t2dm) :
+    error("the non-conditional model takes a network with input_dims = 1")
+embed_single_input(W::Integer, p::AbstractVector{<:Real}) = vcat(p[1:W], zeros(W), p[W+1:end])
+extract_single_input(W::Integer, q::AbstractVector{<:Real}) = vcat(q[1:W], q[2W+1:end])
+carrier(c::Chain) = Chain(2, c.width, c.depth, c.widths)
+function carrier_mask(c::Chain)            # 1 = live entry of the carrier's parameter vector
+    n1 = n_params(Chain(1, c.width, c.depth))
+    embed_single_input(c.width, isempty(c.widths) ? ones(n1) : param_mask(c))
+end
+
 struct Solution{U}               # the fields of Optimization.jl's solution that the reference's scripts read
     u::U; objective::Float64
 end
@@ -461,6 +483,21 @@ function population(models::AbstractVector{CPeptideConditionalUDEModel}, timepoi
         c
     end
 end
+function population(models::AbstractVector{CPeptideUDEModel}, timepoints, cpeptide_data; n_steps = nothing)
+    S = n_steps === nothing ? step_count(timepoints) : n_steps
+    data = cpeptide_data isa AbstractVector ? reshape(Vector{Float64}(cpeptide_data), 1, :) : Matrix{Float64}(cpeptide_data)
+    key = hash((:ude, S, Vector{Float64}(timepoints), data, [(m.glucose, m.age, m.t2dm, m.chain) for m in models]))
+    get!(POPULATIONS, key) do
+        net = models[1].chain
+        all(m -> m.timepoints == timepoints, models) || error("timepoints must equal the models' own timepoints")
+        c = Ctx(Config(MODEL_CPEP, 2, 2, net.width, net.depth, S, 0, 0, 0.0))
+        G = Matrix{Float64}(undef, length(models), length(timepoints))
+        for (i, m) in enumerate(models); G[i, :] .= m.glucose; end
+        set_population!(c, Vector{Float64}(timepoints), G, data, [m.age for m in models], UInt8[m.t2dm for m in models])
+        set_param_mask!(c, carrier_mask(net))
+        c
+    end
+end
 clear_populations!() = empty!(POPULATIONS)
 
 # ----------------------------------------------------------------------------------------------- reference API: loss
@@ -474,6 +511,12 @@ end
 function loss(θ, (model, timepoints, cpeptide_data)::Tuple{CPeptideConditionalUDEModel,AbstractVector{T},AbstractVector{T}}) where T<:Real
     c = population([model], timepoints, cpeptide_data)
     set_params!(c, θ.neural, [θ.conditional[1]])
+    forward(c)[1]
+end
+# loss(θ, (model::CPeptideUDEModel, timepoints, cpeptide_data)): θ = the network's parameters (:56-68)
+function loss(θ, (model, timepoints, cpeptide_data)::Tuple{CPeptideUDEModel,AbstractVector{T},AbstractVector{T}}) where T<:Real
+    c = population([model], timepoints, cpeptide_data)
+    set_params!(c, embed_single_input(model.chain.width, θ), [0.0])
     forward(c)[1]
 end
 # loss(β, (model, timepoints, cpeptide_data, neural_network_parameters)): frozen network (:93-99)
@@ -526,6 +569,27 @@ function train(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints::
     for k in eachindex(obj)
         isfinite(obj[k]) || (println("Optimization failed... Skipping"); continue)
         push!(optsols, Solution((neural = nn[:, k], conditional = repeat(cond[:, k], 1, n_conditional_parameters)), obj[k]))
+    end
+    optsols
+end
+
+# train(model::CPeptideUDEModel, timepoints, cpeptide_data, rng; ...) (:205-247): the conventional UDE on one (mean)
+# subject -- the same two device calls on a population of one
+function train(model::CPeptideUDEModel, timepoints::AbstractVector{T}, cpeptide_data::AbstractVector{T}, rng::AbstractRNG;
+               initial_guesses::Int = 10_000, selected_initials::Int = 10, number_of_iterations_adam::Int = 1000,
+               number_of_iterations_lbfgs::Int = 1000, learning_rate_adam::Real = 1e-2) where T<:Real
+    c = population([model], timepoints, cpeptide_data)
+    W = model.chain.width
+    nn0 = reduce(hcat, [embed_single_input(W, p) for p in initial_parameters(model.chain, initial_guesses; rng = rng)])
+    cond0 = zeros(1, initial_guesses)
+    losses_initial = multistart_forward(c, nn0, cond0)
+    best = partialsortperm(losses_initial, 1:selected_initials)
+    nn, _, obj, _ = train_restarts(c, nn0[:, best], cond0[:, best]; adam_iters = number_of_iterations_adam,
+                                   η = learning_rate_adam, lbfgs_iters = number_of_iterations_lbfgs)
+    optsols = Solution[]
+    for k in eachindex(obj)
+        isfinite(obj[k]) || (println("Optimization failed... Skipping"); continue)
+        push!(optsols, Solution(extract_single_input(W, nn[:, k]), obj[k]))
     end
     optsols
 end

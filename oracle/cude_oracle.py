@@ -204,6 +204,8 @@ def cpep_rhs(xp, pop, nn, eb, arch, t, u, n_state):
     dG = linear_interp(pop.timepoints, G, t) - linear_interp(pop.timepoints, G, pop.timepoints[0])
     if arch[1] == 0:                       # CPeptideODEModel: no baseline term (c-peptide-models.jl:68-75)
         prod = symbolic_production(xp, dG, nn[0], eb)
+    elif arch[0] == 1:                     # CPeptideUDEModel: neural_network_production (c-peptide-models.jl:76-84)
+        prod = mlp(xp, [dG], nn, arch) - mlp(xp, [dG * 0.0], nn, arch)
     elif pop.covariate:
         age = _as(xp, pop.age)
         prod = mlp(xp, [dG, eb, age], nn, arch) - mlp(xp, [dG * 0.0, eb, age], nn, arch)
@@ -230,6 +232,8 @@ def cpep_rhs_scalar(pop, i, nn, cond, arch):
         dG = linear_interp(tpl, G, t) - G[0]
         if arch[1] == 0:
             prod = (p[0] * dG) / (dG + cond) if dG >= 0 else 0.0
+        elif arch[0] == 1:
+            prod = mlp(math, [dG], p, arch) - mlp(math, [0.0], p, arch)
         elif pop.covariate:
             prod = mlp(math, [dG, cond, age], p, arch) - mlp(math, [0.0, cond, age], p, arch)
         else:
@@ -464,8 +468,8 @@ def cpep_loss_grad_torch(nn, beta, pop, arch, n_steps, n_state=2, cond_space="lo
     be_t = torch.tensor(np.asarray(beta, dtype=np.float64), requires_grad=True)
     loss, sse = cpep_loss(torch, nn_t, be_t, pop, arch, n_steps, n_state, cond_space)
     loss.backward()
-    return (float(loss.detach()), nn_t.grad.numpy().copy(), be_t.grad.numpy().copy(),
-            sse.detach().numpy().copy())
+    g_beta = be_t.grad.numpy().copy() if be_t.grad is not None else np.zeros(be_t.shape)   # (1-input network: no beta)
+    return (float(loss.detach()), nn_t.grad.numpy().copy(), g_beta, sse.detach().numpy().copy())
 
 
 def supp_loss_grad_torch(nn, theta, data, timepoints, arch, n_steps, lam):

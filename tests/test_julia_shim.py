@@ -154,6 +154,10 @@ def test_reference_signatures_are_present():
         "function loss(θ, (models, timepoints, cpeptide_data)::Tuple{AbstractVector{CPeptideConditionalUDEModel},AbstractVector{T},AbstractMatrix{T}})",
         "function loss(θ, (model, timepoints, cpeptide_data)::Tuple{CPeptideConditionalUDEModel,AbstractVector{T},AbstractVector{T}})",
         "loss(θ, (model, timepoints, cpeptide_data, nn)::Tuple{CPeptideConditionalUDEModel,AbstractVector{T},AbstractVector{T},AbstractVector{T}})",
+        # src/c-peptide-models.jl:144-145, src/parameter-estimation.jl:56 (UDE model), :211-216
+        "CPeptideUDEModel(glucose_data::AbstractVector{<:Real}, glucose_timepoints::AbstractVector{<:Real}, age::Real, network::Chain, cpeptide_data::AbstractVector{<:Real}, t2dm::Bool)",
+        "function loss(θ, (model, timepoints, cpeptide_data)::Tuple{CPeptideUDEModel,AbstractVector{T},AbstractVector{T}})",
+        "function train(model::CPeptideUDEModel, timepoints::AbstractVector{T}, cpeptide_data::AbstractVector{T}, rng::AbstractRNG;",
         # src/parameter-estimation.jl:340-347
         "function train(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints::AbstractVector{T}, cpeptide_data::AbstractVecOrMat{T}, rng::AbstractRNG;",
         # :272-278, :290
@@ -174,7 +178,7 @@ def test_reference_signatures_are_present():
         "(p_neural = p_neural, p_individuals = p_individuals, Ω = Ω, σ = σ, η = prior_η, total_nll_values = total_nll_values, acceptance_rates = acceptance_rates)",
     ):
         assert re.sub(r"\s+", " ", needle) in flat, needle
-    for kw in ("initial_guesses::Int = 25_000", "selected_initials::Int = 25", "lhs_lower_bound = -2.0", "lhs_upper_bound = 0.0",
+    for kw in ("initial_guesses::Int = 10_000", "selected_initials::Int = 10", "initial_guesses::Int = 25_000", "selected_initials::Int = 25", "lhs_lower_bound = -2.0", "lhs_upper_bound = 0.0",
                "n_conditional_parameters::Int = 1", "number_of_iterations_adam::Int = 1000",
                "number_of_iterations_lbfgs::Int = 1000", "learning_rate_adam::Real = 1e-2", "initial_beta = -2.0",
                "lbfgs_lower_bound = -4.0", "lbfgs_upper_bound = 1.0", "n_burnin_iterations = 100", "Ω_learning_rate = 0.04",
