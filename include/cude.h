@@ -296,8 +296,10 @@ int32_t cude_synchronize(cude_ctx* ctx);
  * runtime (hipOccupancyMaxActiveBlocksPerMultiprocessor with the launch's LDS size) -- registers and LDS as compiled. */
 int32_t cude_grad_occupancy(cude_ctx* ctx, int32_t* waves_per_cu);
 /* n_iters optimiser iterations in one call (the `maxiters` loop of Optimization.solve(prob, Adam, maxiters),
- * src/parameter-estimation.jl:176): one iteration is captured into a hipGraph and replayed without host round
- * trips; losses[n_iters] (optional) receives the loss BEFORE each update, read back once at the end. */
+ * src/parameter-estimation.jl:176): iterations are captured into hipGraphs (eight per graph, single ones for the
+ * remainder; CUDE_GRAPH_UNROLL changes the eight) and replayed without host round trips; losses[n_iters] (optional)
+ * receives the loss BEFORE each update, read back once at the end.  With a communicator attached the iterations are
+ * queued as plain launches (RCCL calls are not captured). */
 int32_t cude_adam_run(cude_ctx* ctx, int32_t n_iters, double* losses);
 
 /* --- bring-your-own collective (MPI.jl, gloo, ...) instead of the built-in RCCL path.
