@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP != 
     const unsigned prio_par = GRAD ? (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u) : 0u;   // HW_ID.wave_id
     const int prio_shift = GRAD ? a.prio_shift : 0;
     // (here, not at the top: the table's global read then travels with the subject's own loads -- one latency, not two)
-    if constexpr (Net::USES_TANH) tanh_tab_init(lane);
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane, !Net::LDS_BIAS);
     Net::bias_init(a.nn + set * a.set_stride_nn, lane);
 #pragma unroll 1
     for (int e = -1; e < 5 * S; e++) {

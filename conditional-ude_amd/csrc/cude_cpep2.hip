@@ -141,13 +141,19 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     double K1a = 0.0, K1b = 0.0;
     int cur_seg = -1;
     double g_lo = 0.0, g_d = 0.0;
-    int oi = 0;
-    while (oi < T && obs_step[oi] < n0) oi++;
+    // first observation of this chunk: the count of observation steps before n0 (obs_step ascends) by a wave vote over
+    // one vector load -- the scalar search loop cost up to T dependent round trips on a cold cache
+    int oi;
+    {
+        const int* os = b.obs_step;
+        const bool before = lane < T && os[lane < T ? lane : 0] < n0;
+        oi = (int)__popcll(__ballot(before));
+    }
     // evaluations: idx = -2 baseline NN([0; e^beta]); idx = -1 forcing at the chunk's first stage-1 time
     // (= last stage time of the previous step; exactly 0 for the first chunk); idx >= 0 own stage times.
     int n = n0, s = 0;
     const int n_own = 5 * (n1 - n0);
-    if constexpr (Net::USES_TANH) tanh_tab_init(lane);    // (here: its global read travels with the subject's own loads)
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane, !Net::LDS_BIAS);    // (here: its global read travels with the subject's own loads)
     Net::bias_init(b.nn + set * b.set_stride_nn, lane);
 #pragma unroll 1
     for (int idx = -2; idx < n_own; idx++) {
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_rev_kernel(Cpep2Args a) {
     int kind = 0, s = 4, n = n1 - 1;
     bool run_ok = false, have_anchor = false;
     // own stage times in reverse order; e = 5 n0 - 1 stands for the baseline with weight -sum(own w)
-    if constexpr (Net::USES_TANH) tanh_tab_init(lane);
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane, !Net::LDS_BIAS);
     Net::bias_init(b.nn + set * b.set_stride_nn, lane);
 #pragma unroll 1
     for (int e = 5 * n1 - 1; e >= 5 * n0 - 1; e--) {

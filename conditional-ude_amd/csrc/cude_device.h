@@ -92,13 +92,15 @@ constexpr int kTanhTabMaxW = CUDE_TANH_TAB_MAXW;
 __device__ const double TANH_TAB_G[kTanhEntries] = {CUDE_TANH_TABLE_VALUES};
 constexpr int kTanhRows = (kTanhEntries + 63) / 64;
 __shared__ double s_tanh_tab[kTanhRows * 64];
-__device__ __forceinline__ void tanh_tab_init(int lane) {
+// (sync = false: the caller fills another LDS table right behind and synchronises once -- bias_lds_init; every global
+// read of a kernel's prologue that is issued behind a wait costs a cold-cache round trip of its own, ~1 us)
+__device__ __forceinline__ void tanh_tab_init(int lane, bool sync = true) {
 #pragma unroll
     for (int r = 0; r < kTanhRows; r++) {
         const int k = lane + 64 * r;
         s_tanh_tab[k] = TANH_TAB_G[k < kTanhEntries ? k : kTanhEntries - 1];
     }
-    __syncthreads();
+    if (sync) __syncthreads();
 }
 // Hidden-layer biases in LDS (networks with LB set: the suppression kernel).  A bias seeds the accumulator of its unit
 // before the layer's FMAs; coming from the scalar unit it costs a v_mov_b64 -- a VALU slot -- per unit (fma(w, h, b) with w
@@ -237,7 +239,22 @@ struct Mlp {
     // 0 when every parameter is finite, NaN otherwise.  The clamped activations swallow
     // NaN/Inf, so non-finite inputs are tracked explicitly to honour the reference's failure
     // convention (non-finite solve => loss = Inf).
+    // (A vector form -- one parameter per lane, all loads in flight together, and a wave vote instead of this rolled
+    // loop of s_load + wait -- was measured: -1 % on the latency-bound time-split forward launch, but its vote changes
+    // the scalar register allocation of the one-lane gradient kernel, 13 -> 25 v_readlane per reverse evaluation,
+    // +2 % there.  Kept behind CUDE_PARAM_CHECK_VECTOR.)
     __device__ static __forceinline__ double param_check(cptr_t p) {
+#ifdef CUDE_PARAM_CHECK_VECTOR
+        const int lane = (int)threadIdx.x & 63;
+        bool bad = false;
+#pragma unroll
+        for (int q0 = 0; q0 < P; q0 += 64) {
+            const int q = q0 + lane;
+            const double v = p[q < P ? q : P - 1];
+            bad |= !(fabs(v) <= 1.79769313486231570815e308);          // NaN or Inf
+        }
+        return __any(bad) ? __builtin_nan("") : 0.0;
+#else
         double chk = 0.0;
         constexpr int P8 = P / 8 * 8;
 #pragma unroll 1
@@ -253,6 +270,7 @@ struct Mlp {
 #pragma unroll
         for (int q = P8; q < P; q++) chk = fma(p[q], 0.0, chk);
         return chk;
+#endif
     }
 
     // ---- layer-1 exponent table (NV == 1: the only varying input is the forcing x(t)).
@@ -867,6 +885,7 @@ using SuppNet = Mlp<4, W, D, 3, true, (CUDE_SUPP_LDS_BIAS != 0)>;
 template <bool RAW>
 struct MmProd {
     static constexpr bool USES_TANH = false;
+    static constexpr bool LDS_BIAS = false;
     __device__ static __forceinline__ void bias_init(const double*, int) {}
     static constexpr int NC = 1, NCST = 1, P = 1;
     static constexpr int NACC = 2;                  // [d/dp0, d/dk]

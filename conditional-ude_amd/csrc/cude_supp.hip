@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
     // st+1 of step n (st = 6: k_7 = f(y_{n+1}), reused as k_1 of the next step).
     double sse = fma(cst[0], 0.0, Net::param_check(p));   // NaN iff a parameter / theta is non-finite
     int oi = 0, n = 0, st = 0;
-    if constexpr (Net::USES_TANH) tanh_tab_init(lane);    // (here: its global read travels with the subject's own loads)
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane, !Net::LDS_BIAS);    // (here: its global read travels with the subject's own loads)
     Net::bias_init(a.nn + set * a.set_stride_nn, lane);
 #pragma unroll 1
     for (int e = 0; e <= 6 * S; e++) {
