@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_cpep_case
+from conftest import make_cpep_case, make_supp_case
 
 pytestmark = pytest.mark.gpu
 
@@ -198,3 +198,53 @@ def test_adam_run_regroups_a_large_adaptive_population_by_itself(monkeypatch):
     assert abs(traces[True][0] - traces[False][0]) <= 1e-13 * abs(traces[False][0])
     # the launch order adam_run put in place is still (nearly) sorted six small steps later; the caller's order never was
     assert spread[True] < spread[False] and spread[False] >= 2
+
+
+@pytest.mark.parametrize("model", ["cpep", "supp"])
+def test_queued_iterations_equal_single_steps_for_every_graph_layout(model):
+    """cude_adam_run captures eight iterations per graph and single ones for the remainder, and the Adam state advance
+    rides in the tail reduction (c-peptide, lambda = 0) or the L2-term kernel (suppression, lambda != 0): for iteration
+    counts that use only the single graph (7), only the eightfold one (8, 16), both (9, 17), the loss trace and the
+    parameters equal those of single cude_adam_step calls bit for bit -- also across a skipped step (a subject whose
+    conditional parameter is NaN for a while: no update, no advance of the bias-correction powers)."""
+    from cude.engine import Engine
+    if model == "cpep":
+        arch = (2, 4, 2)
+        c = make_cpep_case(300, arch)
+        mk = lambda: Engine("cpep", arch, n_steps=30, n_state=2)
+        pop = lambda e: e.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        nn0, cond0 = c["nn"], c["beta"]
+    else:
+        c = make_supp_case(200)
+        mk = lambda: Engine("supp", c["arch"], n_steps=30, lam=0.01)
+        pop = lambda e: e.set_population_supp(c["tp"], c["data"])
+        nn0, cond0 = c["nn"], c["theta"]
+    for n_iters in (7, 8, 9, 16, 17):
+        a, b = mk(), mk()
+        for e in (a, b):
+            pop(e)
+            e.set_params(nn0, cond0)
+            e.adam_init(1e-2)
+        la = a.adam_run(n_iters)
+        lb = np.array([b.adam_step() for _ in range(n_iters)])
+        assert np.array_equal(la, lb), (model, n_iters)
+        pa, pb = a.get_params(), b.get_params()
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+        # a failing subject: the step is skipped (loss +Inf), nothing moves, and the run continues as if it had not been
+        bad = pa[1].copy()
+        bad[3] = np.nan
+        for e in (a, b):
+            e.set_params(None, bad)
+        la = a.adam_run(3)
+        lb = np.array([b.adam_step() for _ in range(3)])
+        assert np.all(np.isinf(la)) and np.all(np.isinf(lb))
+        qa, qb = a.get_params(), b.get_params()
+        assert np.array_equal(qa[0], pa[0]) and np.array_equal(qb[0], pa[0])
+        for e in (a, b):
+            e.set_params(None, pa[1])
+        la = a.adam_run(9)
+        lb = np.array([b.adam_step() for _ in range(9)])
+        assert np.array_equal(la, lb) and np.all(np.isfinite(la))
+        assert np.array_equal(a.get_params()[0], b.get_params()[0])
+        a.close()
+        b.close()
