@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -203,6 +205,10 @@ struct DevBuf {
 
 }  // namespace
 
+// bit pattern the host puts into every slot of cude_ctx::pinned_pairs before a launch it is going to watch: a quiet NaN
+// with a payload no arithmetic produces
+constexpr uint64_t kPairSentinel = 0x7ff8dead5eed0001ull;
+
 struct cude_ctx {
     cude_config cfg;
     cude::NetShape net;
@@ -268,6 +274,7 @@ struct cude_ctx {
     size_t ev_used = 0;
     double host_red[3];
     double* pinned = nullptr;       // page-locked staging of the small result vectors ([g_nn; loss sum; n_failed])
+    bool poll_pairs = false;
     double* pinned_pairs = nullptr; // page-locked [nblocks][2]: per-workgroup (sum SSE, failures) of a forward-only launch,
     int64_t pinned_pairs_n = 0;     // written by the scan kernel itself and added up by the host (finish_loss)
     bool loss_in_pinned = false;    // the last forward launch left its result there
@@ -821,6 +828,15 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                 c->pinned_pairs_n >= c->nblocks && !c->capturing && !no_fuse) {
                 a2.final_host = c->pinned_pairs;
                 fused_final = true;
+                // the host watches the pairs arrive (finish_loss) instead of going through the runtime's completion wait
+                // (forward call at 1e4 subjects 56.9 -> 51.6 us, at 57 subjects 41.3 -> 36.6 us): every slot starts as a
+                // NaN no kernel produces.  CUDE_NO_POLL_PINNED=1: plain hipStreamSynchronize.
+                static const bool poll = getenv("CUDE_NO_POLL_PINNED") == nullptr;
+                c->poll_pairs = poll;
+                if (poll) {
+                    volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(c->pinned_pairs);
+                    for (int64_t q = 0; q < 2 * c->nblocks; q++) w[q] = kPairSentinel;
+                }
             }
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
         } else {
@@ -892,7 +908,23 @@ int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
     } else if (!c->loss_in_pinned) {
         HIP_TRY(hipMemcpyAsync(tmp + P, c->g_nn.p + P, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    bool arrived = false;
+    if (c->loss_in_pinned && !g_nn_host && c->poll_pairs) {
+        // the pairs are written into page-locked host memory by the last kernel of the call: watching them arrive skips
+        // the runtime's completion path; bounded (a faulting kernel never writes them): then the ordinary wait decides
+        volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(c->pinned_pairs);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0; !arrived; spin++) {
+            arrived = true;
+            for (int64_t q = 2 * c->nblocks - 1; q >= 0; q--)
+                if (w[q] == kPairSentinel) { arrived = false; break; }
+            if (!arrived && (spin & 63) == 63 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    c->poll_pairs = false;
+    if (!arrived) HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->loss_in_pinned && !g_nn_host) {
         // the scan kernel's per-workgroup pairs, added in the order of reduce_partials_kernel (256 strided partial sums,
         // then the halving tree), so that the value does not depend on which of the two ways produced it
