@@ -45,6 +45,7 @@ N_STEPS = 30
 T_OBS = 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
+TIMING_PERIOD = 4              # kernel time of the timed region: HIP events around every 4th gradient launch
 PREWARM_STEPS = 64             # untimed launches before the W warm-up steps: the GPU needs ~30 launches (20 ms) to
                                # reach its steady clock after an idle period (profiles/r02/clock_ramp.txt)
 
@@ -684,7 +685,10 @@ def main():
     # the W warm-up steps of the contract
     for _ in range(PREWARM_STEPS):
         train_step(want_loss=False)
-    eng.set_kernel_timing(True)          # the warm-up also creates the HIP events the timed steps will reuse
+    # HIP events around every TIMING_PERIOD-th gradient launch of the timed region (a pair costs ~4.5 us of stream time and
+    # a gap on either side of the kernel: on every launch that is 2 % of the step being measured); the warm-up also
+    # creates the events the timed steps will reuse
+    eng.set_kernel_timing(TIMING_PERIOD)
     for _ in range(args.warmup):
         train_step()
     if transport == "rccl":

@@ -252,11 +252,15 @@ struct cude_ctx {
     bool adam_ready = false;
     DevBuf<double> adam_state, adam_trace;   // device-resident step state and per-iteration loss trace
     int64_t trace_cap = 0;
-    // cude_adam_run: captured optimiser iterations -- [0] one iteration, [1] kGraphUnroll of them back to back (kernels of
-    // one graph follow each other without a gap; between two graph launches the GPU idles ~8 us, tools/step_gaps.py)
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    // cude_adam_run: captured optimiser iterations -- graph [u] holds 2^u of them back to back (kernels of one graph
+    // follow each other without a gap; between two graph launches the GPU idles ~8 us, tools/step_gaps.py); a run of
+    // n iterations is its binary decomposition, largest graphs first (8 at most: CUDE_GRAPH_UNROLL)
+    static constexpr int kGraphKinds = 4;
+    hipGraph_t graph[kGraphKinds] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t graph_exec[kGraphKinds] = {nullptr, nullptr, nullptr, nullptr};
     bool capturing = false;
+    int32_t timing_period = 1;      // kernel timing: events around every timing_period-th ensemble launch
+    int64_t timing_count = 0;
     // Adam state advance (running powers, step counter, loss trace): folded into the kernel that finishes an iteration's
     // [sum loss, n_failed] when the iteration is run by cude_adam_step / cude_adam_run (fold_advance), otherwise -- and
     // with a communicator but no L2 term, where the pair is final only after the all-reduce -- its own launch
@@ -275,6 +279,7 @@ struct cude_ctx {
     double host_red[3];
     double* pinned = nullptr;       // page-locked staging of the small result vectors ([g_nn; loss sum; n_failed])
     bool poll_pairs = false;
+    bool tail_in_pinned = false;    // the tail reduction of the last launch also wrote [sum loss, n_failed] to pinned[P..P+1]
     double* pinned_pairs = nullptr; // page-locked [nblocks][2]: per-workgroup (sum SSE, failures) of a forward-only launch,
     int64_t pinned_pairs_n = 0;     // written by the scan kernel itself and added up by the host (finish_loss)
     bool loss_in_pinned = false;    // the last forward launch left its result there
@@ -527,7 +532,7 @@ int32_t check_times(int32_t n_obs, const double* tp) {
 }
 
 void drop_graph(cude_ctx* c) {
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < cude_ctx::kGraphKinds; u++) {
         if (c->graph_exec[u]) { (void)hipGraphExecDestroy(c->graph_exec[u]); c->graph_exec[u] = nullptr; }
         if (c->graph[u]) { (void)hipGraphDestroy(c->graph[u]); c->graph[u] = nullptr; }
     }
@@ -774,7 +779,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool fused_final = false;
     c->loss_in_pinned = false;
-    if (c->timing && !c->capturing) {
+    if (c->timing && !c->capturing && (c->timing_count++ % c->timing_period) == 0) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -866,24 +871,37 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     const cude::TailAdvance* adv_red = (fold && c->comm == nullptr && c->cfg.lambda == 0.0) ? &adv_args : nullptr;
     const cude::TailAdvance* adv_l2 = (fold && c->cfg.lambda != 0.0) ? &adv_args : nullptr;
     c->advance_done = adv_red != nullptr || adv_l2 != nullptr;
+    // one rank, no L2 term, not capturing: the reduction that finishes [sum loss, n_failed] writes the pair into the
+    // page-locked result buffer too, and finish_loss watches it arrive instead of queueing a copy and waiting for the stream
+    double* host_tail = nullptr;
+    {
+        static const bool poll = getenv("CUDE_NO_POLL_PINNED") == nullptr;
+        if (poll && c->pinned && !c->comm && c->cfg.lambda == 0.0 && !c->capturing && !local_only && !fused_final) {
+            host_tail = c->pinned + P;
+            volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(host_tail);
+            w[0] = kPairSentinel; w[1] = kPairSentinel;
+        }
+        c->tail_in_pinned = host_tail != nullptr;
+    }
     if (grad && is_cpep(c) && c->chunks > 1 && c->blk0 > 0) {
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->blk0, P + 2, 0, P, c->g_nn.p, c->stream, 1, c->param_mask.p, P));
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, (c->nblocks - c->blk0) * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
                                          c->param_mask.p, P, 0, /*accumulate=*/true));
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream, 1, nullptr, 0, 0, false,
-                                         adv_red));
+                                         adv_red, host_tail));
     } else if (grad && is_cpep(c) && c->chunks > 1) {
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
                                          c->param_mask.p, P));
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream, 1, nullptr, 0, 0, false,
-                                         adv_red));
+                                         adv_red, host_tail));
     } else if (grad) {
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, 0, P + 2, c->g_nn.p, c->stream, 1,
-                                         c->param_mask.p, P, 0, false, adv_red));
+                                         c->param_mask.p, P, 0, false, adv_red, host_tail));
     } else if (fused_final) {
         c->loss_in_pinned = true;
     } else {
-        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream));
+        HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream, 1, nullptr, 0, 0, false,
+                                         nullptr, host_tail));
     }
     if (local_only) return CUDE_OK;   // the caller reduces across ranks and applies the L2 term
     if (c->comm) {
@@ -903,12 +921,27 @@ int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
     std::vector<double> pageable;
     if (!c->pinned) pageable.resize(P + 2);
     double* const tmp = c->pinned ? c->pinned : pageable.data();      // page-locked: no staging copy behind the sync
+    const bool watch_tail = c->tail_in_pinned && !g_nn_host && !c->loss_in_pinned && c->pinned;
+    c->tail_in_pinned = false;
     if (g_nn_host) {
         HIP_TRY(hipMemcpyAsync(tmp, c->g_nn.p, (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    } else if (!c->loss_in_pinned) {
+    } else if (!c->loss_in_pinned && !watch_tail) {
         HIP_TRY(hipMemcpyAsync(tmp + P, c->g_nn.p + P, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     bool arrived = false;
+    if (watch_tail) {
+        volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(c->pinned + P);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0; !arrived; spin++) {
+            arrived = w[0] != kPairSentinel && w[1] != kPairSentinel;
+            if (!arrived && (spin & 63) == 63 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!arrived) {     // (a kernel that never got there: let the ordinary path report it / fetch the pair)
+            HIP_TRY(hipMemcpyAsync(tmp + P, c->g_nn.p + P, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+    }
     if (c->loss_in_pinned && !g_nn_host && c->poll_pairs) {
         // the pairs are written into page-locked host memory by the last kernel of the call: watching them arrive skips
         // the runtime's completion path; bounded (a faulting kernel never writes them): then the ordinary wait decides
@@ -1343,10 +1376,13 @@ int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
     HIP_TRY(hipMemsetAsync(c->adam_state.p + 3, 0, sizeof(double), c->stream));     // trace position = 0
     const bool use_graph = (c->comm == nullptr) && !c->timing && getenv("CUDE_NO_GRAPH") == nullptr;
     static const int kGraphUnroll = getenv("CUDE_GRAPH_UNROLL") ? std::max(1, atoi(getenv("CUDE_GRAPH_UNROLL"))) : 8;
-    for (int u = 0; u < 2 && use_graph; u++) {
-        const int reps = u == 0 ? 1 : kGraphUnroll;
-        const bool unrolled = kGraphUnroll >= 2 && n_iters >= kGraphUnroll;
-        if (c->graph_exec[u] || (u == 1 ? !unrolled : (unrolled && n_iters % kGraphUnroll == 0))) continue;
+    int u_max = 0;
+    while (u_max + 1 < cude_ctx::kGraphKinds && (2 << u_max) <= kGraphUnroll) u_max++;
+    for (int u = 0; u <= u_max && use_graph; u++) {
+        const int reps = 1 << u;
+        // needed by this run: the largest kind as often as it fits, the smaller ones by the bits of the remainder
+        const bool needed = u == u_max ? n_iters >= reps : (((n_iters % (1 << u_max)) >> u) & 1) != 0;
+        if (c->graph_exec[u] || !needed) continue;
         c->capturing = true;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) {
@@ -1371,9 +1407,10 @@ int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
     }
     for (int k = 0; k < n_iters;) {
         if (use_graph) {
-            const bool many = c->graph_exec[1] != nullptr && n_iters - k >= kGraphUnroll;
-            HIP_TRY(hipGraphLaunch(c->graph_exec[many ? 1 : 0], c->stream));
-            k += many ? kGraphUnroll : 1;
+            int u = u_max;
+            while (u > 0 && (n_iters - k) < (1 << u)) u--;
+            HIP_TRY(hipGraphLaunch(c->graph_exec[u], c->stream));
+            k += 1 << u;
         } else {
             c->fold_advance = true;
             rc = run_ensemble(c, true, nullptr);
@@ -2154,6 +2191,8 @@ int32_t cude_synchronize(cude_ctx* c) {
 int32_t cude_set_kernel_timing(cude_ctx* c, int32_t enabled) {
     if (!c) return fail(CUDE_ERR_ARG, "null context");
     c->timing = enabled != 0;
+    c->timing_period = enabled > 1 ? enabled : 1;
+    c->timing_count = 0;
     c->ev_used = 0;
     return CUDE_OK;
 }
@@ -2172,6 +2211,7 @@ int32_t cude_kernel_time_ms(cude_ctx* c, double* avg_ms, int64_t* launches) {
     *avg_ms = c->ev_used ? tot / (double)c->ev_used : 0.0;
     if (launches) *launches = (int64_t)c->ev_used;
     c->ev_used = 0;
+    c->timing_count = 0;            // (the first launch after a query is a timed one, whatever the period)
     return CUDE_OK;
 }
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ void adam_advance(const TailAdvance& a, double loss_s
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
                                                               int stride, int col0, double* __restrict__ out,
                                                               const double* __restrict__ mask, int n_mask, int out_stride,
-                                                              int accumulate, TailAdvance adv) {
+                                                              int accumulate, TailAdvance adv, double* host_tail) {
     __shared__ double s[256];
     __shared__ double s2[256];
     const int q = col0 + blockIdx.x;
@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
     }
     if (threadIdx.x == 0) {
         const double v0 = (mask != nullptr && q < n_mask) ? s[0] * mask[q] : s[0];
-        out[q] = accumulate ? out[q] + v0 : v0;         // accumulate: a second group of rows of the same launch
+        const double vq = accumulate ? out[q] + v0 : v0;         // accumulate: a second group of rows of the same launch
+        out[q] = vq;
+        // [sum loss, n_failed] straight into page-locked host memory as well, where the host watches for them
+        if (host_tail != nullptr && q >= stride - 2 && blockIdx.y == 0) host_tail[q - (stride - 2)] = vq;
         if (tail) adam_advance(adv, s2[0], v0);
     }
 }
@@ -103,14 +106,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
                               hipStream_t s, int n_sets, const double* mask, int n_mask, int out_stride, bool accumulate,
-                              const TailAdvance* adv) {
+                              const TailAdvance* adv, double* host_tail) {
     TailAdvance a{};
     if (adv != nullptr) {
         if (accumulate || col0 + ncol != stride || ncol < 2) return hipErrorInvalidValue;
         a = *adv;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol, n_sets), dim3(256), 0, s, partials, nblocks, stride, col0,
-                       out, mask, n_mask, out_stride > 0 ? out_stride : stride, accumulate ? 1 : 0, a);
+                       out, mask, n_mask, out_stride > 0 ? out_stride : stride, accumulate ? 1 : 0, a,
+                       col0 + ncol == stride ? host_tail : nullptr);
     return hipGetLastError();
 }
 

@@ -194,7 +194,8 @@ hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int strid
                               hipStream_t s, int n_sets = 1, const double* mask = nullptr, int n_mask = 0,
                               int out_stride = 0 /* doubles between the sets' output rows; 0 = stride */,
                               bool accumulate = false /* add to out instead of overwriting it */,
-                              const TailAdvance* adv = nullptr);
+                              const TailAdvance* adv = nullptr,
+                              double* host_tail = nullptr /* page-locked [2]: the sums of the last two columns as well */);
 hipError_t launch_adam_advance(const TailAdvance& adv, const double* g_tail, hipStream_t s);
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,

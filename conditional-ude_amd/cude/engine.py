@@ -459,7 +459,8 @@ class Engine:
         return n.value
 
     def set_kernel_timing(self, enabled):
-        check(self._lib.cude_set_kernel_timing(self._h, int(bool(enabled))))
+        """True / 1: HIP events around every ensemble launch; n > 1: around every n-th; False / 0: off."""
+        check(self._lib.cude_set_kernel_timing(self._h, int(enabled)))
 
     def kernel_time_ms(self):
         ms = C.c_double()

@@ -325,7 +325,9 @@ int32_t cude_adam_apply_device(cude_ctx* ctx, double* loss);
 /* Average device time (ms) of the ensemble launches (forward, or forward+adjoint: whatever the calls since the last
  * query ran) measured with HIP events on the context's stream; resets the accumulator. */
 int32_t cude_kernel_time_ms(cude_ctx* ctx, double* avg_ms, int64_t* launches);
-/* Enable(1)/disable(0) the per-launch event timing used by cude_kernel_time_ms. */
+/* Enable / disable (0) the event timing used by cude_kernel_time_ms: 1 = a pair of HIP events around every ensemble
+ * launch, n > 1 = around every n-th launch (a pair costs ~4.5 us of stream time and keeps queued iterations from being
+ * replayed as graphs: sampling keeps a live kernel time at a fraction of that). */
 int32_t cude_set_kernel_timing(cude_ctx* ctx, int32_t enabled);
 
 /* --- multi-GPU: subjects are sharded, one context (process) per GPU; the only exchange is one
