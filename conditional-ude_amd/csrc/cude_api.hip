@@ -278,6 +278,10 @@ struct cude_ctx {
     size_t ev_used = 0;
     double host_red[3];
     double* pinned = nullptr;       // page-locked staging of the small result vectors ([g_nn; loss sum; n_failed])
+    // set by a caller right before run_ensemble when finish_loss(loss, nullptr) follows at once and is the call's ONLY
+    // pending output: then the result slots in page-locked memory may be watched instead of waiting for the stream (a
+    // launch whose result nobody fetches must not write there: a later call's watch would take it for its own)
+    bool allow_watch = false;
     bool poll_pairs = false;
     bool tail_in_pinned = false;    // the tail reduction of the last launch also wrote [sum loss, n_failed] to pinned[P..P+1]
     double* pinned_pairs = nullptr; // page-locked [nblocks][2]: per-workgroup (sum SSE, failures) of a forward-only launch,
@@ -779,6 +783,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool fused_final = false;
     c->loss_in_pinned = false;
+    const bool watch = c->allow_watch;
+    c->allow_watch = false;
     if (c->timing && !c->capturing && (c->timing_count++ % c->timing_period) == 0) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
@@ -837,8 +843,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                 // (forward call at 1e4 subjects 56.9 -> 51.6 us, at 57 subjects 41.3 -> 36.6 us): every slot starts as a
                 // NaN no kernel produces.  CUDE_NO_POLL_PINNED=1: plain hipStreamSynchronize.
                 static const bool poll = getenv("CUDE_NO_POLL_PINNED") == nullptr;
-                c->poll_pairs = poll;
-                if (poll) {
+                c->poll_pairs = poll && watch;
+                if (c->poll_pairs) {
                     volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(c->pinned_pairs);
                     for (int64_t q = 0; q < 2 * c->nblocks; q++) w[q] = kPairSentinel;
                 }
@@ -876,7 +882,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
     double* host_tail = nullptr;
     {
         static const bool poll = getenv("CUDE_NO_POLL_PINNED") == nullptr;
-        if (poll && c->pinned && !c->comm && c->cfg.lambda == 0.0 && !c->capturing && !local_only && !fused_final) {
+        if (poll && watch && c->pinned && !c->comm && c->cfg.lambda == 0.0 && !c->capturing && !local_only && !fused_final) {
             host_tail = c->pinned + P;
             volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(host_tail);
             w[0] = kPairSentinel; w[1] = kPairSentinel;
@@ -1234,6 +1240,7 @@ int32_t cude_forward(cude_ctx* c, double* loss, double* per_subject_sse, double*
         HIP_TRY(c->traj.resize((size_t)c->cfg.n_state * c->T * c->N));
         traj_dev = c->traj.p;
     }
+    c->allow_watch = !per_subject_sse && !traj;        // (copies into caller memory pending: the stream must be waited for)
     if ((rc = run_ensemble(c, false, traj_dev))) return rc;
     if (per_subject_sse)
         HIP_TRY(hipMemcpyAsync(per_subject_sse, c->sse.p, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1342,6 +1349,7 @@ int32_t cude_adam_step(cude_ctx* c, double* loss) {
     if (rc) return rc;
     if (!c->adam_ready) return fail(CUDE_ERR_STATE, "call cude_adam_init first");
     c->fold_advance = true;
+    c->allow_watch = loss != nullptr;
     rc = run_ensemble(c, true, nullptr);
     c->fold_advance = false;
     if (rc) { c->advance_done = false; return rc; }

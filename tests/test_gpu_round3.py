@@ -248,3 +248,31 @@ def test_queued_iterations_equal_single_steps_for_every_graph_layout(model):
         assert np.array_equal(a.get_params()[0], b.get_params()[0])
         a.close()
         b.close()
+
+
+def test_watched_result_slots_never_return_an_earlier_launch():
+    """The reduction writes [sum loss, failures] into page-locked memory and the host watches the slots instead of waiting
+    for the stream -- only for calls whose single pending output is that pair.  Steps whose loss nobody fetches must not
+    write there (a later watch would take their pair for its own), and a forward call that also copies per-subject
+    results still waits for the stream."""
+    from cude.engine import Engine
+    arch = (2, 6, 2)
+    c = make_cpep_case(5000, arch)
+    a = Engine("cpep", arch, n_steps=30, n_state=3)
+    b = Engine("cpep", arch, n_steps=30, n_state=3)
+    for e in (a, b):
+        e.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        e.set_params(c["nn"], c["beta"])
+        e.adam_init(1e-2)
+    for k in range(12):
+        want = k % 4 == 3
+        la = a.adam_step(want_loss=want)                  # three unfetched steps queued in front of every fetched one
+        lb = b.adam_step()
+        if want:
+            assert la == lb, (k, la, lb)
+    out = a.forward(want_sse=True)
+    ref = b.forward(want_sse=True)
+    assert out["loss"] == ref["loss"] and np.array_equal(out["sse"], ref["sse"]) and np.all(out["sse"] > 0)
+    assert a.forward()["loss"] == out["loss"]
+    a.close()
+    b.close()
