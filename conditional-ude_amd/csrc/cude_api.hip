@@ -777,14 +777,14 @@ int prio_shift_for(const cude_ctx* c, int64_t blocks) {
 // after the ensemble kernels (used by the Metropolis E-step, which needs neither loss nor gradient).
 int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only = false,
                      const double* cond_ov = nullptr, double* sse_ov = nullptr) {
+    const bool watch = c->allow_watch;      // (consumed here, before any early return: it belongs to THIS call only)
+    c->allow_watch = false;
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (!c->have_nn || (!c->have_cond && !cond_ov)) return fail(CUDE_ERR_STATE, "parameters not set");
     if (grad) { int32_t rc = ensure_tape(c); if (rc) return rc; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool fused_final = false;
     c->loss_in_pinned = false;
-    const bool watch = c->allow_watch;
-    c->allow_watch = false;
     if (c->timing && !c->capturing && (c->timing_count++ % c->timing_period) == 0) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;

@@ -372,7 +372,8 @@ function grad_occupancy(c::Ctx)
     Int(n[])
 end
 
-set_kernel_timing!(c::Ctx, on::Bool) = check(ccall((:cude_set_kernel_timing, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on ? 1 : 0))
+# on = true / 1: events around every ensemble launch; n > 1: around every n-th; false / 0: off
+set_kernel_timing!(c::Ctx, on::Integer) = check(ccall((:cude_set_kernel_timing, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, Int32(on)))
 
 function kernel_time_ms(c::Ctx)
     ms = Ref{Float64}(); n = Ref{Int64}()
