@@ -74,3 +74,31 @@ def test_kernel_source_digest_matches_the_committed_pmc_record():
     assert note is None or t is not None
     assert 18.0e6 < t < 23.0e6                                       # 18.0 MB algorithmic + the partial rows
     assert abs(rec["calibration"]["ratio"] - 0.5) < 0.03             # FETCH_SIZE counts half of the bytes on gfx950
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r03/bench_final.json is the line bench.py printed on the round's final sources: every contract field is
+    there, the roofline objects are self-consistent, and the counted figures are the ones this file pins."""
+    import json
+    b = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench_final.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    n = d["config"]["subjects_per_gpu"]
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["algorithmic_bytes_per_launch"] == n * b.cpep_algo_bytes(5, 3, True)
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
+    assert r["kernel_ms"] < d["ms_per_step"] and r["launches"] >= 1
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.3
+    v = d["roofline_valu"]
+    assert v["flops_per_trajectory"] == b.cpep_flops() and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 100 * c["value"]
+    for k in ("forward_only_1e4", "train_step_1e5", "cpep2_4_1e5", "cpep2_4_1e5_adaptive", "supp_1e5", "saem_estep_1e4x100"):
+        assert k in d["extra"], k
