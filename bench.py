@@ -17,8 +17,15 @@ Prints ONE JSON line on rank 0.  Besides the contract fields: `roofline` (HBM, t
 `roofline_valu` (the binding one), `cpu_baseline` (reverse-mode CPU port; `cpu_baseline_forward_mode` = the
 reference's own AD method), `extra` (the other BASELINE configs a single GPU can run: forward-only 1e4, the
 reference-faithful 2->4->4->1 and suppression instances at 1e5, the SAEM E-step 1e4 x 100), and for N>1 the proof of
-the transport: `rccl_ranks` / `rccl_version` as the communicator reports them, `allreduce_check` (one optimiser step
-through RCCL inside the library vs through torch.distributed on a twin context), per-rank kernel times.
+the transport: `config.allreduce` ("xchg" = the library's peer-write exchange inside the reduction kernels, "rccl" =
+ncclAllReduce on the context's stream, "torch" = torch.distributed on a tensor aliasing the context's buffer), `xchg` (ranks,
+memory kind, timed-out waits), `rccl_ranks` / `rccl_version` as the communicator reports them, `allreduce_check` (one
+optimiser step through the library's transport vs through torch.distributed on a twin context), `transports` (the same K
+steps through every transport that came up), per-rank kernel times; `cpu_baseline` / `parity_vs_cpu_baseline` are
+rank 0's (its shard against the CPU port) while the other ranks wait at a barrier.
+`launch_mode` says how the timed steps were queued: "plain+events/4" = ordinary launches with HIP events around every
+4th gradient launch (the kernel time of the roofline objects is measured IN the timed region, which keeps the captured
+graphs out of it); `ms_per_step_graph_replay` is the same K steps replayed from captured graphs right afterwards.
 """
 import os
 
@@ -277,7 +284,7 @@ def usable_cores(n_logical):
         return n_logical
 
 
-def cpu_baseline(pop, nn, sample, eng=None):
+def cpu_baseline(pop, nn, sample, eng=None, world=1):
     """Times the CPU port on a bounded sample of the same population: the per-subject reverse-mode gradient with OpenMP
     static scheduling over subjects (oracle/cude_oracle_rev.c), and -- for the record -- the
     reference's own AD method, forward-mode duals with P+1 partials per subject (oracle/cude_oracle.c).  Baseline only."""
@@ -317,7 +324,13 @@ def cpu_baseline(pop, nn, sample, eng=None):
     if eng is not None and n == eng.N:
         # max relative error of loss and gradients against the CPU backend, same run, same inputs
         eng.set_params(nn, pop["beta0"])
-        loss, g_nn, g_cond = eng.loss_grad()
+        if world == 1:
+            loss, g_nn, g_cond = eng.loss_grad()
+        else:
+            # this rank's shard only (no collective: the other ranks are waiting at a barrier): the un-reduced vector
+            # carries 1/N_global, the CPU port on the shard 1/N_local
+            part, g_cond = eng.loss_grad_partial(want_cond_grad=True)
+            loss, g_nn, g_cond = part[-2] / n, part[:-2] * world, g_cond * world
         parity = {"subjects": n, "loss_rel": abs(loss - ref["loss"]) / abs(ref["loss"]),
                   "g_nn_rel_maxnorm": float(np.max(np.abs(g_nn - ref["g_nn"])) / np.max(np.abs(ref["g_nn"]))),
                   "g_cond_rel_maxnorm": float(np.max(np.abs(g_cond - ref["g_beta"])) / np.max(np.abs(ref["g_beta"]))),
@@ -416,9 +429,9 @@ def extras(Engine, device, steps=20, warm=40):
     eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
     eng.set_params(nn4, pop["beta0"])
     eng.adam_init(1e-2)
-    os.environ["CUDE_NO_AUTO_REGROUP"] = "1"                                # (cude_adam_run would regroup by itself)
+    eng.set_option("auto_regroup", 0)                                       # (cude_adam_run would regroup by itself)
     dt_plain, ms_plain, _ = timed_adam(eng, n, steps, warm)                 # subjects in the caller's order
-    del os.environ["CUDE_NO_AUTO_REGROUP"]
+    eng.set_option("auto_regroup", 1)
     eng.loss_grad(want_cond_grad=False)
     spread = eng.adaptive_regroup()        # launch ordered by accepted-step count: a wave's lanes finish together
     dt, ms, launches = timed_adam(eng, n, steps, warm)
@@ -587,26 +600,64 @@ def main():
     n_local = args.subjects_per_gpu
     nn = glorot(ARCH, 1234)
     eng, pop = cpep_engine(Engine, ARCH, N_STATE, n_local, 20250905 + rank, local_rank, nn)
-    transport = "rccl"          # all-reduce of the P+2 doubles inside libcude_hip.so (RCCL on the context's stream)
+    # Transport of the one sum per step, in order of preference: "xchg" = the library's peer-write exchange (inside the
+    # reduction kernels: no extra launch, captured graphs stay, sums in rank order), "rccl" = ncclAllReduce inside the
+    # library on the context's stream, "torch" = torch.distributed on a tensor aliasing the context's P+2 doubles.
+    # CUDE_BENCH_TRANSPORT=rccl|torch skips the ones in front.  Every rank issues the same sequence of collectives
+    # whatever fails locally.
+    want = os.environ.get("CUDE_BENCH_TRANSPORT", "xchg")
+    transport = None
     rccl_info = None
-    rccl_error = None           # why the built-in communicator was not used (this rank's view), for the JSON line
+    xchg_info = None
+    rccl_error = None           # why a transport in front of the chosen one was not used (this rank's view), for the JSON line
+    xchg_error = None
+
+    def agreed(flag):
+        t = torch.tensor([1.0 if flag else 0.0], device=ctl)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.item() != 0
+
     if dist_on:
-        # Every rank issues the same sequence of collectives whatever fails locally: first agree that librccl
-        # is loadable everywhere (each rank draws an id; only rank 0's is used), then build the communicator.
-        ok = torch.ones(1, device=ctl)
+        # ---- the exchange: export the mailbox, all-gather the 128-byte handles, map the peers (self-test inside)
+        mine = bytes(128)
+        ok = want == "xchg"
+        if ok:
+            try:
+                mine = eng.xchg_export(world, rank)
+            except Exception as exc:
+                xchg_error = f"cude_xchg_export: {exc}"
+                ok = False
+        if agreed(ok):
+            h = torch.tensor(list(mine), dtype=torch.uint8, device=ctl)
+            hs = [torch.zeros_like(h) for _ in range(world)]
+            dist.all_gather(hs, h)
+            try:
+                eng.xchg_attach([bytes(t.cpu().tolist()) for t in hs], 30.0)
+                xchg_info = eng.xchg_info()
+            except Exception as exc:
+                xchg_error = f"cude_xchg_attach: {exc}"
+                print(f"[rank {rank}] peer-write exchange unavailable ({exc})", file=sys.stderr)
+                ok = False
+            if agreed(ok):
+                transport = "xchg"
+            elif xchg_error is None:
+                xchg_error = "another rank could not attach the exchange"
+        elif xchg_error is None:
+            xchg_error = "CUDE_BENCH_TRANSPORT skipped it" if want != "xchg" else "another rank could not export its mailbox"
+        if transport is None and xchg_info is not None:   # attached here, not everywhere: start again without it
+            eng.close()
+            eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
+            xchg_info = None
+        # ---- RCCL inside the library: the fallback, and (when the exchange is up) the second transport of `transports`
         my_id = bytes(128)
-        if os.environ.get("CUDE_BENCH_TRANSPORT", "rccl") != "rccl":
-            ok.zero_()
-        else:
+        ok = want in ("xchg", "rccl")
+        if ok:
             try:
                 my_id = Engine.comm_unique_id()
-            except Exception as exc:  # e.g. librccl not loadable: fall back to the host-collective transport
+            except Exception as exc:  # e.g. librccl not loadable
                 rccl_error = f"cude_comm_unique_id: {exc}"
-                print(f"[rank {rank}] built-in RCCL communicator unavailable ({exc}); using torch.distributed",
-                      file=sys.stderr)
-                ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() != 0:
+                ok = False
+        if agreed(ok):
             uid = torch.tensor(list(my_id), dtype=torch.uint8, device=ctl)
             dist.broadcast(uid, 0)
             try:
@@ -616,26 +667,30 @@ def main():
                     raise RuntimeError(f"communicator reports {rccl_info}, expected ({world}, {rank})")
             except Exception as exc:
                 rccl_error = f"cude_comm_init: {exc}"
-                print(f"[rank {rank}] cude_comm_init failed ({exc}); using torch.distributed", file=sys.stderr)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
+                print(f"[rank {rank}] cude_comm_init failed ({exc})", file=sys.stderr)
+                ok = False
+            if agreed(ok):
+                transport = transport or "rccl"
+            else:
+                rccl_info = None
+                if rccl_error is None:
+                    rccl_error = "another rank could not build the communicator"
+        elif rccl_error is None:
+            rccl_error = "CUDE_BENCH_TRANSPORT skipped it" if want == "torch" else "another rank could not load librccl"
+        if rccl_error and rccl_log and os.path.exists(rccl_log):
+            tail = open(rccl_log, errors="replace").read()[-1500:].strip()
+            if tail:
+                rccl_error += " | RCCL: " + tail
+        if transport is None:
             # cude_loss_grad_partial_device -> dist.all_reduce on a tensor ALIASING the context's P+2 doubles (RCCL via
             # PyTorch, in place on the device) -> cude_adam_apply_device: no host copy in the step.  Under rehearsal
             # (gloo, CPU tensors) the vector goes through the host as before.
             transport = "torch" if not rehearsal else "host"
-            rccl_info = None
-            if rccl_error is None:
-                rccl_error = "another rank could not build the communicator" if os.environ.get(
-                    "CUDE_BENCH_TRANSPORT", "rccl") == "rccl" else "CUDE_BENCH_TRANSPORT asked for torch.distributed"
-            if rccl_log and os.path.exists(rccl_log):
-                tail = open(rccl_log, errors="replace").read()[-1500:].strip()
-                if tail:
-                    rccl_error += " | RCCL: " + tail
             eng.close()
             eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
+    lib_transport = transport in ("xchg", "rccl") or not dist_on     # the step is the library's own (cude_adam_step / _run)
     eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])   # global count all-reduced here
-    if transport != "rccl":
+    if not lib_transport:
         eng.set_global_subjects(n_local * world)
     eng.set_params(nn, pop["beta0"])
     eng.adam_init(1e-2)
@@ -656,7 +711,7 @@ def main():
 
     def train_step(want_loss=True):
         """One optimiser iteration over ALL ranks' subjects; returns the global loss."""
-        if transport == "rccl":
+        if lib_transport:
             return eng.adam_step(want_loss=want_loss)
         return host_step(eng)
 
@@ -668,7 +723,7 @@ def main():
 
     # ---- N > 1: the same optimiser step through both transports, from the same state (fresh Adam moments)
     allreduce_check = None
-    if dist_on and transport == "rccl":
+    if dist_on and lib_transport:
         twin = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
         twin.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
         twin.set_global_subjects(n_local * world)
@@ -694,7 +749,7 @@ def main():
     eng.set_kernel_timing(TIMING_PERIOD)
     for _ in range(args.warmup):
         train_step()
-    if transport == "rccl":
+    if lib_transport:
         eng.adam_run(max(args.steps, 1))  # untimed: sizes the event pool and the loss trace for K queued steps
     eng.kernel_time_ms()                  # drop the warm-up's timings
     # ---- timed region: EXACTLY K optimiser steps.  With the library's own transport (one GPU, or RCCL) they are
@@ -703,7 +758,7 @@ def main():
     # vector), so no step waits for the host.  With the torch.distributed transport the host is in every step.
     barrier()
     t0 = time.perf_counter()
-    if transport == "rccl":
+    if lib_transport:
         losses = eng.adam_run(args.steps)
         loss = float(losses[-1])
         assert losses.size == args.steps and np.all(np.isfinite(losses))
@@ -723,6 +778,46 @@ def main():
     barrier()
     dt_sync = time.perf_counter() - t1
 
+    # the same K steps replayed from captured graphs (no kernel timing: cude_adam_run's production mode), and -- N > 1 --
+    # through every other transport that came up, for the record (`transports`): all untimed by the contract's clock
+    def timed_run(k):
+        eng.adam_run(k)                                  # captures / warms
+        barrier()
+        tq = time.perf_counter()
+        tr = eng.adam_run(k)
+        barrier()
+        assert np.all(np.isfinite(tr))
+        return (time.perf_counter() - tq) / k
+
+    dt_graph = None
+    transports = {}
+    if lib_transport:
+        dt_graph = timed_run(args.steps)
+        if dist_on:
+            transports[transport] = {"ms_per_step": dt_graph * 1e3,
+                                     "launch_mode": "graph replay" if transport == "xchg" else "plain"}
+            if transport == "xchg" and rccl_info is not None:
+                eng.xchg_enable(False)                   # RCCL on the context's stream; plain launches (not capturable)
+                transports["rccl"] = {"ms_per_step": timed_run(args.steps) * 1e3, "launch_mode": "plain"}
+                eng.xchg_enable(True)
+            if not rehearsal:
+                tw = time.perf_counter()
+                for _ in range(args.steps):
+                    host_step(eng)
+                barrier()
+                transports["torch"] = {"ms_per_step": (time.perf_counter() - tw) / args.steps * 1e3,
+                                       "launch_mode": "host in every step"}
+
+    # rank 0's shard against the CPU port (the other ranks wait at the barrier behind it)
+    cpu_rev = cpu_fwd = parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_rev, cpu_fwd, parity = cpu_baseline(pop, nn, args.cpu_sample, eng, world if dist_on else 1)
+    if dist_on:
+        eng.synchronize()
+        dist.barrier()
+        if xchg_info is not None:
+            xchg_info = eng.xchg_info()                  # (timed-out waits over the whole run: must be 0)
+
     saem = None
     if dist_on and not rehearsal and not args.no_extra:
         eng.close()
@@ -734,9 +829,13 @@ def main():
 
     kern_min = kern_max = kern_ms
     if dist_on:
-        t = torch.tensor([dt, dt_sync, kern_ms, -kern_ms], dtype=torch.float64, device=ctl)
+        vals = [dt, dt_sync, kern_ms, -kern_ms, dt_graph or 0.0] + [v["ms_per_step"] for v in transports.values()]
+        t = torch.tensor(vals, dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_sync, kern_max, kern_min = float(t[0]), float(t[1]), float(t[2]), -float(t[3])
+        dt_graph = float(t[4]) if dt_graph is not None else None
+        for k, name in enumerate(transports):
+            transports[name]["ms_per_step"] = float(t[5 + k])
         kern_ms = kern_max
 
     if rank == 0:
@@ -760,12 +859,18 @@ def main():
             "roofline": hbm, "roofline_valu": valu,
             "value_with_loss_read_back_every_step": n_total * args.steps / dt_sync,
             "final_loss": loss, "prewarm_steps": PREWARM_STEPS, "kernel_source_sha": kernel_source_sha(),
+            "launch_mode": f"plain+events/{TIMING_PERIOD}" if lib_transport else "host in every step",
+            "ms_per_step_graph_replay": dt_graph * 1e3 if dt_graph is not None else None,
         }
         if dist_on:
             out["rccl_ranks"] = rccl_info[0] if rccl_info else None
             out["rccl_version"] = rccl_info[2] if rccl_info else None
             out["allreduce_check"] = allreduce_check
             out["rccl_error"] = rccl_error
+            out["xchg"] = ({"ranks": xchg_info[0], "memory_kind": {3: "uncached", 1: "fine-grained", 0: "device"}[xchg_info[2]],
+                            "timed_out_waits": xchg_info[3]} if xchg_info else None)
+            out["xchg_error"] = xchg_error
+            out["transports"] = transports
             if saem is not None:
                 out["saem_estep_1e4x100_sharded"] = {
                     "config": f"BASELINE configs[4]: SAEM E-step, 1e4 subjects x 100 Metropolis steps sharded over "
@@ -776,15 +881,14 @@ def main():
                     "subjects_seen": saem["n_seen"]}
             out["kernel_ms_per_rank"] = {"min": kern_min, "max": kern_max}
             out["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
-        if not dist_on:
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"], out["cpu_baseline_forward_mode"], parity = cpu_baseline(pop, nn, args.cpu_sample, eng)
-                if parity is not None:
-                    out["parity_vs_cpu_baseline"] = parity
-            if not args.no_extra:
-                eng.close()
-                eng = None
-                out["extra"] = extras(Engine, local_rank)
+        if cpu_rev is not None:
+            out["cpu_baseline"], out["cpu_baseline_forward_mode"] = cpu_rev, cpu_fwd
+            if parity is not None:
+                out["parity_vs_cpu_baseline"] = parity
+        if not dist_on and not args.no_extra:
+            eng.close()
+            eng = None
+            out["extra"] = extras(Engine, local_rank)
         print(json.dumps(out), flush=True)
     if eng is not None:
         eng.close()

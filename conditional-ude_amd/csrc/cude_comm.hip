@@ -1,0 +1,376 @@
+// libcude_hip.so -- multi-GPU: subjects are sharded, one context per GPU; the shared network's gradient (with the loss
+// sum and the failure count: P+2 doubles) is summed over the ranks once per optimiser step.  Two transports:
+//   * RCCL (dlopen'ed; ncclAllReduce on the context's stream), cude_comm_*;
+//   * the peer-write exchange (cude_xchg.h): mailboxes in device memory mapped into the peers through HIP IPC, the
+//     reduction kernel itself writes and collects the words -- capturable, bitwise reproducible, cude_xchg_*.
+#include <unistd.h>
+
+#include "cude_ctx.h"
+
+namespace cude {
+namespace api {
+
+// ---------------------------------------------------------------------------------- RCCL (dlopen)
+typedef struct { char internal[CUDE_UNIQUE_ID_BYTES]; } nccl_uid;
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(nccl_uid*) = nullptr;
+    int (*CommInitRank)(void**, int, nccl_uid, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    const char* (*GetLastError)(void*) = nullptr;      // NCCL >= 2.13: the library's own description of what went wrong
+};
+Rccl g_rccl;
+
+int32_t load_rccl() {
+    if (g_rccl.handle) return CUDE_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {   // reuse a copy already in the process (e.g. PyTorch's) first
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+    }
+    if (!h)
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+    if (!h) return fail(CUDE_ERR_COMM, std::string("cannot load librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (int (*)(nccl_uid*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, nccl_uid, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce =
+        (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
+    g_rccl.GetVersion = (int (*)(int*))dlsym(h, "ncclGetVersion");
+    g_rccl.GetLastError = (const char* (*)(void*))dlsym(h, "ncclGetLastError");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(CUDE_ERR_COMM, "librccl lacks a required symbol");
+    g_rccl.handle = h;
+    return CUDE_OK;
+}
+
+inline std::string rccl_diagnosis(int r) {
+    std::string m = g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error";
+    if (g_rccl.GetLastError) {
+        const char* last = g_rccl.GetLastError(nullptr);
+        if (last && last[0]) m += std::string(" [") + last + "]";
+    }
+    return m;
+}
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        int _r = (expr);                                                                           \
+        if (_r != 0) return fail(CUDE_ERR_COMM, std::string(#expr) + ": " + rccl_diagnosis(_r));   \
+    } while (0)
+
+// The enumerators of nccl.h this file needs (librccl is dlopen'ed: its header is not compiled against).  They are not
+// trusted: cude_comm_init runs comm_self_test(), which fails unless a sum and a max of known doubles come back right.
+constexpr int kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2;
+
+cude::XchgArgs xchg_args(const cude_ctx* c) {
+    cude::XchgArgs x{};
+    const Exchange& e = c->xchg;
+    if (!e.attached) return x;
+    for (int r = 0; r < c->n_ranks; r++) x.peers[r] = reinterpret_cast<unsigned long long*>(e.peers[r]);
+    x.seq = e.seq;
+    x.status = e.status;
+    x.n_ranks = c->n_ranks; x.rank = c->rank; x.cols = e.cols;
+    x.timeout = (long long)(e.timeout_s * 1e8);         // wall_clock64 counts at 100 MHz
+    return x;
+}
+
+// after a synchronisation of the context's stream: did a device-side wait of the exchange give up?
+int32_t xchg_check(cude_ctx* c) {
+    if (!c->xchg.attached) return CUDE_OK;
+    int32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, c->xchg.status, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st == 0) return CUDE_OK;
+    c->xchg_timeouts += 1;
+    HIP_TRY(hipMemsetAsync(c->xchg.status, 0, sizeof(int32_t), c->stream));
+    return fail(CUDE_ERR_COMM, "peer-write exchange: a rank's contribution did not arrive within the time limit "
+                               "(a peer died, or the ranks are not making the same sequence of calls)");
+}
+
+// op: 0 = sum, 1 = max.  Exchange when it is on, else the communicator, else (one rank) nothing.
+int32_t allreduce_dev(cude_ctx* c, double* buf, size_t count, int op) {
+    if (c->xchg.ready) {
+        HIP_TRY(cude::launch_xchg_allreduce(xchg_args(c), buf, (int64_t)count, op, c->stream));
+        return CUDE_OK;
+    }
+    if (!c->comm) return CUDE_OK;
+    RCCL_TRY(g_rccl.AllReduce(buf, buf, count, kNcclFloat64, op == 1 ? kNcclMax : kNcclSum, c->comm, c->stream));
+    return CUDE_OK;
+}
+
+// sum / max of a small host vector over all ranks through the context's transport (identity on one rank)
+int32_t comm_reduce_host(cude_ctx* c, double* values, int32_t count, int op) {
+    if (!distributed(c)) return CUDE_OK;
+    HIP_TRY(c->red_tmp.reserve((size_t)count));
+    HIP_TRY(hipMemcpyAsync(c->red_tmp.p, values, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int32_t rc = allreduce_dev(c, c->red_tmp.p, (size_t)count, op);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(values, c->red_tmp.p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return c->xchg.ready ? xchg_check(c) : CUDE_OK;
+}
+
+// Every rank contributes [1, 2, rank + 1]: the sum must be [n, 2n, n(n+1)/2] and the max [1, 2, n].  A wrong datatype
+// or operator enumerator (or a communicator that silently spans fewer ranks) cannot produce both.
+int32_t comm_self_test(cude_ctx* c) {
+    const double n = (double)c->n_ranks;
+    double v[3] = {1.0, 2.0, (double)c->rank + 1.0};
+    int32_t rc = comm_reduce_host(c, v, 3, 0);
+    if (rc) return rc;
+    if (v[0] != n || v[1] != 2.0 * n || v[2] != 0.5 * n * (n + 1.0))
+        return fail(CUDE_ERR_COMM, "transport self-test: sum all-reduce of doubles returned a wrong result");
+    double w[3] = {1.0, 2.0, (double)c->rank + 1.0};
+    if ((rc = comm_reduce_host(c, w, 3, 1))) return rc;
+    if (w[0] != 1.0 || w[1] != 2.0 || w[2] != n)
+        return fail(CUDE_ERR_COMM, "transport self-test: max all-reduce of doubles returned a wrong result");
+    return CUDE_OK;
+}
+
+// Multi-process RCCL and HIP IPC need dmabuf IPC on hosts whose driver has no legacy IPC: without
+// HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the first HIP call, ncclCommInitRank / hipIpcGetMemHandle die
+// much later with "invalid argument".  Too late to set it when a communicator is asked for, so it is checked then.
+bool ipc_mode_ok() {
+    const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+    if ((ipc && std::strcmp(ipc, "0") == 0) || getenv("CUDE_ALLOW_LEGACY_IPC")) return true;
+    fail(CUDE_ERR_COMM, "export HSA_ENABLE_IPC_MODE_LEGACY=0 before the process touches the GPU (dmabuf IPC for RCCL and "
+                        "for the exchange's mailboxes); set CUDE_ALLOW_LEGACY_IPC=1 to skip this check");
+    return false;
+}
+
+void comm_release(cude_ctx* c) {
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+}
+
+// What a rank tells its peers about its mailbox (CUDE_XCHG_HANDLE_BYTES = 128): the HIP IPC handle for other processes,
+// the plain address for contexts of the same process (which cannot open their own process's handle).
+struct XchgHandle {
+    uint64_t magic;             // "CUDEXCH1"
+    int64_t pid;
+    uint64_t address;           // of the mailbox in the exporting process
+    int32_t n_ranks, rank, cols, device;
+    hipIpcMemHandle_t ipc;      // 64 bytes
+};
+static_assert(sizeof(XchgHandle) <= CUDE_XCHG_HANDLE_BYTES, "handle layout");
+constexpr uint64_t kXchgMagic = 0x3148435845445543ull;
+
+void xchg_release(cude_ctx* c) {
+    Exchange& e = c->xchg;
+    for (int r = 0; r < CUDE_XCHG_MAX_RANKS; r++) {
+        if (e.opened[r] && e.peers[r]) (void)hipIpcCloseMemHandle(e.peers[r]);
+        e.opened[r] = false;
+        e.peers[r] = nullptr;
+    }
+    if (e.box) (void)hipFree(e.box);
+    if (e.seq) (void)hipFree(e.seq);
+    if (e.status) (void)hipFree(e.status);
+    e = Exchange{};
+}
+
+// cude::ReduceFn over the context's communicator (the L-BFGS stage of cude_train_restarts on a sharded population)
+int32_t lbfgs_comm_reduce(double* values, int32_t count, int32_t op, void* user) {
+    return comm_reduce_host(static_cast<cude_ctx*>(user), values, count, op);
+}
+
+}  // namespace api
+}  // namespace cude
+
+using namespace cude::api;
+
+extern "C" {
+
+int32_t cude_comm_unique_id(uint8_t id[CUDE_UNIQUE_ID_BYTES]) {
+    if (!id) return fail(CUDE_ERR_ARG, "null id");
+    int32_t rc = load_rccl();
+    if (rc) return rc;
+    nccl_uid u;
+    RCCL_TRY(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, u.internal, CUDE_UNIQUE_ID_BYTES);
+    return CUDE_OK;
+}
+
+int32_t cude_comm_init(cude_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t id[CUDE_UNIQUE_ID_BYTES]) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !id) return fail(CUDE_ERR_ARG, "bad communicator arguments");
+    if (c->comm) return fail(CUDE_ERR_STATE, "communicator already attached");
+    if (c->xchg.attached && (c->n_ranks != n_ranks || c->rank != rank))
+        return fail(CUDE_ERR_ARG, "the communicator must span the same ranks as the attached exchange");
+    // Multi-process RCCL needs dmabuf IPC on hosts whose driver has no legacy IPC: without
+    // HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the first HIP call, ncclCommInitRank dies much later
+    // with "hipIpcGetMemHandle: invalid argument".  Too late to set it here, so say so now.
+    if (n_ranks > 1 && !ipc_mode_ok()) return CUDE_ERR_COMM;
+    if ((rc = load_rccl())) return rc;
+    nccl_uid u;
+    std::memcpy(u.internal, id, CUDE_UNIQUE_ID_BYTES);
+    RCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
+    const bool xon = c->xchg.ready;
+    c->xchg.ready = false;                   // the self-test is to go through the communicator
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    rc = comm_self_test(c);
+    c->xchg.ready = xon;
+    if (rc) {          // (collective: every rank runs it, every rank sees the same verdict)
+        comm_release(c);
+        if (!c->xchg.attached) { c->n_ranks = 1; c->rank = 0; }
+        return rc;
+    }
+    return CUDE_OK;
+}
+
+int32_t cude_comm_allreduce_host(cude_ctx* c, double* values, int32_t count) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!values || count < 1) return fail(CUDE_ERR_ARG, "bad buffer");
+    return comm_reduce_host(c, values, count, 0);   // single rank: identity
+}
+
+int32_t cude_xchg_export(cude_ctx* c, int32_t n_ranks, int32_t rank, uint8_t handle[CUDE_XCHG_HANDLE_BYTES]) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (n_ranks < 1 || n_ranks > CUDE_XCHG_MAX_RANKS || rank < 0 || rank >= n_ranks || !handle)
+        return fail(CUDE_ERR_ARG, "bad exchange arguments (1 <= n_ranks <= 16)");
+    if (c->xchg.box) return fail(CUDE_ERR_STATE, "exchange already exported on this context");
+    if (c->comm && (c->n_ranks != n_ranks || c->rank != rank))
+        return fail(CUDE_ERR_ARG, "the exchange must span the same ranks as the attached communicator");
+    if (n_ranks > 1 && !ipc_mode_ok()) return CUDE_ERR_COMM;
+    Exchange& e = c->xchg;
+    e.cols = c->P + 2;
+    e.box_words = (size_t)2 * n_ranks * e.cols * 2;
+    // uncached device memory (what RCCL keeps its flags in): peers' writes and the owner's polls meet in HBM, not in
+    // an L2; fine-grained, then ordinary memory + system-scope accesses as fall-backs (all three measured equal on
+    // one GPU, tools/ubench/xchg_ipc.hip)
+    const unsigned kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, 0u};
+    hipError_t he = hipErrorOutOfMemory;
+    for (unsigned k : kinds) {
+        void* p = nullptr;
+        he = k ? hipExtMallocWithFlags(&p, e.box_words * 8, k) : hipMalloc(&p, e.box_words * 8);
+        if (he == hipSuccess) { e.box = static_cast<uint64_t*>(p); e.kind = (int)k; break; }
+        (void)hipGetLastError();
+    }
+    if (he != hipSuccess) return fail(CUDE_ERR_HIP, std::string("exchange mailbox: ") + hipGetErrorString(he));
+    XchgHandle h{};
+    if ((he = hipMalloc((void**)&e.seq, e.cols * sizeof(uint32_t))) != hipSuccess ||
+        (he = hipMalloc((void**)&e.status, sizeof(int32_t))) != hipSuccess ||
+        (he = hipMemset(e.box, 0, e.box_words * 8)) != hipSuccess ||
+        (he = hipMemset(e.seq, 0, e.cols * sizeof(uint32_t))) != hipSuccess ||
+        (he = hipMemset(e.status, 0, sizeof(int32_t))) != hipSuccess ||
+        (he = hipIpcGetMemHandle(&h.ipc, e.box)) != hipSuccess) {
+        xchg_release(c);
+        return fail(CUDE_ERR_HIP, std::string("exchange mailbox: ") + hipGetErrorString(he));
+    }
+    h.magic = kXchgMagic;
+    h.pid = (int64_t)getpid();
+    h.address = (uint64_t)(uintptr_t)e.box;
+    h.n_ranks = n_ranks; h.rank = rank; h.cols = e.cols; h.device = c->cfg.device;
+    std::memset(handle, 0, CUDE_XCHG_HANDLE_BYTES);
+    std::memcpy(handle, &h, sizeof(h));
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    return CUDE_OK;
+}
+
+int32_t cude_xchg_attach(cude_ctx* c, const uint8_t* handles, double timeout_s) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    Exchange& e = c->xchg;
+    if (!e.box) return fail(CUDE_ERR_STATE, "call cude_xchg_export first");
+    if (e.attached) return fail(CUDE_ERR_STATE, "exchange already attached");
+    if (!handles || !(timeout_s > 0) || !(timeout_s <= 3600)) return fail(CUDE_ERR_ARG, "null handles / bad time limit");
+    const int n = c->n_ranks;
+    for (int r = 0; r < n; r++) {
+        XchgHandle h;
+        std::memcpy(&h, handles + (size_t)r * CUDE_XCHG_HANDLE_BYTES, sizeof(h));
+        if (h.magic != kXchgMagic || h.n_ranks != n || h.rank != r || h.cols != e.cols) {
+            xchg_release(c);
+            return fail(CUDE_ERR_ARG, "exchange handle " + std::to_string(r) + " does not describe rank " + std::to_string(r) +
+                                          " of " + std::to_string(n) + " with the same network shape");
+        }
+        if (r == c->rank) {
+            e.peers[r] = e.box;
+        } else if (h.pid == (int64_t)getpid()) {
+            // a context of this process: its address is ours too (another device of the node: peer access)
+            if (h.device != c->cfg.device) {
+                hipError_t pe = hipDeviceEnablePeerAccess(h.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                    xchg_release(c);
+                    return fail(CUDE_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+                }
+                (void)hipGetLastError();
+            }
+            e.peers[r] = reinterpret_cast<uint64_t*>((uintptr_t)h.address);
+        } else {
+            void* p = nullptr;
+            hipError_t oe = hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess);
+            if (oe != hipSuccess) {
+                xchg_release(c);
+                return fail(CUDE_ERR_HIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " +
+                                              hipGetErrorString(oe));
+            }
+            e.peers[r] = static_cast<uint64_t*>(p);
+            e.opened[r] = true;
+        }
+    }
+    e.timeout_s = timeout_s;
+    e.attached = true;
+    e.ready = true;
+    drop_graph(c);                              // captured iterations carry the reduction kernels' arguments
+    if ((rc = comm_self_test(c))) {             // (collective: every rank runs it; a rank whose peers never write times out)
+        const std::string why = cude_last_error();
+        xchg_release(c);
+        if (!c->comm) { c->n_ranks = 1; c->rank = 0; }
+        return fail(rc, "exchange self-test: " + why);
+    }
+    return CUDE_OK;
+}
+
+int32_t cude_xchg_enable(cude_ctx* c, int32_t enabled) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->xchg.attached) return fail(CUDE_ERR_STATE, "no exchange attached");
+    if (!enabled && !c->comm && c->n_ranks > 1)
+        return fail(CUDE_ERR_STATE, "switching the exchange off needs a communicator to take over (cude_comm_init)");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    c->xchg.ready = enabled != 0;
+    return CUDE_OK;
+}
+
+int32_t cude_xchg_info(cude_ctx* c, int32_t* n_ranks, int32_t* rank, int32_t* memory_kind, int32_t* timeouts) {
+    if (!c) return fail(CUDE_ERR_ARG, "null context");
+    const bool on = c->xchg.attached;
+    if (n_ranks) *n_ranks = on ? c->n_ranks : 1;
+    if (rank) *rank = on ? c->rank : 0;
+    if (memory_kind) *memory_kind = on ? c->xchg.kind : 0;
+    if (timeouts) *timeouts = c->xchg_timeouts;
+    return CUDE_OK;
+}
+
+int32_t cude_comm_info(cude_ctx* c, int32_t* n_ranks, int32_t* rank, int32_t* version) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!n_ranks || !rank || !version) return fail(CUDE_ERR_ARG, "null output");
+    *n_ranks = 1; *rank = 0; *version = 0;
+    if (!c->comm) return CUDE_OK;
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(CUDE_ERR_COMM, "librccl lacks ncclCommCount/ncclCommUserRank");
+    int n = 0, r = 0, v = 0;
+    RCCL_TRY(g_rccl.CommCount(c->comm, &n));
+    RCCL_TRY(g_rccl.CommUserRank(c->comm, &r));
+    if (g_rccl.GetVersion) RCCL_TRY(g_rccl.GetVersion(&v));
+    *n_ranks = n; *rank = r; *version = v;
+    return CUDE_OK;
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@
 #include "cude_device.h"
 #include "cude_kernels.h"
 #include "cude_rng.h"
+#include "cude_xchg.h"
 
 namespace cude {
 
@@ -64,14 +65,21 @@ __device__ __forceinline__ void adam_advance(const TailAdvance& a, double loss_s
 // adv.state != nullptr: the workgroup of the last column (the failure count) sums the column before it (the loss) as
 // well -- same tree, so the same bits as that column's own workgroup -- and advances the optimiser state: the update
 // kernel behind this launch then needs no third launch for it (round 2: 3 launches per step tail, 4.7 us the last).
+// xchg.seq != nullptr: the column's sum is combined with the other ranks' through the peer-write exchange (cude_xchg.h)
+// before it is stored, so that `out` holds the sum over ALL ranks' subjects -- no collective launch behind this one,
+// and the tail workgroup advances the optimiser state with the GLOBAL pair.  With adv the tail workgroup exchanges the
+// loss column as well and the loss column's own workgroup stores nothing.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
                                                               int stride, int col0, double* __restrict__ out,
                                                               const double* __restrict__ mask, int n_mask, int out_stride,
-                                                              int accumulate, TailAdvance adv, double* host_tail) {
+                                                              int accumulate, TailAdvance adv, double* host_tail,
+                                                              XchgArgs xchg) {
     __shared__ double s[256];
     __shared__ double s2[256];
     const int q = col0 + blockIdx.x;
     const bool tail = adv.state != nullptr && q == stride - 1 && blockIdx.y == 0;      // wave-uniform
+    const bool xc = xchg.seq != nullptr && blockIdx.y == 0;
+    if (xc && adv.state != nullptr && q == stride - 2) return;     // the tail workgroup exchanges and stores this column
     partials += (int64_t)blockIdx.y * nblocks * stride;      // multi-start: one row of the grid per parameter set
     out += (int64_t)blockIdx.y * out_stride;
     double v = 0.0, v2 = 0.0;
@@ -95,26 +103,53 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
     }
     if (threadIdx.x == 0) {
         const double v0 = (mask != nullptr && q < n_mask) ? s[0] * mask[q] : s[0];
-        const double vq = accumulate ? out[q] + v0 : v0;         // accumulate: a second group of rows of the same launch
+        double vq = accumulate ? out[q] + v0 : v0;               // accumulate: a second group of rows of the same launch
+        double loss = s2[0];
+        if (xc) {
+            vq = xchg_combine(xchg, q, vq);
+            if (tail) {
+                loss = xchg_combine(xchg, q - 1, loss);
+                out[q - 1] = loss;
+                if (host_tail != nullptr) host_tail[0] = loss;
+            }
+        }
         out[q] = vq;
         // [sum loss, n_failed] straight into page-locked host memory as well, where the host watches for them
         if (host_tail != nullptr && q >= stride - 2 && blockIdx.y == 0) host_tail[q - (stride - 2)] = vq;
-        if (tail) adam_advance(adv, s2[0], v0);
+        if (tail) adam_advance(adv, loss, vq);
     }
 }
 
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
                               hipStream_t s, int n_sets, const double* mask, int n_mask, int out_stride, bool accumulate,
-                              const TailAdvance* adv, double* host_tail) {
+                              const TailAdvance* adv, double* host_tail, const XchgArgs* xchg) {
     TailAdvance a{};
     if (adv != nullptr) {
         if (accumulate || col0 + ncol != stride || ncol < 2) return hipErrorInvalidValue;
         a = *adv;
     }
+    XchgArgs x{};
+    if (xchg != nullptr && xchg->seq != nullptr) {
+        if (n_sets != 1 || stride > xchg->cols) return hipErrorInvalidValue;
+        x = *xchg;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncol, n_sets), dim3(256), 0, s, partials, nblocks, stride, col0,
                        out, mask, n_mask, out_stride > 0 ? out_stride : stride, accumulate ? 1 : 0, a,
-                       col0 + ncol == stride ? host_tail : nullptr);
+                       col0 + ncol == stride ? host_tail : nullptr, x);
+    return hipGetLastError();
+}
+
+// buf[k] <- combination over the ranks, for k in [0, count): one workgroup, lane t exchanges column t of a slab of
+// `cols` elements at a time (the columns' sequence counters advance together on every rank: all ranks make the same calls)
+__global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs x, double* __restrict__ buf, int64_t count, int op) {
+    for (int64_t k0 = 0; k0 < count; k0 += x.cols)
+        for (int t = threadIdx.x; t < x.cols && k0 + t < count; t += 256) buf[k0 + t] = xchg_combine(x, t, buf[k0 + t], op);
+}
+
+hipError_t launch_xchg_allreduce(const XchgArgs& x, double* buf, int64_t count, int op, hipStream_t s) {
+    if (x.seq == nullptr || x.cols < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(1), dim3(256), 0, s, x, buf, count, op);
     return hipGetLastError();
 }
 

@@ -516,7 +516,11 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     if (nblocks < 1 || (a.base.blk0 > 0 && n_sets > 1)) return hipErrorInvalidValue;
     const dim3 grid2((unsigned)nblocks, (unsigned)a.L, n_sets);
     const size_t lds_f = sizeof(double) * 5 * kBlock;
+#ifdef CUDE_ABLATION
     static const bool no_vw = getenv("CUDE_NO_VW2") != nullptr;
+#else
+    constexpr bool no_vw = false;
+#endif
     const bool vwr = Net::HAS_VW && !no_vw && nblocks * a.L * n_sets <= 2 * 1024;       // fits two waves per SIMD at once
     if (vwr) {
         if constexpr (Net::HAS_VW) {

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cude_xchg.h"
+
 namespace cude {
 
 constexpr int kBlock = 64;     // one wave per workgroup: no cross-wave barrier on the path
@@ -190,12 +192,18 @@ struct TailAdvance {
 };
 // adv (optional; the launch must cover the tail columns stride-2, stride-1 and not accumulate): the workgroup of the
 // failure-count column also sums the loss column and advances the optimiser state with the pair
+// xchg (optional; the launch's columns must be final, i.e. not be accumulated into by a later launch): every column's sum
+// goes through the exchange and `out` receives the sum over all ranks; with adv the tail workgroup exchanges both tail
+// columns itself (the loss column's workgroup leaves them to it)
 hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int stride, int col0, int ncol, double* out,
                               hipStream_t s, int n_sets = 1, const double* mask = nullptr, int n_mask = 0,
                               int out_stride = 0 /* doubles between the sets' output rows; 0 = stride */,
                               bool accumulate = false /* add to out instead of overwriting it */,
                               const TailAdvance* adv = nullptr,
-                              double* host_tail = nullptr /* page-locked [2]: the sums of the last two columns as well */);
+                              double* host_tail = nullptr /* page-locked [2]: the sums of the last two columns as well */,
+                              const XchgArgs* xchg = nullptr);
+// buf[0..count) <- sum (op 0) / max (op 1) over the ranks, in place, through the exchange (any count: columns in turn)
+hipError_t launch_xchg_allreduce(const XchgArgs& x, double* buf, int64_t count, int op, hipStream_t s);
 hipError_t launch_adam_advance(const TailAdvance& adv, const double* g_tail, hipStream_t s);
 // out[2k], out[2k+1] = sum_b partials[k][b][col0], [col0+1]  for k < n_sets (multi-start screening)
 hipError_t launch_reduce_sets(const double* partials, int n_sets, int64_t nblocks, int stride, int col0, double* out,

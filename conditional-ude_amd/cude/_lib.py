@@ -16,6 +16,7 @@ MODEL_CPEP_SYM = 2
 COND_LOG = 0
 COND_RAW = 1
 UNIQUE_ID_BYTES = 128
+XCHG_HANDLE_BYTES = 128
 
 
 class CudeError(RuntimeError):
@@ -88,6 +89,12 @@ _SIGNATURES = {
     "cude_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "cude_comm_allreduce_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "cude_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cude_xchg_export": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "cude_xchg_attach": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double]),
+    "cude_xchg_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "cude_xchg_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32)]),
+    "cude_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_char_p]),
 }
 
 _lib = None

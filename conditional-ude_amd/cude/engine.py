@@ -490,5 +490,31 @@ class Engine:
         check(self._lib.cude_comm_allreduce_host(self._h, _ptr(v), v.size))
         return v
 
+    # -- the peer-write exchange (cude_xchg_*): multi-GPU without a collective library
+    def xchg_export(self, n_ranks, rank):
+        """This rank's mailbox as 128 bytes for its peers (cude_xchg_export)."""
+        buf = (C.c_uint8 * _lib.XCHG_HANDLE_BYTES)()
+        check(self._lib.cude_xchg_export(self._h, int(n_ranks), int(rank), buf))
+        return bytes(buf)
+
+    def xchg_attach(self, handles, timeout_s=20.0):
+        """handles: the n_ranks exported handles in rank order (bytes each).  Collective: ends with a self-test."""
+        blob = b"".join(handles)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        check(self._lib.cude_xchg_attach(self._h, buf, float(timeout_s)))
+
+    def xchg_enable(self, enabled=True):
+        check(self._lib.cude_xchg_enable(self._h, 1 if enabled else 0))
+
+    def xchg_info(self):
+        """(ranks, rank, memory kind of the mailbox: 3 uncached / 1 fine-grained / 0 plain, timed-out waits so far)."""
+        n, r, k, t = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(self._lib.cude_xchg_info(self._h, C.byref(n), C.byref(r), C.byref(k), C.byref(t)))
+        return n.value, r.value, k.value, t.value
+
+    def set_option(self, name, value):
+        """cude_set_option: run-time options of the context (include/cude.h lists them)."""
+        check(self._lib.cude_set_option(self._h, str(name).encode(), str(value).encode()))
+
 
 __all__ = ["Engine", "CudeError", "n_params", "device_count"]

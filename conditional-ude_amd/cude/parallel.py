@@ -7,6 +7,9 @@ P+2 doubles) is summed across ranks once per optimiser step.  Two transports:
 
   * "rccl": the sum happens inside libcude_hip.so on the context's stream (cude_comm_init +
     cude_adam_step); the host only ships the 128-byte unique id once.
+  * "xchg": the peer-write exchange (cude_xchg_*): the reduction kernels of every rank write their P+2 doubles into
+    every peer's mailbox over xGMI and add what arrives in rank order -- no collective call at all, captured graphs
+    keep working, sums are bitwise reproducible; the host only ships 128-byte handles once.
   * "host": the host sums the P+2 doubles with ANY collective it likes (torch.distributed gloo/nccl,
     MPI) between cude_loss_grad_partial and cude_adam_apply.
 
@@ -54,6 +57,16 @@ class TorchCollective:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
+    def allgather_bytes(self, payload):
+        """Every rank's `payload` (equal lengths) in rank order."""
+        import torch
+        mine = torch.tensor(list(payload), dtype=torch.uint8)
+        if self.device is not None:
+            mine = mine.to(self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world_size)]
+        self.dist.all_gather(out, mine)
+        return [bytes(t.cpu().tolist()) for t in out]
+
     def broadcast_bytes(self, payload, src=0):
         import torch
         n = len(payload) if payload is not None else 0
@@ -77,8 +90,8 @@ class ShardedTrainer:
 
     def __init__(self, engine, collective, transport="host"):
         self.engine, self.coll, self.transport = engine, collective, transport
-        if transport not in ("host", "rccl"):
-            raise ValueError("transport must be 'host' or 'rccl'")
+        if transport not in ("host", "rccl", "xchg"):
+            raise ValueError("transport must be 'host', 'rccl' or 'xchg'")
 
     @staticmethod
     def attach_rccl(engine_cls, engine, collective):
@@ -87,6 +100,14 @@ class ShardedTrainer:
         uid = engine_cls.comm_unique_id() if collective.rank == 0 else None
         uid = collective.broadcast_bytes(uid, 0)
         engine.comm_init(collective.world_size, collective.rank, uid)
+
+    @staticmethod
+    def attach_xchg(engine, collective, timeout_s=20.0):
+        """Bootstrap the peer-write exchange: every rank exports its mailbox, the handles are all-gathered through the
+        host collective, every rank maps its peers (collective: ends with a self-test).  Before the population is
+        uploaded, as attach_rccl."""
+        mine = engine.xchg_export(collective.world_size, collective.rank)
+        engine.xchg_attach(collective.allgather_bytes(mine), timeout_s)
 
     def sync_population_statistics(self, scale_sums=None):
         """host transport: establish the global subject count (and SUPP's scale = mean_i max_t data)."""
@@ -117,7 +138,7 @@ class ShardedTrainer:
             lam = getattr(self.engine, "lam", 0.0)
         nn, cond = self.engine.get_params()
         P = nn.size
-        if self.transport == "rccl":
+        if self.transport in ("rccl", "xchg"):
             nn_o, cond_o, obj = self.engine.train_restarts(nn[None, :], cond[None, :], 0, 1e-3, int(maxiters))
             self.engine.set_params(nn_o[0], cond_o[0])
             return dict(f=float(obj[0]), iterations=None, f_calls=None, converged=None)
@@ -139,7 +160,7 @@ class ShardedTrainer:
 
     def adam_step(self):
         """One optimiser iteration; returns the GLOBAL loss (identical on every rank)."""
-        if self.transport == "rccl":
+        if self.transport in ("rccl", "xchg"):
             return self.engine.adam_step()
         part, _ = self.engine.loss_grad_partial()
         return self.engine.adam_apply(self.coll.allreduce_sum(part))

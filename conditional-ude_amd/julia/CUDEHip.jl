@@ -320,6 +320,33 @@ function comm_allreduce!(c::Ctx, values::Vector{Float64})
     values
 end
 
+# ---- multi-GPU without a collective library: the peer-write exchange (include/cude.h "cude_xchg_*").  Every rank
+# exports its mailbox, the 128-byte handles travel over any channel (Distributed.jl: `handles = fetch.(...)`; MPI.jl:
+# `MPI.Allgather`), every rank attaches all of them (collective: ends with a self-test).  Afterwards `loss`, the Adam
+# steps, `train` and SAEM sum over the ranks inside the reduction kernels: no RCCL, captured graphs keep working.
+function xchg_export(c::Ctx, n_ranks, rank)
+    h = Vector{UInt8}(undef, 128)
+    GC.@preserve h check(ccall((:cude_xchg_export, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), c.h, n_ranks, rank, h))
+    h
+end
+
+function xchg_attach!(c::Ctx, handles::Vector{Vector{UInt8}}; timeout_s = 20.0)
+    all = reduce(vcat, handles)
+    GC.@preserve all check(ccall((:cude_xchg_attach, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Float64), c.h, all, timeout_s))
+end
+
+xchg_enable!(c::Ctx, on::Bool) = check(ccall((:cude_xchg_enable, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on ? 1 : 0))
+
+function xchg_info(c::Ctx)
+    n = Ref{Int32}(); r = Ref{Int32}(); k = Ref{Int32}(); t = Ref{Int32}()
+    check(ccall((:cude_xchg_info, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}), c.h, n, r, k, t))
+    (ranks = Int(n[]), rank = Int(r[]), memory_kind = Int(k[]), timed_out_waits = Int(t[]))
+end
+
+# run-time options of a context (launch-path override, auto_regroup, poll_pinned ...: include/cude.h)
+set_option!(c::Ctx, name::AbstractString, value) =
+    check(ccall((:cude_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Cstring), c.h, name, string(value)))
+
 # bring-your-own collective (MPI.jl): partial = loss_grad_partial(c); MPI.Allreduce!(partial, +, comm); adam_apply!(c, partial)
 function set_global_subjects!(c::Ctx, n_global; scale = nothing)
     sc = scale === nothing ? nothing : Vector{Float64}(scale)

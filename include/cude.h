@@ -49,6 +49,8 @@ extern "C" {
 #define CUDE_COND_RAW 1 /* k = conditional: the box-constrained fit of 03-symreg.jl:99-106 (p.ode[1] in [0,1000]) */
 
 #define CUDE_UNIQUE_ID_BYTES 128
+#define CUDE_XCHG_HANDLE_BYTES 128 /* a rank's exchange mailbox, as cude_xchg_export describes it to its peers */
+#define CUDE_XCHG_MAX_RANKS 16    /* ranks of one node (the exchange writes into peers' memory over xGMI) */
 
 typedef struct cude_ctx cude_ctx;
 
@@ -344,6 +346,40 @@ int32_t cude_comm_allreduce_host(cude_ctx* ctx, double* values, int32_t count);
 /* What the attached communicator itself reports: ncclCommCount, ncclCommUserRank, ncclGetVersion (1, 0, 0 without a
  * communicator) -- lets a launcher prove which transport and how many ranks a multi-GPU run really used. */
 int32_t cude_comm_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* version);
+
+/* --- multi-GPU without a collective library: the peer-write exchange.  Same role as the communicator above (the
+ * data-parallel form of EnsembleThreads, suppression_model.jl:113,123; the one sum of P+2 doubles per optimiser step
+ * that replaces ForwardDiff's accumulation over all subjects, src/parameter-estimation.jl:126-140,370), built for this
+ * message size: every rank owns a mailbox in its GPU's memory, mapped into its peers through HIP IPC; the kernel that
+ * finishes a rank's [g_nn; sum loss; n_failed] writes each double straight into a slot of EVERY rank's mailbox over
+ * xGMI (two 8-byte words carrying the step's sequence number: a word is valid when its sequence matches, so no fence
+ * and no flag ordering is needed), waits for the other ranks' words in its own mailbox and adds the n_ranks values IN
+ * RANK ORDER.  Every rank therefore forms bit-identical sums, run to run and whatever the arrival order; there is no
+ * extra launch in the step, and cude_adam_run keeps replaying captured graphs (it cannot with RCCL calls).  A wait
+ * that sees no peer for `timeout_s` gives up: the step's loss becomes NaN and the next call that synchronises returns
+ * CUDE_ERR_COMM (a kernel never spins for ever).
+ *   every rank:  cude_xchg_export(ctx, n_ranks, rank, mine)        -> 128 bytes describing its mailbox
+ *   the host:    all-gather of those bytes (any channel: torch.distributed, MPI.jl, a file)
+ *   every rank:  cude_xchg_attach(ctx, all[n_ranks][128], timeout_s)   (collective: ends with a self-test)
+ * Ranks may live in one process (several contexts) or in several; all on ONE node.  Attach before the population is
+ * uploaded, as with cude_comm_init (the global subject count is summed there).  With an exchange attached every
+ * reduction of the library goes through it and no RCCL communicator is needed; when both are attached the exchange
+ * is used while enabled (cude_xchg_enable(ctx, 0) switches to the communicator, for comparisons). */
+int32_t cude_xchg_export(cude_ctx* ctx, int32_t n_ranks, int32_t rank, uint8_t handle[CUDE_XCHG_HANDLE_BYTES]);
+int32_t cude_xchg_attach(cude_ctx* ctx, const uint8_t* handles /* [n_ranks][CUDE_XCHG_HANDLE_BYTES] */, double timeout_s);
+int32_t cude_xchg_enable(cude_ctx* ctx, int32_t enabled);
+/* n_ranks / rank of the attached exchange (1, 0 without), how its mailbox memory was allocated (3 = uncached, 1 =
+ * fine-grained, 0 = ordinary device memory) and how many device-side waits have run out of time so far. */
+int32_t cude_xchg_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* memory_kind, int32_t* timeouts);
+
+/* --- run-time options (cude_ctx.h `Options` lists them): launch-path override of the tests ("cpep_path" = "1" |
+ * "2:L" | "3:B:L"), "cpep_keep", "supp_store", "supp_ckpt", "tape_steps", "exp_table", "ms_split", "auto_regroup",
+ * "poll_pinned", "debug_selector".  Values are decimal integers as text unless noted.  Every option is also read once
+ * at cude_create from its environment variable (CUDE_CPEP_PATH, CUDE_CPEP_KEEP, CUDE_SUPP_STORE, CUDE_SUPP_CKPT,
+ * CUDE_TAPE_STEPS, CUDE_NO_EXPTAB, CUDE_NO_MS_SPLIT, CUDE_NO_AUTO_REGROUP, CUDE_NO_POLL_PINNED, CUDE_DEBUG_SELECTOR).
+ * Options that shape the launch path take effect at the next cude_set_population_*.  No reference line: these are
+ * properties of this implementation. */
+int32_t cude_set_option(cude_ctx* ctx, const char* name, const char* value);
 
 #ifdef __cplusplus
 }

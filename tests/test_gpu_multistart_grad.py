@@ -77,7 +77,7 @@ def test_sets_on_the_time_split_path(arch, n_state, N, monkeypatch):
         eng.set_params(nn_sets[k], cond_sets[k])
         l1, gn1, gc1 = eng.loss_grad()
         assert l1 == loss[k] and np.array_equal(gn1, g_nn[k]) and np.array_equal(gc1, g_cond[k])
-    monkeypatch.setenv("CUDE_NO_MS_SPLIT", "1")                  # the one-lane kernel with the sets in grid y
+    eng.set_option("ms_split", 0)                                # the one-lane kernel with the sets in grid y
     loss1, g_nn1, g_cond1 = eng.multistart_loss_grad(nn_sets, cond_sets)
     eng.close()
     ok = np.arange(K) != 4

@@ -118,7 +118,9 @@ def test_every_ccall_matches_its_prototype():
         assert len(args) == len(types), f"{sym}: {len(args)} values for {len(types)} argument types"
         for pos, (jt, ck) in enumerate(zip(types, c_kinds)):
             jk = _jl_kind(jt)
-            if isinstance(ck, tuple):
+            if isinstance(ck, tuple) and jk == "cstring":
+                assert ck[1] == "char", f"{sym} argument {pos}: Cstring vs {ck[1]}*"
+            elif isinstance(ck, tuple):
                 assert isinstance(jk, tuple), f"{sym} argument {pos}: {jt} where the header has a pointer"
                 assert ck[1] in _POINTEE.get(jk[1], set()), f"{sym} argument {pos}: {jt} vs {ck[1]}*"
             else:
