@@ -74,30 +74,86 @@ TANH_TABLE_MAX_WIDTH_CPEP = 4   # csrc/cude_device.h CUDE_TANH_TAB_MAXW: fixed-s
                                 # fixed-step suppression kernel always) evaluate tanh by table + addition theorem
 
 
+class Ops:
+    """Executed vector instructions of a piece of a kernel, per lane, in three classes:
+      fma    fused multiply-adds (2 floating-point operations, 1 issue slot each);
+      fp1    other floating-point arithmetic: add / sub / mul and the reciprocal seed v_rcp_f64 (1 operation each; the
+             reciprocal occupies four issue cycles, counted as ONE instruction here as the SQ counters count it);
+      other  VALU instructions that do no floating-point arithmetic: min / max clamps, round-to-integer, int conversion,
+             ldexp, sign transfer (v_bfi), compares and the two v_cndmask a double select takes, shifts.
+    flops = 2 fma + fp1 is the numerator of roofline_valu; slots = fma + fp1 + other is what SQ_INSTS_VALU / SQ_WAVES
+    counts per wave (register moves, accumulator seeds and address arithmetic excepted: the structural tally leaves
+    those to the counter).  Counted from the kernels' source (cude_math.h, cude_device.h), one entry per operation."""
+
+    def __init__(self, fma=0, fp1=0, other=0):
+        self.fma, self.fp1, self.other = fma, fp1, other
+
+    def __add__(self, o):
+        return Ops(self.fma + o.fma, self.fp1 + o.fp1, self.other + o.other)
+
+    def __sub__(self, o):
+        return Ops(self.fma - o.fma, self.fp1 - o.fp1, self.other - o.other)
+
+    def __mul__(self, k):
+        return Ops(self.fma * k, self.fp1 * k, self.other * k)
+
+    __rmul__ = __mul__
+
+    @property
+    def flops(self):
+        return 2 * self.fma + self.fp1
+
+    @property
+    def slots(self):
+        return self.fma + self.fp1 + self.other
+
+    def __repr__(self):
+        return f"Ops(fma={self.fma}, fp1={self.fp1}, other={self.other})"
+
+
+RCP = Ops(fma=3, fp1=1)                 # m_rcp: v_rcp_f64 + one cubic Newton step
+# m_exp2x_t: x * 2 log2 e (mul), rint, cvt, two reduction FMAs, ten Horner FMAs, ldexp
+EXP2X = Ops(fma=12, fp1=1, other=3)
+# per neuron, exponential form (m_tanh_den + m_tanh_vec): clamp (min), EXP2X, + 1, 1 - 2 inv (FMA), copysign (v_bfi)
+TANH_EXP_NEURON = EXP2X + Ops(fma=1, fp1=1, other=2)
+# per neuron, table form (m_tanh_cell + m_tanh_vec_tab): clamp (min); xa + magic, t - magic, xa - (.), b b, u + 10.5,
+# b (.), u + 45, (.) 0.1 (8 fp1); fma(u, ., 105), numerator, denominator (3 FMA); index shift (other); the quotient's
+# multiply (fp1); sign transfer (other)
+TANH_TAB_NEURON = Ops(fma=3, fp1=9, other=3)
+# m_softplus_t: -0.5 |x| (mul), clamp (max), EXP2X, 1 + e, compare, e - 1 / select (2 cndmask), e + 3, e + 2 / select,
+# d den (mul), RCP, rp den, rp d, num (.), e inv_d / compare / select, s s, eight atanh FMAs, 2 s p (two muls), max(x, 0),
+# + ln 2 / select, final sum
+SOFTPLUS = EXP2X + RCP + Ops(fma=8, fp1=15, other=12)
+# ... of which only the VALUE needs (the reverse sweeps re-evaluate the network for its derivative and never execute it):
+# e - 1 / select, rp d, num (.), s s, the eight FMAs, the two muls of 2 s p, + ln 2 / select, max(x, 0), the final sum
+SOFTPLUS_VALUE_ONLY = Ops(fma=8, fp1=8, other=5)
+
+
+def tanh_layer(w, table_tanh):
+    """one hidden layer's activations: W neurons, ONE shared reciprocal, 3 (W - 1) prefix / back-substitution multiplies"""
+    return w * (TANH_TAB_NEURON if table_tanh else TANH_EXP_NEURON) + RCP + Ops(fp1=3 * (w - 1))
+
+
+def mlp_ops(nv, w, d, n_dx=0, table_tanh=False):
+    """(forward, backward) Ops of one network evaluation as the kernels execute it (Mlp::forward / backward,
+    cude_device.h); n_dx = number of inputs whose derivative is formed."""
+    fwd = Ops(fma=w * nv + (d - 1) * w * w + w) + d * tanh_layer(w, table_tanh) + SOFTPLUS
+    out = Ops(fma=w, fp1=w + 2)                                           # dz = wgt sig; d/db; d/dw_out, dh = dz w_out
+    hidden = (d - 1) * (w * Ops(fma=1, fp1=2) + w * w * Ops(fma=2) + Ops(fp1=w))   # d = dh (1 - h^2), d/db; d/dW, W^T d; s0 + s1
+    first = w * (Ops(fma=1, fp1=2) + Ops(fma=nv))                         # d = dh (1 - h^2), d/dc; d/dW1 (varying inputs)
+    dx = n_dx * Ops(fma=w, fp1=2)                                         # W1^T d for the wanted inputs: s0 + s1, dx +=
+    return fwd, out + hidden + first + dx
+
+
 def mlp_flops(nv, w, d, want_dx=False, table_tanh=False):
-    """(forward, backward) fp64 flops of one network evaluation as the kernels execute it (FMA = 2; cude_math.h)."""
-    if table_tanh:
-        # m_tanh_vec_tab per neuron: min, add, sub, sub, shift, mul, add, mul, add, mul (10 x 1) + 3 FMA (d, numerator,
-        # denominator) + the quotient's multiply and the sign (2); per layer: one reciprocal (rcp + 3 FMA) + 3(W-1)
-        tanh_layer = w * (10 + 3 * 2 + 2) + (1 + 3 * 2) + 3 * (w - 1)
-    else:
-        # m_tanh_vec per neuron: min, mul, rndne, cvt, ldexp, add, bfi (7 x 1 flop) + 13 FMA (2 reduction, 10 Horner,
-        # 1 final); per layer: one reciprocal (rcp + 3 FMA) + 3(W-1) multiplies
-        tanh_layer = w * (7 + 13 * 2) + (1 + 3 * 2) + 3 * (w - 1)
-    softplus = 23 * 2 + 22      # exp (12 FMA) + shared reciprocal (3 FMA) + atanh polynomial (8 FMA) + 22 other ops
-    fwd = 2 * (w * nv + (d - 1) * w * w + w) + d * tanh_layer + softplus
-    bwd = (2 * w + w + 2) + (d - 1) * w * (4 + 4 * w) + w * (4 + 2 * nv) + (2 * nv * w if want_dx else 0)
-    return fwd, bwd
-
-
-# of a softplus evaluation, the part only the VALUE needs (atanh polynomial: 8 FMA; s, z, 2 s p, + ln 2, max(x, 0), the
-# final sum: 9 single ops): the reverse sweeps re-evaluate the network for its derivative and never execute it
-SOFTPLUS_VALUE_ONLY_FLOPS = 8 * 2 + 9
+    """(forward, backward) floating-point operations of one network evaluation (FMA = 2)."""
+    f, b = mlp_ops(nv, w, d, nv if want_dx else 0, table_tanh)
+    return f.flops, b.flops
 
 
 def table_steps(n_steps, n_obs):
     """(number of steps that lie inside one glucose piece, number of runs of such steps) for equidistant
-    observation times -- the classification of step_tables() in csrc/cude_api.hip."""
+    observation times -- the classification of step_tables() in csrc/cude_context.hip."""
     piece = []
     for n in range(n_steps):
         a, b = n * (n_obs - 1) / n_steps, (n + 1) * (n_obs - 1) / n_steps      # in units of one piece
@@ -107,41 +163,54 @@ def table_steps(n_steps, n_obs):
     return sum(1 for p in piece if p >= 0), runs
 
 
-def cpep_flops(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS, n_state=N_STATE, grad=True):
-    """fp64 flops the one-lane-per-subject c-peptide kernel executes per subject (FMA = 2), counted from the kernel's
-    structure (cude_cpep.hip): 5 S + 1 network evaluations per sweep, the Runge-Kutta algebra per step."""
+def cpep_ops(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS, n_state=N_STATE, grad=True):
+    """Ops the one-lane-per-subject c-peptide kernel executes per subject, counted from the kernel's structure
+    (cude_cpep.hip): 5 S + 1 network evaluations per sweep, the Runge-Kutta algebra per step."""
     nin, w, d = arch
-    fwd_eval, bwd_eval = mlp_flops(1, w, d, table_tanh=(w <= TANH_TABLE_MAX_WIDTH_CPEP and nin == 2))
+    table = w <= TANH_TABLE_MAX_WIDTH_CPEP and nin == 2
+    fwd_eval, bwd_eval = mlp_ops(1, w, d, 0, table)
     n_eval = 5 * n_steps + 1
-    stage_fwd = 2 * (2 * 21 + 2 * 6 + 7 * 4) + (2 * 6 if n_state == 3 else 0)   # stage sums, Y, A*Y+g [, quadrature]
-    stage_rev = 2 * (2 * 21 + 6 * 4 + 12) + 12
-    obs_fl = n_obs * (2 * (3 if n_state == 3 else 2) * 7 + 8)
-    total = n_eval * fwd_eval + n_steps * stage_fwd + obs_fl
+    stage_fwd = Ops(fma=2 * 21 + 2 * 6 + 7 * 4 + (6 if n_state == 3 else 0))   # stage sums, Y, A Y + g [, quadrature]
+    stage_rev = Ops(fma=2 * 21 + 6 * 4 + 12, fp1=12)
+    obs = n_obs * Ops(fma=(3 if n_state == 3 else 2) * 7, fp1=8)
+    total = n_eval * fwd_eval + n_steps * stage_fwd + obs
     if grad:
-        total += n_eval * (fwd_eval - SOFTPLUS_VALUE_ONLY_FLOPS + bwd_eval) + n_steps * stage_rev + obs_fl
+        total = total + n_eval * (fwd_eval - SOFTPLUS_VALUE_ONLY + bwd_eval) + n_steps * stage_rev + obs
     if 6 <= w <= 7:
         # layer-1 exponent table (cude_device.h Mlp::HAS_TAB): inside a run of steps within one glucose piece the W
-        # layer-1 exponentials (7 + 13 FMA each) and the W first-layer FMAs are replaced by one multiply + min + add
-        # per neuron; per run and sweep: 6 W exponentials (table + anchor) and the range check; per step W multiplies
+        # layer-1 exponentials (clamp + EXP2X + 1) and the W first-layer FMAs are replaced by one multiply + clamp + add
+        # per neuron; per run and sweep: 6 W exponentials (table + anchor) and the range check (5 W compares / selects,
+        # 5 W multiplies / adds); per step W multiplies
         n_tab_steps, n_runs = table_steps(n_steps, n_obs)
-        saved_per_eval = w * (7 + 13 * 2) + 2 * w - 3 * w
-        per_run = 6 * w * (6 + 12 * 2) + 10 * w
-        total += (2 if grad else 1) * (-5 * n_tab_steps * saved_per_eval + n_runs * per_run + n_tab_steps * w)
+        saved_per_eval = w * (EXP2X + Ops(fp1=1, other=1) + Ops(fma=1)) - w * Ops(fp1=2, other=1)
+        per_run = 6 * w * EXP2X + w * Ops(fp1=5, other=5)
+        total = total + (2 if grad else 1) * (n_runs * per_run + n_tab_steps * Ops(fp1=w) - 5 * n_tab_steps * saved_per_eval)
+    return total
+
+
+def cpep_flops(arch=ARCH, n_steps=N_STEPS, n_obs=T_OBS, n_state=N_STATE, grad=True):
+    return cpep_ops(arch, n_steps, n_obs, n_state, grad).flops
+
+
+def supp_ops(arch, n_steps, n_obs, grad=True):
+    """The same count for supp_kernel (cude_supp.hip): 6 S + 1 evaluations per sweep; the reverse sweep re-evaluates the
+    network at the stored stage inputs (no kept activations at this size).  State 1 (du1 = -0.4 u1) is a table lookup:
+    one multiply per evaluation, no Runge-Kutta sums, no adjoint -- the stage algebra is that of states 2 and 3, and the
+    input-derivative of the first layer is formed for two of the three inputs."""
+    nin, w, d = arch
+    fwd_eval, bwd_eval = mlp_ops(3, w, d, 2, table_tanh=True)
+    n_eval = 6 * n_steps + 1
+    stage = Ops(fma=2 * 21 + 6 * 2)                   # per step: stage sums + Y per stage, two states
+    rhs = Ops(fma=2, fp1=1)                           # per evaluation: u1 from the table; du2, du3 (one FMA each)
+    total = n_eval * (fwd_eval + rhs) + n_steps * stage + n_obs * Ops(fma=2 * 7 + 2 + 3, fp1=2 * 2 + 2)
+    if grad:
+        vjp = Ops(fma=1, fp1=4)                       # u1 from the table; weight kb3 - kb2; ub2 += dx2; ub3 += -0.3 kb3 + dx3
+        total = total + n_eval * (fwd_eval - SOFTPLUS_VALUE_ONLY + bwd_eval + vjp) + n_steps * stage + n_obs * Ops(fma=2 * 7, fp1=2 * 3)
     return total
 
 
 def supp_flops(arch, n_steps, n_obs, grad=True):
-    """The same count for supp_kernel (cude_supp.hip): 6 S + 1 evaluations per sweep, all three inputs varying; the
-    reverse sweep re-evaluates the network at the stored stage inputs (no kept activations at this size)."""
-    nin, w, d = arch
-    fwd_eval, bwd_eval = mlp_flops(3, w, d, want_dx=True, table_tanh=True)
-    n_eval = 6 * n_steps + 1
-    stage = 2 * 3 * 21 + 6 * 3 * 2 + 6 * 4            # stage sums + Y per stage + RHS algebra
-    obs_fl = n_obs * (2 * 3 * 7 + 3 * 5)
-    total = n_eval * fwd_eval + n_steps * stage + obs_fl
-    if grad:
-        total += n_eval * (fwd_eval - SOFTPLUS_VALUE_ONLY_FLOPS + bwd_eval + 10) + n_steps * (2 * 3 * 21 + 6 * 3 * 2) + obs_fl
-    return total
+    return supp_ops(arch, n_steps, n_obs, grad).flops
 
 
 def kernel_source_sha():
@@ -155,8 +224,9 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_key, n_local):
-    """HBM bytes per launch from the committed PMC passes, or (None, reason)."""
+def pmc_record(kernel_key, n_local):
+    """The committed PMC record of a kernel (profiles/pmc_traffic.json), or (None, reason): quoted only for the code it
+    was measured on and the population size it was measured at."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(path))
@@ -169,18 +239,47 @@ def pmc_traffic(kernel_key, n_local):
         return None, f"stale PMC record (kernel sources changed since {rec.get('source_sha')})"
     if rec.get("subjects_per_gpu") != n_local:
         return None, f"PMC record is for {rec.get('subjects_per_gpu')} subjects"
-    return rec.get("hbm_bytes_per_launch"), None
+    return rec, None
 
 
-def rooflines(kernel, kern_ms, launches, n_subjects, bytes_per_subject, flops_per_subject, traffic=None, note=None):
+def pmc_traffic(kernel_key, n_local):
+    """HBM bytes per launch from the committed PMC passes, or (None, reason)."""
+    rec, why = pmc_record(kernel_key, n_local)
+    return (rec.get("hbm_bytes_per_launch"), None) if rec else (None, why)
+
+
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4                # the clock FP64_VALU_PEAK_TF is quoted at
+VALU_CYCLES_PER_INSTRUCTION = 4     # a wave64 fp64 (or any full-rate VALU) instruction occupies its SIMD for four cycles
+
+
+def rooflines(kernel, kern_ms, launches, n_subjects, bytes_per_subject, ops, traffic=None, note=None, sq=None):
+    """The contract's `roofline` object (HBM) and `roofline_valu` (the binding one).  `ops` = Ops per subject-trajectory:
+    roofline_valu.frac is floating-point operations (FMA = 2, add / mul / rcp = 1) over the fp64 vector peak;
+    clamps, conversions, selects and sign transfers occupy the same issue slots but are NOT floating-point work and
+    are listed beside it (`other_valu_slots_per_trajectory`).  `valu_slot_utilisation` says how busy the vector issue
+    slots were, whatever they issued: SQ_INSTS_VALU (committed PMC pass of these sources) x 4 cycles / (1024 SIMDs x
+    kernel time x 2.4 GHz)."""
     gbs = bytes_per_subject * n_subjects / (kern_ms * 1e-3) / 1e9
-    tfs = flops_per_subject * n_subjects / (kern_ms * 1e-3) / 1e12
+    tfs = ops.flops * n_subjects / (kern_ms * 1e-3) / 1e12
     hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "traffic": traffic, "kernel": kernel, "kernel_ms": kern_ms, "launches": launches,
            "algorithmic_bytes_per_launch": bytes_per_subject * n_subjects,
            "note": note or "path is fp64-VALU bound (SURVEY.md 8d), see roofline_valu"}
     valu = {"bound": "valu_fp64", "achieved": tfs, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-            "frac": tfs / FP64_VALU_PEAK_TF, "flops_per_trajectory": flops_per_subject}
+            "frac": tfs / FP64_VALU_PEAK_TF, "flops_per_trajectory": ops.flops,
+            "counted": {"fma": ops.fma, "other_fp_ops": ops.fp1, "other_valu_slots_per_trajectory": ops.other,
+                        "valu_slots_per_trajectory": ops.slots,
+                        "note": "flops = 2 fma + other_fp_ops (add, mul, rcp); other_valu_slots = clamps, rounding / "
+                                "conversion, ldexp, selects, sign transfer: issue slots without floating-point work, "
+                                "not in the numerator"},
+            "valu_slot_utilisation": None}
+    if sq and sq.get("SQ_INSTS_VALU") and sq.get("SQ_WAVES"):
+        cycles = N_SIMD * kern_ms * 1e-3 * CLOCK_GHZ * 1e9
+        valu["valu_slot_utilisation"] = sq["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INSTRUCTION / cycles
+        valu["valu_instructions_per_wave"] = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
+        valu["valu_slot_note"] = ("SQ_INSTS_VALU of the committed PMC pass (profiles/pmc_traffic.json, same sources) x 4 "
+                                  "cycles / (1024 SIMDs x this run's kernel time x 2.4 GHz)")
     return hbm, valu
 
 
@@ -386,7 +485,7 @@ def extras(Engine, device, steps=20, warm=40):
     ms, launches = eng.kernel_time_ms()
     eng.set_kernel_timing(False)
     hbm, valu = rooflines("cpep2_fwd_kernel<2,6,2,3> + cpep2_scan_kernel (time-split forward)", ms, launches, n,
-                          cpep_algo_bytes(T_OBS, N_STATE, False), cpep_flops(grad=False))
+                          cpep_algo_bytes(T_OBS, N_STATE, False), cpep_ops(grad=False))
     out["forward_only_1e4"] = {"config": "BASELINE configs[1]: CPEP3 2x6x6x1, 1e4 subjects, forward-only loss",
                                "value": n / dt, "unit": "subject-trajectories/s", "ms_per_call": dt * 1e3,
                                "roofline": hbm, "roofline_valu": valu}
@@ -403,7 +502,7 @@ def extras(Engine, device, steps=20, warm=40):
     hbm, valu = rooflines("mixed gradient launch: cpep_kernel<Mlp<2,6,2,1>,3,grad> on 1024 workgroups (one long wave per "
                           "SIMD) beside cpep2_fwd / scan / rev <2,6,2,3> on the other 539 (library's path selector)", ms,
                           launches, n,
-                          cpep_algo_bytes(T_OBS, N_STATE, True), cpep_flops())
+                          cpep_algo_bytes(T_OBS, N_STATE, True), cpep_ops())
     out["train_step_1e5"] = {"config": "BASELINE configs[2]: CPEP3 2x6x6x1, exactly 1e5 subjects, fwd + adjoint + Adam",
                              "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
                              "roofline": hbm, "roofline_valu": valu}
@@ -417,7 +516,7 @@ def extras(Engine, device, steps=20, warm=40):
     eng.adam_init(1e-2)
     dt, ms, launches = timed_adam(eng, n, steps, warm)
     hbm, valu = rooflines("cpep gradient launch <2,4,2,2> (library's path selector)", ms, launches, n,
-                          cpep_algo_bytes(T_OBS, 2, True), cpep_flops(arch, N_STEPS, T_OBS, 2, True))
+                          cpep_algo_bytes(T_OBS, 2, True), cpep_ops(arch, N_STEPS, T_OBS, 2, True))
     out["cpep2_4_1e5"] = {"config": "reference c-peptide cUDE (02-conditional.jl:22): 2x4x4x1, 2 states, 1e5 subjects, "
                                     "fwd + adjoint + Adam",
                           "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
@@ -460,9 +559,11 @@ def extras(Engine, device, steps=20, warm=40):
     eng.set_params(glorot(arch, 1234), theta)
     eng.adam_init(1e-3)
     dt, ms, launches = timed_adam(eng, n, steps, 10)
-    scratch = 2 * (6 * N_STEPS + 1) * 3 * 8          # stage inputs written by the forward and read by the reverse sweep
+    scratch = 2 * (6 * N_STEPS + 1) * 2 * 8          # stage inputs (states 2, 3) written by the forward, read by the reverse sweep
+    srec, _ = pmc_record("supp_stage_inputs", n)
     hbm, valu = rooflines("supp_kernel<3,5,grad>", ms, launches, n, supp_algo_bytes(8, True),
-                          supp_flops(arch, N_STEPS, 8, True),
+                          supp_ops(arch, N_STEPS, 8, True), traffic=srec.get("hbm_bytes_per_launch") if srec else None,
+                          sq=srec.get("sq") if srec else None,
                           note=f"+ {scratch} B/subject of stage-input scratch (stored linearisation points instead of "
                                f"a recomputed forward sweep; profiles/r02/supp_scratch_tradeoff.txt)")
     out["supp_1e5"] = {"config": "suppression cUDE (suppression.jl:18): 4x3x3x3x3x3x1, 3 states, T=8, 1e5 subjects, "
@@ -492,7 +593,7 @@ def extras(Engine, device, steps=20, warm=40):
     ms, launches = eng.kernel_time_ms()
     eng.set_kernel_timing(False)
     hbm, valu = rooflines("time-split forward launches <2,4,2,2> inside cude_mh_estep", ms, launches, n,
-                          cpep_algo_bytes(T_OBS, 2, False), cpep_flops(arch, N_STEPS, T_OBS, 2, False))
+                          cpep_algo_bytes(T_OBS, 2, False), cpep_ops(arch, N_STEPS, T_OBS, 2, False))
     out["saem_estep_1e4x100"] = {"config": "BASELINE configs[4] on one GPU: SAEM E-step (saem.jl:86-108,177-186), 1e4 "
                                            "subjects x 100 Metropolis steps (gamma = 1: burn-in phase), 2x4x4x1, "
                                            "draws generated on the device (counter-based Philox4x32-10)",
@@ -841,9 +942,10 @@ def main():
     if rank == 0:
         n_total = n_local * world
         value = n_total * args.steps / dt
-        traffic, traffic_note = pmc_traffic("headline", n_local)
+        hrec, traffic_note = pmc_record("headline", n_local)
+        traffic = hrec.get("hbm_bytes_per_launch") if hrec else None
         hbm, valu = rooflines("cpep_kernel<Mlp<2,6,2,1>,3,grad>", kern_ms, n_launch, n_local,
-                              cpep_algo_bytes(T_OBS, N_STATE, True), cpep_flops(), traffic)
+                              cpep_algo_bytes(T_OBS, N_STATE, True), cpep_ops(), traffic, sq=hrec.get("sq") if hrec else None)
         if traffic is None:
             hbm["traffic_note"] = traffic_note
         out = {

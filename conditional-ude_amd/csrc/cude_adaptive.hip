@@ -125,6 +125,7 @@ struct CpepAd {
         return r * r;
     }
     // ---- gradient
+    static constexpr int A0 = 0;                   // first state that has an adjoint
     static constexpr bool NEED_Y = false;          // J_f = A: the stage inputs are not linearisation points
     using NetT = Net;
     static constexpr int NCST = Net::NC;
@@ -193,20 +194,25 @@ struct SuppAd {
         return s2;
     }
     // ---- gradient
+    // State 1 (du1 = -0.4 u1, suppression_model.jl:91) depends on no parameter and on no other state: nothing that
+    // reaches d/d(network) or d/d(theta) passes through its adjoint (the VJP weight is kb[2] - kb[1]).  The forward
+    // sweep integrates it like the others -- the step-size controller's error norm weighs it -- and the tape keeps it
+    // (it is a network input); the reverse sweep carries adjoints for states 2 and 3 only.
+    static constexpr int A0 = 1;
     static constexpr bool NEED_Y = true;
     using NetT = Net;
     static constexpr int NCST = 1;
     __device__ __forceinline__ void residual_bar(const Args& a, int oi, int64_t i, const double (&o)[NS], double (&ob)[NS]) const {
+        ob[0] = 0.0;
 #pragma unroll
-        for (int s = 0; s < 3; s++) ob[s] = 2.0 * a.iscale2[s] * (o[s] - a.data[((int64_t)s * a.T + oi) * a.N + i]);
+        for (int s = 1; s < 3; s++) ob[s] = 2.0 * a.iscale2[s] * (o[s] - a.data[((int64_t)s * a.T + oi) * a.N + i]);
     }
     template <class A>
     __device__ __forceinline__ void vjp(double, const double (&u)[NS], const double (&kb)[NS], double (&ub)[NS], A& acc,
                                         double&) const {
         const double wgt = kb[2] - kb[1];
         double dx[3] = {0.0, 0.0, 0.0};
-        Net::template eval_grad<true, A, kAdaptivePin>(p, c, u, wgt, acc, dx);
-        ub[0] += fma(-0.4, kb[0], fma(0.4, kb[1], dx[0]));
+        Net::template eval_grad<true, A, kAdaptivePin, 1>(p, c, u, wgt, acc, dx);
         ub[1] += dx[1];
         ub[2] += fma(-0.3, kb[2], dx[2]);
     }
@@ -477,6 +483,7 @@ void adaptive_kernel(typename M::Args a) {
     } else {
         // ------------------------------------------------------------------ reverse sweep over the tape
         using Net = typename M::NetT;
+        constexpr int A0 = M::A0;
 #define BROW(j, s) s_B[((j) * NS + (s)) * kBlock + lane]
 #define YROW(j, s) s_Y[((j) * NS + (s)) * kBlock + lane]
         double acc[Net::NACC];
@@ -612,14 +619,17 @@ void adaptive_kernel(typename M::Args a) {
                     for (int s = 0; s < NS; s++) dd[s] = k1_next[s];
                 }
 #pragma unroll
-                for (int s = 0; s < NS; s++) { KROW(sq, s) = dd[s]; BROW(sq, s) = 0.0; }
+                for (int s = 0; s < NS; s++) {
+                    KROW(sq, s) = dd[s];
+                    if (s >= A0) BROW(sq, s) = 0.0;
+                }
             }
 #pragma unroll
             for (int s = 0; s < NS; s++) k1_next[s] = KROW(0, s);
             // ---- the observations that were saved from this step: adjoint of o = y_n + h sum_j w_j(theta) k_j
             double yb[NS];
 #pragma unroll
-            for (int s = 0; s < NS; s++) yb[s] = 0.0;
+            for (int s = A0; s < NS; s++) yb[s] = 0.0;
             while (__any(on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12)) {
                 const bool mine = on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12;
                 if (mine) {
@@ -640,11 +650,11 @@ void adaptive_kernel(typename M::Args a) {
                     for (int s = 0; s < NS; s++) o[s] = fma(h, o[s], y[s]);
                     m.residual_bar(a, oi, i, o, ob);
 #pragma unroll
-                    for (int s = 0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
+                    for (int s = A0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
 #pragma unroll 1
                     for (int j = 0; j < 7; j++) {
 #pragma unroll
-                        for (int s = 0; s < NS; s++) BROW(j, s) = fma(w[j], ob[s], BROW(j, s));
+                        for (int s = A0; s < NS; s++) BROW(j, s) = fma(w[j], ob[s], BROW(j, s));
                     }
                     hi--;
                 }
@@ -655,28 +665,28 @@ void adaptive_kernel(typename M::Args a) {
                 double kb[NS], ub[NS], uu[NS];
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
-                    kb[s] = BROW(sq, s) + (sq == 6 ? kcar[s] : 0.0);
-                    ub[s] = sq == 6 ? lam[s] : 0.0;            // Y_7 = y_{n+1}
+                    kb[s] = s >= A0 ? BROW(sq, s) + (sq == 6 ? kcar[s] : 0.0) : 0.0;
+                    ub[s] = (s >= A0 && sq == 6) ? lam[s] : 0.0;    // Y_7 = y_{n+1}
                     uu[s] = M::NEED_Y ? YROW(sq, s) : 0.0;
                 }
                 if (sq == 0) {                                 // applied with k_7 of the step before (finish_grad for step 0)
 #pragma unroll
-                    for (int s = 0; s < NS; s++) kcar[s] = kb[s];
+                    for (int s = A0; s < NS; s++) kcar[s] = kb[s];
                     break;
                 }
                 const double te = sq < 6 ? fma(TS_C[sq], h, tn) : tn + h;
                 m.vjp(te, uu, kb, ub, acc, wsum);
 #pragma unroll
-                for (int s = 0; s < NS; s++) yb[s] += ub[s];
+                for (int s = A0; s < NS; s++) yb[s] += ub[s];
 #pragma unroll 1
                 for (int j = 0; j < sq; j++) {                 // Y_sq = y_n + h sum_{j<sq} a(sq, j) k_j
                     const double aj = h * TS_A[sq][j];
 #pragma unroll
-                    for (int s = 0; s < NS; s++) BROW(j, s) = fma(aj, ub[s], BROW(j, s));
+                    for (int s = A0; s < NS; s++) BROW(j, s) = fma(aj, ub[s], BROW(j, s));
                 }
             }
 #pragma unroll
-            for (int s = 0; s < NS; s++) lam[s] = yb[s];
+            for (int s = A0; s < NS; s++) lam[s] = yb[s];
             }
         }
         if (active && a.tape_n != nullptr) a.tape_n[set * a.N + i] = n_acc;

@@ -10,6 +10,15 @@ thread_local std::string g_err;
 // ---------------------------------------------------------------------------------- solver tables
 const double TA7[6] = {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
                        2.324710524099774};
+// rows 2..6 of the tableau (row 7 = TA7): a(st, j), j < st
+const double TA[7][6] = {{0, 0, 0, 0, 0, 0},
+                         {0.161, 0, 0, 0, 0, 0},
+                         {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+                         {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+                         {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+                         {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+                         {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+                          2.324710524099774}};
 const double TC[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
 const double TR[7][4] = {{1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
                          {0.0, 0.13169999999999998, -0.2234, 0.1017},
@@ -52,6 +61,35 @@ void glucose_tables(const std::vector<double>& tp, int S, std::vector<int32_t>& 
             seg[(size_t)n * 5 + s] = j;
             phi[(size_t)n * 5 + s] = (t - tp[j]) / (tp[j + 1] - tp[j]);
         }
+    }
+}
+
+// Suppression model, state 1: du1 = -0.4 u1 (suppression/src/suppression_model.jl:91).  Fixed-step Tsit5 on a scalar
+// linear equation multiplies by constants of z = -0.4 h alone: stage input Y_st = u1_n rho_st with rho_0 = 1,
+// rho_st = 1 + z sum_{j<st} a(st, j) rho_j, and u1_{n+1} = u1_n rho_6.  rho[e] = u1 at evaluation e = 6n + st relative
+// to u1(t_0); obs_rho[oi] = the dense output at observation oi (step[oi], weights w[oi][0..6]) relative to u1(t_0).
+void linear_state_tables(int S, double h, const std::vector<int32_t>& step, const std::vector<double>& w,
+                         std::vector<double>& rho, std::vector<double>& obs_rho) {
+    const double z = -0.4 * h;
+    double r[7];
+    r[0] = 1.0;
+    for (int st = 1; st <= 6; st++) {
+        double acc = 0.0;
+        for (int j = 0; j < st; j++) acc = std::fma(TA[st][j], r[j], acc);
+        r[st] = std::fma(z, acc, 1.0);
+    }
+    rho.assign((size_t)6 * S + 1, 1.0);
+    std::vector<double> pw((size_t)S + 1, 1.0);             // R^n
+    for (int n = 0; n < S; n++) {
+        for (int st = 1; st <= 6; st++) rho[(size_t)6 * n + st] = pw[n] * r[st];
+        pw[n + 1] = rho[(size_t)6 * n + 6];
+    }
+    const size_t T = step.size();
+    obs_rho.assign(T, 1.0);
+    for (size_t oi = 0; oi < T; oi++) {
+        double acc = 0.0;
+        for (int j = 0; j < 7; j++) acc = std::fma(w[oi * 7 + j], r[j], acc);
+        obs_rho[oi] = pw[step[oi]] * std::fma(z, acc, 1.0);
     }
 }
 
@@ -250,6 +288,16 @@ int32_t upload_tables(cude_ctx* c, bool glucose) {
     HIP_TRY(c->obs_w.resize(w.size()));
     HIP_TRY(hipMemcpyAsync(c->obs_step.p, step.data(), step.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->obs_w.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!glucose) {                          // suppression model: the closed-form Tsit5 factors of its first state
+        std::vector<double> rho, obs_rho;
+        linear_state_tables(c->cfg.n_steps, step_size(c), step, w, rho, obs_rho);
+        HIP_TRY(c->supp_rho.resize(rho.size()));
+        HIP_TRY(c->supp_obs_rho.resize(obs_rho.size()));
+        HIP_TRY(hipMemcpyAsync(c->supp_rho.p, rho.data(), rho.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->supp_obs_rho.p, obs_rho.data(), obs_rho.size() * sizeof(double), hipMemcpyHostToDevice,
+                               c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));          // rho / obs_rho die at the end of this block
+    }
     if (glucose) {
         std::vector<int32_t> seg;
         std::vector<double> phi;

@@ -121,6 +121,7 @@ struct cude_ctx {
     // tables
     cude::api::DevBuf<int32_t> seg, obs_step, stepk;
     cude::api::DevBuf<double> phi, obs_w, stepd, tp_dev;
+    cude::api::DevBuf<double> supp_rho, supp_obs_rho;   // SUPP, fixed step: state 1 per evaluation / observation relative to u1(t_0)
     double abstol = 1e-6, reltol = 1e-3;   // adaptive mode (n_steps == 0): OrdinaryDiffEq's defaults
     // parameters / gradients / optimiser
     cude::api::DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;

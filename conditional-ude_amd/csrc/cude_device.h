@@ -605,7 +605,7 @@ struct Mlp {
     // SIG_IN: the output unit's logistic derivative comes from the caller (kept by the forward sweep, CpepArgs::act);
     // neither the output pre-activation nor the softplus is evaluated (52 of ~375 instructions of a 2-6-6-1 reverse
     // evaluation) and the return value is 0
-    template <bool WANT_DX, class A, bool SIG_IN = false, bool PIN = kPinLayers>
+    template <bool WANT_DX, class A, bool SIG_IN = false, bool PIN = kPinLayers, int DX0 = 0>
     __device__ static __forceinline__ double eval_grad_pf(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                           double wgt, A& acc, double (&dx)[NV],
                                                           bool use_tab, const Exps* E1, double sig_in = 0.0) {
@@ -678,7 +678,7 @@ struct Mlp {
         }
         if (WANT_DX) {
 #pragma unroll
-            for (int i = 0; i < NV; i++) {
+            for (int i = DX0; i < NV; i++) {
                 CUDE_FENCE();
                 const SCol<W> col = ld_col<W>(p, W * i);
                 double s0 = 0.0, s1 = 0.0;
@@ -698,19 +698,20 @@ struct Mlp {
     // PIN: hidden-layer accumulators pinned behind their update (default: the network's own rule, kPinLayers; the adaptive
     // kernels ask for it -- their evaluation sits inside a conditional of the replay loop and, unpinned, every
     // accumulator is copied to another register at the end of it: 32 v_mov_b64 per evaluation of a 2-4-4-1 network)
-    template <bool WANT_DX, class A, bool PIN = kPinLayers>
+    // DX0: first input whose derivative is wanted (the suppression model's input 1 has no adjoint: cude_supp.hip)
+    template <bool WANT_DX, class A, bool PIN = kPinLayers, int DX0 = 0>
     __device__ static __forceinline__ double eval_grad(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                        double wgt, A& acc, double (&dx)[NV],
                                                        bool use_tab = false, const Exps* E1 = nullptr) {
 #ifndef CUDE_NO_PREFETCH
-        if constexpr (HAS_PF) return eval_grad_pf<WANT_DX, A, false, PIN>(p, c, x, wgt, acc, dx, use_tab, E1);
+        if constexpr (HAS_PF) return eval_grad_pf<WANT_DX, A, false, PIN, DX0>(p, c, x, wgt, acc, dx, use_tab, E1);
 #endif
         p = launder(p);
         double h[D][W];
         const double zo = forward(p, c, x, h, use_tab, E1);
         double sig;
         const double y = act_softplus<TT>(zo, &sig);
-        backward<WANT_DX, A, PIN>(p, x, h, sig, wgt, acc, dx);
+        backward<WANT_DX, A, PIN, DX0>(p, x, h, sig, wgt, acc, dx);
         return y;
     }
 
@@ -724,7 +725,7 @@ struct Mlp {
 
     // weighted reverse sweep from kept activations:  acc += wgt * d(out)/d(params);  if WANT_DX,
     // dx[i] += wgt * d(out)/dx_i
-    template <bool WANT_DX, class A, bool PIN = kPinLayers>
+    template <bool WANT_DX, class A, bool PIN = kPinLayers, int DX0 = 0>
     __device__ static __forceinline__ void backward(cptr_t p, const double (&x)[NV], const double (&h)[D][W], double sig,
                                                     double wgt, A& acc, double (&dx)[NV]) {
         const double dz = wgt * sig;
@@ -789,7 +790,7 @@ struct Mlp {
         }
         if (WANT_DX) {
 #pragma unroll
-            for (int i = 0; i < NV; i++) {
+            for (int i = DX0; i < NV; i++) {
                 CUDE_FENCE();
                 const SCol<W> col = ld_col<W>(p, W * i);
                 double s0 = 0.0, s1 = 0.0;

@@ -133,7 +133,8 @@ hipError_t launch_cpep2(const NetShape& net, int n_state, bool grad, const Cpep2
 
 // suppression cUDE (nonlinear: NN input is the state)
 // rows of N doubles in one parameter set's gradient scratch
-inline __host__ __device__ int64_t supp_ckpt_rows(int S, int T) { return (int64_t)(6 * S + 1) * 3 + 3 * (int64_t)T; }
+// (states 2 and 3 only: state 1 is parameter-independent and never stored, cude_supp.hip)
+inline __host__ __device__ int64_t supp_ckpt_rows(int S, int T) { return (int64_t)(6 * S + 1) * 2 + 2 * (int64_t)T; }
 
 struct SuppArgs {
     int64_t N;
@@ -145,10 +146,13 @@ struct SuppArgs {
     int32_t T, S;
     double h, inv_n;
     double iscale2[3];       // 1/scale_s^2
-    double* ckpt;            // [n_sets][supp_ckpt_rows][N]: [6S+1][3] stage inputs (linearisation points of the
-                             // reverse sweep), then [T][3] residuals
+    double* ckpt;            // [n_sets][supp_ckpt_rows][N]: [6S+1][2] stage inputs of states 2, 3 (linearisation points of
+                             // the reverse sweep), then [T][2] their residuals
+    const double* rho;       // [6S+1] fixed-step mode: state 1 at evaluation e = u1(t_0) * rho[e] (Tsit5 on du1 = -0.4 u1:
+                             // a constant of the step size alone), wave-uniform
+    const double* obs_rho;   // [T] ... and at observation oi = u1(t_0) * obs_rho[oi] (its dense output)
     double* act;             // [n_sets][6S+1][D*W+1][N] kept network activations, or nullptr = recompute them
-    int32_t ckpt_steps_only; // 1: ckpt holds only the step states [S+1][3][N]; the reverse sweep re-runs the stages
+    int32_t ckpt_steps_only; // 1: ckpt holds only the step states [S+1][2][N]; the reverse sweep re-runs the stages
     double* sse;             // [N] or nullptr (already divided by scale^2)
     double* traj;            // [3 x T x N] column-major or nullptr
     double* g_cond;          // [n_sets][N]

@@ -65,6 +65,7 @@ cude::SuppArgs supp_args(const cude_ctx* c) {
     a.N = c->N;
     a.data = c->data.p;
     a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;
+    a.rho = c->supp_rho.p; a.obs_rho = c->supp_obs_rho.p;
     a.T = c->T; a.S = c->cfg.n_steps; a.h = step_size(c); a.inv_n = 1.0 / c->n_global;
     for (int s = 0; s < 3; s++) a.iscale2[s] = 1.0 / (c->scale[s] * c->scale[s]);
     a.out_times = c->tp_dev.p;

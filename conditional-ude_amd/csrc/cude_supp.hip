@@ -7,10 +7,20 @@
 //   suppression_loss (+ its ForwardDiffSensitivity gradient)   :117-130, :155
 //
 // One lane = one subject.  The forward sweep stores the input of every stage evaluation (the
-// linearisation points Y_i, 3 doubles each, 6 per step) to an HBM scratch laid out
-// [evaluation][state][subject] (coalesced); the reverse sweep reloads them and applies the stage VJPs in
-// reverse order without recomputing the forward stages: 4.3 KB per subject of traffic
-// buys a third of the network evaluations (measured 2.32 -> 1.78 ms at 1e5 subjects).
+// linearisation points Y_i, 6 per step) to an HBM scratch laid out [evaluation][state][subject]
+// (coalesced); the reverse sweep reloads them and applies the stage VJPs in reverse order
+// without recomputing the forward stages: scratch traffic buys a third of the network evaluations
+// (measured 2.32 -> 1.78 ms at 1e5 subjects).
+//
+// State 1 obeys du1 = -0.4 u1 (suppression_model.jl:91): it depends on no parameter and on no other state.
+// Under fixed-step Tsit5 every stage input of it is u1(t_0) times a constant of the step size alone
+// (Y_st[1] = u1_n rho_st(-0.4 h), u1_{n+1} = u1_n R(-0.4 h): the tableau applied to a scalar linear equation), so
+//   * it is not carried through the Runge-Kutta sums: the stage input comes from a wave-uniform table
+//     SuppArgs::rho[evaluation] (one scalar load), the observation from SuppArgs::obs_rho[observation];
+//   * it has no adjoint at all: nothing that reaches d/d(network) or d/d(theta) passes through it (the VJP weight is
+//     kb[3] - kb[2]; the first-layer column of input 1 would only feed u1's own adjoint chain);
+//   * it is neither written to nor read from the scratch: 2 rows per evaluation instead of 3.
+// It is still an INPUT of the network (value and first-layer weight gradient use it) and still part of the loss.
 #include "cude_device.h"
 #include "cude_kernels.h"
 
@@ -19,50 +29,46 @@ namespace cude {
 template <int W, int D>
 struct SuppRhs {
     using Net = SuppNet<W, D>;
-    __device__ static __forceinline__ void f(cptr_t p, const double (&c)[W], const double (&u)[3], double (&du)[3]) {
+    // derivatives of states 2 and 3 (du[0], du[1]); u = (u1, u2, u3)
+    __device__ static __forceinline__ void f(cptr_t p, const double (&c)[W], const double (&u)[3], double (&du)[2]) {
         const double uh = Net::eval(p, c, u);
-        du[0] = -0.4 * u[0];
-        du[1] = fma(0.4, u[0], -uh);
-        du[2] = fma(-0.3, u[2], uh);
+        du[0] = fma(0.4, u[0], -uh);
+        du[1] = fma(-0.3, u[2], uh);
     }
-    // ub += J_f(u)^T kb ; acc += (df/dparams)^T kb
+    // (ub2, ub3) += rows 2, 3 of J_f(u)^T kb ; acc += (df/dparams)^T kb      [kb = (kb2, kb3): state 1 has no adjoint]
     template <class A>
     __device__ static __forceinline__ void vjp(cptr_t p, const double (&c)[W], const double (&u)[3],
-                                               const double (&kb)[3], double (&ub)[3], A& acc) {
-        const double wgt = kb[2] - kb[1];
+                                               const double (&kb)[2], double (&ub)[2], A& acc) {
+        const double wgt = kb[1] - kb[0];
         double dx[3] = {0.0, 0.0, 0.0};
-        Net::template eval_grad<true>(p, c, u, wgt, acc, dx);
-        ub[0] += fma(-0.4, kb[0], fma(0.4, kb[1], dx[0]));
-        ub[1] += dx[1];
-        ub[2] += fma(-0.3, kb[2], dx[2]);
+        Net::template eval_grad<true, A, Net::kPinLayers, 1>(p, c, u, wgt, acc, dx);
+        ub[0] += dx[1];
+        ub[1] += fma(-0.3, kb[1], dx[2]);
     }
     // the same pair with the network activations kept by the forward sweep instead of recomputed in the reverse one
-    __device__ static __forceinline__ void f_keep(cptr_t p, const double (&c)[W], const double (&u)[3], double (&du)[3],
+    __device__ static __forceinline__ void f_keep(cptr_t p, const double (&c)[W], const double (&u)[3], double (&du)[2],
                                                   double (&h)[D][W], double* sig) {
         const double uh = Net::eval_keep(p, c, u, h, sig);
-        du[0] = -0.4 * u[0];
-        du[1] = fma(0.4, u[0], -uh);
-        du[2] = fma(-0.3, u[2], uh);
+        du[0] = fma(0.4, u[0], -uh);
+        du[1] = fma(-0.3, u[2], uh);
     }
     template <class A>
     __device__ static __forceinline__ void vjp_kept(cptr_t p, const double (&u)[3], const double (&h)[D][W], double sig,
-                                                    const double (&kb)[3], double (&ub)[3], A& acc) {
-        const double wgt = kb[2] - kb[1];
+                                                    const double (&kb)[2], double (&ub)[2], A& acc) {
+        const double wgt = kb[1] - kb[0];
         double dx[3] = {0.0, 0.0, 0.0};
-        Net::template backward<true>(launder(p), u, h, sig, wgt, acc, dx);
-        ub[0] += fma(-0.4, kb[0], fma(0.4, kb[1], dx[0]));
-        ub[1] += dx[1];
-        ub[2] += fma(-0.3, kb[2], dx[2]);
+        Net::template backward<true, A, Net::kPinLayers, 1>(launder(p), u, h, sig, wgt, acc, dx);
+        ub[0] += dx[1];
+        ub[1] += fma(-0.3, kb[1], dx[2]);
     }
 };
 
-// LDS rows of kBlock doubles (one per lane):
-//   s_K [7][3]  stage derivatives k_i (forward) / their adjoints (reverse); after the time loops: reduction scratch
-//   s_Y [7][3]  stage inputs Y_i of the step being reversed (YONLY only)
-// 10.5 KB per wave (21 KB in the step-state mode).  The residuals kept for the reverse sweep (3T doubles per subject)
-// live behind the stage inputs in the HBM scratch, not in LDS: with them the kernel needed 33 KB per wave = 4 waves
-// per CU whatever its register count.
-constexpr int kSuppRowsK = 21;
+// LDS rows of kBlock doubles (one per lane), states 2 and 3 only:
+//   s_K [7][2]  stage derivatives k_i (forward) / their adjoints (reverse); after the time loops: reduction scratch
+//   s_Y [7][2]  stage inputs Y_i of the step being reversed (YONLY only)
+// 7 KB per wave (14 KB in the step-state mode; never less than the kRedRows the final reduction needs).  The residuals
+// kept for the reverse sweep (2T doubles per subject) live behind the stage inputs in the HBM scratch, not in LDS.
+constexpr int kSuppRowsK = 14 > kRedRows ? 14 : kRedRows;
 
 // accumulator container per network shape: registers while they fit next to two resident waves, split otherwise
 // (round 3: with the accumulator updates pinned behind their FMAs -- AccPin, cude_device.h -- the reference's 4-3x5-1
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
     extern __shared__ double smem[];
     double* s_K = smem;
     double* s_Y = smem + kSuppRowsK * kBlock;
-    double* s_S = smem + kSuppRowsK * (YONLY ? 2 : 1) * kBlock;     // [9] cold adjoint state of the reverse sweep
+    double* s_S = smem + kSuppRowsK * (YONLY ? 2 : 1) * kBlock;     // [6] cold adjoint state of the reverse sweep
     double* s_red = s_K;
 
     const int lane = threadIdx.x;
@@ -126,18 +132,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
     const int64_t set = blockIdx.y;      // multi-start screening: one parameter set per grid row
     cptr_t p = as_const(a.nn + set * a.set_stride_nn);
     cptr_t obs_w = as_const(a.obs_w);
+    cptr_t rho = as_const(a.rho);
+    cptr_t obs_rho = as_const(a.obs_rho);
     ciptr_t obs_step = as_const(a.obs_step);
     const int S = a.S, T = a.T;
     const double h = a.h;
     double* ckpt = GRAD ? a.ckpt + set * (supp_ckpt_rows(S, T) * N) : nullptr;        // one scratch per parameter set
-    double* res = GRAD ? ckpt + (int64_t)(6 * S + 1) * 3 * N : nullptr;               // [T][3][N] residuals
+    double* res = GRAD ? ckpt + (int64_t)(6 * S + 1) * 2 * N : nullptr;               // [T][2][N] residuals of states 2, 3
     constexpr int NACT = D * W + 1;
     double* act = STORE ? a.act + set * ((int64_t)(6 * S + 1) * NACT * N) : nullptr;
-#define KROW(j, s) s_K[((j) * 3 + (s)) * kBlock + lane]
-#define YROW(j, s) s_Y[((j) * 3 + (s)) * kBlock + lane]
+    // rows of states 2 and 3 (s = 0, 1 below): state 1 is a table lookup (header comment)
+#define KROW(j, s) s_K[((j) * 2 + (s)) * kBlock + lane]
+#define YROW(j, s) s_Y[((j) * 2 + (s)) * kBlock + lane]
 #define LAM(s) s_S[(s) * kBlock + lane]           /* adjoint of y_{n+1} */
-#define KAP(s) s_S[(3 + (s)) * kBlock + lane]     /* adjoint of k_7 of step n from step n+1's use as k_1 */
-#define YB(s) s_S[(6 + (s)) * kBlock + lane]      /* adjoint of y_n being assembled */
+#define KAP(s) s_S[(2 + (s)) * kBlock + lane]     /* adjoint of k_7 of step n from step n+1's use as k_1 */
+#define YB(s) s_S[(4 + (s)) * kBlock + lane]      /* adjoint of y_n being assembled */
 
     double cst[1] = {exp(a.cond[set * a.set_stride_cond + i])};
     double c[W];
@@ -146,52 +155,54 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
 #pragma unroll
     for (int j = 0; j < 7; j++)
 #pragma unroll
-        for (int s = 0; s < 3; s++) KROW(j, s) = 0.0;
+        for (int s = 0; s < 2; s++) KROW(j, s) = 0.0;
 
-    double y[3];
+    const double u10 = a.data[((int64_t)0 * T + 0) * N + i];     // u1(t_0): every later u1 is this times a table entry
+    double y[2];
 #pragma unroll
-    for (int s = 0; s < 3; s++) y[s] = a.data[((int64_t)s * T + 0) * N + i];
+    for (int s = 0; s < 2; s++) y[s] = a.data[((int64_t)(s + 1) * T + 0) * N + i];
 
     // ------------------------------------------------------------------ forward
     // One network call site: evaluation e = 0 is k_1 of step 0; e = 6n+st (st = 1..6) is stage
     // st+1 of step n (st = 6: k_7 = f(y_{n+1}), reused as k_1 of the next step).
-    double sse = fma(cst[0], 0.0, Net::param_check(p));   // NaN iff a parameter / theta is non-finite
+    double sse = fma(cst[0] + u10, 0.0, Net::param_check(p));   // NaN iff a parameter / theta / u1(t_0) is non-finite
     int oi = 0, n = 0, st = 0;
     if constexpr (Net::USES_TANH) tanh_tab_init(lane, !Net::LDS_BIAS);    // (here: its global read travels with the subject's own loads)
     Net::bias_init(a.nn + set * a.set_stride_nn, lane);
 #pragma unroll 1
     for (int e = 0; e <= 6 * S; e++) {
         double u[3];
+        u[0] = u10 * rho[e];
         if (st == 0) {
 #pragma unroll
-            for (int s = 0; s < 3; s++) u[s] = y[s];
+            for (int s = 0; s < 2; s++) u[1 + s] = y[s];
         } else {
             // all six stage rows and the (zero-padded) tableau row at once: one LDS and one scalar round trip per
             // evaluation instead of one pair per earlier stage
-            double kk[6][3], aj[6];
+            double kk[6][2], aj[6];
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 aj[j] = TS_A[st][j];
 #pragma unroll
-                for (int s = 0; s < 3; s++) kk[j][s] = KROW(j, s);
+                for (int s = 0; s < 2; s++) kk[j][s] = KROW(j, s);
             }
-            double t[3] = {0.0, 0.0, 0.0};
+            double t[2] = {0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < 6; j++)
 #pragma unroll
-                for (int s = 0; s < 3; s++) t[s] = fma(aj[j], kk[j][s], t[s]);
+                for (int s = 0; s < 2; s++) t[s] = fma(aj[j], kk[j][s], t[s]);
 #pragma unroll
-            for (int s = 0; s < 3; s++) u[s] = fma(h, t[s], y[s]);
+            for (int s = 0; s < 2; s++) u[1 + s] = fma(h, t[s], y[s]);
         }
         if (GRAD && !YONLY) {      // linearisation point of evaluation e = 6n+st, reloaded by the reverse sweep
 #pragma unroll
-            for (int s = 0; s < 3; s++) ckpt[((int64_t)e * 3 + s) * N + i] = u[s];
+            for (int s = 0; s < 2; s++) ckpt[((int64_t)e * 2 + s) * N + i] = u[1 + s];
         }
         if (GRAD && YONLY && (e == 0 || st == 6)) {     // step states only: y_0, then y_{n+1} at the end of step n
 #pragma unroll
-            for (int s = 0; s < 3; s++) ckpt[((int64_t)(e == 0 ? 0 : n + 1) * 3 + s) * N + i] = u[s];
+            for (int s = 0; s < 2; s++) ckpt[((int64_t)(e == 0 ? 0 : n + 1) * 2 + s) * N + i] = u[1 + s];
         }
-        double du[3];
+        double du[2];
         if (STORE) {
             double hk[D][W], sg;
             R::f_keep(p, c, u, du, hk, &sg);
@@ -205,30 +216,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
             R::f(p, c, u, du);
         }
 #pragma unroll
-        for (int s = 0; s < 3; s++) KROW(st, s) = du[s];
+        for (int s = 0; s < 2; s++) KROW(st, s) = du[s];
         if (e == 0) { st = 1; continue; }
         if (st < 6) { st++; continue; }
         // ---- end of step n: u = y_{n+1}, KROW(6) = k_7
         while (oi < T && obs_step[oi] == n) {
-            double o[3] = {0.0, 0.0, 0.0};
+            double o[2] = {0.0, 0.0};
 #pragma unroll 1
             for (int j = 0; j < 7; j++) {
                 const double w = obs_w[oi * 7 + j];
 #pragma unroll
-                for (int s = 0; s < 3; s++) o[s] = fma(w, KROW(j, s), o[s]);
+                for (int s = 0; s < 2; s++) o[s] = fma(w, KROW(j, s), o[s]);
+            }
+            {   // state 1 at the observation: the dense output of the scalar linear equation, from the table
+                const double ov = u10 * obs_rho[oi];
+                const double r = ov - a.data[((int64_t)0 * T + oi) * N + i];
+                sse = fma(r * a.iscale2[0], r, sse);
+                if (a.traj != nullptr && active) a.traj[0 + 3 * (oi + (int64_t)T * i)] = ov;
             }
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
+            for (int s = 0; s < 2; s++) {
                 const double ov = fma(h, o[s], y[s]);
-                const double r = ov - a.data[((int64_t)s * T + oi) * N + i];
-                sse = fma(r * a.iscale2[s], r, sse);
-                if (GRAD) res[(int64_t)(oi * 3 + s) * N + i] = r;
-                if (a.traj != nullptr && active) a.traj[s + 3 * (oi + (int64_t)T * i)] = ov;
+                const double r = ov - a.data[((int64_t)(s + 1) * T + oi) * N + i];
+                sse = fma(r * a.iscale2[s + 1], r, sse);
+                if (GRAD) res[(int64_t)(oi * 2 + s) * N + i] = r;
+                if (a.traj != nullptr && active) a.traj[(s + 1) + 3 * (oi + (int64_t)T * i)] = ov;
             }
             oi++;
         }
 #pragma unroll
-        for (int s = 0; s < 3; s++) { y[s] = u[s]; KROW(0, s) = du[s]; }
+        for (int s = 0; s < 2; s++) { y[s] = u[1 + s]; KROW(0, s) = du[s]; }
         st = 1;
         n++;
     }
@@ -248,13 +265,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
         // them all (measured at 1e5 subjects, 4-3x5-1: 1.563 -> 1.506 ms; also moving the last hidden layer's, which are
         // updated while the next weight group is in flight, costs more than it frees: 1.85 ms)
         typename SuppAcc<Net>::type acc;
-        SuppAcc<Net>::init(acc, s_S + 9 * kBlock + lane);
+        SuppAcc<Net>::init(acc, s_S + 6 * kBlock + lane);
 #pragma unroll
         for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
-        // lam / kap / yb are touched once per evaluation or per step: they live in LDS (there is room -- one wave per
-        // SIMD -- and every VGPR saved is one less accumulator shuttled through the AGPRs)
+        // lam / kap / yb are touched once per evaluation or per step: they live in LDS (every VGPR saved is one less
+        // accumulator shuttled through the AGPRs)
 #pragma unroll
-        for (int s = 0; s < 3; s++) { LAM(s) = 0.0; KAP(s) = 0.0; YB(s) = 0.0; }
+        for (int s = 0; s < 2; s++) { LAM(s) = 0.0; KAP(s) = 0.0; YB(s) = 0.0; }
         const double gs = 2.0 * a.inv_n;
         oi = T - 1;
         n = S - 1;
@@ -264,42 +281,43 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
         // stage inputs of the NEXT evaluation are requested one evaluation ahead: each is an HBM round trip that the
         // evaluation would otherwise start with (evaluation 0's input y_0 is row 0 of the same scratch)
         constexpr bool kAhead = !YONLY && !STORE;       // (with kept activations the extra live registers cost more)
-        double un[3] = {0.0, 0.0, 0.0};
+        double un[2] = {0.0, 0.0};
         if (kAhead) {
 #pragma unroll
-            for (int s = 0; s < 3; s++) un[s] = ckpt[((int64_t)(6 * S) * 3 + s) * N + i];
+            for (int s = 0; s < 2; s++) un[s] = ckpt[((int64_t)(6 * S) * 2 + s) * N + i];
         }
 #pragma unroll 1
         for (int idx = 6 * S; idx >= 0; idx--) {
             if (YONLY && idx > 0 && st == 6) {
                 // ---- re-run stages 1..6 of step n from y_n: their inputs Y_0..Y_5 and Y_6 = y_{n+1} go to s_Y
-                double yn[3];
+                double yn[2];
 #pragma unroll
-                for (int s = 0; s < 3; s++) yn[s] = ckpt[((int64_t)n * 3 + s) * N + i];
+                for (int s = 0; s < 2; s++) yn[s] = ckpt[((int64_t)n * 2 + s) * N + i];
 #pragma unroll 1
                 for (int sq = 0; sq <= 6; sq++) {
                     double uu[3];
+                    uu[0] = u10 * rho[6 * n + sq];      // (sq = 0: y_n, the input of evaluation 6n)
                     if (sq == 0) {
 #pragma unroll
-                        for (int s = 0; s < 3; s++) uu[s] = yn[s];
+                        for (int s = 0; s < 2; s++) uu[1 + s] = yn[s];
                     } else {
-                        double t[3] = {0.0, 0.0, 0.0};
+                        double t[2] = {0.0, 0.0};
 #pragma unroll 1
                         for (int j = 0; j < sq; j++) {
                             const double aj = TS_A[sq][j];
 #pragma unroll
-                            for (int s = 0; s < 3; s++) t[s] = fma(aj, KROW(j, s), t[s]);
+                            for (int s = 0; s < 2; s++) t[s] = fma(aj, KROW(j, s), t[s]);
                         }
 #pragma unroll
-                        for (int s = 0; s < 3; s++) uu[s] = fma(h, t[s], yn[s]);
+                        for (int s = 0; s < 2; s++) uu[1 + s] = fma(h, t[s], yn[s]);
                     }
 #pragma unroll
-                    for (int s = 0; s < 3; s++) YROW(sq, s) = uu[s];
+                    for (int s = 0; s < 2; s++) YROW(sq, s) = uu[1 + s];
                     if (sq == 6) break;
-                    double dd[3];
+                    double dd[2];
                     R::f(p, c, uu, dd);
 #pragma unroll
-                    for (int s = 0; s < 3; s++) KROW(sq, s) = dd[s];
+                    for (int s = 0; s < 2; s++) KROW(sq, s) = dd[s];
                 }
             }
             if (idx > 0 && st == 6) {
@@ -307,15 +325,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
 #pragma unroll 1
                 for (int j = 0; j < 6; j++) {
 #pragma unroll
-                    for (int s = 0; s < 3; s++) KROW(j, s) = 0.0;
+                    for (int s = 0; s < 2; s++) KROW(j, s) = 0.0;
                 }
 #pragma unroll
-                for (int s = 0; s < 3; s++) { KROW(6, s) = KAP(s); YB(s) = 0.0; }
+                for (int s = 0; s < 2; s++) { KROW(6, s) = KAP(s); YB(s) = 0.0; }
                 while (oi >= 0 && obs_step[oi] == n) {
-                    double hg[3];
+                    double hg[2];
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
-                        const double g = gs * a.iscale2[s] * res[(int64_t)(oi * 3 + s) * N + i];
+                    for (int s = 0; s < 2; s++) {
+                        const double g = gs * a.iscale2[s + 1] * res[(int64_t)(oi * 2 + s) * N + i];
                         YB(s) += g;
                         hg[s] = h * g;
                     }
@@ -323,32 +341,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
                     for (int j = 0; j < 7; j++) {
                         const double w = obs_w[oi * 7 + j];
 #pragma unroll
-                        for (int s = 0; s < 3; s++) KROW(j, s) = fma(w, hg[s], KROW(j, s));
+                        for (int s = 0; s < 2; s++) KROW(j, s) = fma(w, hg[s], KROW(j, s));
                     }
                     oi--;
                 }
             }
-            double u[3], kb[3], ub[3];
+            double u[3], kb[2], ub[2];
+            u[0] = u10 * rho[idx];
             if (idx > 0) {
 #pragma unroll
-                for (int s = 0; s < 3; s++) {
-                    u[s] = YONLY ? YROW(st, s) : (kAhead ? un[s] : ckpt[((int64_t)idx * 3 + s) * N + i]);
+                for (int s = 0; s < 2; s++) {
+                    u[1 + s] = YONLY ? YROW(st, s) : (kAhead ? un[s] : ckpt[((int64_t)idx * 2 + s) * N + i]);
                     kb[s] = KROW(st, s);
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < 3; s++) { u[s] = kAhead ? un[s] : a.data[((int64_t)s * T + 0) * N + i]; kb[s] = KAP(s); }
+                for (int s = 0; s < 2; s++) {
+                    u[1 + s] = kAhead ? un[s] : a.data[((int64_t)(s + 1) * T + 0) * N + i];
+                    kb[s] = KAP(s);
+                }
             }
             if (kAhead && idx > 0) {
 #pragma unroll
-                for (int s = 0; s < 3; s++) un[s] = ckpt[((int64_t)(idx - 1) * 3 + s) * N + i];
+                for (int s = 0; s < 2; s++) un[s] = ckpt[((int64_t)(idx - 1) * 2 + s) * N + i];
             }
             if (idx > 0 && st == 6) {
 #pragma unroll
-                for (int s = 0; s < 3; s++) ub[s] = LAM(s);     // stage 7 adds into the adjoint of y_{n+1}
+                for (int s = 0; s < 2; s++) ub[s] = LAM(s);     // stage 7 adds into the adjoint of y_{n+1}
             } else {
 #pragma unroll
-                for (int s = 0; s < 3; s++) ub[s] = 0.0;
+                for (int s = 0; s < 2; s++) ub[s] = 0.0;
             }
             if (STORE) {
                 double hk[D][W];
@@ -364,19 +386,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
             if (idx == 0) break;
             // propagate ub through  Y_st = y_n + h sum_{j<st} a(st,j) k_j
 #pragma unroll
-            for (int s = 0; s < 3; s++) YB(s) += ub[s];
+            for (int s = 0; s < 2; s++) YB(s) += ub[s];
             const int nj = st < 6 ? st : 6;
 #pragma unroll 1
             for (int j = 0; j < nj; j++) {
                 const double aj = h * TS_A[st][j];
 #pragma unroll
-                for (int s = 0; s < 3; s++) KROW(j, s) = fma(aj, ub[s], KROW(j, s));
+                for (int s = 0; s < 2; s++) KROW(j, s) = fma(aj, ub[s], KROW(j, s));
             }
             if (st > 1) {
                 st--;
             } else {
 #pragma unroll
-                for (int s = 0; s < 3; s++) { LAM(s) = YB(s); KAP(s) = KROW(0, s); }
+                for (int s = 0; s < 2; s++) { LAM(s) = YB(s); KAP(s) = KROW(0, s); }
                 st = 6;
                 n--;
             }
@@ -397,7 +419,8 @@ template <int W, int D, bool GRAD, bool STORE, bool YONLY = false>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(kSuppRowsK * (YONLY ? 2 : 1) +
-                                                 (GRAD ? 9 + SuppAcc<SuppNet<W, D>>::rows : 0)) * kBlock;
+                                                 (GRAD ? 6 + SuppAcc<SuppNet<W, D>>::rows : 0)) * kBlock;
+    if (a.rho == nullptr || a.obs_rho == nullptr) return hipErrorInvalidValue;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE, YONLY>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
@@ -409,7 +432,7 @@ static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
 template <int W, int D>
 static int supp_grad_occupancy() {
     int n = 0;
-    const size_t lds = sizeof(double) * (size_t)(kSuppRowsK + 9 + SuppAcc<SuppNet<W, D>>::rows) * kBlock;
+    const size_t lds = sizeof(double) * (size_t)(kSuppRowsK + 6 + SuppAcc<SuppNet<W, D>>::rows) * kBlock;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, supp_kernel<W, D, true, false, false>, kBlock, lds) != hipSuccess)
         return 0;
     return n;

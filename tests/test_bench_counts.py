@@ -27,37 +27,55 @@ def test_algorithmic_bytes():
     assert b.supp_algo_bytes(8, False) == 200 + 8
 
 
-def test_executed_flops_of_the_headline_kernel():
+def test_executed_operations_of_the_kernels():
+    """Round 4: the tally keeps three classes apart -- FMAs, other floating-point arithmetic (add, mul, rcp), and VALU
+    instructions that do no floating-point work (clamps, rounding / conversion, ldexp, selects, sign transfer).  Only the
+    first two form `flops_per_trajectory`; rounds 1-3 had counted every single-slot instruction as one flop (178 973 for
+    the headline kernel, of which 10 173 were not floating-point operations)."""
     b = _bench()
     w, d, S, T = 6, 2, 30, 5
-    # one network evaluation as executed (cude_math.h): per tanh neuron 7 single-flop ops + 13 FMAs, per layer one shared
-    # reciprocal (rcp + 3 FMAs) and 3 (W - 1) prefix / back-substitution multiplies; softplus 23 FMAs + 22 other ops
-    # (round 3: the atanh polynomial of the logarithm is a degree-7 interpolant, 8 FMAs instead of 11)
-    tanh_layer = w * (7 + 26) + 7 + 3 * (w - 1)
-    fwd = 2 * (w * 1 + w * w + w) + d * tanh_layer + (23 * 2 + 22)
-    assert b.mlp_flops(1, w, d) == (fwd, (2 * w + w + 2) + w * (4 + 4 * w) + w * (4 + 2))
-    assert fwd == 604
+    O = b.Ops
+    # the pieces (cude_math.h): reciprocal, exponential, one tanh neuron in either form, softplus
+    assert (b.RCP.fma, b.RCP.fp1, b.RCP.other) == (3, 1, 0)
+    assert (b.EXP2X.fma, b.EXP2X.fp1, b.EXP2X.other) == (12, 1, 3)
+    assert b.TANH_EXP_NEURON.slots == 20 and b.TANH_EXP_NEURON.flops == 2 * 13 + 2       # 13 FMAs, mul, add; 5 others
+    assert b.TANH_TAB_NEURON.slots == 15 and b.TANH_TAB_NEURON.flops == 2 * 3 + 9
+    assert (b.SOFTPLUS.fma, b.SOFTPLUS.fp1, b.SOFTPLUS.other) == (23, 17, 15)
+    assert (b.SOFTPLUS_VALUE_ONLY.fma, b.SOFTPLUS_VALUE_ONLY.fp1, b.SOFTPLUS_VALUE_ONLY.other) == (8, 8, 5)
+    # one evaluation of the headline network 2-6-6-1 (one varying input): 48 FMAs of the linear maps, two tanh layers
+    # with one reciprocal each, the softplus; backward: output unit, one hidden layer, the first layer
+    fwd, bwd = b.mlp_ops(1, w, d)
+    lin = w * 1 + w * w + w
+    assert fwd.fma == lin + d * (w * 13 + 3) + 23 == 233
+    assert fwd.fp1 == d * (w * 2 + 1 + 3 * (w - 1)) + 17 == 73 and fwd.other == d * w * 5 + 15 == 75
+    assert (bwd.fma, bwd.fp1, bwd.other) == (w + (w + 2 * w * w) + 2 * w, (w + 2) + (2 * w + w) + 2 * w, 0) == (96, 38, 0)
+    assert b.mlp_flops(1, w, d) == (fwd.flops, bwd.flops) == (539, 230)
     # table bookkeeping of the headline grid: 30 steps over 4 glucose pieces of 7.5 steps: 2 straddle a knot (steps 7, 22),
     # step 15 starts exactly on one: 28 steps inside a piece, in 4 runs
     assert b.table_steps(S, T) == (28, 4)
-    assert b.cpep_flops() == 178973                                  # the figure quoted in DESIGN.md / profiles
-    # without the layer-1 table the same kernel would execute the round-1 count
+    head = b.cpep_ops()
+    assert (head.fma, head.fp1, head.other) == (70460, 27880, 17959)
+    assert b.cpep_flops() == head.flops == 168800                    # the figure quoted in DESIGN.md / profiles
+    assert head.slots == 116299                                      # structural; SQ_INSTS_VALU / SQ_WAVES measures ~128.8 k
+    # without the layer-1 table every evaluation pays its W exponentials and first-layer FMAs
     n_eval = 5 * S + 1
-    # (the reverse sweep's re-evaluation never executes the value-only part of the softplus: 8 FMAs + 9 single ops)
-    assert b.SOFTPLUS_VALUE_ONLY_FLOPS == 25
-    plain = n_eval * (2 * fwd - 25 + b.mlp_flops(1, w, d)[1]) + S * (2 * (2 * 21 + 2 * 6 + 7 * 4) + 12 + 2 * (2 * 21 + 6 * 4 + 12) + 12) \
-        + 2 * T * (2 * 3 * 7 + 8)
-    assert plain == 223277                                          # (rounds 1 / 2 counted 228 864: longer series, value part twice)
-    saved_per_eval, per_run = w * (7 + 26) + 2 * w - 3 * w, 6 * w * (6 + 24) + 10 * w
-    assert plain - b.cpep_flops() == 2 * (5 * 28 * saved_per_eval - 4 * per_run - 28 * w)
-    # forward-only and the 2-state / width-4 instances scale as their structure says
+    plain = n_eval * (fwd + fwd - b.SOFTPLUS_VALUE_ONLY + bwd) \
+        + S * (O(fma=2 * 21 + 2 * 6 + 7 * 4 + 6) + O(fma=2 * 21 + 6 * 4 + 12, fp1=12)) + 2 * T * O(fma=3 * 7, fp1=8)
+    saved = w * (b.EXP2X + O(fp1=1, other=1) + O(fma=1)) - w * O(fp1=2, other=1)
+    per_run = 6 * w * b.EXP2X + w * O(fp1=5, other=5)
+    diff = plain - head
+    want = 2 * (5 * 28 * saved - 4 * per_run - 28 * O(fp1=w))
+    assert (diff.fma, diff.fp1, diff.other) == (want.fma, want.fp1, want.other)
     assert b.cpep_flops(grad=False) < 0.45 * b.cpep_flops()
-    # round 3: the width-4 c-peptide kernels and the suppression kernel evaluate tanh by table + addition theorem
-    # (18 flops per neuron instead of 33): 2 x 151 evaluations x 2 layers x 4 neurons x 15 fewer, resp. 2 x 181 x 5 x 3 x 15
-    assert b.mlp_flops(1, 4, 2, table_tanh=True)[0] == b.mlp_flops(1, 4, 2)[0] - 2 * 4 * 15
-    exp_form = b.cpep_flops((2, 4, 2), S, T, 2, True) + 2 * 151 * 2 * 4 * 15
-    assert b.cpep_flops((2, 4, 2), S, T, 2, True) == 112547 and exp_form == 154374 - 151 * (2 * 6 + 25)
-    assert b.supp_flops((4, 3, 5), S, 8, True) == 322853 - 2 * 181 * 5 * 3 * 15 - 181 * (2 * 6 + 25) == 234706
+    # the width-4 c-peptide kernels and the suppression kernel evaluate tanh by table + addition theorem
+    assert b.mlp_ops(1, 4, 2, table_tanh=True)[0].flops == b.mlp_ops(1, 4, 2)[0].flops - 2 * 4 * (28 - 15)
+    assert b.cpep_flops((2, 4, 2), S, T, 2, True) == 104544
+    # suppression kernel, round 4: state 1 is a table lookup (one multiply per evaluation), the Runge-Kutta algebra and
+    # the adjoint are those of two states, the first layer's input derivative is formed for two inputs
+    supp = b.supp_ops((4, 3, 5), S, 8, True)
+    assert (supp.fma, supp.fp1, supp.other) == (69026, 76478, 20815) and b.supp_flops((4, 3, 5), S, 8, True) == 214530
+    f3, b3 = b.mlp_ops(3, 3, 5, 2, table_tanh=True)
+    assert f3.slots == 378 and (b3.fma, b3.fp1) == (105, 51)        # (the forward loop body of the ISA: 381 VALU instructions)
 
 
 def test_kernel_source_digest_matches_the_committed_pmc_record():
@@ -77,11 +95,15 @@ def test_kernel_source_digest_matches_the_committed_pmc_record():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r03/bench_final.json is the line bench.py printed on the round's final sources: every contract field is
+    """profiles/r04/bench_final.json is the line bench.py printed on the round's final sources: every contract field is
     there, the roofline objects are self-consistent, and the counted figures are the ones this file pins."""
     import json
+    import pytest
     b = _bench()
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench_final.json")))
+    path = os.path.join(ROOT, "profiles", "r04", "bench_final.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-4 bench line committed yet")
+    d = json.load(open(path))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -97,6 +119,11 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.3
     v = d["roofline_valu"]
     assert v["flops_per_trajectory"] == b.cpep_flops() and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-12
+    assert v["counted"]["valu_slots_per_trajectory"] == b.cpep_ops().slots
+    assert 2 * v["counted"]["fma"] + v["counted"]["other_fp_ops"] == v["flops_per_trajectory"]
+    if v["valu_slot_utilisation"] is not None:
+        assert 0.5 < v["valu_slot_utilisation"] < 1.0 and v["valu_instructions_per_wave"] >= v["counted"]["valu_slots_per_trajectory"]
+    assert d["launch_mode"].startswith("plain+events")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 100 * c["value"]
