@@ -13,9 +13,12 @@
 // Gradient of the adaptive solve = what the reference's AutoForwardDiff computes (src/parameter-estimation.jl:165,
 // suppression_model.jl:155): under ForwardDiff only p = theta carries partials, tspan and dt stay Float64, so the
 // derivative is that of the accepted step sequence as fixed arithmetic (controller and initial-step heuristic are not
-// differentiated).  Here: the forward sweep writes (t_n, dt_n, y_n) of every accepted step to a per-subject tape in
-// HBM ([step][2 + NS][subject], coalesced); the reverse sweep walks the tape backwards, re-runs the seven stage
-// evaluations of the step and applies their VJPs in reverse order, including the `saveat` interpolation weights of the
+// differentiated).  Here: the forward sweep writes every accepted step to a per-subject tape in HBM ([step][rows]
+// [subject], coalesced) -- (t_n, dt_n, y_n) for the suppression model, whose reverse sweep re-runs the stage evaluations
+// from y_n; dt_n ALONE (8 B per step) for the c-peptide models, whose Jacobian is constant: their reverse sweep needs
+// the stage TIMES only and steps back from the final time, t_n = t_{n+1} - dt_n (within an ulp of the forward sweep's
+// t_n: the forward sum is not exactly invertible; 1e-16 relative in a network input) -- and the reverse sweep walks the
+// tape backwards and applies the stage VJPs in reverse order, including the `saveat` interpolation weights of the
 // observations that fell into the step.  (OrdinaryDiffEq's error norm under duals also weighs the partials -- its
 // documented behaviour -- so the reference's accepted steps during a gradient call can differ from those of a plain
 // solve; the sequence here is the plain solve's.)  Lanes with more accepted steps than the tape holds fail (+Inf).
@@ -253,7 +256,7 @@ void adaptive_kernel(typename M::Args a) {
     constexpr int NS = M::NS;
     constexpr int P = M::P;
     constexpr int KROWS = 7 * NS > kRedRows ? 7 * NS : kRedRows;
-    constexpr int TROWS = 2 + NS;                  // tape entry: t_n, dt_n, y_n
+    constexpr int TROWS = M::NEED_Y ? 2 + NS : 1;  // tape entry: t_n, dt_n, y_n -- or dt_n alone (constant Jacobian)
     extern __shared__ double smem[];
     double* s_K = smem;
     double* s_B = smem + KROWS * kBlock;
@@ -277,10 +280,14 @@ void adaptive_kernel(typename M::Args a) {
 #define OUTV(oi) tape[((int64_t)a.tape_cap * TROWS + (oi)) * a.N]     /* saved output (state 1) behind the steps */
     int n_acc = 0;
     if (GRAD) {                                    // entry 0 always holds finite numbers (parked lanes read it)
-        TAPE(0, 0) = a.t_begin;
-        TAPE(0, 1) = 0.0;
+        if constexpr (M::NEED_Y) {
+            TAPE(0, 0) = a.t_begin;
+            TAPE(0, 1) = 0.0;
 #pragma unroll
-        for (int s = 0; s < NS; s++) TAPE(0, 2 + s) = y[s];
+            for (int s = 0; s < NS; s++) TAPE(0, 2 + s) = y[s];
+        } else {
+            TAPE(0, 0) = 0.0;
+        }
     }
     const double abstol = a.abstol, reltol = a.reltol;
     const double t0 = a.t_begin, t1 = a.t_end;
@@ -439,15 +446,20 @@ void adaptive_kernel(typename M::Args a) {
         }
         if (GRAD && live && !failed && accept) {
             if (n_acc < a.tape_cap) {
-                TAPE(n_acc, 0) = t;
-                TAPE(n_acc, 1) = dt;
+                if constexpr (M::NEED_Y) {
+                    TAPE(n_acc, 0) = t;
+                    TAPE(n_acc, 1) = dt;
 #pragma unroll
-                for (int s = 0; s < NS; s++) TAPE(n_acc, 2 + s) = y[s];
+                    for (int s = 0; s < NS; s++) TAPE(n_acc, 2 + s) = y[s];
+                } else {
+                    TAPE(n_acc, 0) = dt;
+                }
                 n_acc++;
             } else {
                 failed = true;                    // more accepted steps than the tape holds
             }
         }
+        if (!GRAD && live && !failed && accept) n_acc++;      // (forward launches report the count too: cude_adaptive_regroup)
         if (live && !failed) {
             if (accept) {
 #ifndef CUDE_ADAPT_POW
@@ -478,6 +490,7 @@ void adaptive_kernel(typename M::Args a) {
     if (active && a.sse != nullptr) a.sse[set * a.set_stride_cond + i] = sse;
     double* out = a.partials + ((int64_t)set * gridDim.x + blockIdx.x) * (P + 2);
     if constexpr (!GRAD) {
+        if (active && a.tape_n != nullptr && set == 0) a.tape_n[i] = n_acc;
         const double v2[2] = {active ? sse : 0.0, (active && bad) ? 1.0 : 0.0};
         block_reduce_store<2>(v2, smem, out + P, lane);
     } else {
@@ -500,6 +513,12 @@ void adaptive_kernel(typename M::Args a) {
         int n_max = n_acc;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
+        double t_next = t;                         // constant-Jacobian models: end of the step being reversed (t = final time)
+        // the step size of the next iteration is requested one iteration ahead (a dependent HBM round trip otherwise)
+        double h_ahead = 0.0;
+        if constexpr (!M::NEED_Y) {
+            if (n_max > 0) h_ahead = TAPE(n_max - 1 < n_acc ? n_max - 1 : (n_acc > 0 ? n_acc - 1 : 0), 0);
+        }
 #pragma unroll 1
         for (int n = n_max - 1; n >= 0; n--) {
             // a lane with fewer accepted steps idles on its last entry with zero adjoints until its own steps come up
@@ -509,7 +528,16 @@ void adaptive_kernel(typename M::Args a) {
             }
             const bool on = n < n_acc;
             const int src = on ? n : (n_acc > 0 ? n_acc - 1 : 0);
-            const double tn = TAPE(src, 0), h = TAPE(src, 1);
+            double tn, h;
+            if constexpr (M::NEED_Y) {
+                tn = TAPE(src, 0);
+                h = TAPE(src, 1);
+            } else {
+                h = h_ahead;
+                if (n > 0) h_ahead = TAPE(n - 1 < n_acc ? n - 1 : (n_acc > 0 ? n_acc - 1 : 0), 0);
+                tn = t_next - h;
+                if (on) t_next = tn;
+            }
             if constexpr (!M::NEED_Y) {
                 // ---- linear kinetics + a forcing that depends on time only: J_f = A, nothing to re-run.  The outputs
                 // were saved by the forward sweep; stages 6 and 7 of this step and stage 1 of the next share one time,
@@ -689,7 +717,7 @@ void adaptive_kernel(typename M::Args a) {
             for (int s = A0; s < NS; s++) lam[s] = yb[s];
             }
         }
-        if (active && a.tape_n != nullptr) a.tape_n[set * a.N + i] = n_acc;
+        if (active && a.tape_n != nullptr && set == 0) a.tape_n[i] = n_acc;
         if constexpr (M::NEED_Y) {                 // k_1 of the first step: linearisation point y_0 (entry 0 of the tape)
             double y0[NS], ub0[NS];
 #pragma unroll

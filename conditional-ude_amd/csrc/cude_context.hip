@@ -261,7 +261,10 @@ int32_t alloc_common(cude_ctx* c) {
     c->slot_of.clear();
     HIP_TRY(c->tape.resize(0));          // adaptive gradient tape: allocated by the first gradient evaluation
     c->tape_cap = 0;
+    HIP_TRY(c->tape_n.resize(adaptive(c) ? (size_t)N : 0));      // accepted-step counts: written by every adaptive launch
     c->have_tape = false;
+    c->have_counts = false;
+    c->evals_since_regroup = 0;
     c->run_iters = 0;
     c->regroup_done_at = -1;
     HIP_TRY(c->m_cond.resize(N));

@@ -196,7 +196,9 @@ struct cude_ctx {
     int64_t run_iters = 0;                          // iterations cude_adam_run has made on this population
     int64_t regroup_done_at = -1;                   // ... and the count at which it last re-ordered the launch by itself
     int tape_cap = 0;
-    bool have_tape = false;
+    bool have_tape = false;         // the tape of the last gradient evaluation is readable (it is in the current launch order)
+    bool have_counts = false;       // tape_n holds every subject's accepted-step count of some adaptive evaluation
+    int64_t evals_since_regroup = 0;
     cude::api::DevBuf<double> red_tmp; // staging of small host vectors reduced through the communicator
     std::vector<double> ms_host;
 #ifdef CUDE_WAVE_TIMING
@@ -236,6 +238,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
                      double* sse_ov = nullptr);
 int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host);
 int32_t adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after);
+int32_t maybe_regroup(cude_ctx* c);
 // ---- cude_optimise.hip
 void drop_graph(cude_ctx* c);
 int32_t ensure_trace(cude_ctx* c, int64_t n);

@@ -69,9 +69,9 @@ struct CpepArgs {
     int64_t blk0, blk_count;
     int32_t prio_shift;      // one-lane gradient kernel: co-resident waves alternate issue priority every 2^prio_shift
                              // evaluations (0 = off); set by the host for single-round launches with two waves per SIMD
-    double* tape;            // adaptive gradient: [n_sets][tape_cap][2 + NS][N] accepted steps (t_n, dt_n, y_n)
+    double* tape;            // adaptive gradient: [n_sets][tape_cap][N] step sizes dt_n of the accepted steps (+ T saved outputs)
     int32_t tape_cap;
-    int32_t* tape_n;         // [n_sets][N] accepted steps per subject, or nullptr
+    int32_t* tape_n;         // [N] accepted steps per subject of parameter set 0 (forward and gradient launches), or nullptr
     const int32_t* perm;     // adaptive kernels: lane `gid` works on subject perm[gid] (nullptr = identity).  Lanes of a wave
                              // run as long as the slowest of them: cude_adaptive_regroup orders the subjects by their
                              // accepted-step counts so that a wave's lanes finish together.  The tape is kept in LANE order.
@@ -178,10 +178,14 @@ int supp_grad_waves_per_cu(const NetShape& net);
 // route here when args.S == 0
 hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
 hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
-// rows of N doubles per accepted step on the adaptive gradient's tape: t_n, dt_n, y_n
-inline __host__ __device__ int adaptive_tape_rows(int n_state) { return 2 + n_state; }
+// rows of N doubles per accepted step on the adaptive gradient's tape: (t_n, dt_n, y_n) for the suppression model
+// (3 states: the reverse sweep re-runs the stages from y_n), dt_n alone for the c-peptide models (2 states, constant
+// Jacobian: the reverse sweep needs the stage times only and steps back from the final time)
+inline __host__ __device__ int adaptive_tape_rows(int n_state) { return n_state == 3 ? 2 + n_state : 1; }
 // ... and of one parameter set's tape: the steps, then T saved outputs
-inline __host__ __device__ int64_t adaptive_tape_rows(int n_state, int cap, int T) { return (int64_t)cap * (2 + n_state) + T; }
+inline __host__ __device__ int64_t adaptive_tape_rows(int n_state, int cap, int T) {
+    return (int64_t)cap * adaptive_tape_rows(n_state) + T;
+}
 
 // common kernels
 // out[q] = sum_b partials[b][stride*b + q] (fixed order, deterministic) for q in [col0, col0+ncol); with n_sets > 1

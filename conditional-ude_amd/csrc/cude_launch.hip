@@ -76,7 +76,8 @@ cude::SuppArgs supp_args(const cude_ctx* c) {
     return a;
 }
 
-// Tape of the adaptive gradient: (2 + NS) doubles per accepted step and subject + T saved outputs.  The reference's
+// Tape of the adaptive gradient: per accepted step and subject the step size (c-peptide models: 8 B) or (t, dt, y) (the
+// suppression model: 40 B), + T saved outputs.  The reference's
 // problems take 10-40 steps at its tolerances; the capacity is what ~4 GB hold, between 64 and 1024 steps
 // (option "tape_steps" overrides).  A subject with more accepted steps fails its gradient evaluation (+Inf), not the
 // process.  Allocated by the first gradient evaluation (forward-only users of the adaptive mode never pay for it), never
@@ -85,13 +86,12 @@ int32_t ensure_tape(cude_ctx* c) {
     if (!adaptive(c) || c->tape.p) return CUDE_OK;
     if (c->capturing) return fail(CUDE_ERR_STATE, "adaptive gradient tape not allocated before stream capture");
     const int64_t N = c->N;
-    const int rows = cude::adaptive_tape_rows(c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2);
-    int64_t cap = (int64_t)(4e9 / (8.0 * rows * (double)N));
+    const int n_state = c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2;
+    int64_t cap = (int64_t)(4e9 / (8.0 * cude::adaptive_tape_rows(n_state) * (double)N));
     cap = std::max<int64_t>(64, std::min<int64_t>(1024, cap));
     if (c->opt.tape_steps > 0) cap = c->opt.tape_steps;
     c->tape_cap = (int)cap;
-    HIP_TRY(c->tape.resize((size_t)cude::adaptive_tape_rows(rows - 2, (int)cap, c->T) * N));
-    HIP_TRY(c->tape_n.resize((size_t)N));
+    HIP_TRY(c->tape.resize((size_t)cude::adaptive_tape_rows(n_state, (int)cap, c->T) * N));
     return CUDE_OK;
 }
 
@@ -391,7 +391,10 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only, 
         HIP_TRY(cude::launch_supp(c->net, grad, a, c->stream));
     }
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
-    if (grad && adaptive(c)) c->have_tape = true;
+    if (adaptive(c)) {
+        c->have_counts = true;              // (adaptive launches leave every subject's accepted-step count behind)
+        if (grad) c->have_tape = true;
+    }
     if (sse_ov) return CUDE_OK;
     const int P = c->P;
     const bool fold = c->fold_advance && grad && !local_only;
@@ -530,8 +533,19 @@ int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
 }
 
 // (see cude_adaptive_regroup in include/cude.h)
+// Entry points that launch a large adaptive population again and again (restarts trained side by side, per-subject
+// fits) keep the launch ordered by accepted-step count as cude_adam_run does: once the counts of a first evaluation are
+// there, then after every kRegroupEvals-th evaluation they make (the counts drift with the parameters).  Per-subject
+// results do not depend on the order; the shared gradient's summation order does (rounding).
+int32_t maybe_regroup(cude_ctx* c) {
+    constexpr int64_t kRegroupEvals = 200;
+    if (!adaptive(c) || c->N < 8192 || !c->opt.auto_regroup || !c->have_counts || c->capturing) return CUDE_OK;
+    if (!c->slot_of.empty() && c->evals_since_regroup < kRegroupEvals) { c->evals_since_regroup++; return CUDE_OK; }
+    return adaptive_regroup(c, nullptr, nullptr);
+}
+
 int32_t adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after) {
-    if (!adaptive(c) || !c->have_tape) return fail(CUDE_ERR_STATE, "no adaptive gradient evaluation on this context yet");
+    if (!adaptive(c) || !c->have_counts) return fail(CUDE_ERR_STATE, "no adaptive evaluation on this context yet");
     const int64_t N = c->N;
     std::vector<int32_t> n_acc((size_t)N);
     HIP_TRY(hipMemcpyAsync(n_acc.data(), c->tape_n.p, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -566,6 +580,7 @@ int32_t adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_af
     c->slot_of.assign((size_t)N, 0);
     for (int64_t k = 0; k < N; k++) c->slot_of[(size_t)order[(size_t)k]] = (int32_t)k;
     c->have_tape = false;                           // the tape on the device is in the OLD launch order
+    c->evals_since_regroup = 0;
     return CUDE_OK;
 }
 
@@ -812,6 +827,7 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
                        c->opt.ms_split;
     // sets per launch: bounded by the grid's y / z dimension and ~512 MB of scratch
     if ((rc = ensure_tape(c))) return rc;                 // (fixes the capacity the per-set tapes share)
+    if ((rc = maybe_regroup(c))) return rc;
     const int64_t tape_rows = adaptive(c) ? cude::adaptive_tape_rows(supp ? 3 : 2, c->tape_cap, c->T) : 0;
     const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (double)tape_rows * N +
                                   (supp && !adaptive(c) ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
@@ -853,13 +869,13 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
             a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
             a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
-            if (adaptive(c)) { a.tape = c->ms_tape.p; a.tape_n = nullptr; }
+            if (adaptive(c)) a.tape = c->ms_tape.p;     // (tape_n: the counts of set 0, for the re-ordering below)
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));     // one-lane kernel: the sets fill the chip
         } else {
             cude::SuppArgs a = supp_args(c);
             a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
             a.ckpt = c->ms_ckpt.p; a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
-            if (adaptive(c)) { a.tape = c->ms_tape.p; a.tape_n = nullptr; }
+            if (adaptive(c)) a.tape = c->ms_tape.p;
             if (!adaptive(c) && !a.ckpt_steps_only && supp_keep_activations(c, kn)) {
                 HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
                 a.act = c->ms_act.p;
@@ -920,17 +936,28 @@ int32_t cude_adaptive_steps(cude_ctx* c, int64_t subject, int32_t cap, double* t
     HIP_TRY(hipMemcpyAsync(&n, c->tape_n.p + subject, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *n_steps = n;
-    const int rows = cude::adaptive_tape_rows(c->cfg.model == CUDE_MODEL_SUPP ? 3 : 2);
+    const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
+    const int rows = cude::adaptive_tape_rows(supp ? 3 : 2);
     const int m = std::min(std::min(n, cap), c->tape_cap);
     const int64_t slot = c->slot_of.empty() ? subject : c->slot_of[(size_t)subject];      // the tape is in launch order
-    for (int r = 0; r < 2 && m > 0; r++) {
-        double* dst = r == 0 ? t_out : dt_out;
-        if (!dst) continue;
-        // entry k, row r of the tape: one double every rows * N
-        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double), c->tape.p + (size_t)r * c->N + slot, (size_t)rows * c->N * sizeof(double),
-                                 sizeof(double), (size_t)m, hipMemcpyDeviceToHost, c->stream));
-    }
+    if (m < 1) return CUDE_OK;
+    // entry k, row r of the tape: one double every rows * N.  Suppression model: rows 0 and 1 are (t_n, dt_n); c-peptide
+    // models keep dt_n alone and t_n is the forward sweep's own running sum t_{n+1} = t_n + dt_n from the initial time
+    // (the same additions in the same order: the same bits)
+    std::vector<double> dts;
+    double* dt_dst = dt_out;
+    if (!supp && !dt_dst) { dts.resize((size_t)m); dt_dst = dts.data(); }
+    if (supp && t_out)
+        HIP_TRY(hipMemcpy2DAsync(t_out, sizeof(double), c->tape.p + slot, (size_t)rows * c->N * sizeof(double), sizeof(double),
+                                 (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (dt_dst)
+        HIP_TRY(hipMemcpy2DAsync(dt_dst, sizeof(double), c->tape.p + (size_t)(supp ? 1 : 0) * c->N + slot,
+                                 (size_t)rows * c->N * sizeof(double), sizeof(double), (size_t)m, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!supp && t_out) {
+        double t = c->tp.front();
+        for (int k = 0; k < m; k++) { t_out[k] = t; t += dt_dst[k]; }
+    }
     return CUDE_OK;
 }
 
@@ -1001,6 +1028,7 @@ int32_t cude_fit_conditional(cude_ctx* c, double lower, double upper, int32_t n_
     for (int k = 0; k < n_grid; k++) {                    // coarse scan of the box
         const double x = (k == n_grid - 1) ? upper : std::fma((double)k, f.step, lower);
         HIP_TRY(cude::launch_fill(N, x, f.c, c->stream));
+        if (k == 1 && (rc = maybe_regroup(c))) return rc;     // (adaptive mode: the first probe has told the step counts)
         if ((rc = run_ensemble(c, false, nullptr, true, f.c, sse_c))) return rc;
         HIP_TRY(cude::launch_fit(0, f, k, x, c->stream));
     }

@@ -146,7 +146,7 @@ int32_t queue_iterations(cude_ctx* c, int32_t n) {
             k++;
         }
     }
-    if (adaptive(c)) c->have_tape = true;       // (a replayed graph writes the tape as a plain launch does)
+    if (adaptive(c)) c->have_tape = c->have_counts = true;     // (a replayed graph writes the tape as a plain launch does)
     return CUDE_OK;
 }
 
@@ -171,7 +171,7 @@ int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
     const bool regroup = adaptive(c) && c->N >= 8192 && c->opt.auto_regroup;
     auto boundary = [&](int64_t k) { return k == 1 || (k > 0 && k % kRegroupEvery == 0); };
     for (int32_t done = 0; done < n_iters;) {
-        if (regroup && boundary(c->run_iters) && c->regroup_done_at != c->run_iters && c->have_tape) {
+        if (regroup && boundary(c->run_iters) && c->regroup_done_at != c->run_iters && c->have_counts) {
             if ((rc = adaptive_regroup(c, nullptr, nullptr))) return rc;
             c->regroup_done_at = c->run_iters;
         }

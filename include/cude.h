@@ -91,13 +91,22 @@ int32_t cude_set_tolerances(cude_ctx* ctx, double abstol, double reltol);
  * *n_steps = number of accepted steps; at most `cap` of them are written to t_out / dt_out (either may be NULL).
  * CUDE_ERR_STATE before the first such evaluation or outside the adaptive mode. */
 int32_t cude_adaptive_steps(cude_ctx* ctx, int64_t subject, int32_t cap, double* t_out, double* dt_out, int32_t* n_steps);
-/* Adaptive mode at large populations: a wave's 64 lanes run until the slowest of them has finished, and subjects differ
- * in how many steps the controller lets them take (14 ... 23 at the reference's tolerances).  cude_adaptive_regroup
- * orders the launch by the accepted-step counts of the LAST gradient evaluation (most steps first), so that lanes of a
- * wave finish together; every later launch on this context uses that order (per-subject results are unchanged bit for
- * bit -- only which lane computes which subject, and with it the order of the shared-gradient sum, changes).
- * spread_* (optional): mean over the waves of (max - min accepted steps within the wave), before and after.  A new
- * population resets the order.  (No reference line: EnsembleThreads has no lock-step lanes.) */
+/* Adaptive mode, large populations: order the launch by accepted-step count.  A wave's 64 lanes run until the slowest of
+ * them has finished, and subjects differ in how many steps the controller grants them (8 ... 23 on the c-peptide data).
+ * Every adaptive launch (forward or gradient) leaves each subject's accepted-step count behind; this call sorts the
+ * launch by them (stable, most steps first) so that the lanes of a wave finish together: lane k of the next launches
+ * works on the subject that came k-th, inputs are gathered through the permutation, the tape stays in lane order
+ * (coalesced), every per-subject output lands at its subject's own index.  Per-subject results are unchanged bit for
+ * bit; the shared gradient is summed in the new order (rounding).  spread_* (optional): mean over the waves of (max -
+ * min accepted steps within the wave), before and after.  Until the next gradient evaluation cude_adaptive_steps returns
+ * CUDE_ERR_STATE (the tape on the device is in the old order).  A new population resets the order.
+ * WHO CALLS IT BY ITSELF (populations of >= 8192 subjects; option "auto_regroup" = 0 / CUDE_NO_AUTO_REGROUP=1 turns all
+ * of this off): cude_adam_run -- after its 1st, 200th, 400th ... iteration on the population, counted over calls, so
+ * that adam_run(400) and 2 x adam_run(200) produce the same bits (single cude_adam_step calls never re-order);
+ * cude_multistart_loss_grad / cude_train_restarts -- at the first call that finds counts, then after every 200th
+ * evaluation; cude_fit_conditional -- after its first probe.  A caller who needs one summation order across entry
+ * points switches the option off and calls this function where it wants the order to change.  (No reference line:
+ * the reference solves its subjects one after the other, suppression_model.jl:113,123; parameter-estimation.jl:126-140.) */
 int32_t cude_adaptive_regroup(cude_ctx* ctx, int32_t* spread_before, int32_t* spread_after);
 
 /* --- population (replaces the CPeptideConditionalUDEModel constructor loop,
@@ -299,9 +308,11 @@ int32_t cude_synchronize(cude_ctx* ctx);
 int32_t cude_grad_occupancy(cude_ctx* ctx, int32_t* waves_per_cu);
 /* n_iters optimiser iterations in one call (the `maxiters` loop of Optimization.solve(prob, Adam, maxiters),
  * src/parameter-estimation.jl:176): iterations are captured into hipGraphs (eight per graph, single ones for the
- * remainder; CUDE_GRAPH_UNROLL changes the eight) and replayed without host round trips; losses[n_iters] (optional)
- * receives the loss BEFORE each update, read back once at the end.  With a communicator attached the iterations are
- * queued as plain launches (RCCL calls are not captured). */
+ * remainder) and replayed without host round trips; losses[n_iters] (optional) receives the loss BEFORE each update,
+ * read back once at the end.  The peer-write exchange (cude_xchg_*) is part of the captured reduction kernels; with an
+ * RCCL communicator as the transport the iterations are queued as plain launches (RCCL calls are not captured).
+ * Adaptive populations of >= 8192 subjects are re-ordered by accepted-step count on a schedule that counts this entry
+ * point's iterations (see cude_adaptive_regroup). */
 int32_t cude_adam_run(cude_ctx* ctx, int32_t n_iters, double* losses);
 
 /* --- bring-your-own collective (MPI.jl, gloo, ...) instead of the built-in RCCL path.

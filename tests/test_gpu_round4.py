@@ -75,3 +75,53 @@ def test_options_replace_the_environment_switches(monkeypatch):
     with pytest.raises(CudeError):
         eng.set_option("tape_steps", "many")
     eng.close()
+
+
+def test_forward_launches_tell_the_step_counts_and_the_other_entry_points_regroup_too():
+    """Every adaptive launch -- forward-only ones included -- leaves the accepted-step counts behind, so the launch can be
+    ordered before any gradient has been taken; cude_fit_conditional (after its first probe) and
+    cude_multistart_loss_grad / cude_train_restarts (from their second evaluation on) do it by themselves for >= 8192
+    subjects.  Per-subject results do not depend on the order (bit for bit); the shared gradient is a sum in another
+    order (rounding)."""
+    from cude.engine import Engine
+    arch, N = (2, 4, 2), 8400
+    c = make_cpep_case(N, arch)
+
+    def make(auto):
+        eng = Engine("cpep", arch, n_steps=0, n_state=2)
+        eng.set_option("auto_regroup", 1 if auto else 0)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], c["beta"])
+        return eng
+    # ---- explicit call behind a forward launch
+    eng = make(False)
+    sse0 = eng.forward(want_sse=True)["sse"]
+    before, after = eng.adaptive_regroup()
+    assert after <= 1 < before
+    assert np.array_equal(eng.forward(want_sse=True)["sse"], sse0)
+    eng.close()
+    # ---- per-subject fits: same optimum, same objective, whatever the order
+    fits, left = {}, {}
+    for auto in (False, True):
+        eng = make(auto)
+        fits[auto] = eng.fit_conditional(-3.0, 2.0, n_grid=7, n_iters=6)
+        left[auto] = eng.adaptive_regroup()[0]           # spread of the last launch's counts in the order the fit left behind
+        eng.close()
+    for x, y in zip(fits[False], fits[True]):
+        assert np.array_equal(x, y)
+    assert left[True] < left[False]                      # (ordered by the first probe's counts: closer, not sorted, at the optimum)
+    # ---- restarts side by side: the second evaluation runs in the sorted order
+    rng = np.random.default_rng(3)
+    nn_sets = c["nn"][None, :] * (1.0 + 0.05 * rng.standard_normal((2, c["nn"].size)))
+    cond_sets = np.stack([c["beta"], c["beta"] + 0.1])
+    out = {}
+    for auto in (False, True):
+        eng = make(auto)
+        eng.multistart_loss_grad(nn_sets, cond_sets)
+        out[auto] = eng.multistart_loss_grad(nn_sets, cond_sets)
+        spread = eng.adaptive_regroup()
+        assert (spread[0] <= 2) == auto
+        eng.close()
+    assert np.array_equal(out[False][2], out[True][2])                                   # dL/dbeta: per subject
+    assert np.allclose(out[False][0], out[True][0], rtol=1e-13)
+    assert np.allclose(out[False][1], out[True][1], rtol=0, atol=1e-12 * np.max(np.abs(out[False][1])))
