@@ -133,3 +133,36 @@ def supp(timepoints, data, arch, nn, theta, lam, n_steps, want_grad=True, want_t
     if traj is not None:
         traj = traj.transpose(2, 1, 0)                         # -> 3 x T x N
     return dict(loss=loss.value, sse=sse, g_nn=g_nn, g_theta=g_th, traj=traj, n_failed=rc)
+
+
+def supp_adaptive(timepoints, data, arch, nn, theta, abstol=1e-6, reltol=1e-3, nthreads=0):
+    """Trajectories (3 x T x N) of the suppression model integrated with the adaptive restatement
+    (cude_oracle.solve_adaptive + supp_rhs in C): u0 = data[:, 0, :], outputs at `timepoints`.  A failed subject's
+    slice is NaN.  The loss is formed by the caller (cude_oracle.supp_scale etc.)."""
+    data = np.asarray(data, dtype=np.float64)
+    _, T, N = data.shape
+    dcol = np.ascontiguousarray(data.transpose(2, 1, 0))      # memory: i slowest, s fastest
+    tp = np.ascontiguousarray(timepoints, dtype=np.float64)
+    nn = np.ascontiguousarray(nn, dtype=np.float64)
+    eth = np.ascontiguousarray(np.exp(np.asarray(theta, dtype=np.float64)))
+    nin, width, depth = arch
+    assert nin == 4 and nn.size == _n_params(*arch) and eth.size == N
+    out = np.zeros((N, T, 3))
+    rc = lib().cude_oracle_supp_adaptive(C.c_int(N), C.c_int(T), _p(tp), _p(dcol), C.c_int(width), C.c_int(depth),
+                                         _p(nn), _p(eth), C.c_double(abstol), C.c_double(reltol), C.c_int(nthreads),
+                                         _p(out))
+    if rc < 0:
+        raise ValueError("cude_oracle_supp_adaptive: unsupported size")
+    return np.ascontiguousarray(out.transpose(2, 1, 0))
+
+
+def supp_adaptive_loss(timepoints, data, arch, nn, theta, lam, abstol=1e-6, reltol=1e-3):
+    """suppression_loss (suppression/src/suppression_model.jl:117-130) on the adaptive trajectories: +Inf when a solve
+    failed."""
+    data = np.asarray(data, dtype=np.float64)
+    sims = supp_adaptive(timepoints, data, arch, nn, theta, abstol, reltol)
+    if not np.all(np.isfinite(sims)):
+        return np.inf
+    scale = data.max(axis=1).mean(axis=1)
+    r = (sims - data) / scale[:, None, None]
+    return float(np.sum(r * r)) / data.shape[2] + lam * float(np.sum(np.asarray(nn) ** 2))

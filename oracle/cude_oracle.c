@@ -522,4 +522,110 @@ int cude_oracle_cpep_adaptive(int N, int T, const double* tp, const double* gluc
     }
     return nfail;
 }
+/* The same solver on the suppression model's three states (cude_oracle.solve_adaptive + supp_rhs, suppression/src/
+ * suppression_model.jl:88-95,107-115): N independent subjects, u0 = data[:, 1, i], outputs at the T observation times.
+ * data is Julia's column-major 3 x T x N; etheta[i] = exp(theta_i); out is N x T x 3 (a failed subject's rows are NaN).
+ * It exists so that the reference's stored objectives of whole result directories (hundreds of networks:
+ * tests/test_known_answers_runs.py) can be checked in seconds; tests/test_oracle.py holds it to the Python statement. */
+typedef struct { int width, depth; const double* nn; double eth; } supp_ctx;
+
+static void rhs_supp_plain(const supp_ctx* c, const double* u, double* du) {
+    double in[4] = {u[0], u[1], u[2], c->eth};
+    double uh = mlp_plain(in, 4, c->width, c->depth, c->nn);
+    du[0] = -0.4 * u[0];
+    du[1] = 0.4 * u[0] - uh;
+    du[2] = uh - 0.3 * u[2];
+}
+
+static double rms3(const double* v) { return sqrt((v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) / 3); }
+
+static int solve_adaptive_supp(const supp_ctx* c, const double* u0, int n_out, const double* tout,
+                               double abstol, double reltol, double* out) {
+    const double beta1 = 7.0 / 50, beta2 = 2.0 / 25, gamma = 0.9, qmin = 0.2, qmax = 10.0;
+    double t0 = tout[0], t1 = tout[n_out - 1];
+    double y[3], ynew[3], Y[3], k[7][3], f1[3], y1[3], sk[3], v[3];
+    for (int s = 0; s < 3; s++) { y[s] = u0[s]; out[s] = y[s]; }
+    int nxt = 1;
+    rhs_supp_plain(c, y, k[0]);
+    for (int s = 0; s < 3; s++) sk[s] = abstol + reltol * fabs(y[s]);
+    for (int s = 0; s < 3; s++) v[s] = y[s] / sk[s];
+    double d0 = rms3(v);
+    for (int s = 0; s < 3; s++) v[s] = k[0][s] / sk[s];
+    double d1 = rms3(v);
+    double dt = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    for (int s = 0; s < 3; s++) y1[s] = y[s] + dt * k[0][s];
+    rhs_supp_plain(c, y1, f1);
+    for (int s = 0; s < 3; s++) v[s] = (f1[s] - k[0][s]) / sk[s];
+    double d2 = rms3(v) / dt;
+    double dm = d1 > d2 ? d1 : d2;
+    double dt1 = dm <= 1e-15 ? fmax(1e-6, dt * 1e-3) : pow(0.01 / dm, 1.0 / 5);
+    dt = fmin(fmin(100 * dt, dt1), t1 - t0);
+    double t = t0, qold = 1e-4;
+    for (int it = 0; it < 100000; it++) {
+        if (t >= t1 - 1e-14 * fmax(1.0, fabs(t1))) break;
+        dt = fmin(dt, t1 - t);
+        for (int i = 1; i < 7; i++) {
+            for (int s = 0; s < 3; s++) {
+                double acc = 0.0;
+                for (int j = 0; j < i; j++) acc = acc + TA[i][j] * k[j][s];
+                Y[s] = y[s] + dt * acc;
+            }
+            if (i < 6) rhs_supp_plain(c, Y, k[i]);
+            else { for (int s = 0; s < 3; s++) ynew[s] = Y[s]; rhs_supp_plain(c, ynew, k[6]); }
+        }
+        double e[3];
+        for (int s = 0; s < 3; s++) {
+            double acc = 0.0;
+            for (int j = 0; j < 7; j++) acc = acc + TBT[j] * k[j][s];
+            e[s] = dt * acc / (abstol + reltol * fmax(fabs(y[s]), fabs(ynew[s])));
+        }
+        double est = rms3(e);
+        if (!isfinite(est)) return 1;
+        double q11 = est > 0 ? pow(est, beta1) : 1e-12;
+        if (est <= 1.0) {
+            while (nxt < n_out && tout[nxt] <= t + dt + 1e-12) {
+                double th = fmin(1.0, (tout[nxt] - t) / dt), w[7];
+                interp_weights_nc(th, w);
+                for (int s = 0; s < 3; s++) {
+                    double acc = 0.0;
+                    for (int j = 0; j < 7; j++) acc = acc + w[j] * k[j][s];
+                    out[nxt * 3 + s] = y[s] + dt * acc;
+                }
+                nxt++;
+            }
+            double q = q11 / pow(qold, beta2);
+            q = fmax(1 / qmax, fmin(1 / qmin, q / gamma));
+            t = t + dt;
+            for (int s = 0; s < 3; s++) { y[s] = ynew[s]; k[0][s] = k[6][s]; }
+            qold = fmax(est, 1e-4);
+            dt = dt / q;
+        } else {
+            dt = dt / fmin(1 / qmin, q11 / gamma);
+        }
+    }
+    return nxt < n_out;
+}
+
+int cude_oracle_supp_adaptive(int N, int T, const double* tp, const double* data, int width, int depth, const double* nn,
+                              const double* etheta, double abstol, double reltol, int nthreads, double* out) {
+    if (T > MAXT || T < 2 || width > MAXW) return -1;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    int nfail = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : nfail)
+    for (int i = 0; i < N; i++) {
+        supp_ctx c;
+        c.width = width; c.depth = depth; c.nn = nn; c.eth = etheta[i];
+        const double* u0 = data + (size_t)i * T * 3;            /* data[:, 1, i] */
+        if (solve_adaptive_supp(&c, u0, T, tp, abstol, reltol, out + (size_t)i * T * 3)) {
+            for (int j = 0; j < T * 3; j++) out[(size_t)i * T * 3 + j] = NAN;
+            nfail += 1;
+        }
+    }
+    return nfail;
+}
 #pragma GCC pop_options
+

@@ -13,6 +13,10 @@ Sources (paths relative to /root/reference):
   source_data/ude_neural_parameters.jld2      decoded content + SHA-256 of its 1455 bytes: target of the JLD2 writer test
   suppression/results/lambda=0.0.jld2         25 x 67 weights (4->3x5->1), group_data 3x8x37, losses, correlations
       (written by suppression/suppression.jl:76-91)
+  suppression/results/lambda=0.001|0.01|0.010000000000000002|0.1.jld2   85 more trained 4->3x5->1 networks on the same
+      data, their final objectives and validation objectives (round 4: soft pins for every stored network)
+  source_data/advi/cude_result_{1..25}.jld2   25 more (network, 57 betas) pairs of the 2->4->4->1 c-peptide model (no
+      producing script in the reference tree; same subjects and order as cude_neural_parameters.jld2, checked below)
   data/ohashi_production.csv                  dose-response table of the symbolic regression
 The .jld2 files are decoded with the build's own reader (conditional-ude_amd/cude/jld2.py).
 """
@@ -99,6 +103,25 @@ def main():
     _save("suppression_lambda1.npz", nn_4x3x5x1=np.stack(s1["neural_parameters"]),
                         losses=s1["losses"], losses_valid=s1["losses_valid"],
                         losses_valid_nonoise=s1["losses_valid_nonoise"])
+    # the runs in between (round 4): live networks, the same three data sets -- soft pins (the per-subject global
+    # minimum over theta of the data term must be <= and close to the stored objective)
+    mids = {}
+    for tag, fname in (("0.001", "lambda=0.001.jld2"), ("0.01", "lambda=0.01.jld2"),
+                       ("0.01b", "lambda=0.010000000000000002.jld2"), ("0.1", "lambda=0.1.jld2")):
+        sm = jld2.load(os.path.join(REF, "suppression/results", fname))
+        assert np.array_equal(sm["group_data"], group)
+        assert all(np.array_equal(sm[k], supp[k]) for k in ("validation_data", "validation_data_nonoise"))
+        mids["lam_" + tag] = np.float64(sm["λ"])
+        mids["nn_" + tag] = np.stack(sm["neural_parameters"])
+        for k in ("losses", "losses_valid", "losses_valid_nonoise", "correlations", "correlations_valid",
+                  "correlations_valid_nonoise"):
+            mids[k + "_" + tag] = sm[k]
+    _save("suppression_lambda_mid.npz", **mids)
+    # 25 more stored (network, betas) pairs of the c-peptide model
+    advi = [jld2.load(os.path.join(REF, "source_data/advi", f"cude_result_{k}.jld2")) for k in range(1, 26)]
+    assert all(a["width"] == 4 and a["depth"] == 2 for a in advi)
+    _save("advi_cude.npz", nn_2x4x4x1=np.stack([a["parameters"] for a in advi]),
+          betas_train=np.stack([a["betas"] for a in advi]))
     # dose-response table the reference's symbolic regression was run on (30 exp(beta) x 30 dG values)
     prod = pd.read_csv(os.path.join(REF, "data/ohashi_production.csv"))
     _save("ohashi_production.npz", beta=prod["Beta"].to_numpy(dtype=np.float64),
