@@ -883,6 +883,7 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
         }
+        if (adaptive(c)) c->have_counts = true;     // (the launch left the step counts of its first parameter set behind)
         if (!split)
             HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, c->ms_out.p, c->stream, (int)kn,
                                              c->param_mask.p, P));

@@ -90,6 +90,7 @@ def cpep_adaptive(timepoints, glucose, cpeptide, age, t2dm, arch, nn, cond, out_
     nin, width, depth = arch
     assert cond.size == N and age.size == N and nn.size == (1 if width == 0 else _n_params(*arch))
     out = np.zeros((N, tout.size))
+    nthreads = nthreads or default_threads()
     rc = lib().cude_oracle_cpep_adaptive(C.c_int(N), C.c_int(T), _p(tp), _p(glucose), _p(cpeptide), _p(age), _p(t2),
                                          C.c_int(int(covariate)), C.c_int(nin), C.c_int(width), C.c_int(depth),
                                          _p(nn), _p(cond), C.c_int(tout.size), _p(tout), C.c_double(abstol),
@@ -135,6 +136,24 @@ def supp(timepoints, data, arch, nn, theta, lam, n_steps, want_grad=True, want_t
     return dict(loss=loss.value, sse=sse, g_nn=g_nn, g_theta=g_th, traj=traj, n_failed=rc)
 
 
+def default_threads():
+    """Threads for the many small parallel regions of the parameter scans: the container's CPU quota when one is set
+    (a GPU box shows 256 logical CPUs to a 16-core share: 256 OpenMP threads for 37 subjects turn a 0.1 ms region into
+    seconds), never more than 16."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return max(1, min(n, 16))
+
+
 def supp_adaptive(timepoints, data, arch, nn, theta, abstol=1e-6, reltol=1e-3, nthreads=0):
     """Trajectories (3 x T x N) of the suppression model integrated with the adaptive restatement
     (cude_oracle.solve_adaptive + supp_rhs in C): u0 = data[:, 0, :], outputs at `timepoints`.  A failed subject's
@@ -148,6 +167,7 @@ def supp_adaptive(timepoints, data, arch, nn, theta, abstol=1e-6, reltol=1e-3, n
     nin, width, depth = arch
     assert nin == 4 and nn.size == _n_params(*arch) and eth.size == N
     out = np.zeros((N, T, 3))
+    nthreads = nthreads or default_threads()
     rc = lib().cude_oracle_supp_adaptive(C.c_int(N), C.c_int(T), _p(tp), _p(dcol), C.c_int(width), C.c_int(depth),
                                          _p(nn), _p(eth), C.c_double(abstol), C.c_double(reltol), C.c_int(nthreads),
                                          _p(out))

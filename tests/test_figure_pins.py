@@ -405,6 +405,18 @@ def _recover_profile(sub, k, y, n_fine=1001, half_width=5e-3, edge_width=0.0, co
     cand = np.array(found)
     s, res_all = score(cand, sub.adaptive_many, np.arange(k.size))
     j = int(np.argmin(np.median(res_all, axis=1)))
+    if np.median(res_all[j]) >= 1e-3 and edge == 0:
+        # (round 4) A steep profile (plotted value = 60 ... 70 x the SSE difference) moves by 0.1 when its centre moves
+        # by 1e-3, and the smooth fixed-step loss the coarse stage ranks with sits up to 0.03 beside the adaptive one
+        # there: the +-0.02 window of the fine stage then misses the centre altogether (curve 27).  Second try, on the
+        # adaptive loss throughout: 1e-3 spacing over the coarse window, then 1e-6 spacing around the best.
+        centre = best(np.clip(b_star + np.linspace(-coarse_width, coarse_width, int(2 * coarse_width / 1e-3) + 1), *sub.box),
+                      sub.adaptive_many, 0.5)
+        for half, n in ((1e-3, 2001), (2e-5, 41)):
+            centre = best(np.clip(centre + np.linspace(-half, half, n), *sub.box), sub.adaptive_many, 0.75)
+        s2, res2 = score(np.array([centre]), sub.adaptive_many, np.arange(k.size))
+        if np.median(res2[0]) < np.median(res_all[j]):
+            return float(centre), float(s2[0]), res2[0]
     return cand[j], float(s[j]), res_all[j]
 
 

@@ -270,9 +270,10 @@ def test_product_reproduces_the_likelihood_profiles_of_all_subjects():
     at 1000 values of beta per subject with the stored best network) through the product: cude_profile_conditional in
     adaptive mode, one launch of 1000 scan values per subject, compared with the plotted vertices (1.9e-4 quantisation)
     after the curve's one unknown -- the fitted beta_i it is centred on -- has been recovered by scans that are
-    themselves populations of copies of the subject (one launch each).  At least 104 of the 117 curves must match at
-    the figure's resolution and 112 to 1e-3 (the others: fits on the edge of the optimiser's box and shallow optima,
-    where the recovery of beta_i -- not the loss -- is what fails; the CPU restatement fails on the same curves)."""
+    themselves populations of copies of the subject (one launch each).  At least 104 of the 116 curves with visible
+    vertices must match at the figure's resolution (median deviation < 1.5e-4 = 0.8 quantisation steps) and 115 to 1e-3;
+    the curves that do not are a fixed, known set of near misses (1 ... 3 steps: the ripple of the adaptive objective,
+    where one rounding flips a step acceptance; profiles/r04/profiles_missed.txt)."""
     import torch  # noqa: F401
     import test_figure_pins as F
     from cude.engine import Engine
@@ -280,6 +281,7 @@ def test_product_reproduces_the_likelihood_profiles_of_all_subjects():
     nn, arch, _ = d.network(False)
     stored_betas = d.g["betas_train"][int(d.g["best_model_index"]) - 1]
     good, near, bad, n_vertices = 0, 0, [], 0
+    records, n_fallback = [], 0
     for part, off, n in (("train", 0, 82), ("test", 82, 35)):
         for i in range(n):
             k, y = F._profile_vertices(d.fig, off + i)
@@ -287,10 +289,12 @@ def test_product_reproduces_the_likelihood_profiles_of_all_subjects():
                 continue
             sub = _GpuSubject(F._Subject(d, part, i, covariate=False))
             beta, _, res0 = F._recover_profile(sub, k, y, n_fine=4001, half_width=2e-2, edge_width=4e-2, coarse_width=0.6)
+            beta_curve, fallback = beta, False
             if part == "train" and np.median(res0) >= 1.5e-4:
                 # (round 3) the curve alone did not pin its centre: try the stored fitted betas of the best model too
                 beta, _, _ = F._recover_profile(sub, k, y, n_fine=4001, half_width=2e-2, edge_width=4e-2,
                                                 coarse_width=0.6, stored=stored_betas)
+                fallback = abs(beta - beta_curve) > 1e-9      # a stored beta won over the curve-derived centre
             # the reference's own call sequence for this subject: likelihood_profile(beta_i, ...; steps = 1000)
             eng = Engine("cpep", arch, n_steps=0, n_state=2)
             eng.set_population_cpep(d.tp, *(a for a in sub.row))
@@ -303,10 +307,32 @@ def test_product_reproduces_the_likelihood_profiles_of_all_subjects():
             res = np.abs(y - scale * dd)
             ok = np.median(res) < 1.5e-4 and np.quantile(res, 0.9) < F.TOLP and abs(scale * 2 * sse_min / 5 - 1) < 0.05
             good += ok
+            n_fallback += bool(ok and fallback)
             near += bool(np.median(res) < 1e-3 and abs(scale * 2 * sse_min / 5 - 1) < 0.05)
             n_vertices += k.size if ok else 0
+            b_star, _ = sub.argmin_sse()
+            records.append((off + i, part, int(d.fig["profiles_class"][off + i]), bool(ok), bool(fallback), float(beta),
+                            float(b_star), float(np.median(res)), float(np.quantile(res, 0.9)), float(res.max()),
+                            float(scale * 2 * sse_min / 5), int(k.size), int(k.min()), int(k.max()),
+                            int(np.max(np.diff(np.sort(k)))) if k.size > 1 else 0, float(np.finfo(float).eps + sse_min)))
             if not ok:
                 bad.append((off + i, int(d.fig["profiles_class"][off + i]), round(float(beta), 5),
                             float(np.median(res)), float(np.quantile(res, 0.9)), float(scale * 2 * sse_min / 5)))
-    print("profiles reproduced:", good, "vertices:", n_vertices, "not reproduced:", bad)
-    assert good >= 104 and near >= 112 and n_vertices > 5000, (good, near, bad)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):           # the per-curve record behind profiles/r04/profiles_missed.txt
+        with open(os.path.join(out_dir, "profiles_r04.txt"), "w") as fh:
+            fh.write("# curve part class ok stored_beta_used beta_centre beta_argmin median|res| q90|res| max|res| "
+                     "scale*2sse/5 n_vertices k_min k_max largest_gap_in_k sse_min   (res in plotted units: 1 px = 1.9e-4 x ...)\n")
+            for r in records:
+                fh.write(" ".join(str(v) for v in r) + "\n")
+    print("profiles reproduced:", good, "of them through a stored beta:", n_fallback, "vertices:", n_vertices,
+          "not reproduced:", bad)
+    assert good >= 104 and near >= 115 and n_vertices > 5000, (good, near, bad)
+    # (advisor, round 3) the stored fitted betas are a help for the curves whose shape does not identify their centre --
+    # they must stay the exception (measured: ONE of the 108 reproduced curves owes its centre to a stored beta)
+    assert n_fallback <= 3 and good - n_fallback >= 104, (good, n_fallback)
+    # the curves that miss the figure's resolution are known, and all of them miss it narrowly: median deviation 0.8 ... 3.3
+    # quantisation steps of the plot where 0.8 is the bar (profiles/r04/profiles_missed.txt has them one by one)
+    KNOWN_NEAR_MISSES = {14, 27, 53, 61, 72, 90, 111, 116}
+    assert {b[0] for b in bad} <= KNOWN_NEAR_MISSES, bad
+    assert all(b[3] < 1e-3 for b in bad), bad

@@ -1,0 +1,53 @@
+#!/bin/bash
+# Round-4 profiles on the GPU box: rocprofv3 kernel-trace stats of the bench command, separate PMC passes (FETCH_SIZE /
+# WRITE_SIZE / SQ counters: --pmc is never combined with trace domains other than --kernel-trace), the same for the
+# suppression gradient kernel in its two checkpoint modes.  usage: tools/profile_r04.sh   -> gpurun_out/prof_r04/
+set -u
+# (rocprofv3 -L lists the counters this GPU exposes: kept beside the profiles)
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_r04
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 -L > $OUT/counters_available.txt 2>&1
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/bench_stats.json 2> $OUT/stats.err
+echo "stats rc=$?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $BENCH > /dev/null 2> $OUT/fetch.err
+echo "fetch rc=$?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $BENCH > /dev/null 2> $OUT/write.err
+echo "write rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o sq -- $BENCH > /dev/null 2> $OUT/sq.err
+echo "sq rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o sq2 -- $BENCH > /dev/null 2> $OUT/sq2.err
+echo "sq2 rc=$?"
+# round 4: where do the idle issue slots go?  SQ_WAIT_INST_ANY is 24 % of the wave-cycles: its parts (each group in its
+# own pass; a counter this GPU does not have fails its pass alone)
+for grp in "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES" "SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES" "SQ_WAVE_DEP_WAIT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INSTS_VSKIPPED SQ_WAVE_CYCLES"; do
+  tag=$(echo $grp | cut -d" " -f1)
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_w_$tag -o w -- $BENCH > /dev/null 2> $OUT/w_$tag.err
+  echo "wait group $tag rc=$?"
+done
+SUPP="python3 $ROOT/tools/bench_supp.py 100000 --no-cpu"
+for mode in stage_inputs steps; do
+  if [ $mode = steps ]; then export CUDE_SUPP_CKPT=steps; else unset CUDE_SUPP_CKPT; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/supp_${mode}_stats -o stats -- $SUPP > $OUT/supp_${mode}.log 2> $OUT/supp_${mode}.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/supp_${mode}_fetch -o fetch -- $SUPP > /dev/null 2>> $OUT/supp_${mode}.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/supp_${mode}_write -o write -- $SUPP > /dev/null 2>> $OUT/supp_${mode}.err
+  echo "supp $mode rc=$?"
+done
+unset CUDE_SUPP_CKPT
+# SQ counters of the suppression gradient kernel (instructions per wave, busy share) and its granted occupancy
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/supp_sq -o sq -- $SUPP > /dev/null 2> $OUT/supp_sq.err
+echo "supp sq rc=$?"
+python3 $ROOT/tools/occupancy.py > $OUT/occupancy.txt 2>&1
+cat $OUT/occupancy.txt
+# adaptive mode: forward and gradient launches of the reference's c-peptide instance at 1e5 subjects
+ADAPT="python3 $ROOT/tools/bench_adaptive.py 100000 4"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/adaptive_stats -o stats -- $ADAPT > $OUT/adaptive.log 2> $OUT/adaptive.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/adaptive_fetch -o fetch -- $ADAPT > /dev/null 2>> $OUT/adaptive.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/adaptive_write -o write -- $ADAPT > /dev/null 2>> $OUT/adaptive.err
+echo "adaptive rc=$?"
+cd $ROOT
+python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt

@@ -46,7 +46,8 @@ def mean_ctr(tag, kern_sub, ctr, skip=0):
 
 
 stats = kernel_stats("stats")
-for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+wait_tags = sorted(os.path.basename(p) for p in glob.glob(os.path.join(out, "pmc_w_*")))
+for tag in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"] + wait_tags:
     print(f"== {tag}")
     for k, d in counters(tag).items():
         if "cude::" not in k:
@@ -73,6 +74,15 @@ if f is not None and w is not None:
     rec["kernels"]["headline"] = {"kernel": "cpep_kernel<Mlp<2,6,2,1>,3,grad>", "subjects_per_gpu": n, "launches": nf,
                                   "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "source_sha": rec["source_sha"],
                                   "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024}
+    # SQ counters of the same kernel (per launch, summed over the chip): issue-slot utilisation in bench.py
+    sq = {}
+    for ctr in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+                "SQ_ACTIVE_INST_VALU"):
+        v, nv = mean_ctr("pmc_sq", GRAD, ctr)
+        if v is not None:
+            sq[ctr] = v
+    if sq:
+        rec["kernels"]["headline"]["sq"] = sq
     if pf and n:
         rec["calibration"] = {"kernel": "prepare_cpep_kernel", "known_read_bytes": n * (7 * 8 + 1), "FETCH_SIZE_KB": pf,
                               "ratio": pf * 1024 / (n * (7 * 8 + 1))}
@@ -85,6 +95,15 @@ for mode in ("stage_inputs", "steps"):
                                          "subjects_per_gpu": 100000, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                                          "source_sha": rec["source_sha"],
                                          "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024}
+        if mode == "stage_inputs":
+            sq = {}
+            for ctr in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+                        "SQ_ACTIVE_INST_VALU"):
+                v, nv = mean_ctr("supp_sq", "true, false, false>(cude::SuppArgs)", ctr, skip=3)
+                if v is not None:
+                    sq[ctr] = v
+            if sq:
+                rec["kernels"][f"supp_{mode}"]["sq"] = sq
     try:
         print(open(os.path.join(out, f"supp_{mode}.log")).read().strip())
     except Exception:
@@ -107,8 +126,8 @@ if f is not None and w is not None:
                                        "launches": nf, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                                        "source_sha": rec["source_sha"],
                                        "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024,
-                                       "note": "tape: 32 B per accepted step and subject written, its 16 B of "
-                                               "(t, dt) read back (20 steps typical) + 5 saved outputs"}
+                                       "note": "tape: 8 B (dt) per accepted step and subject written and read back (20 steps "
+                                               "typical) + 5 saved outputs each way"}
 try:
     print(open(os.path.join(out, "adaptive.log")).read().strip())
 except Exception:
