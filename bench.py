@@ -445,9 +445,10 @@ def cpu_baseline(pop, nn, sample, eng=None, world=1):
 
 # ------------------------------------------------------------------------------------------ extra configurations
 def timed_adam(eng, n, steps, warm):
-    """(seconds per queued step, kernel ms by HIP events, timed launches) -- the step time with kernel timing OFF (captured
-    iterations, as in the headline's timed region), the kernel time in a separate pass of the same iterations with the
-    events on (plain launches: an event pair costs ~4.5 us of stream time)."""
+    """(seconds per queued step, kernel ms by HIP events, timed launches) -- the step time with kernel timing OFF (replayed
+    graphs: the `ms_per_step_graph_replay` mode of the headline, NOT the mode of its timed region, which carries the
+    sampled events and therefore plain launches), the kernel time in a separate pass of the same iterations with an event
+    pair around every launch (plain launches: a pair costs ~4.5 us of stream time)."""
     for _ in range(warm):
         eng.adam_step(want_loss=False)
     eng.adam_run(steps)                              # captures the iteration graphs, sizes the loss trace

@@ -165,10 +165,10 @@ struct CpepAd {
 };
 
 // suppression cUDE: f(u) = [-0.4 u1, 0.4 u1 - NN(u, e^theta), NN(u, e^theta) - 0.3 u3]
-template <int W, int D>
+template <int W, int D, int HA = kActHiddenTanh, int OA = kActOutSoftplus>
 struct SuppAd {
     static constexpr int NS = 3;
-    using Net = Mlp<4, W, D, 3>;
+    using Net = Mlp<4, W, D, 3, false, false, HA, OA>;
     static constexpr int P = Net::P;
     using Args = SuppArgs;
     double c[W];
@@ -756,12 +756,35 @@ static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, boo
 #define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
 #define CUDE_SUPP_AD_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
 
+// (the shapes compiled with the other activation functions: as CUDE_CPEP_GENERAL_SHAPES / CUDE_SUPP_GENERAL_SHAPES)
+template <int NIN, int W, int D>
+static hipError_t launch_cpep_adaptive_general(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
+#define Y(HA, OA) \
+    if (net.hact == HA && net.oact == OA) return launch_adaptive<CpepAd<CpepNetG<NIN, W, D, HA, OA>>, true>(a, a.TG, grad, s);
+    CUDE_GENERAL_ACTS(Y)
+#undef Y
+    return hipErrorInvalidValue;
+}
+template <int W, int D>
+static hipError_t launch_supp_adaptive_general(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
+#define Y(HA, OA) if (net.hact == HA && net.oact == OA) return launch_adaptive<SuppAd<W, D, HA, OA>, false>(a, 0, grad, s);
+    CUDE_GENERAL_ACTS(Y)
+#undef Y
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
     if (a.TG < 2 || a.TG > kMaxObs || a.T < 1) return hipErrorInvalidValue;
     if (grad && a.obs == nullptr) return hipErrorInvalidValue;
     if (net.symbolic())
         return a.cond_raw ? launch_adaptive<CpepAd<MmProd<true>>, true>(a, a.TG, grad, s)
                           : launch_adaptive<CpepAd<MmProd<false>>, true>(a, a.TG, grad, s);
+    if (net.general()) {
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return launch_cpep_adaptive_general<NIN, W, D>(net, grad, a, s);
+        X(2, 4, 2) X(2, 6, 2) X(3, 4, 2)
+#undef X
+        return hipErrorInvalidValue;
+    }
 #define X(NIN, W, D) \
     if (net.nin == NIN && net.width == W && net.depth == D) return launch_adaptive<CpepAd<Mlp<NIN, W, D, 1>>, true>(a, a.TG, grad, s);
     CUDE_CPEP_AD_SHAPES(X)
@@ -771,6 +794,12 @@ hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& 
 
 hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
     if (net.nin != 4 || a.T < 1) return hipErrorInvalidValue;
+    if (net.general()) {
+#define X(W, D) if (net.width == W && net.depth == D) return launch_supp_adaptive_general<W, D>(net, grad, a, s);
+        X(3, 5) X(3, 3)
+#undef X
+        return hipErrorInvalidValue;
+    }
 #define X(W, D) if (net.width == W && net.depth == D) return launch_adaptive<SuppAd<W, D>, false>(a, 0, grad, s);
     CUDE_SUPP_AD_SHAPES(X)
 #undef X

@@ -192,6 +192,34 @@ const OptionEntry kOptions[] = {
 
 int32_t apply_option(cude_ctx* c, const char* name, const char* value) {
     if (!name || !value) return fail(CUDE_ERR_ARG, "null option name / value");
+    // activation functions of `chain(widths, activations; output_activation)` (src/neural-network.jl:42-58): part of the
+    // network's shape, fixed before the population is uploaded
+    const bool hidden = std::strcmp(name, "hidden_activation") == 0;
+    if (hidden || std::strcmp(name, "output_activation") == 0) {
+        if (c->have_pop) return fail(CUDE_ERR_STATE, "set the activation functions before the population");
+        if (c->cfg.model == CUDE_MODEL_CPEP_SYM) return fail(CUDE_ERR_ARG, "the symbolic model has no network");
+        cude::NetShape net = c->net;
+        if (hidden) {
+            if (std::strcmp(value, "tanh") == 0) net.hact = cude::kActHiddenTanh;
+            else if (std::strcmp(value, "relu") == 0) net.hact = cude::kActHiddenRelu;
+            else if (std::strcmp(value, "sigmoid") == 0) net.hact = cude::kActHiddenSigmoid;
+            else return fail(CUDE_ERR_UNSUPPORTED, std::string("hidden activation not compiled in: ") + value +
+                                                       " (tanh, relu, sigmoid)");
+        } else {
+            if (std::strcmp(value, "softplus") == 0) net.oact = cude::kActOutSoftplus;
+            else if (std::strcmp(value, "identity") == 0) net.oact = cude::kActOutIdentity;
+            else return fail(CUDE_ERR_UNSUPPORTED, std::string("output activation not compiled in: ") + value +
+                                                       " (softplus, identity)");
+        }
+        const bool ok = c->cfg.model == CUDE_MODEL_SUPP ? cude::supp_shape_supported(net)
+                                                        : cude::cpep_shape_supported(net, c->cfg.n_state);
+        if (!ok)
+            return fail(CUDE_ERR_UNSUPPORTED, "activation functions other than tanh / softplus are compiled for the networks "
+                                              "2-4-4-1, 2-6-6-1, 3-4-4-1 (c-peptide) and 4-3x5-1, 4-3x3-1 (suppression)");
+        c->net = net;
+        drop_graph(c);
+        return CUDE_OK;
+    }
     for (const OptionEntry& o : kOptions) {
         if (std::strcmp(o.name, name) != 0) continue;
         Options& opt = c->opt;

@@ -435,6 +435,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KEEP != 
 // ------------------------------------------------------------------------------------ dispatch
 #define CUDE_CPEP_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
 
+// ... and the shapes that are also compiled with the other activation functions (CUDE_GENERAL_ACTS, cude_device.h)
+#define CUDE_CPEP_GENERAL_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2)
+
 // shapes with a kept-activation variant of the gradient kernel: the forward sweep must already hold the upper layers'
 // weights in VGPRs (Mlp::HAS_VW) and there must be an upper layer to keep
 template <class Net>
@@ -483,9 +486,24 @@ static int grad_occupancy(int n_state, int T) {
                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpep_kernel<Net, 2, true>, kBlock, lds);
     return e == hipSuccess ? n : 0;
 }
+template <int NIN, int W, int D>
+static hipError_t launch_general(const NetShape& net, int n_state, bool grad, const CpepArgs& a, hipStream_t s) {
+#define Y(HA, OA) if (net.hact == HA && net.oact == OA) return launch_shape<CpepNetG<NIN, W, D, HA, OA>>(n_state, grad, a, s);
+    CUDE_GENERAL_ACTS(Y)
+#undef Y
+    return hipErrorInvalidValue;
+}
+static bool general_shape(const NetShape& net) {
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return true;
+    CUDE_CPEP_GENERAL_SHAPES(X)
+#undef X
+    return false;
+}
+
 // resident waves per CU of the one-lane-per-subject gradient kernel (0 = unknown)
 int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T) {
     if (net.symbolic()) return grad_occupancy<MmProd<false>>(n_state, T);
+    if (net.general()) return 4;             // (not tuned: the path selector only needs "at least one wave per SIMD")
 #define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return grad_occupancy<CpepNet<NIN, W, D>>(n_state, T);
     CUDE_CPEP_SHAPES(X)
 #undef X
@@ -494,7 +512,7 @@ int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T) {
 
 // kept values per evaluation of the gradient kernel's kept-activation variant (0: the shape has none)
 int cpep_keep_values(const NetShape& net) {
-    if (net.symbolic()) return 0;
+    if (net.symbolic() || net.general()) return 0;
 #define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return cpep_can_keep<CpepNet<NIN, W, D>>() ? CpepNet<NIN, W, D>::NKEEP : 0;
     CUDE_CPEP_SHAPES(X)
 #undef X
@@ -504,6 +522,7 @@ int cpep_keep_values(const NetShape& net) {
 bool cpep_shape_supported(const NetShape& net, int n_state) {
     if (n_state != 2 && n_state != 3) return false;
     if (net.symbolic()) return true;
+    if (net.general()) return general_shape(net) && general_acts_compiled(net.hact, net.oact);
 #define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return true;
     CUDE_CPEP_SHAPES(X)
 #undef X
@@ -514,6 +533,12 @@ hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepAr
     if (a.S == 0) return n_state != 2 ? hipErrorInvalidValue : launch_cpep_adaptive(net, grad, a, s);
     if (net.symbolic())
         return a.cond_raw ? launch_shape<MmProd<true>>(n_state, grad, a, s) : launch_shape<MmProd<false>>(n_state, grad, a, s);
+    if (net.general()) {
+#define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return launch_general<NIN, W, D>(net, n_state, grad, a, s);
+        CUDE_CPEP_GENERAL_SHAPES(X)
+#undef X
+        return hipErrorInvalidValue;
+    }
 #define X(NIN, W, D) \
     if (net.nin == NIN && net.width == W && net.depth == D) return launch_shape<CpepNet<NIN, W, D>>(n_state, grad, a, s);
     CUDE_CPEP_SHAPES(X)

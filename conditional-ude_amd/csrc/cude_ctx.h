@@ -68,6 +68,7 @@ struct Options {
     int auto_regroup = 1;       // "auto_regroup" / CUDE_NO_AUTO_REGROUP: adaptive launches re-ordered by accepted-step count
     int poll_pinned = 1;        // "poll_pinned" / CUDE_NO_POLL_PINNED: watch page-locked result slots instead of the stream wait
     int debug_selector = 0;     // "debug_selector" / CUDE_DEBUG_SELECTOR: print the launch-path decision
+    // ("hidden_activation" = tanh | relu | sigmoid, "output_activation" = softplus | identity: kept in cude_ctx::net)
     // ---- ablation
     int mixed = 1;              // CUDE_NO_MIXED
     int mixed_one_stream = 0;   // CUDE_MIXED_ONE_STREAM

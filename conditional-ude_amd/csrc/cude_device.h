@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cude_kernels.h"
 #include "cude_math.h"
 
 namespace cude {
@@ -120,6 +121,58 @@ __device__ __forceinline__ void act_tanh_vec(const double (&z)[W], double (&t)[W
     else m_tanh_vec<W>(z, t);
 }
 
+// ---- the other activation functions `chain(widths, activations; output_activation)` can be built with
+// (src/neural-network.jl:42-58: any hidden activation, any output activation; the reference's scripts use tanh and
+// softplus, which the specialised paths of Mlp are written for).  Codes = cude_kernels.h kActHidden* / kActOut*.
+// hidden layer of W units; the derivative is always a function of the OUTPUT h (what the reverse sweep has at hand)
+template <int W, int HA, bool TT>
+__device__ __forceinline__ void act_hidden_vec(const double (&z)[W], double (&h)[W]) {
+    if constexpr (HA == kActHiddenTanh) {
+        act_tanh_vec<W, TT>(z, h);
+    } else if constexpr (HA == kActHiddenRelu) {
+#pragma unroll
+        for (int j = 0; j < W; j++) h[j] = fmax(z[j], 0.0);
+    } else if constexpr (HA == kActHiddenSigmoid) {
+        // logistic function 1 / (1 + exp(-z)), all W units through ONE reciprocal (prefix products, as the tanh layer):
+        // e = exp(-|z|) in (0, 1], sigma(|z|) = 1 / (1 + e), sigma(-|z|) = e / (1 + e)
+        static_assert(W <= 8, "batched reciprocal");
+        double e[W], d[W], pre[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            e[j] = m_exp2x(fmax(-0.5 * fabs(z[j]), -350.0));
+            d[j] = 1.0 + e[j];
+            pre[j] = j == 0 ? d[0] : pre[j - 1] * d[j];
+        }
+        double r = m_rcp(pre[W - 1]);
+#pragma unroll
+        for (int j = W - 1; j >= 0; j--) {
+            const double inv = j > 0 ? r * pre[j - 1] : r;
+            if (j > 0) r = r * d[j];
+            h[j] = z[j] >= 0.0 ? inv : e[j] * inv;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < W; j++) h[j] = z[j];
+    }
+}
+template <int HA>
+__device__ __forceinline__ double act_hidden_deriv(double h) {
+    if constexpr (HA == kActHiddenTanh) return fma(-h, h, 1.0);
+    else if constexpr (HA == kActHiddenRelu) return h > 0.0 ? 1.0 : 0.0;       // (0 at the kink, as ForwardDiff's max)
+    else if constexpr (HA == kActHiddenSigmoid) return h * (1.0 - h);
+    else return 1.0;
+}
+// output unit: value and derivative
+template <int OA, bool LONE>
+__device__ __forceinline__ double act_out(double x, double* sig) {
+    if constexpr (OA == kActOutSoftplus) {
+        return m_softplus_t<LONE>(x, sig);
+    } else {
+        *sig = 1.0;
+        return x;
+    }
+}
+
 // softplus(x) = log(1+exp(x)) (reference form, evaluated stably); *sig receives the logistic derivative.
 // (LONE: no other exponential in the kernel -- networks with the table tanh; see m_exp2x_t)
 template <bool LONE>
@@ -200,9 +253,14 @@ __device__ __forceinline__ double seed_from_sgpr(double b) {
 #endif
 }
 
-template <int NIN, int W, int D, int NV, bool TT = false, bool LB = false>   // TT: tanh by table; LB: hidden biases from LDS
+// HA / OA: hidden and output activation (kActHidden* / kActOut*); anything but tanh / softplus runs on the general
+// evaluation path only (no exponent table, no register-resident weights, no pipelined weight stream, biases from the
+// scalar unit): correct for every combination, tuned for none
+template <int NIN, int W, int D, int NV, bool TT_ = false, bool LB = false, int HA = kActHiddenTanh, int OA = kActOutSoftplus>
 struct Mlp {
-    static constexpr bool LDS_BIAS = LB && D >= 2;
+    static constexpr bool GENERAL = (HA != kActHiddenTanh || OA != kActOutSoftplus);
+    static constexpr bool TT = TT_ && HA == kActHiddenTanh;         // tanh by table
+    static constexpr bool LDS_BIAS = LB && D >= 2 && !GENERAL;
     // fills s_bias for this workgroup's network (call once, before the first evaluation, where LDS_BIAS)
     __device__ static __forceinline__ void bias_init(const double* p, int lane) {
         if constexpr (LDS_BIAS) bias_lds_init<W, D, W * NIN + W, W * W + W>(p, lane);
@@ -281,7 +339,7 @@ struct Mlp {
     // forward kernel -9 % / -1.5 %.  For width 4 the 36 extra VGPRs drop the kernel from 3 to 2 waves per SIMD and
     // the gain is lost (+2.7 % at 1e6); for width 8 (351 VGPRs, one wave per SIMD, 25 KB of LDS per wave) the
     // exposed LDS latency makes it slower (+6 % / +18 %).  So the table is compiled in for widths 6 and 7 only.
-    static constexpr bool HAS_TAB = (NV == 1 && W >= 6 && W <= 7);
+    static constexpr bool HAS_TAB = (NV == 1 && W >= 6 && W <= 7) && !GENERAL;
     struct Exps {
         double v[W];
     };
@@ -334,7 +392,7 @@ struct Mlp {
 #pragma unroll
                 for (int j = 0; j < W; j++) z[j] = fma(col.v[j], x[i], i == 0 ? c[j] : z[j]);
             }
-            act_tanh_vec<W, TT>(z, h[0]);
+            act_hidden_vec<W, HA, TT>(z, h[0]);
         }
 #pragma unroll
         for (int l = 1; l < D; l++) {
@@ -360,7 +418,7 @@ struct Mlp {
                         if (i0 + g < W) z[j] = fma(col.v[g * W + j], h[l - 1][i0 + g], z[j]);
             }
             CUDE_FENCE();
-            act_tanh_vec<W, TT>(z, h[l]);
+            act_hidden_vec<W, HA, TT>(z, h[l]);
         }
         CUDE_FENCE();
         const SCol<W> wo = ld_col<W>(p, OUT);
@@ -381,7 +439,7 @@ struct Mlp {
     // 4.30 ms at 1e6 (bit-identical results).  Enabled where it does not cost a resident wave: the 2-4-4-1 kernels sit
     // at 151 VGPRs = 3 waves per SIMD and would drop to 2.
     static constexpr int NVW = (D - 1) * LH + W + 1;
-    static constexpr bool HAS_VW = (NV == 1 && NVW <= 49 && (W >= 6 || D >= 3));
+    static constexpr bool HAS_VW = (NV == 1 && NVW <= 49 && (W >= 6 || D >= 3)) && !GENERAL;
     struct VW {
         double w[NVW];
     };
@@ -506,7 +564,8 @@ struct Mlp {
         double h[D][W];
         // (the pipelined weight stream of eval_grad_pf does not pay here: measured +1 ... +7 % on the forward-only
         // kernels, which run at 3-4 waves per SIMD and lose a wave or spill SGPRs to the extra groups in flight)
-        return act_softplus_val<TT>(forward(p, c, x, h, use_tab, E1));
+        double sig;
+        return act_out<OA, TT>(forward(p, c, x, h, use_tab, E1), &sig);
     }
 
     // ---- value + weighted reverse sweep with a SOFTWARE-PIPELINED weight stream.
@@ -535,7 +594,7 @@ struct Mlp {
 #else
     static constexpr bool kPinLayers = (NV > 1);
 #endif
-    static constexpr bool HAS_PF = (D >= 2);
+    static constexpr bool HAS_PF = (D >= 2) && !GENERAL;
     // forward half: hidden activations h, output pre-activation returned; wo and (KEEP) the last hidden layer's last
     // column group stay loaded for the backward half
     // SKIP_OUT: the output unit is not evaluated (its logistic derivative is supplied: eval_grad_pf with SIG_IN)
@@ -710,7 +769,7 @@ struct Mlp {
         double h[D][W];
         const double zo = forward(p, c, x, h, use_tab, E1);
         double sig;
-        const double y = act_softplus<TT>(zo, &sig);
+        const double y = act_out<OA, TT>(zo, &sig);
         backward<WANT_DX, A, PIN, DX0>(p, x, h, sig, wgt, acc, dx);
         return y;
     }
@@ -720,7 +779,7 @@ struct Mlp {
     __device__ static __forceinline__ double eval_keep(cptr_t p, const double (&c)[W], const double (&x)[NV],
                                                        double (&h)[D][W], double* sig) {
         p = launder(p);
-        return act_softplus<TT>(forward(p, c, x, h), sig);
+        return act_out<OA, TT>(forward(p, c, x, h), sig);
     }
 
     // weighted reverse sweep from kept activations:  acc += wgt * d(out)/d(params);  if WANT_DX,
@@ -747,7 +806,7 @@ struct Mlp {
             double d[W];
 #pragma unroll
             for (int j = 0; j < W; j++) {
-                d[j] = dh[j] * fma(-h[l][j], h[l][j], 1.0);
+                d[j] = dh[j] * act_hidden_deriv<HA>(h[l][j]);
                 acc[go + W * W + j] += d[j];
             }
 #pragma unroll
@@ -782,7 +841,7 @@ struct Mlp {
         }
 #pragma unroll
         for (int j = 0; j < W; j++) {
-            const double d = dh[j] * fma(-h[0][j], h[0][j], 1.0);
+            const double d = dh[j] * act_hidden_deriv<HA>(h[0][j]);
             dh[j] = d;
             acc[G_C + j] += d;
 #pragma unroll
@@ -876,6 +935,21 @@ using SuppNet = Mlp<4, W, D, 3, false>;
 template <int W, int D>
 using SuppNet = Mlp<4, W, D, 3, true, (CUDE_SUPP_LDS_BIAS != 0)>;
 #endif
+
+// Networks with other activation functions (Mlp::GENERAL): compiled for the shapes the reference's experiments use and
+// the combinations below -- hidden tanh | relu | sigmoid, output softplus | identity, (tanh, softplus) being the
+// specialised default.  Y(hidden, output)
+#define CUDE_GENERAL_ACTS(Y) Y(0, 1) Y(1, 0) Y(1, 1) Y(2, 0) Y(2, 1)
+template <int NIN, int W, int D, int HA, int OA>
+using CpepNetG = Mlp<NIN, W, D, 1, false, false, HA, OA>;
+template <int W, int D, int HA, int OA>
+using SuppNetG = Mlp<4, W, D, 3, false, false, HA, OA>;
+inline bool general_acts_compiled(int hact, int oact) {
+#define Y(HA, OA) if (hact == HA && oact == OA) return true;
+    CUDE_GENERAL_ACTS(Y)
+#undef Y
+    return false;
+}
 
 // ------------------------------------------------------------------------------------ analytic production
 // Drop-in for Mlp<2, W, D, 1> in the c-peptide kernel: the production term found by symbolic regression,

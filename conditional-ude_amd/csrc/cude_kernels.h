@@ -10,8 +10,15 @@ namespace cude {
 constexpr int kBlock = 64;     // one wave per workgroup: no cross-wave barrier on the path
 constexpr int kMaxObs = 32;
 
+// activation functions a network can be built with (`chain(widths, activations; output_activation)`,
+// src/neural-network.jl:42-58); tanh / softplus are what every script of the reference uses
+constexpr int kActHiddenTanh = 0, kActHiddenRelu = 1, kActHiddenSigmoid = 2, kActHiddenIdentity = 3;
+constexpr int kActOutSoftplus = 0, kActOutIdentity = 1;
+
 struct NetShape {
     int nin, width, depth;
+    int hact = kActHiddenTanh, oact = kActOutSoftplus;
+    bool general() const { return hact != kActHiddenTanh || oact != kActOutSoftplus; }
     bool symbolic() const { return width == 0; }   // analytic production p0*dG/(dG+k): P = 1
     int n_params() const {
         if (symbolic()) return 1;

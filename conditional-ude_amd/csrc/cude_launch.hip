@@ -14,6 +14,7 @@ size_t supp_act_doubles(const cude_ctx* c) {
     return (size_t)(6 * c->cfg.n_steps + 1) * (size_t)(c->net.depth * c->net.width + 1) * (size_t)c->N;
 }
 bool supp_keep_activations(const cude_ctx* c, int64_t n_sets) {
+    if (c->net.general()) return false;      // (other activation functions: the plain stage-input kernels only)
     if (c->opt.supp_store == 0 || c->opt.supp_store == 1) return c->opt.supp_store == 1;
     return (double)n_sets * (double)supp_act_doubles(c) * 8.0 <= 256e6;
 }
@@ -61,7 +62,7 @@ bool supp_steps_only(const cude_ctx* c) { return c->opt.supp_ckpt_steps != 0; }
 
 cude::SuppArgs supp_args(const cude_ctx* c) {
     cude::SuppArgs a{};
-    a.ckpt_steps_only = supp_steps_only(c) ? 1 : 0;
+    a.ckpt_steps_only = (supp_steps_only(c) && !c->net.general()) ? 1 : 0;
     a.N = c->N;
     a.data = c->data.p;
     a.obs_step = c->obs_step.p; a.obs_w = c->obs_w.p;

@@ -26,9 +26,15 @@
 
 namespace cude {
 
+// HA / OA: activation functions other than tanh / softplus (cude_device.h CUDE_GENERAL_ACTS) select the general network
+template <int W, int D, int HA, int OA>
+struct SuppNetSel { using type = SuppNetG<W, D, HA, OA>; };
 template <int W, int D>
+struct SuppNetSel<W, D, kActHiddenTanh, kActOutSoftplus> { using type = SuppNet<W, D>; };
+
+template <int W, int D, int HA = kActHiddenTanh, int OA = kActOutSoftplus>
 struct SuppRhs {
-    using Net = SuppNet<W, D>;
+    using Net = typename SuppNetSel<W, D, HA, OA>::type;
     // derivatives of states 2 and 3 (du[0], du[1]); u = (u1, u2, u3)
     __device__ static __forceinline__ void f(cptr_t p, const double (&c)[W], const double (&u)[3], double (&du)[2]) {
         const double uh = Net::eval(p, c, u);
@@ -113,9 +119,9 @@ constexpr int supp_waves() {
     return (GRAD && SuppNet<W, D>::NACC <= 64) ? 2 : 1;
 #endif
 }
-template <int W, int D, bool GRAD, bool STORE, bool YONLY>
+template <int W, int D, bool GRAD, bool STORE, bool YONLY, int HA = kActHiddenTanh, int OA = kActOutSoftplus>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_waves<W, D, GRAD>()))) void supp_kernel(SuppArgs a) {
-    using R = SuppRhs<W, D>;
+    using R = SuppRhs<W, D, HA, OA>;
     using Net = typename R::Net;
     constexpr int P = Net::P;
     extern __shared__ double smem[];
@@ -415,15 +421,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
 #undef YB
 }
 
-template <int W, int D, bool GRAD, bool STORE, bool YONLY = false>
+template <int W, int D, bool GRAD, bool STORE, bool YONLY = false, int HA = kActHiddenTanh, int OA = kActOutSoftplus>
 static hipError_t launch_one(const SuppArgs& a, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)(kSuppRowsK * (YONLY ? 2 : 1) +
-                                                 (GRAD ? 6 + SuppAcc<SuppNet<W, D>>::rows : 0)) * kBlock;
+                                                 (GRAD ? 6 + SuppAcc<typename SuppRhs<W, D, HA, OA>::Net>::rows : 0)) * kBlock;
     if (a.rho == nullptr || a.obs_rho == nullptr) return hipErrorInvalidValue;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
-    hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE, YONLY>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((supp_kernel<W, D, GRAD, STORE, YONLY, HA, OA>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     return hipGetLastError();
+}
+
+// the shape of the reference's experiment with the other activation functions (stage-input mode only)
+#define CUDE_SUPP_GENERAL_SHAPES(X) X(3, 5) X(3, 3)
+template <int W, int D>
+static hipError_t launch_general(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
+#define Y(HA, OA)                                                                                 \
+    if (net.hact == HA && net.oact == OA)                                                         \
+        return grad ? launch_one<W, D, true, false, false, HA, OA>(a, s) : launch_one<W, D, false, false, false, HA, OA>(a, s);
+    CUDE_GENERAL_ACTS(Y)
+#undef Y
+    return hipErrorInvalidValue;
 }
 
 #define CUDE_SUPP_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
@@ -438,6 +456,7 @@ static int supp_grad_occupancy() {
     return n;
 }
 int supp_grad_waves_per_cu(const NetShape& net) {
+    if (net.general()) return 4;
 #define X(W, D) if (net.width == W && net.depth == D) return supp_grad_occupancy<W, D>();
     CUDE_SUPP_SHAPES(X)
 #undef X
@@ -446,6 +465,13 @@ int supp_grad_waves_per_cu(const NetShape& net) {
 
 bool supp_shape_supported(const NetShape& net) {
     if (net.nin != 4) return false;
+    if (net.general()) {
+        if (!general_acts_compiled(net.hact, net.oact)) return false;
+#define X(W, D) if (net.width == W && net.depth == D) return true;
+        CUDE_SUPP_GENERAL_SHAPES(X)
+#undef X
+        return false;
+    }
 #define X(W, D) if (net.width == W && net.depth == D) return true;
     CUDE_SUPP_SHAPES(X)
 #undef X
@@ -455,6 +481,13 @@ bool supp_shape_supported(const NetShape& net) {
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
     if (net.nin != 4) return hipErrorInvalidValue;
     if (a.S == 0) return launch_supp_adaptive(net, grad, a, s);
+    if (net.general()) {
+        if (a.ckpt_steps_only || a.act != nullptr) return hipErrorInvalidValue;
+#define X(W, D) if (net.width == W && net.depth == D) return launch_general<W, D>(net, grad, a, s);
+        CUDE_SUPP_GENERAL_SHAPES(X)
+#undef X
+        return hipErrorInvalidValue;
+    }
 #define X(W, D)                                                                                   \
     if (net.width == W && net.depth == D)                                                         \
         return !grad ? launch_one<W, D, false, false>(a, s)                                       \

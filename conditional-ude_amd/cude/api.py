@@ -67,9 +67,12 @@ class Chain:
     (cude_set_param_mask): parameter vectors have THAT layout (n_params entries, `mask` marks the live ones;
     pad_network / unpad_network convert to and from SimpleChains' own layout)."""
 
-    def __init__(self, input_dims, width, depth, widths=None):
+    def __init__(self, input_dims, width, depth, widths=None, activation="tanh", output_activation="softplus"):
         self.input_dims, self.width, self.depth = int(input_dims), int(width), int(depth)
         self.widths = None if widths is None else [int(w) for w in widths]
+        # hidden tanh | relu | sigmoid, output softplus | identity: what libcude_hip.so compiles (the reference's
+        # scripts build tanh / softplus networks only; src/neural-network.jl:42-58 accepts any function)
+        self.activation, self.output_activation = activation, output_activation
 
     @property
     def mask(self):
@@ -85,7 +88,14 @@ class Chain:
 
     @property
     def key(self):
-        return self.arch + (tuple(self.widths) if self.widths else ())
+        return self.arch + (tuple(self.widths) if self.widths else ()) + (self.activation, self.output_activation)
+
+    def configure(self, engine):
+        """tell a fresh engine the activation functions (before the population is uploaded)"""
+        if self.activation != "tanh":
+            engine.set_option("hidden_activation", self.activation)
+        if self.output_activation != "softplus":
+            engine.set_option("output_activation", self.output_activation)
 
     @property
     def n_params(self):
@@ -96,9 +106,15 @@ class Chain:
         return p + fan + 1
 
 
+_HIDDEN = ("tanh", "relu", "sigmoid")
+_OUTPUT = ("softplus", "identity")
+
+
 def chain(width, depth=None, activation="tanh", *, input_dims=2, output_dims=1, output_activation="softplus"):
-    """chain(width, depth, tanh) / chain(widths::Vector, tanh).  Only what the kernels implement is accepted:
-    equal hidden widths, tanh hidden layers, one softplus output (every network the reference builds)."""
+    """chain(width, depth, act) / chain(widths::Vector, act) / chain(widths, acts::Vector) (src/neural-network.jl:42-58,
+    85-87, 105-107).  What the kernels implement is accepted: ONE activation function for all hidden layers out of tanh,
+    relu, sigmoid (functions are recognised by name: `sigmoid` also as `σ`, `sigmoid_fast`), one output unit with softplus
+    or identity; unequal hidden widths with tanh / softplus only (zero-padded + masked, class Chain)."""
     if isinstance(width, (list, tuple, np.ndarray)):
         widths = list(width)
         if depth is not None and not isinstance(depth, (int, np.integer)):
@@ -108,17 +124,20 @@ def chain(width, depth=None, activation="tanh", *, input_dims=2, output_dims=1, 
         if isinstance(activation, (list, tuple)):
             if len(activation) != len(widths):
                 raise ValueError("The number of widths must match the number of activation functions.")
-            if any(_act_name(a) != "tanh" for a in activation):
-                raise NotImplementedError("only tanh hidden layers are compiled into the HIP kernels")
-            activation = "tanh"
+            if len({_act_name(a) for a in activation}) != 1:
+                raise NotImplementedError("one activation function for all hidden layers is what the HIP kernels implement")
+            activation = activation[0]
+        act, out = _act_name(activation), _act_name(output_activation)
         if len(set(widths)) != 1:
-            if _act_name(activation) != "tanh" or _act_name(output_activation) != "softplus" or output_dims != 1:
-                raise NotImplementedError("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
+            if act != "tanh" or out != "softplus" or output_dims != 1:
+                raise NotImplementedError("unequal hidden widths are compiled for tanh hidden layers with one softplus output")
             return Chain(input_dims, max(widths), len(widths), widths=widths)     # zero-padded + masked (class Chain)
         width, depth = widths[0], len(widths)
-    if _act_name(activation) != "tanh" or _act_name(output_activation) != "softplus" or output_dims != 1:
-        raise NotImplementedError("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
-    return Chain(input_dims, width, depth)
+    act, out = _act_name(activation), _act_name(output_activation)
+    if act not in _HIDDEN or out not in _OUTPUT or output_dims != 1:
+        raise NotImplementedError(f"compiled into the HIP kernels: hidden activation in {_HIDDEN}, ONE output with "
+                                  f"activation in {_OUTPUT} (got {act!r}, {out!r}, {output_dims} outputs)")
+    return Chain(input_dims, width, depth, activation=act, output_activation=out)
 
 
 def _layer_slices(input_dims, widths):
@@ -173,7 +192,8 @@ def unpad_network(widths, padded, *, input_dims=2):
 
 
 def _act_name(a):
-    return a if isinstance(a, str) else getattr(a, "__name__", str(a))
+    name = a if isinstance(a, str) else getattr(a, "__name__", str(a))
+    return {"σ": "sigmoid", "sigmoid_fast": "sigmoid", "tanh_fast": "tanh", "identity": "identity"}.get(name, name)
 
 
 def neural_network_model(depth, width, *, input_dims=2):
@@ -342,6 +362,7 @@ class _Pop:
         else:
             net = getattr(models[0], "_carrier", models[0].chain)      # (CPeptideUDEModel: its 2-input carrier)
             self.engine = Engine("cpep", net.arch, n_steps=n_steps, n_state=n_state, device=device)
+            net.configure(self.engine)
             if net.mask is not None:
                 self.engine.set_param_mask(net.mask)
         G = np.stack([m.glucose for m in models])
@@ -768,6 +789,7 @@ def likelihood_profiles(betas, neural_network_parameters, models, timepoints, cp
 class _SuppPop:
     def __init__(self, data, timepoints, net, lam, n_steps, device):
         self.engine = Engine("supp", net.arch, n_steps=n_steps, lam=lam, device=device)
+        net.configure(self.engine)
         if net.mask is not None:
             self.engine.set_param_mask(net.mask)
         self.engine.set_population_supp(np.asarray(timepoints, dtype=np.float64), data)

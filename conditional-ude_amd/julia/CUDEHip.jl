@@ -409,15 +409,30 @@ function kernel_time_ms(c::Ctx)
 end
 
 # ----------------------------------------------------------------------------------------------- reference API: models
-# chain(width, depth, tanh; input_dims = 2): only what the kernels compile (equal widths, tanh, one softplus output)
+# chain(width, depth, act; input_dims = 2, output_activation = softplus): what the kernels compile -- equal widths, ONE
+# hidden activation out of tanh / relu / sigmoid, one output unit with softplus or identity (recognised by name)
 struct Chain
     input_dims::Int; width::Int; depth::Int
     widths::Vector{Int}     # empty = equal widths; otherwise the network is carried zero-padded to width = maximum(widths)
+    activation::String; output_activation::String
 end
-Chain(input_dims::Integer, width::Integer, depth::Integer) = Chain(input_dims, width, depth, Int[])
-chain(width::Integer, depth::Integer, activation = tanh; input_dims::Integer = 2, output_dims::Integer = 1) =
-    (output_dims == 1 && activation === tanh) ? Chain(input_dims, width, depth) :
-    error("only tanh hidden layers with one softplus output are compiled into the HIP kernels")
+Chain(input_dims::Integer, width::Integer, depth::Integer, widths::Vector{Int} = Int[]) =
+    Chain(input_dims, width, depth, widths, "tanh", "softplus")
+softplus(x) = log(1 + exp(x))                                   # src/neural-network.jl:13-15
+act_name(f) = (n = string(nameof(f)); n in ("σ", "sigmoid_fast") ? "sigmoid" : n == "tanh_fast" ? "tanh" : n)
+function chain(width::Integer, depth::Integer, activation = tanh; input_dims::Integer = 2, output_dims::Integer = 1,
+               output_activation = softplus)
+    a, o = act_name(activation), act_name(output_activation)
+    (output_dims == 1 && a in ("tanh", "relu", "sigmoid") && o in ("softplus", "identity")) ||
+        error("compiled into the HIP kernels: hidden tanh / relu / sigmoid, one output with softplus / identity")
+    Chain(input_dims, width, depth, Int[], a, o)
+end
+# the activation functions travel to the library as options of the context, before the population is uploaded
+function configure!(c, net::Chain)
+    net.activation == "tanh" || set_option!(c, "hidden_activation", net.activation)
+    net.output_activation == "softplus" || set_option!(c, "output_activation", net.output_activation)
+    c
+end
 # chain(widths, tanh) (src/neural-network.jl:42-58): unequal widths = the equal-width network of width maximum(widths)
 # whose extra units have zero weights, frozen through cude_set_param_mask; parameter vectors carry THAT layout
 function chain(widths::AbstractVector{<:Integer}, activation = tanh; input_dims::Integer = 2, output_dims::Integer = 1)
@@ -481,7 +496,7 @@ CPeptideUDEModel(glucose_data::AbstractVector{<:Real}, glucose_timepoints::Abstr
     error("the non-conditional model takes a network with input_dims = 1")
 embed_single_input(W::Integer, p::AbstractVector{<:Real}) = vcat(p[1:W], zeros(W), p[W+1:end])
 extract_single_input(W::Integer, q::AbstractVector{<:Real}) = vcat(q[1:W], q[2W+1:end])
-carrier(c::Chain) = Chain(2, c.width, c.depth, c.widths)
+carrier(c::Chain) = Chain(2, c.width, c.depth, c.widths, c.activation, c.output_activation)
 function carrier_mask(c::Chain)            # 1 = live entry of the carrier's parameter vector
     n1 = n_params(Chain(1, c.width, c.depth))
     embed_single_input(c.width, isempty(c.widths) ? ones(n1) : param_mask(c))
@@ -503,7 +518,7 @@ function population(models::AbstractVector{CPeptideConditionalUDEModel}, timepoi
     get!(POPULATIONS, key) do
         net = models[1].chain
         all(m -> m.timepoints == timepoints, models) || error("timepoints must equal the models' own timepoints")
-        c = Ctx(Config(MODEL_CPEP, 2, net.input_dims, net.width, net.depth, S, 0, 0, 0.0))
+        c = configure!(Ctx(Config(MODEL_CPEP, 2, net.input_dims, net.width, net.depth, S, 0, 0, 0.0)), net)
         G = Matrix{Float64}(undef, length(models), length(timepoints))
         for (i, m) in enumerate(models); G[i, :] .= m.glucose; end
         set_population!(c, Vector{Float64}(timepoints), G, data, [m.age for m in models], UInt8[m.t2dm for m in models])
@@ -683,7 +698,8 @@ function supp_population(prob::SuppressionProblem, data::AbstractArray{<:Real,3}
     d = Array{Float64,3}(data)
     key = hash((n_steps, prob.network, Vector{Float64}(timepoints), d, Float64(λ)))
     get!(SUPP_POPULATIONS, key) do
-        c = Ctx(Config(MODEL_SUPP, 3, 4, prob.network.width, prob.network.depth, n_steps, 0, 0, Float64(λ)))
+        c = configure!(Ctx(Config(MODEL_SUPP, 3, 4, prob.network.width, prob.network.depth, n_steps, 0, 0, Float64(λ))),
+                       prob.network)
         set_population_supp!(c, Vector{Float64}(timepoints), d)
     end
 end

@@ -62,7 +62,8 @@ typedef struct cude_config {
     int32_t nn_in;    /* CPEP: 2 = [dG, exp(beta)], 3 = [dG, exp(beta), age] (covariate model,
                          src/c-peptide-models.jl:96-104); SUPP: 4 = [u1,u2,u3,exp(theta)] */
     int32_t nn_width; /* hidden width (0 for CUDE_MODEL_CPEP_SYM) */
-    int32_t nn_depth; /* number of tanh hidden layers; output layer is softplus, 1 unit (0 for CPEP_SYM) */
+    int32_t nn_depth; /* number of hidden layers (tanh unless cude_set_option says otherwise); output layer: 1 unit, softplus
+                         unless cude_set_option says otherwise (0 for CPEP_SYM) */
     int32_t n_steps;  /* fixed Tsit5 steps over the time span; 0 = ADAPTIVE Tsit5 as the reference runs it
                          (OrdinaryDiffEq defaults abstol 1e-6 / reltol 1e-3, PI controller, cude_set_tolerances), in
                          every entry point.  Gradients in this mode are those of the accepted step sequence taken as
@@ -383,7 +384,13 @@ int32_t cude_xchg_enable(cude_ctx* ctx, int32_t enabled);
  * fine-grained, 0 = ordinary device memory) and how many device-side waits have run out of time so far. */
 int32_t cude_xchg_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* memory_kind, int32_t* timeouts);
 
-/* --- run-time options (cude_ctx.h `Options` lists them): launch-path override of the tests ("cpep_path" = "1" |
+/* --- run-time options.
+ * The network's activation functions -- `chain(widths, activations; output_activation)`, src/neural-network.jl:42-58 --:
+ * "hidden_activation" = "tanh" (default) | "relu" | "sigmoid", "output_activation" = "softplus" (default) | "identity";
+ * set them before the population is uploaded.  tanh / softplus (every network of the reference's scripts) run on the
+ * tuned kernels; the other combinations on the general evaluation path of the same kernels, compiled for the shapes
+ * 2-4-4-1, 2-6-6-1, 3-4-4-1 (c-peptide) and 4-3x5-1, 4-3x3-1 (suppression): CUDE_ERR_UNSUPPORTED otherwise.
+ * Implementation switches (cude_ctx.h `Options` lists them): launch-path override of the tests ("cpep_path" = "1" |
  * "2:L" | "3:B:L"), "cpep_keep", "supp_store", "supp_ckpt", "tape_steps", "exp_table", "ms_split", "auto_regroup",
  * "poll_pinned", "debug_selector".  Values are decimal integers as text unless noted.  Every option is also read once
  * at cude_create from its environment variable (CUDE_CPEP_PATH, CUDE_CPEP_KEEP, CUDE_SUPP_STORE, CUDE_SUPP_CKPT,

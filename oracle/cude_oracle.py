@@ -111,7 +111,7 @@ SYMBOLIC = (1, 0, 0)     # "architecture" of the analytic production model: one 
 
 
 def n_params(arch):
-    nin, width, depth = arch
+    nin, width, depth = arch[:3]
     if width == 0:
         return 1
     p, fan_in = 0, nin
@@ -125,10 +125,28 @@ def softplus(xp, x):
     return xp.log(1.0 + xp.exp(x))
 
 
+def _relu(xp, z):
+    if xp is np:
+        return np.maximum(z, 0.0)
+    if xp is math:
+        return z if z > 0.0 else 0.0
+    return xp.clamp(z, min=0.0)          # torch
+
+
+# `chain(widths, activations; output_activation)` (src/neural-network.jl:42-58) takes any activation functions; the
+# reference's scripts pass tanh and softplus.  An `arch` tuple may name others behind its three sizes:
+# (nin, width, depth, hidden, output) with hidden in HIDDEN_ACTS and output in OUTPUT_ACTS.
+HIDDEN_ACTS = {"tanh": lambda xp, z: xp.tanh(z), "relu": _relu,
+               "sigmoid": lambda xp, z: 1.0 / (1.0 + xp.exp(-z)), "identity": lambda xp, z: z}
+OUTPUT_ACTS = {"softplus": softplus, "identity": lambda xp, z: z}
+
+
 def mlp(xp, inputs, p, arch):
     """inputs: list of nin arrays (N,) or scalars; p: (P,) parameter vector.
     Returns the scalar network output per subject (N,)."""
-    nin, width, depth = arch
+    nin, width, depth = arch[:3]
+    act = HIDDEN_ACTS[arch[3] if len(arch) > 3 else "tanh"]
+    out = OUTPUT_ACTS[arch[4] if len(arch) > 4 else "softplus"]
     h = list(inputs)
     off, fan_in = 0, nin
     for _ in range(depth):
@@ -137,13 +155,13 @@ def mlp(xp, inputs, p, arch):
             z = p[off + fan_in * width + j]                      # bias
             for i in range(fan_in):
                 z = z + p[off + j + width * i] * h[i]            # W[j,i], column-major
-            nxt.append(xp.tanh(z))
+            nxt.append(act(xp, z))
         off += fan_in * width + width
         h, fan_in = nxt, width
     z = p[off + fan_in]
     for i in range(fan_in):
         z = z + p[off + i] * h[i]
-    return softplus(xp, z)
+    return out(xp, z)
 
 
 def symbolic_production(xp, dG, p0, k):
@@ -671,7 +689,7 @@ def synthetic_cpep_population(N, seed=20250905):
 
 def glorot_params(arch, seed):
     rng = np.random.default_rng(seed)
-    nin, width, depth = arch
+    nin, width, depth = arch[:3]
     parts, fan_in = [], nin
     for _ in range(depth):
         parts.append(rng.standard_normal(width * fan_in) * math.sqrt(2.0 / (fan_in + width)))

@@ -23,8 +23,13 @@ def test_chain_mirrors_reference_argument_errors():
     assert api.chain([4, 5], "tanh").arch == (2, 5, 2)                 # unequal widths: zero-padded + masked (class Chain)
     with pytest.raises(NotImplementedError):
         api.chain([4, 5], ["tanh", "relu"])
+    relu = api.chain(4, 2, "relu", output_activation="identity")       # (round 4) relu / sigmoid, softplus / identity
+    assert (relu.activation, relu.output_activation) == ("relu", "identity") and relu.key != api.chain(4, 2, "tanh").key
+    assert api.chain([4, 4], ["sigmoid", "sigmoid"]).activation == "sigmoid"
     with pytest.raises(NotImplementedError):
-        api.chain(4, 2, "relu")
+        api.chain(4, 2, "gelu")
+    with pytest.raises(NotImplementedError):
+        api.chain([4, 5], "relu")                                      # unequal widths: tanh / softplus only
     net = api.chain(4, 2, "tanh")
     with pytest.raises(ValueError):
         api.CPeptideConditionalUDEModel([1, 2, 3], [0, 1, 2], 40, net, [1, 2], False)
