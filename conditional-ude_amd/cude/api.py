@@ -287,7 +287,8 @@ class CPeptideUDEModel:
         W = network.width
         base = network.mask if network.mask is not None else np.ones(network.n_params)
         mask = embed_single_input(W, base)                     # (zero where the second input's weights sit)
-        self._carrier = SimpleNamespace(arch=(2, W, network.depth), mask=mask, key=("ude",) + tuple(network.key))
+        self._carrier = SimpleNamespace(arch=(2, W, network.depth), mask=mask, key=("ude",) + tuple(network.key),
+                                        configure=network.configure)
         self._key = _model_key(self, ("ude", network.key))
 
     def embed(self, params):

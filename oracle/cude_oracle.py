@@ -130,7 +130,9 @@ def _relu(xp, z):
         return np.maximum(z, 0.0)
     if xp is math:
         return z if z > 0.0 else 0.0
-    return xp.clamp(z, min=0.0)          # torch
+    # torch: d relu / dz = 0 AT the kink, as ForwardDiff differentiates Julia's max(zero(x), x) (a tie returns the
+    # constant); torch.clamp would pass the gradient through at z == 0, which a dead layer with zero biases hits exactly
+    return z * (z > 0.0).to(z.dtype)
 
 
 # `chain(widths, activations; output_activation)` (src/neural-network.jl:42-58) takes any activation functions; the
