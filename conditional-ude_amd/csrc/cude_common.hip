@@ -105,13 +105,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
         const double v0 = (mask != nullptr && q < n_mask) ? s[0] * mask[q] : s[0];
         double vq = accumulate ? out[q] + v0 : v0;               // accumulate: a second group of rows of the same launch
         double loss = s2[0];
-        if (xc) {
+        if (xc && tail) {               // loss sum (column q - 1) and failure count (q): both written, then both waited for
+            xchg_combine2(xchg, q - 1, loss, vq);
+            out[q - 1] = loss;
+            if (host_tail != nullptr) host_tail[0] = loss;
+        } else if (xc) {
             vq = xchg_combine(xchg, q, vq);
-            if (tail) {
-                loss = xchg_combine(xchg, q - 1, loss);
-                out[q - 1] = loss;
-                if (host_tail != nullptr) host_tail[0] = loss;
-            }
         }
         out[q] = vq;
         // [sum loss, n_failed] straight into page-locked host memory as well, where the host watches for them

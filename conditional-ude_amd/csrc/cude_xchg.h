@@ -59,11 +59,12 @@ CUDE_XCHG_HD inline double xchg_value(unsigned long long u) {
     return c.d;
 }
 
-// op: 0 = sum, 1 = max.  Called by ONE lane / thread per column; columns are independent of each other.
-// Mem: store(p, word), load(p) -- untorn 8-byte accesses that reach / come from the memory all ranks see --, now(),
-// pause().
+// The two halves of an exchange, so that a lane that exchanges several columns (the tail workgroup of the reduction: loss
+// sum and failure count) has all its writes in flight before it starts to wait.
+// xchg_push: writes this rank's value of `col` into every mailbox; returns the sequence number the wait must see.
+// Mem: store(p, word), load(p) -- untorn 8-byte accesses that reach / come from the memory all ranks see --, now(), pause().
 template <class Mem>
-CUDE_XCHG_HD inline double xchg_combine(const XchgArgs& x, int col, double v, int op, Mem mem) {
+CUDE_XCHG_HD inline unsigned xchg_push(const XchgArgs& x, int col, double v, Mem mem) {
     const unsigned s = x.seq[col] + 1u;
     const unsigned long long bits = xchg_bits(v);
     const unsigned long long w0 = ((unsigned long long)s << 32) | (bits & 0xffffffffull);
@@ -73,7 +74,14 @@ CUDE_XCHG_HD inline double xchg_combine(const XchgArgs& x, int col, double v, in
         mem.store(x.peers[r] + mine, w0);
         mem.store(x.peers[r] + mine + 1, w1);
     }
-    const long long t0 = mem.now();
+    return s;
+}
+
+// xchg_wait: polls the n_ranks slots of `col` in the own mailbox until each carries sequence s and combines the values
+// in rank order (op: 0 = sum, 1 = max); advances the column's counter.  t0: the time the caller started waiting
+// (one time limit for all the columns a lane waits for).
+template <class Mem>
+CUDE_XCHG_HD inline double xchg_wait(const XchgArgs& x, int col, unsigned s, int op, long long t0, Mem mem) {
     double acc = 0.0;
     bool lost = false;
     for (int r = 0; r < x.n_ranks && !lost; r++) {
@@ -98,6 +106,13 @@ CUDE_XCHG_HD inline double xchg_combine(const XchgArgs& x, int col, double v, in
     return acc;
 }
 
+// one column: push, then wait.  Called by ONE lane / thread per column; columns are independent of each other.
+template <class Mem>
+CUDE_XCHG_HD inline double xchg_combine(const XchgArgs& x, int col, double v, int op, Mem mem) {
+    const unsigned s = xchg_push(x, col, v, mem);
+    return xchg_wait(x, col, s, op, mem.now(), mem);
+}
+
 #ifdef __HIPCC__
 struct XchgDeviceMem {
     __device__ __forceinline__ void store(unsigned long long* p, unsigned long long w) const {
@@ -111,6 +126,14 @@ struct XchgDeviceMem {
 };
 __device__ __forceinline__ double xchg_combine(const XchgArgs& x, int col, double v, int op = 0) {
     return xchg_combine(x, col, v, op, XchgDeviceMem{});
+}
+// two columns at once (col and col + 1): both values written before either is waited for
+__device__ __forceinline__ void xchg_combine2(const XchgArgs& x, int col, double& v0, double& v1) {
+    const XchgDeviceMem mem{};
+    const unsigned s0 = xchg_push(x, col, v0, mem), s1 = xchg_push(x, col + 1, v1, mem);
+    const long long t0 = mem.now();
+    v0 = xchg_wait(x, col, s0, 0, t0, mem);
+    v1 = xchg_wait(x, col + 1, s1, 0, t0, mem);
 }
 #endif
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch  # noqa: F401  (first: shared HIP runtime)
 
-from conftest import make_cpep_case, make_supp_case
+from conftest import make_cpep_case, make_supp_case, free_port
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -234,7 +234,7 @@ def test_two_rank_sharded_training_matches_single_engine(tmp_path):
     import torch.multiprocessing as mp
     from cude.engine import Engine
     n_total, world = 333, 2
-    port = 29700 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_gpu_rank, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["losses"], r1["losses"]) and np.array_equal(r0["nn"], r1["nn"])
@@ -449,7 +449,7 @@ def test_two_rank_sharded_lbfgs_matches_single_engine(tmp_path):
     import torch.multiprocessing as mp
     from cude.engine import Engine
     n_total, world = 157, 2
-    port = 32700 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_gpu_lbfgs_rank, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "lb0.npz"), np.load(tmp_path / "lb1.npz")
     for k in r0.files:
@@ -511,7 +511,7 @@ def test_two_rank_sharded_saem_matches_single_engine(tmp_path):
     import torch.multiprocessing as mp
     from cude.parallel import saem_loop
     n_total, world = 201, 2
-    port = 30700 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_gpu_saem_rank, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "saem0.npz"), np.load(tmp_path / "saem1.npz")
     for k in r0.files:

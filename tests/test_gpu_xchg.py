@@ -16,7 +16,7 @@ import threading
 import numpy as np
 import pytest
 
-from conftest import make_cpep_case, make_supp_case
+from conftest import make_cpep_case, make_supp_case, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -119,7 +119,7 @@ def test_two_processes_on_one_gpu_train_as_one_engine(cfg, tmp_path):
     from cude.engine import Engine  # noqa: F401
     model, arch, lam, n_total, path = cfg
     world = 2
-    port = 29900 + (os.getpid() % 1500)
+    port = free_port()
     mp.spawn(_rank, args=(world, port, cfg, str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     # every rank formed the same sums in the same order: identical bits

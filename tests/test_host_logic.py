@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import make_cpep_case
+from conftest import make_cpep_case, free_port
 
 
 def test_chain_mirrors_reference_argument_errors():
@@ -259,7 +259,7 @@ def test_two_rank_gloo_training_matches_single_process(tmp_path, world):
     import c_oracle as co
     import cude_oracle as o
     n_total = 23
-    port = 29500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / f"rank{world - 1}.npz")
     assert np.array_equal(r0["losses"], r1["losses"]) and np.array_equal(r0["nn"], r1["nn"])
@@ -314,7 +314,7 @@ def test_sharded_lbfgs_follows_the_single_process_iterates(tmp_path, world):
     import cude_oracle as o
     from cude.engine import lbfgs_minimize
     n_total = 17
-    port = 33500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_lbfgs_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "lbfgs0.npz"), np.load(tmp_path / f"lbfgs{world - 1}.npz")
     for k in r0.files:
@@ -377,7 +377,7 @@ def test_two_rank_gloo_saem_matches_single_process(tmp_path, world):
     import torch.multiprocessing as mp
     from cude.parallel import saem_loop
     n_total = 11
-    port = 31500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_saem_rank_main, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "saem0.npz"), np.load(tmp_path / f"saem{world - 1}.npz")
     for k in r0.files:

@@ -99,7 +99,7 @@ for mode in ("stage_inputs", "steps"):
             sq = {}
             for ctr in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
                         "SQ_ACTIVE_INST_VALU"):
-                v, nv = mean_ctr("supp_sq", "true, false, false>(cude::SuppArgs)", ctr, skip=3)
+                v, nv = mean_ctr("supp_sq", "supp_kernel<3, 5, true, false, false", ctr, skip=3)
                 if v is not None:
                     sq[ctr] = v
             if sq:
