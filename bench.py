@@ -984,6 +984,9 @@ def main():
                     "subjects_seen": saem["n_seen"]}
             out["kernel_ms_per_rank"] = {"min": kern_min, "max": kern_max}
             out["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+            if rehearsal:
+                out["rehearsal"] = (f"{world} ranks time-share {torch.cuda.device_count()} GPU(s): a dry run of the "
+                                    "N > 1 control flow, not a throughput measurement")
         if cpu_rev is not None:
             out["cpu_baseline"], out["cpu_baseline_forward_mode"] = cpu_rev, cpu_fwd
             if parity is not None:
