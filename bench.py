@@ -253,7 +253,19 @@ CLOCK_GHZ = 2.4                # the clock FP64_VALU_PEAK_TF is quoted at
 VALU_CYCLES_PER_INSTRUCTION = 4     # a wave64 fp64 (or any full-rate VALU) instruction occupies its SIMD for four cycles
 
 
-def rooflines(kernel, kern_ms, launches, n_subjects, bytes_per_subject, ops, traffic=None, note=None, sq=None):
+def rocprof_figures(rec):
+    """The profiler's own durations of the kernel, from the committed `rocprofv3 --kernel-trace --stats` pass of the same
+    command on the same sources (None without a current record): printed beside the HIP-event figure of this run."""
+    if not rec or "rocprof_avg_ms" not in rec:
+        return None
+    return {"mean_ms": rec["rocprof_avg_ms"], "median_ms": rec.get("rocprof_median_ms"), "launches": rec.get("rocprof_calls"),
+            "note": "every launch of the profiled process: the mean includes the clock-ramp launches at its start (the "
+                    "first tens run 15-25 % long), the median does not; kernel_ms of this line is HIP events over the "
+                    "timed region only"}
+
+
+def rooflines(kernel, kern_ms, launches, n_subjects, bytes_per_subject, ops, traffic=None, note=None, sq=None,
+              rocprof=None):
     """The contract's `roofline` object (HBM) and `roofline_valu` (the binding one).  `ops` = Ops per subject-trajectory:
     roofline_valu.frac is floating-point operations (FMA = 2, add / mul / rcp = 1) over the fp64 vector peak;
     clamps, conversions, selects and sign transfers occupy the same issue slots but are NOT floating-point work and
@@ -266,6 +278,8 @@ def rooflines(kernel, kern_ms, launches, n_subjects, bytes_per_subject, ops, tra
            "traffic": traffic, "kernel": kernel, "kernel_ms": kern_ms, "launches": launches,
            "algorithmic_bytes_per_launch": bytes_per_subject * n_subjects,
            "note": note or "path is fp64-VALU bound (SURVEY.md 8d), see roofline_valu"}
+    if rocprof_figures(rocprof):
+        hbm["kernel_ms_rocprof"] = rocprof_figures(rocprof)
     valu = {"bound": "valu_fp64", "achieved": tfs, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
             "frac": tfs / FP64_VALU_PEAK_TF, "flops_per_trajectory": ops.flops,
             "counted": {"fma": ops.fma, "other_fp_ops": ops.fp1, "other_valu_slots_per_trajectory": ops.other,
@@ -564,7 +578,7 @@ def extras(Engine, device, steps=20, warm=40):
     srec, _ = pmc_record("supp_stage_inputs", n)
     hbm, valu = rooflines("supp_kernel<3,5,grad>", ms, launches, n, supp_algo_bytes(8, True),
                           supp_ops(arch, N_STEPS, 8, True), traffic=srec.get("hbm_bytes_per_launch") if srec else None,
-                          sq=srec.get("sq") if srec else None,
+                          sq=srec.get("sq") if srec else None, rocprof=srec,
                           note=f"+ {scratch} B/subject of stage-input scratch (stored linearisation points instead of "
                                f"a recomputed forward sweep; profiles/r02/supp_scratch_tradeoff.txt)")
     out["supp_1e5"] = {"config": "suppression cUDE (suppression.jl:18): 4x3x3x3x3x3x1, 3 states, T=8, 1e5 subjects, "
@@ -946,7 +960,8 @@ def main():
         hrec, traffic_note = pmc_record("headline", n_local)
         traffic = hrec.get("hbm_bytes_per_launch") if hrec else None
         hbm, valu = rooflines("cpep_kernel<Mlp<2,6,2,1>,3,grad>", kern_ms, n_launch, n_local,
-                              cpep_algo_bytes(T_OBS, N_STATE, True), cpep_ops(), traffic, sq=hrec.get("sq") if hrec else None)
+                              cpep_algo_bytes(T_OBS, N_STATE, True), cpep_ops(), traffic, sq=hrec.get("sq") if hrec else None,
+                              rocprof=hrec)
         if traffic is None:
             hbm["traffic_note"] = traffic_note
         out = {

@@ -26,7 +26,23 @@ def kernel_stats(tag):
     for r in rows(f"{tag}/**/*kernel_stats.csv"):
         print(f"{r.get('Name','')[:86]:86s} calls={r.get('Calls'):>5s} total_ns={r.get('TotalDurationNs'):>12s} "
               f"avg_ns={r.get('AverageNs'):>12s} pct={r.get('Percentage')}")
-        res[r.get("Name", "")] = float(r.get("AverageNs", 0))
+        res[r.get("Name", "")] = (float(r.get("AverageNs", 0)), int(r.get("Calls", 0)))
+    return res
+
+
+def rocprof_avg(st, kern_sub, tag="stats"):
+    """{"rocprof_avg_ms", "rocprof_calls", "rocprof_median_ms"} of the kernel whose name contains kern_sub: the
+    profiler's own average over every launch of the run (kernel_stats() result st) and the median of the per-launch
+    durations of its kernel trace (the mean includes the clock-ramp launches at the start of the process, the median
+    does not).  bench.py prints them beside its HIP-event figure."""
+    res = {}
+    for name, (avg, calls) in st.items():
+        if kern_sub in name:
+            res = {"rocprof_avg_ms": avg * 1e-6, "rocprof_calls": calls}
+    d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows(f"{tag}/**/*kernel_trace.csv")
+               if kern_sub in r.get("Kernel_Name", ""))
+    if d:
+        res["rocprof_median_ms"] = 0.5e-6 * (d[(len(d) - 1) // 2] + d[len(d) // 2])
     return res
 
 
@@ -83,11 +99,12 @@ if f is not None and w is not None:
             sq[ctr] = v
     if sq:
         rec["kernels"]["headline"]["sq"] = sq
+    rec["kernels"]["headline"].update(rocprof_avg(stats, GRAD))
     if pf and n:
         rec["calibration"] = {"kernel": "prepare_cpep_kernel", "known_read_bytes": n * (7 * 8 + 1), "FETCH_SIZE_KB": pf,
                               "ratio": pf * 1024 / (n * (7 * 8 + 1))}
 for mode in ("stage_inputs", "steps"):
-    kernel_stats(f"supp_{mode}_stats")
+    sst = kernel_stats(f"supp_{mode}_stats")
     f, nf = mean_ctr(f"supp_{mode}_fetch", "supp_kernel", "FETCH_SIZE", skip=3)
     w, nw = mean_ctr(f"supp_{mode}_write", "supp_kernel", "WRITE_SIZE", skip=3)
     if f is not None and w is not None:
@@ -104,6 +121,7 @@ for mode in ("stage_inputs", "steps"):
                     sq[ctr] = v
             if sq:
                 rec["kernels"][f"supp_{mode}"]["sq"] = sq
+        rec["kernels"][f"supp_{mode}"].update(rocprof_avg(sst, "supp_kernel<3, 5, true, false, false", f"supp_{mode}_stats"))
     try:
         print(open(os.path.join(out, f"supp_{mode}.log")).read().strip())
     except Exception:
@@ -117,7 +135,7 @@ try:
     print(open(os.path.join(out, "occupancy.txt")).read().strip())
 except Exception:
     pass
-kernel_stats("adaptive_stats")
+ast = kernel_stats("adaptive_stats")
 AGRAD = "> >, true, true>("                   # adaptive_kernel<CpepAd<...>, IS_CPEP, GRAD>
 f, nf = mean_ctr("adaptive_fetch", AGRAD, "FETCH_SIZE", skip=3)
 w, nw = mean_ctr("adaptive_write", AGRAD, "WRITE_SIZE", skip=3)
@@ -128,6 +146,7 @@ if f is not None and w is not None:
                                        "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024,
                                        "note": "tape: 8 B (dt) per accepted step and subject written and read back (20 steps "
                                                "typical) + 5 saved outputs each way"}
+    rec["kernels"]["adaptive_grad"].update(rocprof_avg(ast, AGRAD, "adaptive_stats"))
 try:
     print(open(os.path.join(out, "adaptive.log")).read().strip())
 except Exception:
