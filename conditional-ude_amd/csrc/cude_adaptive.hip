@@ -748,10 +748,33 @@ void adaptive_kernel(typename M::Args a) {
 // arithmetic in the same order: results are bit-identical to the kernel above.
 template <class M>
 struct unrolled_stages { static constexpr bool value = false; };
-#define CUDE_CPEP_AD_UNROLLED(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2)
-#define X(NIN, W, D) template <> struct unrolled_stages<CpepAd<Mlp<NIN, W, D, 1>>> { static constexpr bool value = true; };
-CUDE_CPEP_AD_UNROLLED(X)
-#undef X
+constexpr int kUnrolledKnots = 5;                  // the reference's five sampling times (c-peptide/02-conditional.jl)
+template <int NIN, int W, int D>
+struct unrolled_stages<CpepAd<Mlp<NIN, W, D, 1>>> { static constexpr bool value = true; };
+
+// adjoints of the seven stage derivatives of the step being reversed: registers (indices are literals after unrolling),
+// or one LDS row each for the networks whose gradient accumulators fill the register file
+template <int NS, bool IN_LDS>
+struct StageAdjoints {
+    double v[7][NS];
+    __device__ __forceinline__ StageAdjoints(double*, int) {}
+    __device__ __forceinline__ double get(int j, int s) const { return v[j][s]; }
+    __device__ __forceinline__ void set(int j, int s, double x) { v[j][s] = x; }
+};
+template <int NS>
+struct StageAdjoints<NS, true> {
+    double* row;
+    __device__ __forceinline__ StageAdjoints(double* s_B, int lane) : row(s_B + lane) {}
+    __device__ __forceinline__ double get(int j, int s) const { return row[(j * NS + s) * kBlock]; }
+    __device__ __forceinline__ void set(int j, int s, double x) { row[(j * NS + s) * kBlock] = x; }
+};
+#ifndef CUDE_ADAPT_BLDS_NACC
+#define CUDE_ADAPT_BLDS_NACC 40
+#endif
+template <class M, bool GRAD>
+constexpr bool unrolled_adjoints_in_lds() { return GRAD && M::NetT::NACC > CUDE_ADAPT_BLDS_NACC; }
+template <class M, bool GRAD>
+constexpr int unrolled_fixed_rows() { return kRedRows + (unrolled_adjoints_in_lds<M, GRAD>() ? 7 * M::NS : 0); }
 
 template <class M, bool GRAD>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(adaptive_waves<M, GRAD>())))
@@ -759,7 +782,11 @@ void adaptive_unrolled_kernel(typename M::Args a) {
     static_assert(!M::NEED_Y, "constant-Jacobian models only");
     constexpr int NS = M::NS;
     constexpr int P = M::P;
-    extern __shared__ double smem[];               // [kRedRows] reduction scratch, then TG glucose rows and TG - 1 slope rows
+    constexpr bool B_LDS = unrolled_adjoints_in_lds<M, GRAD>();
+    constexpr int FIXED = unrolled_fixed_rows<M, GRAD>();
+    // [kRedRows] reduction scratch, (large networks) 7 NS rows of stage adjoints, then TG glucose rows and TG - 1 slope rows
+    extern __shared__ double smem[];
+    double* const s_B = smem + kRedRows * kBlock;
     const int lane = threadIdx.x;
     if constexpr (M::NetT::USES_TANH) tanh_tab_init(lane);
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
@@ -772,16 +799,23 @@ void adaptive_unrolled_kernel(typename M::Args a) {
 
     M m;
     double y[NS];
-    const double chk = m.init(a, smem + kRedRows * kBlock, lane, i, set, y);
-    double* const s_S = smem + (kRedRows + a.TG) * kBlock;
+    const double chk = m.init(a, smem + FIXED * kBlock, lane, i, set, y);
+    double* const s_S = smem + (FIXED + a.TG) * kBlock;
     for (int j = 0; j + 1 < a.TG; j++)
         s_S[j * kBlock + lane] = (m.s_G[(j + 1) * kBlock + lane] - m.s_G[j * kBlock + lane]) / (m.tp[j + 1] - m.tp[j]);
+    // knot search: the (at most kUnrolledKnots - 2) interior knots are held in scalar registers and compared without a
+    // loop, so the searches of a step's five stage times overlap instead of queueing behind one scalar load each
+    // (longer sampling grids run the kernel above: launch_adaptive)
+    const double tp0 = m.tp[0];
+    double kn[kUnrolledKnots - 2];
+#pragma unroll
+    for (int q = 0; q < kUnrolledKnots - 2; q++) kn[q] = q + 1 < a.TG - 1 ? m.tp[q + 1] : __builtin_inf();
     auto forcing = [&](double t) {
         int j = 0;
-        double tlo = m.tp[0];
-        for (int q = 1; q < m.TG - 1; q++) {
-            const double tq = m.tp[q];
-            if (tq <= t) { j = q; tlo = tq; }
+        double tlo = tp0;
+#pragma unroll
+        for (int q = 0; q < kUnrolledKnots - 2; q++) {
+            if (kn[q] <= t) { j = q + 1; tlo = kn[q]; }
         }
         return fma(t - tlo, s_S[j * kBlock + lane], m.s_G[j * kBlock + lane]);
     };
@@ -985,11 +1019,12 @@ void adaptive_unrolled_kernel(typename M::Args a) {
             if (n > 0) h_ahead = TAPE(n - 1 < n_acc ? n - 1 : (n_acc > 0 ? n_acc - 1 : 0));
             const double tn = t_next - h;
             if (on) t_next = tn;
-            double B[7][NS], yb[NS];
+            StageAdjoints<NS, B_LDS> B(s_B, lane);
+            double yb[NS];
 #pragma unroll
             for (int j = 0; j < 7; j++) {
 #pragma unroll
-                for (int s = 0; s < NS; s++) B[j][s] = 0.0;
+                for (int s = 0; s < NS; s++) B.set(j, s, 0.0);
             }
 #pragma unroll
             for (int s = 0; s < NS; s++) yb[s] = 0.0;
@@ -1011,7 +1046,7 @@ void adaptive_unrolled_kernel(typename M::Args a) {
                         const double w = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
                                                 : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
 #pragma unroll
-                        for (int s = 0; s < NS; s++) B[j][s] = fma(w, ob[s], B[j][s]);
+                        for (int s = 0; s < NS; s++) B.set(j, s, fma(w, ob[s], B.get(j, s)));
                     }
                     hi--;
                 }
@@ -1022,7 +1057,7 @@ void adaptive_unrolled_kernel(typename M::Args a) {
                 __builtin_amdgcn_sched_barrier(0);             // one VJP body at a time: the accumulators fill the file
                 double kb[NS], ub[NS];
 #pragma unroll
-                for (int s = 0; s < NS; s++) { kb[s] = B[sq][s]; ub[s] = sq == 6 ? lam[s] : 0.0; }
+                for (int s = 0; s < NS; s++) { kb[s] = B.get(sq, s); ub[s] = sq == 6 ? lam[s] : 0.0; }
                 m.vjp_linear(kb, ub);
                 if (sq == 6) {
                     wacc += kb[0];
@@ -1040,7 +1075,7 @@ void adaptive_unrolled_kernel(typename M::Args a) {
                 for (int j = 0; j < sq; j++) {
                     const double aj = h * TS_A[sq][j];
 #pragma unroll
-                    for (int s = 0; s < NS; s++) B[j][s] = fma(aj, ub[s], B[j][s]);
+                    for (int s = 0; s < NS; s++) B.set(j, s, fma(aj, ub[s], B.get(j, s)));
                 }
             }
 #pragma unroll
@@ -1066,12 +1101,15 @@ static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, boo
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     if (grad && (a.tape == nullptr || a.tape_cap < 1 || a.g_cond == nullptr)) return hipErrorInvalidValue;
     if constexpr (unrolled_stages<M>::value) {
-        const size_t lds_u = sizeof(double) * (size_t)(kRedRows + 2 * extra_rows) * kBlock;
+      if (extra_rows <= kUnrolledKnots) {          // extra_rows = knots of the sampling grid (CpepArgs::TG)
+        const size_t lds_u = sizeof(double) * (size_t)((grad ? unrolled_fixed_rows<M, true>() : unrolled_fixed_rows<M, false>()) +
+                                                        2 * extra_rows) * kBlock;
         if (grad)
             hipLaunchKernelGGL((adaptive_unrolled_kernel<M, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds_u, s, a);
         else
             hipLaunchKernelGGL((adaptive_unrolled_kernel<M, false>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds_u, s, a);
         return hipGetLastError();
+      }
     }
     if (grad) {
         hipLaunchKernelGGL((adaptive_kernel<M, IS_CPEP, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);

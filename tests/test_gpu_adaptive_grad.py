@@ -67,6 +67,42 @@ def test_cpep_adaptive_gradient(arch, N):
     eng.close()
 
 
+@pytest.mark.parametrize("tp", [[0.0, 120.0], [0.0, 60.0, 120.0], [0.0, 10.0, 45.0, 50.0, 120.0],
+                                [0.0, 15.0, 30.0, 45.0, 60.0, 75.0, 90.0, 120.0]], ids=["2", "3", "5-irregular", "8"])
+@pytest.mark.parametrize("arch", [(2, 4, 2), (2, 6, 2)])
+def test_cpep_adaptive_other_sampling_grids(tp, arch):
+    """Sampling grids other than the reference's five times: up to five knots run the kernel whose stages are unrolled
+    (interior knots in scalar registers, absent ones at +inf), longer grids the phase-machine kernel.  Steps straddle
+    knots, several observations fall into one step, T = 2 has no interior knot at all."""
+    import cude_oracle as o
+    from cude.engine import Engine
+    N = 67
+    rng = np.random.default_rng(11)
+    tp = np.array(tp)
+    age, t2 = rng.uniform(20, 79, N), rng.random(N) < 0.4
+    G = 5.0 + np.abs(rng.standard_normal((N, tp.size))).cumsum(1)
+    obs = 0.5 + rng.random((N, tp.size))
+    nn, beta = o.glorot_params(arch, 9), rng.normal(-0.6, 0.5, N)
+    pop = o.CPepPopulation(tp, G, obs, age, t2)
+    eng = Engine("cpep", arch, n_steps=0, n_state=2)
+    eng.set_population_cpep(tp, G, obs, age, t2)
+    eng.set_params(nn, beta)
+    fwd = eng.forward(want_sse=True, want_traj=True)
+    loss, g_nn, g_b = eng.loss_grad()
+    assert abs(loss - fwd["loss"]) <= 1e-14 * loss
+    steps = [eng.adaptive_steps(i) for i in range(N)]
+    rl, rg, rb, rsse = o.cpep_replay_loss_grad(nn, beta, pop, arch, [list(zip(t, dt)) for t, dt in steps])
+    assert abs(loss - rl) <= 1e-10 * rl
+    assert np.max(np.abs(fwd["sse"] - rsse)) <= 1e-10 * np.max(rsse)
+    assert np.max(np.abs(g_nn - rg)) <= 1e-8 * np.max(np.abs(rg))
+    assert np.max(np.abs(g_b - rb)) <= 1e-8 * np.max(np.abs(rb))
+    # the oracle's own adaptive solve: same trajectories at the solver's tolerance
+    ol, og, ob, _ = o.cpep_adaptive_loss_grad(nn, beta, pop, arch)
+    assert abs(loss - ol) <= 1e-4 * ol
+    assert np.max(np.abs(g_nn - og)) <= 5e-3 * np.max(np.abs(og))
+    eng.close()
+
+
 def test_supp_adaptive_gradient():
     import cude_oracle as o
     from cude.engine import Engine
