@@ -27,211 +27,9 @@
 // phases (k1, the f1 probe of the initial step, then stages 2..7 of step after step) with ONE inlined network body;
 // a lane that has reached t_end stops committing and the wave leaves when all of its lanes are done (or after the
 // solver's own step limit, so every wave terminates).
-#include "cude_device.h"
-#include "cude_kernels.h"
+#include "cude_adaptive.h"
 
 namespace cude {
-
-__device__ __constant__ const double TS_C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
-__device__ __constant__ const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
-                                                 -0.1447110071732629, 0.5823571654525552, -0.45808210592918697,
-                                                 0.015151515151515152};
-__device__ __constant__ const double TS_R[7][4] = {{1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
-                                                   {0.0, 0.13169999999999998, -0.2234, 0.1017},
-                                                   {0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253},
-                                                   {0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902},
-                                                   {0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928},
-                                                   {0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661},
-                                                   {0.0, 1.5, -4.0, 2.5}};
-
-constexpr int kAdaptiveMaxSteps = 100000;     // OrdinaryDiffEq's default maxiters
-#ifndef CUDE_ADAPT_2W_NACC
-#define CUDE_ADAPT_2W_NACC 64
-#endif
-
-// ---------------------------------------------------------------------------------- model policies
-// c-peptide cUDE / symbolic model: f(t, u) = A u + [k0 c0 + q(t); 0],  q(t) = P(dG(t)) - P(0)
-// accumulators pinned behind their updates in every network evaluation of the replay loop (Mlp::eval_grad, PIN)
-#ifndef CUDE_ADAPTIVE_PIN
-#define CUDE_ADAPTIVE_PIN 1
-#endif
-constexpr bool kAdaptivePin = CUDE_ADAPTIVE_PIN != 0;
-
-template <class Net>
-struct CpepAd {
-    static constexpr int NS = 2;
-    static constexpr int P = Net::P;
-    using Args = CpepArgs;
-    double a11, a12, a21, a22, f0, base;
-    double c[Net::NCST];
-    double cst0;
-    const double* s_G;             // [TG][kBlock] glucose increments at the knots (LDS)
-    cptr_t tp;
-    int TG, lane;
-    cptr_t p;
-    static __device__ __forceinline__ int lds_rows(const Args& a) { return a.TG; }
-    __device__ __forceinline__ double init(const Args& a, double* s_extra, int lane_, int64_t i, int64_t set, double (&y)[NS]) {
-        constexpr int NC = Net::NC;
-        lane = lane_;
-        p = as_const(a.nn + set * a.set_stride_nn);
-        tp = as_const(a.tp);
-        TG = a.TG;
-        const double k0 = a.k0[i], k1 = a.k1[i], k2 = a.k2[i], c0 = a.c0[i];
-        a11 = -(k0 + k2); a12 = k1; a21 = k2; a22 = -k1; f0 = k0 * c0;
-        double cst[NC];
-        cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
-        if (NC > 1) cst[1] = a.age[i];
-        cst0 = cst[0];
-        Net::first_layer_offset(p, cst, c);
-        double* g = s_extra;
-        double chk = fma(cst[0], 0.0, Net::param_check(p));
-        if (NC > 1) chk = fma(cst[1], 0.0, chk);
-        for (int m = 0; m < TG; m++) {
-            const double v = a.dG[(int64_t)m * a.N + i];
-            g[m * kBlock + lane] = v;
-            chk = fma(v, 0.0, chk);
-        }
-        s_G = g;
-        y[0] = c0;
-        y[1] = (k2 / k1) * c0;
-        base = 0.0;
-        return chk;                               // NaN iff an input of this subject is non-finite
-    }
-    // network input at time t: glucose(t) - glucose(t_0), linear between the knots (DataInterpolations.LinearInterpolation)
-    __device__ __forceinline__ double forcing_input(double t) const {
-        int j = 0;
-        double tlo = tp[0], thi = tp[1];
-        for (int m = 1; m < TG - 1; m++) {
-            const double tm = tp[m];
-            if (tm <= t) { j = m; tlo = tm; thi = tp[m + 1]; }
-        }
-        const double glo = s_G[j * kBlock + lane], ghi = s_G[(j + 1) * kBlock + lane];
-        return fma(t - tlo, (ghi - glo) / (thi - tlo), glo);
-    }
-    // production P(x) (the only network call site of the kernel goes through here)
-    __device__ __forceinline__ double production(double x) const {
-        const double xx[1] = {x};
-        return Net::eval(p, c, xx);
-    }
-    __device__ __forceinline__ void finish_rhs(double prod, const double (&u)[NS], double (&du)[NS]) const {
-        du[0] = fma(a11, u[0], fma(a12, u[1], f0 + (prod - base)));
-        du[1] = fma(a21, u[0], a22 * u[1]);
-    }
-    __device__ __forceinline__ double residual2(const Args& a, int oi, int64_t i, const double (&o)[NS], bool active) const {
-        if (a.traj != nullptr && active) {
-            double* tr = a.traj + (int64_t)NS * (oi + (int64_t)a.T * i);
-            tr[0] = o[0];
-            tr[1] = o[1];
-        }
-        if (a.obs == nullptr) return 0.0;
-        const double r = o[0] - a.obs[(int64_t)oi * a.N + i];
-        return r * r;
-    }
-    // ---- gradient
-    static constexpr int A0 = 0;                   // first state that has an adjoint
-    static constexpr bool NEED_Y = false;          // J_f = A: the stage inputs are not linearisation points
-    using NetT = Net;
-    static constexpr int NCST = Net::NC;
-    // d residual2 / d o
-    __device__ __forceinline__ void residual_bar(const Args& a, int oi, int64_t i, const double (&o)[NS], double (&ob)[NS]) const {
-        ob[0] = 2.0 * (o[0] - a.obs[(int64_t)oi * a.N + i]);
-        ob[1] = 0.0;
-    }
-    // acc += wgt * d production(te) / d params  (the baseline term is collected by the caller)
-    template <class A>
-    __device__ __forceinline__ void vjp_net(double te, double wgt, A& acc) const {
-        const double xx[1] = {forcing_input(te)};
-        double dx[1] = {0.0};
-        Net::template eval_grad<false, A, kAdaptivePin>(p, c, xx, wgt, acc, dx);
-    }
-    __device__ __forceinline__ void vjp_linear(const double (&kb)[NS], double (&ub)[NS]) const {
-        ub[0] += fma(a11, kb[0], a21 * kb[1]);
-        ub[1] += fma(a12, kb[0], a22 * kb[1]);
-    }
-    template <class A>
-    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A& acc, double wsum, double carry,
-                                                double (&cst)[NCST]) const {
-        double dx[1] = {0.0};
-        // one call site for the two closing evaluations: k_1 of the first step (time t_0, weight carry), then the
-        // baseline term  - sum(kb) * d NN([0; e^beta]) / d params
-#pragma unroll 1
-        for (int r = 0; r < 2; r++) {
-            const double xx[1] = {r == 0 ? forcing_input(a.t_begin) : 0.0};
-            Net::template eval_grad<false, A, kAdaptivePin>(p, c, xx, r == 0 ? carry : -wsum, acc, dx);
-        }
-        cst[0] = Net::cond_input(a.cond[set * a.set_stride_cond + i]);
-        if (NCST > 1) cst[NCST - 1] = a.age[i];
-    }
-};
-
-// suppression cUDE: f(u) = [-0.4 u1, 0.4 u1 - NN(u, e^theta), NN(u, e^theta) - 0.3 u3]
-template <int W, int D, int HA = kActHiddenTanh, int OA = kActOutSoftplus>
-struct SuppAd {
-    static constexpr int NS = 3;
-    using Net = Mlp<4, W, D, 3, false, false, HA, OA>;
-    static constexpr int P = Net::P;
-    using Args = SuppArgs;
-    double c[W];
-    cptr_t p;
-    static __device__ __forceinline__ int lds_rows(const Args&) { return 0; }
-    __device__ __forceinline__ double init(const Args& a, double*, int, int64_t i, int64_t set, double (&y)[NS]) {
-        p = as_const(a.nn + set * a.set_stride_nn);
-        double cst[1] = {exp(a.cond[set * a.set_stride_cond + i])};
-        Net::first_layer_offset(p, cst, c);
-        double chk = fma(cst[0], 0.0, Net::param_check(p));
-#pragma unroll
-        for (int s = 0; s < 3; s++) {
-            y[s] = a.data[((int64_t)s * a.T + 0) * a.N + i];
-            chk = fma(y[s], 0.0, chk);
-        }
-        return chk;
-    }
-    __device__ __forceinline__ double residual2(const Args& a, int oi, int64_t i, const double (&o)[NS], bool active) const {
-        double s2 = 0.0;
-#pragma unroll
-        for (int s = 0; s < 3; s++) {
-            if (a.traj != nullptr && active) a.traj[s + 3 * (oi + (int64_t)a.T * i)] = o[s];
-            const double r = o[s] - a.data[((int64_t)s * a.T + oi) * a.N + i];
-            s2 = fma(r * a.iscale2[s], r, s2);
-        }
-        return s2;
-    }
-    // ---- gradient
-    // State 1 (du1 = -0.4 u1, suppression_model.jl:91) depends on no parameter and on no other state: nothing that
-    // reaches d/d(network) or d/d(theta) passes through its adjoint (the VJP weight is kb[2] - kb[1]).  The forward
-    // sweep integrates it like the others -- the step-size controller's error norm weighs it -- and the tape keeps it
-    // (it is a network input); the reverse sweep carries adjoints for states 2 and 3 only.
-    static constexpr int A0 = 1;
-    static constexpr bool NEED_Y = true;
-    using NetT = Net;
-    static constexpr int NCST = 1;
-    __device__ __forceinline__ void residual_bar(const Args& a, int oi, int64_t i, const double (&o)[NS], double (&ob)[NS]) const {
-        ob[0] = 0.0;
-#pragma unroll
-        for (int s = 1; s < 3; s++) ob[s] = 2.0 * a.iscale2[s] * (o[s] - a.data[((int64_t)s * a.T + oi) * a.N + i]);
-    }
-    template <class A>
-    __device__ __forceinline__ void vjp(double, const double (&u)[NS], const double (&kb)[NS], double (&ub)[NS], A& acc,
-                                        double&) const {
-        const double wgt = kb[2] - kb[1];
-        double dx[3] = {0.0, 0.0, 0.0};
-        Net::template eval_grad<true, A, kAdaptivePin, 1>(p, c, u, wgt, acc, dx);
-        ub[1] += dx[1];
-        ub[2] += fma(-0.3, kb[2], dx[2]);
-    }
-    template <class A>
-    __device__ __forceinline__ void finish_grad(const Args& a, int64_t i, int64_t set, A&, double, double,
-                                                double (&cst)[NCST]) const {
-        cst[0] = exp(a.cond[set * a.set_stride_cond + i]);
-    }
-
-};
-
-__device__ __forceinline__ double rms(const double* v, int n) {
-    double s = 0.0;
-    for (int k = 0; k < n; k++) s = fma(v[k], v[k], s);
-    return sqrt(s / n);
-}
 
 // ---------------------------------------------------------------------------------- the integrator
 // LDS: s_K [7][NS] stage derivatives (one row of kBlock doubles each; >= kRedRows rows for the final reduction),
@@ -241,13 +39,6 @@ template <class M>
 constexpr int adaptive_rows(bool grad) {
     constexpr int KROWS = 7 * M::NS > kRedRows ? 7 * M::NS : kRedRows;
     return KROWS + (grad ? 7 * M::NS * (M::NEED_Y ? 2 : 1) : 0);
-}
-
-// waves per SIMD the register allocation aims at: the solve is a latency chain, so a second resident wave is worth more
-// than unrolling room, as long as the gradient accumulators (2 VGPRs each) leave space for it
-template <class M, bool GRAD>
-constexpr int adaptive_waves() {
-    return !GRAD ? 2 : (M::NetT::NACC <= (M::NEED_Y ? 24 : CUDE_ADAPT_2W_NACC) ? 2 : 1);
 }
 
 template <class M, bool IS_CPEP, bool GRAD>
@@ -738,361 +529,6 @@ void adaptive_kernel(typename M::Args a) {
 #undef OUTV
 }
 
-// ---------------------------------------------------------------------------------- the same integrator, stages unrolled
-// The kernel above walks ONE network body through every phase: small code, but each evaluation pays for it -- the stage
-// sums run over LDS rows with tableau entries fetched by index (a scalar load and an LDS round trip per term, exposed at
-// the one or two waves per SIMD a 1e5-subject launch has).  For the constant-Jacobian (c-peptide) models of the shapes
-// the reference trains, this variant unrolls the six stages of a trial step and the five VJPs of a reversed step:
-// stage derivatives and their adjoints live in registers, tableau entries are literals, the glucose slope of each knot
-// interval is formed once (same operands, same quotient as forcing_input) instead of once per evaluation.  Same
-// arithmetic in the same order: results are bit-identical to the kernel above.
-template <class M>
-struct unrolled_stages { static constexpr bool value = false; };
-constexpr int kUnrolledKnots = 5;                  // the reference's five sampling times (c-peptide/02-conditional.jl)
-template <int NIN, int W, int D>
-struct unrolled_stages<CpepAd<Mlp<NIN, W, D, 1>>> { static constexpr bool value = true; };
-
-// adjoints of the seven stage derivatives of the step being reversed: registers (indices are literals after unrolling),
-// or one LDS row each for the networks whose gradient accumulators fill the register file
-template <int NS, bool IN_LDS>
-struct StageAdjoints {
-    double v[7][NS];
-    __device__ __forceinline__ StageAdjoints(double*, int) {}
-    __device__ __forceinline__ double get(int j, int s) const { return v[j][s]; }
-    __device__ __forceinline__ void set(int j, int s, double x) { v[j][s] = x; }
-};
-template <int NS>
-struct StageAdjoints<NS, true> {
-    double* row;
-    __device__ __forceinline__ StageAdjoints(double* s_B, int lane) : row(s_B + lane) {}
-    __device__ __forceinline__ double get(int j, int s) const { return row[(j * NS + s) * kBlock]; }
-    __device__ __forceinline__ void set(int j, int s, double x) { row[(j * NS + s) * kBlock] = x; }
-};
-#ifndef CUDE_ADAPT_BLDS_NACC
-#define CUDE_ADAPT_BLDS_NACC 40
-#endif
-template <class M, bool GRAD>
-constexpr bool unrolled_adjoints_in_lds() { return GRAD && M::NetT::NACC > CUDE_ADAPT_BLDS_NACC; }
-template <class M, bool GRAD>
-constexpr int unrolled_fixed_rows() { return kRedRows + (unrolled_adjoints_in_lds<M, GRAD>() ? 7 * M::NS : 0); }
-
-template <class M, bool GRAD>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(adaptive_waves<M, GRAD>())))
-void adaptive_unrolled_kernel(typename M::Args a) {
-    static_assert(!M::NEED_Y, "constant-Jacobian models only");
-    constexpr int NS = M::NS;
-    constexpr int P = M::P;
-    constexpr bool B_LDS = unrolled_adjoints_in_lds<M, GRAD>();
-    constexpr int FIXED = unrolled_fixed_rows<M, GRAD>();
-    // [kRedRows] reduction scratch, (large networks) 7 NS rows of stage adjoints, then TG glucose rows and TG - 1 slope rows
-    extern __shared__ double smem[];
-    double* const s_B = smem + kRedRows * kBlock;
-    const int lane = threadIdx.x;
-    if constexpr (M::NetT::USES_TANH) tanh_tab_init(lane);
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
-    const bool active = gid < a.N;
-    const int64_t slot = active ? gid : a.N - 1;
-    const int64_t i = a.perm != nullptr ? (int64_t)a.perm[slot] : slot;
-    const int64_t set = blockIdx.y;
-    cptr_t tout = as_const(a.out_times);
-    const int n_out = a.T;
-
-    M m;
-    double y[NS];
-    const double chk = m.init(a, smem + FIXED * kBlock, lane, i, set, y);
-    double* const s_S = smem + (FIXED + a.TG) * kBlock;
-    for (int j = 0; j + 1 < a.TG; j++)
-        s_S[j * kBlock + lane] = (m.s_G[(j + 1) * kBlock + lane] - m.s_G[j * kBlock + lane]) / (m.tp[j + 1] - m.tp[j]);
-    // knot search: the (at most kUnrolledKnots - 2) interior knots are held in scalar registers and compared without a
-    // loop, so the searches of a step's five stage times overlap instead of queueing behind one scalar load each
-    // (longer sampling grids run the kernel above: launch_adaptive)
-    const double tp0 = m.tp[0];
-    double kn[kUnrolledKnots - 2];
-#pragma unroll
-    for (int q = 0; q < kUnrolledKnots - 2; q++) kn[q] = q + 1 < a.TG - 1 ? m.tp[q + 1] : __builtin_inf();
-    auto forcing = [&](double t) {
-        int j = 0;
-        double tlo = tp0;
-#pragma unroll
-        for (int q = 0; q < kUnrolledKnots - 2; q++) {
-            if (kn[q] <= t) { j = q + 1; tlo = kn[q]; }
-        }
-        return fma(t - tlo, s_S[j * kBlock + lane], m.s_G[j * kBlock + lane]);
-    };
-    double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + slot : nullptr;
-#define TAPE(n) tape[(int64_t)(n) * a.N]
-#define OUTV(oi) tape[((int64_t)a.tape_cap + (oi)) * a.N]
-    int n_acc = 0;
-    if (GRAD) TAPE(0) = 0.0;
-    const double abstol = a.abstol, reltol = a.reltol;
-    const double t0 = a.t_begin, t1 = a.t_end;
-    const double t_stop = t1 - 1e-14 * fmax(1.0, fabs(t1));
-    double t = t0, dt = 0.0, sse = chk;
-    double qold_pow = 0.47863009232263831;          // (1e-4)^(2/25)
-    int nxt = 0;
-    bool failed = false;
-    while (nxt < n_out && tout[nxt] <= t0 + 1e-12) {
-        sse += m.residual2(a, nxt, i, y, active);
-        nxt++;
-    }
-    bool done = !(t < t_stop);
-    int n_steps = 0;
-    double K[7][NS];
-    // ---- NN([0; e^beta]), k1 = f(t0, y0) and the f1 probe of Hairer's initial-step heuristic: one network body
-    {
-        double sk[NS], d0 = 0.0, d1 = 0.0;
-#pragma unroll 1
-        for (int r = 0; r < 3; r++) {
-            double Y[NS], x = 0.0;
-            if (r == 1) {
-                x = forcing(t0);
-#pragma unroll
-                for (int s = 0; s < NS; s++) Y[s] = y[s];
-            } else if (r == 2) {
-                double v0[NS], v1[NS];
-#pragma unroll
-                for (int s = 0; s < NS; s++) {
-                    sk[s] = fma(reltol, fabs(y[s]), abstol);
-                    v0[s] = y[s] / sk[s];
-                    v1[s] = K[0][s] / sk[s];
-                }
-                d0 = rms(v0, NS);
-                d1 = rms(v1, NS);
-                dt = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-                x = forcing(t0 + dt);
-#pragma unroll
-                for (int s = 0; s < NS; s++) Y[s] = fma(dt, K[0][s], y[s]);
-            }
-            const double prod = m.production(x);
-            if (r == 0) { m.base = prod; continue; }
-            double du[NS];
-            m.finish_rhs(prod, Y, du);
-            if (r == 1) {
-#pragma unroll
-                for (int s = 0; s < NS; s++) K[0][s] = du[s];
-            } else {
-                double v2[NS];
-#pragma unroll
-                for (int s = 0; s < NS; s++) v2[s] = (du[s] - K[0][s]) / sk[s];
-                const double d2 = rms(v2, NS) / dt;
-                const double dm = fmax(d1, d2);
-                const double dt1 = dm <= 1e-15 ? fmax(1e-6, dt * 1e-3) : pow(0.01 / dm, 0.2);
-                dt = fmin(fmin(100.0 * dt, dt1), t1 - t0);
-            }
-        }
-    }
-    int prio_shift = 0;
-    unsigned prio_par = 0, it = 0;
-    if constexpr (GRAD) {
-        prio_shift = a.prio_shift;
-        prio_par = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u;       // HW_ID.wave_id
-    }
-#pragma unroll 1
-    while (true) {
-        if (GRAD && prio_shift > 0) {              // (six evaluations per trial step)
-            if ((((it++) >> (prio_shift > 2 ? prio_shift - 2 : 0)) ^ prio_par) & 1u) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        dt = fmin(dt, t1 - t);
-        double ynew[NS];
-        double prod_last = 0.0;
-#pragma unroll
-        for (int st = 1; st <= 6; st++) {
-            double acc[NS], Y[NS];
-#pragma unroll
-            for (int s = 0; s < NS; s++) acc[s] = 0.0;
-#pragma unroll
-            for (int j = 0; j < st; j++) {
-#pragma unroll
-                for (int s = 0; s < NS; s++) acc[s] = fma(TS_A[st][j], K[j][s], acc[s]);
-            }
-#pragma unroll
-            for (int s = 0; s < NS; s++) Y[s] = fma(dt, acc[s], y[s]);
-            // the forcing depends on time only and c_6 = c_7 = 1: stage 7 reuses stage 6's value
-            if (st != 6) prod_last = m.production(forcing(st < 6 ? fma(TS_C[st], dt, t) : t + dt));
-            m.finish_rhs(prod_last, Y, K[st]);
-            if (st == 6) {
-#pragma unroll
-                for (int s = 0; s < NS; s++) ynew[s] = Y[s];
-            }
-        }
-        double ev[NS];
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            double e = 0.0;
-#pragma unroll
-            for (int j = 0; j < 7; j++) e = fma(TS_BT[j], K[j][s], e);
-            ev[s] = dt * e / fma(reltol, fmax(fabs(y[s]), fabs(ynew[s])), abstol);
-        }
-        const double est = rms(ev, NS);
-        const bool live = !done && !failed;
-        if (live && !(fabs(est) <= 1.79769313486231570815e308)) failed = true;
-        const double log_est = est > 0.0 ? log(est) : -1e3;
-        const double q11 = est > 0.0 ? exp((7.0 / 50.0) * log_est) : 1e-12;
-        const bool accept = est <= 1.0;
-        if (live && !failed) {
-            n_steps++;
-            if (n_steps >= kAdaptiveMaxSteps) failed = true;
-        }
-        if (accept) {
-            while (__any(live && !failed && nxt < n_out && tout[nxt < n_out ? nxt : n_out - 1] <= t + dt + 1e-12)) {
-                const bool mine = live && !failed && nxt < n_out && tout[nxt < n_out ? nxt : n_out - 1] <= t + dt + 1e-12;
-                if (mine) {
-                    const double th = fmin(1.0, (tout[nxt] - t) / dt);
-                    double o[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; s++) o[s] = 0.0;
-                    const bool at_end = fabs(th - 1.0) < 1e-12;
-#pragma unroll
-                    for (int j = 0; j < 7; j++) {
-                        const double w = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
-                                                : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
-#pragma unroll
-                        for (int s = 0; s < NS; s++) o[s] = fma(w, K[j][s], o[s]);
-                    }
-#pragma unroll
-                    for (int s = 0; s < NS; s++) o[s] = fma(dt, o[s], y[s]);
-                    sse += m.residual2(a, nxt, i, o, active);
-                    if (GRAD) OUTV(nxt) = o[0];
-                    nxt++;
-                }
-            }
-        }
-        if (GRAD && live && !failed && accept) {
-            if (n_acc < a.tape_cap) {
-                TAPE(n_acc) = dt;
-                n_acc++;
-            } else {
-                failed = true;
-            }
-        }
-        if (!GRAD && live && !failed && accept) n_acc++;
-        if (live && !failed) {
-            if (accept) {
-                double q = q11 / qold_pow;
-                q = fmax(1.0 / 10.0, fmin(1.0 / 0.2, q / 0.9));
-                t = t + dt;
-#pragma unroll
-                for (int s = 0; s < NS; s++) { y[s] = ynew[s]; K[0][s] = K[6][s]; }
-                qold_pow = exp((2.0 / 25.0) * fmax(log_est, -9.21034037197618273607));     // log 1e-4
-                dt = dt / q;
-                if (!(t < t_stop)) done = true;
-            } else {
-                dt = dt / fmin(1.0 / 0.2, q11 / 0.9);
-            }
-        }
-        if (done || failed) dt = 0.0;
-        if (__all(done || failed)) break;
-    }
-    if (failed || nxt < n_out) sse = __builtin_nan("");
-    const bool bad = !(fabs(sse) <= 1.79769313486231570815e308);
-    if (active && a.sse != nullptr) a.sse[set * a.set_stride_cond + i] = sse;
-    double* out = a.partials + ((int64_t)set * gridDim.x + blockIdx.x) * (P + 2);
-    if constexpr (!GRAD) {
-        if (active && a.tape_n != nullptr && set == 0) a.tape_n[i] = n_acc;
-        const double v2[2] = {active ? sse : 0.0, (active && bad) ? 1.0 : 0.0};
-        block_reduce_store<2>(v2, smem, out + P, lane);
-    } else {
-        using Net = typename M::NetT;
-        double acc[Net::NACC];
-#pragma unroll
-        for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
-        double lam[NS], wsum = 0.0, carry = 0.0;
-#pragma unroll
-        for (int s = 0; s < NS; s++) lam[s] = 0.0;
-        const double gs = a.inv_n;
-        int hi = n_out;
-        int n_max = n_acc;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
-        double t_next = t;
-        double h_ahead = 0.0;
-        if (n_max > 0) h_ahead = TAPE(n_max - 1 < n_acc ? n_max - 1 : (n_acc > 0 ? n_acc - 1 : 0));
-#pragma unroll 1
-        for (int n = n_max - 1; n >= 0; n--) {
-            if (prio_shift > 0) {
-                if ((((unsigned)n >> (prio_shift > 2 ? prio_shift - 2 : 0)) ^ prio_par) & 1u) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(0);
-            }
-            const bool on = n < n_acc;
-            const double h = h_ahead;
-            if (n > 0) h_ahead = TAPE(n - 1 < n_acc ? n - 1 : (n_acc > 0 ? n_acc - 1 : 0));
-            const double tn = t_next - h;
-            if (on) t_next = tn;
-            StageAdjoints<NS, B_LDS> B(s_B, lane);
-            double yb[NS];
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-#pragma unroll
-                for (int s = 0; s < NS; s++) B.set(j, s, 0.0);
-            }
-#pragma unroll
-            for (int s = 0; s < NS; s++) yb[s] = 0.0;
-            while (__any(on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12)) {
-                const bool mine = on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12;
-                if (mine) {
-                    const int oi = hi - 1;
-                    const double th = fmin(1.0, (tout[oi] - tn) / h);
-                    const bool at_end = fabs(th - 1.0) < 1e-12;
-                    double o[NS], ob[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; s++) o[s] = 0.0;
-                    o[0] = OUTV(oi);
-                    m.residual_bar(a, oi, i, o, ob);
-#pragma unroll
-                    for (int s = 0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
-#pragma unroll
-                    for (int j = 0; j < 7; j++) {
-                        const double w = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
-                                                : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
-#pragma unroll
-                        for (int s = 0; s < NS; s++) B.set(j, s, fma(w, ob[s], B.get(j, s)));
-                    }
-                    hi--;
-                }
-            }
-            double wacc = carry;
-#pragma unroll
-            for (int sq = 6; sq >= 0; sq--) {
-                __builtin_amdgcn_sched_barrier(0);             // one VJP body at a time: the accumulators fill the file
-                double kb[NS], ub[NS];
-#pragma unroll
-                for (int s = 0; s < NS; s++) { kb[s] = B.get(sq, s); ub[s] = sq == 6 ? lam[s] : 0.0; }
-                m.vjp_linear(kb, ub);
-                if (sq == 6) {
-                    wacc += kb[0];
-                } else if (sq == 0) {
-                    carry = kb[0];
-                } else {
-                    double dx[1] = {0.0};
-                    const double xx[1] = {forcing(sq == 5 ? tn + h : fma(TS_C[sq], h, tn))};
-                    Net::template eval_grad<false, decltype(acc), kAdaptivePin>(m.p, m.c, xx, sq == 5 ? wacc + kb[0] : kb[0], acc, dx);
-                }
-                wsum += kb[0];
-#pragma unroll
-                for (int s = 0; s < NS; s++) yb[s] += ub[s];
-#pragma unroll
-                for (int j = 0; j < sq; j++) {
-                    const double aj = h * TS_A[sq][j];
-#pragma unroll
-                    for (int s = 0; s < NS; s++) B.set(j, s, fma(aj, ub[s], B.get(j, s)));
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < NS; s++) lam[s] = yb[s];
-        }
-        if (active && a.tape_n != nullptr && set == 0) a.tape_n[i] = n_acc;
-        double cst[M::NCST];
-        m.finish_grad(a, i, set, acc, wsum, carry, cst);
-        __syncthreads();
-        if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(m.p, acc, cst);
-        block_reduce_expand<Net, M::NCST>(acc, cst, active ? 1.0 : 0.0, active ? sse : 0.0, (active && bad) ? 1.0 : 0.0,
-                                          smem, out, lane);
-    }
-#undef TAPE
-#undef OUTV
-}
-
 // ---------------------------------------------------------------------------------- dispatch
 template <class M, bool IS_CPEP>
 static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, bool grad, hipStream_t s) {
@@ -1100,17 +536,6 @@ static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, boo
     const size_t lds = sizeof(double) * (size_t)(adaptive_rows<M>(grad) + extra_rows) * kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
     if (grad && (a.tape == nullptr || a.tape_cap < 1 || a.g_cond == nullptr)) return hipErrorInvalidValue;
-    if constexpr (unrolled_stages<M>::value) {
-      if (extra_rows <= kUnrolledKnots) {          // extra_rows = knots of the sampling grid (CpepArgs::TG)
-        const size_t lds_u = sizeof(double) * (size_t)((grad ? unrolled_fixed_rows<M, true>() : unrolled_fixed_rows<M, false>()) +
-                                                        2 * extra_rows) * kBlock;
-        if (grad)
-            hipLaunchKernelGGL((adaptive_unrolled_kernel<M, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds_u, s, a);
-        else
-            hipLaunchKernelGGL((adaptive_unrolled_kernel<M, false>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds_u, s, a);
-        return hipGetLastError();
-      }
-    }
     if (grad) {
         hipLaunchKernelGGL((adaptive_kernel<M, IS_CPEP, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     } else {
@@ -1119,7 +544,6 @@ static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, boo
     return hipGetLastError();
 }
 
-#define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
 #define CUDE_SUPP_AD_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
 
 // (the shapes compiled with the other activation functions: as CUDE_CPEP_GENERAL_SHAPES / CUDE_SUPP_GENERAL_SHAPES)
@@ -1142,6 +566,10 @@ static hipError_t launch_supp_adaptive_general(const NetShape& net, bool grad, c
 hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
     if (a.TG < 2 || a.TG > kMaxObs || a.T < 1) return hipErrorInvalidValue;
     if (grad && a.obs == nullptr) return hipErrorInvalidValue;
+    if (!net.symbolic() && !net.general() && a.TG <= kUnrolledKnots) {
+        const hipError_t e = launch_cpep_adaptive_unrolled(net, grad, a, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (net.symbolic())
         return a.cond_raw ? launch_adaptive<CpepAd<MmProd<true>>, true>(a, a.TG, grad, s)
                           : launch_adaptive<CpepAd<MmProd<false>>, true>(a, a.TG, grad, s);

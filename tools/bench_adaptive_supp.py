@@ -33,4 +33,16 @@ for n_steps in (0, 30):
     if n_steps == 0:
         cnt = np.array([len(eng.adaptive_steps(i)[0]) for i in range(0, N, max(1, N // 400))])
         print(f"   accepted steps per subject: min {cnt.min()} median {int(np.median(cnt))} max {cnt.max()}")
+        before, after = eng.adaptive_regroup()
+        print(f"   cude_adaptive_regroup: mean (max - min accepted steps) within a wave {before} -> {after}")
+        for what, call in (("forward", eng.forward), ("loss+gradient", lambda: eng.loss_grad(want_cond_grad=False))):
+            for _ in range(10):
+                call()
+            eng.set_kernel_timing(True)
+            for _ in range(20):
+                call()
+            ms, n = eng.kernel_time_ms()
+            eng.set_kernel_timing(False)
+            print(f"N={N} supp 4x3x5x1 adaptive, regrouped {what}: {ms:.4f} ms per launch ({n} launches), "
+                  f"{N / ms * 1e3:.3e} subject-trajectories/s")
     eng.close()
