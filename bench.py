@@ -554,7 +554,7 @@ def extras(Engine, device, steps=20, warm=40):
         "config": "reference c-peptide cUDE, 2x4x4x1, 2 states, 1e5 subjects, ADAPTIVE Tsit5 forward (the reference's "
                   "solver settings) + adjoint of the accepted steps + Adam",
         "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
-        "kernel": "adaptive_kernel<CpepAd<Mlp<2,4,2,1>>,grad>", "kernel_ms": ms, "launches": launches,
+        "kernel": "adaptive_unrolled_kernel<CpepAd<Mlp<2,4,2,1>>,grad>", "kernel_ms": ms, "launches": launches,
         "accepted_steps_per_subject": {"min": int(acc_steps.min()), "median": float(np.median(acc_steps)),
                                        "max": int(acc_steps.max())},
         "regrouped": {"note": "launch ordered by the accepted-step counts of the last evaluation (cude_adaptive_regroup; "

@@ -215,10 +215,30 @@ constexpr int adaptive_waves() {
     return !GRAD ? 2 : (M::NetT::NACC <= (M::NEED_Y ? 24 : CUDE_ADAPT_2W_NACC) ? 2 : 1);
 }
 
+// a step's seven stage rows (derivatives, inputs or adjoints) in the unrolled kernels: registers (indices are literals
+// after unrolling), or one LDS row each at a constant offset
+template <int NS, bool IN_LDS>
+struct StageRows {
+    double v[7][NS];
+    __device__ __forceinline__ StageRows(double*, int) {}
+    __device__ __forceinline__ double get(int j, int s) const { return v[j][s]; }
+    __device__ __forceinline__ void set(int j, int s, double x) { v[j][s] = x; }
+};
+template <int NS>
+struct StageRows<NS, true> {
+    double* row;
+    __device__ __forceinline__ StageRows(double* rows, int lane) : row(rows + lane) {}
+    __device__ __forceinline__ double get(int j, int s) const { return row[(j * NS + s) * kBlock]; }
+    __device__ __forceinline__ void set(int j, int s, double x) { row[(j * NS + s) * kBlock] = x; }
+};
+
 constexpr int kUnrolledKnots = 5;                  // the reference's five sampling times (c-peptide/02-conditional.jl)
 #define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
 // cude_adaptive_unrolled.hip: the c-peptide MLP shapes above on grids of at most kUnrolledKnots times; hipErrorNotSupported
 // for any other shape (the caller then runs the phase-machine kernel)
 hipError_t launch_cpep_adaptive_unrolled(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
+// cude_adaptive_unrolled_supp.hip: the suppression model, shapes of the reference's experiments
+#define CUDE_SUPP_AD_UNROLLED(X) X(3, 5) X(3, 3) X(3, 4) X(3, 2)
+hipError_t launch_supp_adaptive_unrolled(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
 
 }  // namespace cude

@@ -588,6 +588,10 @@ hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& 
 
 hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
     if (net.nin != 4 || a.T < 1) return hipErrorInvalidValue;
+    if (!net.general()) {
+        const hipError_t e = launch_supp_adaptive_unrolled(net, grad, a, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (net.general()) {
 #define X(W, D) if (net.width == W && net.depth == D) return launch_supp_adaptive_general<W, D>(net, grad, a, s);
         X(3, 5) X(3, 3)

@@ -14,22 +14,8 @@ namespace cude {
 // no loop.  Same arithmetic in the same order: results are bit-identical to that kernel
 // (tests/test_gpu_adaptive_grad.py).  At 1e5 subjects, 2x4x4x1: forward 0.282 -> 0.195 ms, gradient 0.524 -> 0.369 ms.
 
-// adjoints of the seven stage derivatives of the step being reversed: registers (indices are literals after unrolling),
-// or one LDS row each for the networks whose gradient accumulators fill the register file
-template <int NS, bool IN_LDS>
-struct StageAdjoints {
-    double v[7][NS];
-    __device__ __forceinline__ StageAdjoints(double*, int) {}
-    __device__ __forceinline__ double get(int j, int s) const { return v[j][s]; }
-    __device__ __forceinline__ void set(int j, int s, double x) { v[j][s] = x; }
-};
-template <int NS>
-struct StageAdjoints<NS, true> {
-    double* row;
-    __device__ __forceinline__ StageAdjoints(double* s_B, int lane) : row(s_B + lane) {}
-    __device__ __forceinline__ double get(int j, int s) const { return row[(j * NS + s) * kBlock]; }
-    __device__ __forceinline__ void set(int j, int s, double x) { row[(j * NS + s) * kBlock] = x; }
-};
+// stage adjoints of the step being reversed: registers, or LDS rows for the networks whose gradient accumulators fill
+// the register file
 #ifndef CUDE_ADAPT_BLDS_NACC
 #define CUDE_ADAPT_BLDS_NACC 40
 #endif
@@ -281,7 +267,7 @@ void adaptive_unrolled_kernel(typename M::Args a) {
             if (n > 0) h_ahead = TAPE(n - 1 < n_acc ? n - 1 : (n_acc > 0 ? n_acc - 1 : 0));
             const double tn = t_next - h;
             if (on) t_next = tn;
-            StageAdjoints<NS, B_LDS> B(s_B, lane);
+            StageRows<NS, B_LDS> B(s_B, lane);
             double yb[NS];
 #pragma unroll
             for (int j = 0; j < 7; j++) {

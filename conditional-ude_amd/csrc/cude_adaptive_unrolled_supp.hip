@@ -1,0 +1,386 @@
+// Adaptive Tsit5 ensemble kernels for gfx950, stages unrolled -- the suppression model
+// (solve(ensemble, Tsit5(), EnsembleThreads(); saveat, trajectories = N), suppression/src/suppression_model.jl:113,123,
+//  and its gradient under AutoForwardDiff, :155).
+//
+// Same integrator, same arithmetic in the same order as adaptive_kernel<SuppAd<W, D>> (cude_adaptive.hip), which walks
+// one network body through every phase with the stage rows in LDS.  Here the six evaluations of a trial step, and -- in
+// the reverse sweep over the tape -- the re-run of a step's stages and its six VJPs are unrolled: tableau entries are
+// literals, stage derivatives, stage inputs and their adjoints have fixed places (registers, or LDS rows at constant
+// offsets), and the tape entry of the step reversed next is requested one iteration ahead.  Against that kernel
+// (tools/abl_adaptive_bits.py): losses, trajectories and accepted steps bit for bit, gradients to 3e-15 (the compiler
+// fuses multiply-add pairs of the adjoint differently in the two code shapes).
+// 1e5 subjects, 4x3x3x3x3x3x1: forward 0.468 -> 0.388 ms, gradient 1.823 -> 1.107 ms.  The re-run stage rows live in LDS
+// (CUDE_ADAPT_SUPP_KY_LDS; two waves per SIMD, 78 spilled VGPRs): with every row in registers and one wave per SIMD the
+// gradient takes 1.275 ms.
+#include "cude_adaptive.h"
+
+namespace cude {
+
+#ifndef CUDE_ADAPT_SUPP_KY_LDS
+#define CUDE_ADAPT_SUPP_KY_LDS 1
+#endif
+
+// rows of LDS the kernel asks for: the final reduction's scratch, which the re-run stage rows (dead by then) share
+template <bool GRAD, bool KY_LDS>
+constexpr int unrolled_supp_rows() { return (GRAD && KY_LDS) ? (2 * 7 * 3 > kRedRows ? 2 * 7 * 3 : kRedRows) : kRedRows; }
+
+template <class M, bool GRAD, bool KY_LDS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((!GRAD || KY_LDS) ? 2 : 1)))
+void adaptive_unrolled_supp_kernel(SuppArgs a) {
+    static_assert(M::NEED_Y && M::NS == 3, "the suppression model");
+    constexpr int NS = 3;
+    constexpr int P = M::P;
+    constexpr int TROWS = 2 + NS;                  // tape entry: t_n, dt_n, y_n
+    using Net = typename M::NetT;
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    if constexpr (Net::USES_TANH) tanh_tab_init(lane);
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const bool active = gid < a.N;
+    const int64_t slot = active ? gid : a.N - 1;
+    const int64_t i = a.perm != nullptr ? (int64_t)a.perm[slot] : slot;
+    const int64_t set = blockIdx.y;
+    cptr_t tout = as_const(a.out_times);
+    const int n_out = a.T;
+
+    M m;
+    double y[NS];
+    const double chk = m.init(a, nullptr, lane, i, set, y);
+    auto rhs = [&](const double (&Y)[NS], double (&du)[NS]) {
+        const double uh = Net::eval(m.p, m.c, Y);
+        du[0] = -0.4 * Y[0];
+        du[1] = fma(0.4, Y[0], -uh);
+        du[2] = fma(-0.3, Y[2], uh);
+    };
+    double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + slot : nullptr;
+#define TAPE(n, r) tape[((int64_t)(n) * TROWS + (r)) * a.N]
+    int n_acc = 0;
+    if (GRAD) {                                    // entry 0 always holds finite numbers (parked lanes read it)
+        TAPE(0, 0) = a.t_begin;
+        TAPE(0, 1) = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) TAPE(0, 2 + s) = y[s];
+    }
+    const double abstol = a.abstol, reltol = a.reltol;
+    const double t0 = a.t_begin, t1 = a.t_end;
+    const double t_stop = t1 - 1e-14 * fmax(1.0, fabs(t1));
+    double t = t0, dt = 0.0, sse = chk;
+    double qold_pow = 0.47863009232263831;          // (1e-4)^(2/25)
+    int nxt = 0;
+    bool failed = false;
+    while (nxt < n_out && tout[nxt] <= t0 + 1e-12) {
+        sse += m.residual2(a, nxt, i, y, active);
+        nxt++;
+    }
+    bool done = !(t < t_stop);
+    int n_steps = 0;
+    double K[7][NS];
+    // ---- k1 = f(y0) and the f1 probe of Hairer's initial-step heuristic: one network body
+    {
+        double sk[NS], d0 = 0.0, d1 = 0.0;
+#pragma unroll 1
+        for (int r = 1; r < 3; r++) {
+            double Y[NS];
+            if (r == 1) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) Y[s] = y[s];
+            } else {
+                double v0[NS], v1[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    sk[s] = fma(reltol, fabs(y[s]), abstol);
+                    v0[s] = y[s] / sk[s];
+                    v1[s] = K[0][s] / sk[s];
+                }
+                d0 = rms(v0, NS);
+                d1 = rms(v1, NS);
+                dt = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+#pragma unroll
+                for (int s = 0; s < NS; s++) Y[s] = fma(dt, K[0][s], y[s]);
+            }
+            double du[NS];
+            rhs(Y, du);
+            if (r == 1) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) K[0][s] = du[s];
+            } else {
+                double v2[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) v2[s] = (du[s] - K[0][s]) / sk[s];
+                const double d2 = rms(v2, NS) / dt;
+                const double dm = fmax(d1, d2);
+                const double dt1 = dm <= 1e-15 ? fmax(1e-6, dt * 1e-3) : pow(0.01 / dm, 0.2);
+                dt = fmin(fmin(100.0 * dt, dt1), t1 - t0);
+            }
+        }
+    }
+#pragma unroll 1
+    while (true) {
+        dt = fmin(dt, t1 - t);
+        double ynew[NS];
+#pragma unroll
+        for (int st = 1; st <= 6; st++) {
+            double acc[NS], Y[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc[s] = 0.0;
+#pragma unroll
+            for (int j = 0; j < st; j++) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) acc[s] = fma(TS_A[st][j], K[j][s], acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++) Y[s] = fma(dt, acc[s], y[s]);
+            rhs(Y, K[st]);
+            if (st == 6) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) ynew[s] = Y[s];
+            }
+        }
+        double ev[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            double e = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; j++) e = fma(TS_BT[j], K[j][s], e);
+            ev[s] = dt * e / fma(reltol, fmax(fabs(y[s]), fabs(ynew[s])), abstol);
+        }
+        const double est = rms(ev, NS);
+        const bool live = !done && !failed;
+        if (live && !(fabs(est) <= 1.79769313486231570815e308)) failed = true;
+        const double log_est = est > 0.0 ? log(est) : -1e3;
+        const double q11 = est > 0.0 ? exp((7.0 / 50.0) * log_est) : 1e-12;
+        const bool accept = est <= 1.0;
+        if (live && !failed) {
+            n_steps++;
+            if (n_steps >= kAdaptiveMaxSteps) failed = true;
+        }
+        if (accept) {
+            while (__any(live && !failed && nxt < n_out && tout[nxt < n_out ? nxt : n_out - 1] <= t + dt + 1e-12)) {
+                const bool mine = live && !failed && nxt < n_out && tout[nxt < n_out ? nxt : n_out - 1] <= t + dt + 1e-12;
+                if (mine) {
+                    const double th = fmin(1.0, (tout[nxt] - t) / dt);
+                    double o[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) o[s] = 0.0;
+                    const bool at_end = fabs(th - 1.0) < 1e-12;
+#pragma unroll
+                    for (int j = 0; j < 7; j++) {
+                        const double w = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
+                                                : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+#pragma unroll
+                        for (int s = 0; s < NS; s++) o[s] = fma(w, K[j][s], o[s]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; s++) o[s] = fma(dt, o[s], y[s]);
+                    sse += m.residual2(a, nxt, i, o, active);
+                    nxt++;
+                }
+            }
+        }
+        if (GRAD && live && !failed && accept) {
+            if (n_acc < a.tape_cap) {
+                TAPE(n_acc, 0) = t;
+                TAPE(n_acc, 1) = dt;
+#pragma unroll
+                for (int s = 0; s < NS; s++) TAPE(n_acc, 2 + s) = y[s];
+                n_acc++;
+            } else {
+                failed = true;                    // more accepted steps than the tape holds
+            }
+        }
+        if (!GRAD && live && !failed && accept) n_acc++;
+        if (live && !failed) {
+            if (accept) {
+                double q = q11 / qold_pow;
+                q = fmax(1.0 / 10.0, fmin(1.0 / 0.2, q / 0.9));
+                t = t + dt;
+#pragma unroll
+                for (int s = 0; s < NS; s++) { y[s] = ynew[s]; K[0][s] = K[6][s]; }
+                qold_pow = exp((2.0 / 25.0) * fmax(log_est, -9.21034037197618273607));     // log 1e-4
+                dt = dt / q;
+                if (!(t < t_stop)) done = true;
+            } else {
+                dt = dt / fmin(1.0 / 0.2, q11 / 0.9);
+            }
+        }
+        if (done || failed) dt = 0.0;
+        if (__all(done || failed)) break;
+    }
+    if (failed || nxt < n_out) sse = __builtin_nan("");
+    const bool bad = !(fabs(sse) <= 1.79769313486231570815e308);
+    if (active && a.sse != nullptr) a.sse[set * a.set_stride_cond + i] = sse;
+    double* out = a.partials + ((int64_t)set * gridDim.x + blockIdx.x) * (P + 2);
+    if constexpr (!GRAD) {
+        if (active && a.tape_n != nullptr && set == 0) a.tape_n[i] = n_acc;
+        const double v2[2] = {active ? sse : 0.0, (active && bad) ? 1.0 : 0.0};
+        block_reduce_store<2>(v2, smem, out + P, lane);
+    } else {
+        // ------------------------------------------------------------------ reverse sweep over the tape
+        constexpr int A0 = M::A0;
+        double acc[Net::NACC];
+#pragma unroll
+        for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
+        double lam[NS], wsum = 0.0;
+        double k1_next[NS], kcar[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) { k1_next[s] = 0.0; kcar[s] = 0.0; lam[s] = 0.0; }
+        const double gs = a.inv_n;
+        int hi = n_out;                            // observations [hi, n_out) are already accounted for
+        int n_max = n_acc;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
+        // a lane with fewer accepted steps idles on its last entry with zero adjoints until its own steps come up
+        auto entry = [&](int n) { return n < n_acc ? n : (n_acc > 0 ? n_acc - 1 : 0); };
+        double e_ahead[TROWS];                     // the tape entry of the next iteration, requested one iteration ahead
+#pragma unroll
+        for (int r = 0; r < TROWS; r++) e_ahead[r] = n_max > 0 ? TAPE(entry(n_max - 1), r) : 0.0;
+#pragma unroll 1
+        for (int n = n_max - 1; n >= 0; n--) {
+            const bool on = n < n_acc;
+            const double tn = e_ahead[0], h = e_ahead[1];
+#pragma unroll
+            for (int s = 0; s < NS; s++) y[s] = e_ahead[2 + s];
+            if (n > 0) {
+#pragma unroll
+                for (int r = 0; r < TROWS; r++) e_ahead[r] = TAPE(entry(n - 1), r);
+            }
+            // ---- re-run the stages of the step: k_1 .. k_6 and Y_7 = y_{n+1}.  k_7 = f(y_{n+1}) is k_1 of the step after
+            // this one (FSAL), which the sweep has just re-run: it is carried over (k1_next), and so is the adjoint of
+            // that k_1 (kcar), applied together with k_7's at the shared linearisation point.  A lane's LAST step (and
+            // an idling lane) has no later step: the seventh evaluation is made whenever some lane of the wave needs it.
+            const bool last = !(n + 1 < n_acc);
+            const bool need7 = __any(last);
+            StageRows<NS, KY_LDS> Kr(smem, lane), Yr(smem + 7 * NS * kBlock, lane);
+            StageRows<NS, false> B(nullptr, lane);
+#pragma unroll
+            for (int sq = 0; sq <= 6; sq++) {
+                double uu[NS], dd[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) uu[s] = 0.0;
+#pragma unroll
+                for (int j = 0; j < sq; j++) {
+#pragma unroll
+                    for (int s = 0; s < NS; s++) uu[s] = fma(TS_A[sq][j], Kr.get(j, s), uu[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; s++) uu[s] = sq == 0 ? y[s] : fma(h, uu[s], y[s]);
+#pragma unroll
+                for (int s = 0; s < NS; s++) Yr.set(sq, s, uu[s]);
+                if (sq < 6) {
+                    rhs(uu, dd);
+                } else {
+                    if (need7) rhs(uu, dd);
+                    if (!last) {
+#pragma unroll
+                        for (int s = 0; s < NS; s++) dd[s] = k1_next[s];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    Kr.set(sq, s, dd[s]);
+                    B.set(sq, s, 0.0);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++) k1_next[s] = Kr.get(0, s);
+            // ---- the observations that were saved from this step: adjoint of o = y_n + h sum_j w_j(theta) k_j
+            double yb[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) yb[s] = 0.0;
+            while (__any(on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12)) {
+                const bool mine = on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12;
+                if (mine) {
+                    const int oi = hi - 1;
+                    const double th = fmin(1.0, (tout[oi] - tn) / h);
+                    const bool at_end = fabs(th - 1.0) < 1e-12;
+                    double w[7], o[NS], ob[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) o[s] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 7; j++) {
+                        w[j] = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
+                                      : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+#pragma unroll
+                        for (int s = 0; s < NS; s++) o[s] = fma(w[j], Kr.get(j, s), o[s]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; s++) o[s] = fma(h, o[s], y[s]);
+                    m.residual_bar(a, oi, i, o, ob);
+#pragma unroll
+                    for (int s = A0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
+#pragma unroll
+                    for (int j = 0; j < 7; j++) {
+#pragma unroll
+                        for (int s = A0; s < NS; s++) B.set(j, s, fma(w[j], ob[s], B.get(j, s)));
+                    }
+                    hi--;
+                }
+            }
+            // ---- stage VJPs, last stage first
+#pragma unroll
+            for (int sq = 6; sq >= 1; sq--) {
+                double kb[NS], ub[NS], uu[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    kb[s] = s >= A0 ? B.get(sq, s) + (sq == 6 ? kcar[s] : 0.0) : 0.0;
+                    ub[s] = (s >= A0 && sq == 6) ? lam[s] : 0.0;    // Y_7 = y_{n+1}
+                    uu[s] = Yr.get(sq, s);
+                }
+                m.vjp(0.0, uu, kb, ub, acc, wsum);
+#pragma unroll
+                for (int s = A0; s < NS; s++) yb[s] += ub[s];
+#pragma unroll
+                for (int j = 0; j < sq; j++) {                 // Y_sq = y_n + h sum_{j<sq} a(sq, j) k_j
+                    const double aj = h * TS_A[sq][j];
+#pragma unroll
+                    for (int s = A0; s < NS; s++) B.set(j, s, fma(aj, ub[s], B.get(j, s)));
+                }
+            }
+            // k_1's adjoint is applied with k_7 of the step before (below for step 0)
+#pragma unroll
+            for (int s = 0; s < NS; s++) kcar[s] = s >= A0 ? B.get(0, s) + 0.0 : 0.0;
+#pragma unroll
+            for (int s = A0; s < NS; s++) lam[s] = yb[s];
+        }
+        if (active && a.tape_n != nullptr && set == 0) a.tape_n[i] = n_acc;
+        {                                          // k_1 of the first step: linearisation point y_0 (entry 0 of the tape)
+            double y0[NS], ub0[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) { y0[s] = TAPE(0, 2 + s); ub0[s] = 0.0; }
+            m.vjp(a.t_begin, y0, kcar, ub0, acc, wsum);
+        }
+        double cst[M::NCST];
+        m.finish_grad(a, i, set, acc, wsum, 0.0, cst);
+        __syncthreads();                   // the reduction scratch aliases the stage rows
+        if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(m.p, acc, cst);
+        block_reduce_expand<Net, M::NCST>(acc, cst, active ? 1.0 : 0.0, active ? sse : 0.0, (active && bad) ? 1.0 : 0.0,
+                                          smem, out, lane);
+    }
+#undef TAPE
+}
+
+template <class M>
+static hipError_t launch_unrolled_supp(const SuppArgs& a, bool grad, hipStream_t s) {
+    constexpr bool KY_LDS = CUDE_ADAPT_SUPP_KY_LDS != 0;
+    const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
+    const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
+    if (grad) {
+        if (a.tape == nullptr || a.tape_cap < 1 || a.g_cond == nullptr) return hipErrorInvalidValue;
+        const size_t lds = sizeof(double) * (size_t)unrolled_supp_rows<true, KY_LDS>() * kBlock;
+        hipLaunchKernelGGL((adaptive_unrolled_supp_kernel<M, true, KY_LDS>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    } else {
+        const size_t lds = sizeof(double) * (size_t)unrolled_supp_rows<false, KY_LDS>() * kBlock;
+        hipLaunchKernelGGL((adaptive_unrolled_supp_kernel<M, false, KY_LDS>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_supp_adaptive_unrolled(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
+    if (net.general() || net.nin != 4 || a.T < 1) return hipErrorNotSupported;
+#define X(W, D) if (net.width == W && net.depth == D) return launch_unrolled_supp<SuppAd<W, D>>(a, grad, s);
+    CUDE_SUPP_AD_UNROLLED(X)
+#undef X
+    return hipErrorNotSupported;
+}
+
+}  // namespace cude

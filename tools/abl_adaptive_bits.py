@@ -33,6 +33,20 @@ for arch in ((2, 4, 2), (2, 6, 2), (2, 8, 3), (2, 5, 1)):
     out[key + "_sse"], out[key + "_traj"], out[key + "_g_nn"], out[key + "_g_b"] = f["sse"], f["traj"], g_nn, g_b
     out[key + "_dt17"] = eng.adaptive_steps(17)[1]
     eng.close()
+for arch in ((4, 3, 5), (4, 3, 3), (4, 6, 2)):
+    N = 3000
+    tp, data, theta = bench.synthetic_suppression(N, 779)
+    nn = bench.glorot(arch, 1234)
+    eng = Engine("supp", arch, n_steps=0, lam=0.01)
+    eng.set_population_supp(tp, data)
+    eng.set_params(nn, theta)
+    f = eng.forward(want_sse=True, want_traj=True)
+    loss, g_nn, g_b = eng.loss_grad()
+    key = "supp" + "x".join(map(str, arch))
+    out[key + "_loss"] = np.array([f["loss"], loss])
+    out[key + "_sse"], out[key + "_traj"], out[key + "_g_nn"], out[key + "_g_b"] = f["sse"], f["traj"], g_nn, g_b
+    out[key + "_dt17"] = eng.adaptive_steps(17)[1]
+    eng.close()
 np.savez(sys.argv[1], **out)
 if len(sys.argv) > 2:
     other = np.load(sys.argv[2])

@@ -10,6 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "conditional-ude_amd"))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+if os.environ.get("CUDE_ABL"):                       # A/B runs: a library variant from tools/abl_so/
+    from cude import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "abl_so", os.environ["CUDE_ABL"] + ".so")
+    _lib.STRICT = False
 from cude.engine import Engine  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000

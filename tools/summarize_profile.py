@@ -136,11 +136,11 @@ try:
 except Exception:
     pass
 ast = kernel_stats("adaptive_stats")
-AGRAD = "> >, true, true>("                   # adaptive_kernel<CpepAd<...>, IS_CPEP, GRAD>
+AGRAD = "> >, true>(cude::CpepArgs)"         # adaptive_unrolled_kernel<CpepAd<...>, GRAD>
 f, nf = mean_ctr("adaptive_fetch", AGRAD, "FETCH_SIZE", skip=3)
 w, nw = mean_ctr("adaptive_write", AGRAD, "WRITE_SIZE", skip=3)
 if f is not None and w is not None:
-    rec["kernels"]["adaptive_grad"] = {"kernel": "adaptive_kernel<CpepAd<Mlp<2,4,2,1>>,grad>", "subjects_per_gpu": 100000,
+    rec["kernels"]["adaptive_grad"] = {"kernel": "adaptive_unrolled_kernel<CpepAd<Mlp<2,4,2,1>>,grad>", "subjects_per_gpu": 100000,
                                        "launches": nf, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                                        "source_sha": rec["source_sha"],
                                        "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024,
