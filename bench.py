@@ -564,7 +564,15 @@ def extras(Engine, device, steps=20, warm=40):
                       "ms_per_step_in_the_callers_order": dt_plain * 1e3, "kernel_ms_in_the_callers_order": ms_plain},
         "note": "work per subject is data-dependent (a wave runs as long as its slowest lane): no fixed algorithmic "
                 "flop count, hence no roofline fraction; 5 network evaluations per trial step forward, 5 VJPs per "
-                "accepted step in reverse, 32 B/subject/step of tape (PMC: profiles/pmc_traffic.json)"}
+                "accepted step in reverse, 8 B/subject/step of tape (PMC: profiles/pmc_traffic.json)"}
+    arec, _ = pmc_record("adaptive_grad", n)
+    if arec and arec.get("sq", {}).get("SQ_INSTS_VALU"):
+        a = out["cpep2_4_1e5_adaptive"]
+        a["hbm_traffic_per_launch"] = arec.get("hbm_bytes_per_launch")
+        a["valu_slot_utilisation"] = (arec["sq"]["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INSTRUCTION /
+                                      (N_SIMD * ms * 1e-3 * CLOCK_GHZ * 1e9))
+        a["valu_instructions_per_wave"] = arec["sq"]["SQ_INSTS_VALU"] / arec["sq"]["SQ_WAVES"]
+        a["kernel_ms_rocprof"] = rocprof_figures(arec)
     eng.close()
     # ---- suppression instance: 4->3x5->1, 3 states, T = 8, 1e5 subjects, fwd + adjoint + Adam
     n, arch = 100000, (4, 3, 5)

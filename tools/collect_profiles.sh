@@ -14,6 +14,8 @@ cp $SRC/summary.txt $DST/rocprof_summary.txt
 cp $SRC/bench_stats.json $DST/bench_under_rocprof.json
 cp $SRC/occupancy.txt $DST/occupancy.txt
 grep -v "^\[\|^W2\|^E2\|^I2" $SRC/adaptive.log > $DST/adaptive.txt || true
+cp $SRC/adaptive_supp_stats/stats_kernel_stats.csv $DST/kernel_stats_adaptive_supp.csv
+grep -v "^\[\|^W2\|^E2\|^I2" $SRC/adaptive_supp.log > $DST/adaptive_supp.txt || true
 cp $SRC/pmc_traffic.json $ROOT/profiles/pmc_traffic.json
 grep -o "SQ_[A-Z_0-9]*" $SRC/counters_available.txt | sort -u | tr '\n' ' ' > $DST/sq_counters_available.txt || true
 echo "collected into $DST"

@@ -48,6 +48,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/adaptive_stats -o s
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/adaptive_fetch -o fetch -- $ADAPT > /dev/null 2>> $OUT/adaptive.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/adaptive_write -o write -- $ADAPT > /dev/null 2>> $OUT/adaptive.err
 echo "adaptive rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/adaptive_sq -o sq -- $ADAPT > /dev/null 2>> $OUT/adaptive.err
+echo "adaptive sq rc=$?"
+# ... and of the suppression model (the reference's EnsembleThreads solve, suppression_model.jl:113,123)
+ADAPTS="python3 $ROOT/tools/bench_adaptive_supp.py 100000"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/adaptive_supp_stats -o stats -- $ADAPTS > $OUT/adaptive_supp.log 2> $OUT/adaptive_supp.err
+echo "adaptive supp rc=$?"
 cd $ROOT
 python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -136,7 +136,7 @@ try:
 except Exception:
     pass
 ast = kernel_stats("adaptive_stats")
-AGRAD = "> >, true>(cude::CpepArgs)"         # adaptive_unrolled_kernel<CpepAd<...>, GRAD>
+AGRAD = "> >, true>(cude::CpepAd<"            # adaptive_unrolled_kernel<CpepAd<...>, GRAD = true>(CpepAd<...>::Args)
 f, nf = mean_ctr("adaptive_fetch", AGRAD, "FETCH_SIZE", skip=3)
 w, nw = mean_ctr("adaptive_write", AGRAD, "WRITE_SIZE", skip=3)
 if f is not None and w is not None:
@@ -147,8 +147,21 @@ if f is not None and w is not None:
                                        "note": "tape: 8 B (dt) per accepted step and subject written and read back (20 steps "
                                                "typical) + 5 saved outputs each way"}
     rec["kernels"]["adaptive_grad"].update(rocprof_avg(ast, AGRAD, "adaptive_stats"))
+    sq = {}
+    for ctr in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+                "SQ_ACTIVE_INST_VALU"):
+        v, nv = mean_ctr("adaptive_sq", AGRAD, ctr, skip=3)
+        if v is not None:
+            sq[ctr] = v
+    if sq:
+        rec["kernels"]["adaptive_grad"]["sq"] = sq
 try:
     print(open(os.path.join(out, "adaptive.log")).read().strip())
+except Exception:
+    pass
+kernel_stats("adaptive_supp_stats")
+try:
+    print(open(os.path.join(out, "adaptive_supp.log")).read().strip())
 except Exception:
     pass
 json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
