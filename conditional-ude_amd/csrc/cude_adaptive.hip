@@ -47,7 +47,8 @@ void adaptive_kernel(typename M::Args a) {
     constexpr int NS = M::NS;
     constexpr int P = M::P;
     constexpr int KROWS = 7 * NS > kRedRows ? 7 * NS : kRedRows;
-    constexpr int TROWS = M::NEED_Y ? 2 + NS : 1;  // tape entry: t_n, dt_n, y_n -- or dt_n alone (constant Jacobian)
+    constexpr int TROWS = M::NEED_Y ? kSuppTapeRows : 1;   // tape entry: t_n, dt_n, y_n (+ rows this kernel leaves unused:
+                                                           // cude_kernels.h) -- or dt_n alone (constant Jacobian)
     extern __shared__ double smem[];
     double* s_K = smem;
     double* s_B = smem + KROWS * kBlock;
@@ -566,10 +567,12 @@ static hipError_t launch_supp_adaptive_general(const NetShape& net, bool grad, c
 hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
     if (a.TG < 2 || a.TG > kMaxObs || a.T < 1) return hipErrorInvalidValue;
     if (grad && a.obs == nullptr) return hipErrorInvalidValue;
+#ifndef CUDE_ADAPT_ONE_BODY                        /* (A/B builds: tools/abl_adaptive_bits.py) */
     if (!net.symbolic() && !net.general() && a.TG <= kUnrolledKnots) {
         const hipError_t e = launch_cpep_adaptive_unrolled(net, grad, a, s);
         if (e != hipErrorNotSupported) return e;
     }
+#endif
     if (net.symbolic())
         return a.cond_raw ? launch_adaptive<CpepAd<MmProd<true>>, true>(a, a.TG, grad, s)
                           : launch_adaptive<CpepAd<MmProd<false>>, true>(a, a.TG, grad, s);
@@ -588,10 +591,12 @@ hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& 
 
 hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
     if (net.nin != 4 || a.T < 1) return hipErrorInvalidValue;
+#ifndef CUDE_ADAPT_ONE_BODY
     if (!net.general()) {
         const hipError_t e = launch_supp_adaptive_unrolled(net, grad, a, s);
         if (e != hipErrorNotSupported) return e;
     }
+#endif
     if (net.general()) {
 #define X(W, D) if (net.width == W && net.depth == D) return launch_supp_adaptive_general<W, D>(net, grad, a, s);
         X(3, 5) X(3, 3)

@@ -3,34 +3,26 @@
 //  and its gradient under AutoForwardDiff, :155).
 //
 // Same integrator, same arithmetic in the same order as adaptive_kernel<SuppAd<W, D>> (cude_adaptive.hip), which walks
-// one network body through every phase with the stage rows in LDS.  Here the six evaluations of a trial step, and -- in
-// the reverse sweep over the tape -- the re-run of a step's stages and its six VJPs are unrolled: tableau entries are
-// literals, stage derivatives, stage inputs and their adjoints have fixed places (registers, or LDS rows at constant
-// offsets), and the tape entry of the step reversed next is requested one iteration ahead.  Against that kernel
-// (tools/abl_adaptive_bits.py): losses, trajectories and accepted steps bit for bit, gradients to 3e-15 (the compiler
-// fuses multiply-add pairs of the adjoint differently in the two code shapes).
-// 1e5 subjects, 4x3x3x3x3x3x1: forward 0.468 -> 0.388 ms, gradient 1.823 -> 1.107 ms.  The re-run stage rows live in LDS
-// (CUDE_ADAPT_SUPP_KY_LDS; two waves per SIMD, 78 spilled VGPRs): with every row in registers and one wave per SIMD the
-// gradient takes 1.275 ms.
+// one network body through every phase with the stage rows in LDS.  Here the six evaluations of a trial step and the six
+// VJPs of a reversed step are unrolled: tableau entries are literals, stage derivatives and adjoints sit in registers.
+// The gradient launch also keeps, per accepted step, the inputs of stages 2..7 (states 2 and 3: 96 B beside the 40 B of
+// (t, dt, y); state 1's inputs follow from y_n by the same arithmetic as in the forward sweep) and, per observation, the
+// residual's derivative: the reverse sweep then re-runs nothing -- six VJPs per step instead of seven evaluations and
+// six VJPs -- and needs no LDS beyond the final reduction's.  Against the one-body kernel (tools/abl_adaptive_bits.py):
+// losses, trajectories and accepted steps bit for bit, gradients to 3e-15 (the compiler fuses other multiply-add pairs).
+// 1e5 subjects, 4x3x3x3x3x3x1, one box: forward 0.468 -> 0.388 ms; gradient 1.814 ms (one body) -> 1.107 ms (unrolled,
+// stages re-run from y_n, stage rows in LDS) -> 0.819 ms (inputs kept on the tape).
 #include "cude_adaptive.h"
 
 namespace cude {
 
-#ifndef CUDE_ADAPT_SUPP_KY_LDS
-#define CUDE_ADAPT_SUPP_KY_LDS 1
-#endif
-
-// rows of LDS the kernel asks for: the final reduction's scratch, which the re-run stage rows (dead by then) share
-template <bool GRAD, bool KY_LDS>
-constexpr int unrolled_supp_rows() { return (GRAD && KY_LDS) ? (2 * 7 * 3 > kRedRows ? 2 * 7 * 3 : kRedRows) : kRedRows; }
-
-template <class M, bool GRAD, bool KY_LDS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((!GRAD || KY_LDS) ? 2 : 1)))
+template <class M, bool GRAD>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2)))
 void adaptive_unrolled_supp_kernel(SuppArgs a) {
     static_assert(M::NEED_Y && M::NS == 3, "the suppression model");
     constexpr int NS = 3;
     constexpr int P = M::P;
-    constexpr int TROWS = 2 + NS;                  // tape entry: t_n, dt_n, y_n
+    constexpr int TROWS = kSuppTapeRows;           // tape entry: t_n, dt_n, y_n, inputs of stages 2..7 (states 2, 3)
     using Net = typename M::NetT;
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
@@ -54,6 +46,7 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
     };
     double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + slot : nullptr;
 #define TAPE(n, r) tape[((int64_t)(n) * TROWS + (r)) * a.N]
+#define SEED(oi, s) tape[((int64_t)a.tape_cap * TROWS + (oi) * 2 + (s)) * a.N]   /* d residual2(oi) / d state 2 + s */
     int n_acc = 0;
     if (GRAD) {                                    // entry 0 always holds finite numbers (parked lanes read it)
         TAPE(0, 0) = a.t_begin;
@@ -118,6 +111,7 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
     while (true) {
         dt = fmin(dt, t1 - t);
         double ynew[NS];
+        double yin[6][2];                          // GRAD: inputs of stages 2..7 of this trial step, states 2 and 3
 #pragma unroll
         for (int st = 1; st <= 6; st++) {
             double acc[NS], Y[NS];
@@ -131,6 +125,7 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
 #pragma unroll
             for (int s = 0; s < NS; s++) Y[s] = fma(dt, acc[s], y[s]);
             rhs(Y, K[st]);
+            if (GRAD) { yin[st - 1][0] = Y[1]; yin[st - 1][1] = Y[2]; }
             if (st == 6) {
 #pragma unroll
                 for (int s = 0; s < NS; s++) ynew[s] = Y[s];
@@ -173,6 +168,12 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
 #pragma unroll
                     for (int s = 0; s < NS; s++) o[s] = fma(dt, o[s], y[s]);
                     sse += m.residual2(a, nxt, i, o, active);
+                    if (GRAD) {
+                        double ob[NS];
+                        m.residual_bar(a, nxt, i, o, ob);
+                        SEED(nxt, 0) = ob[1];
+                        SEED(nxt, 1) = ob[2];
+                    }
                     nxt++;
                 }
             }
@@ -183,6 +184,11 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
                 TAPE(n_acc, 1) = dt;
 #pragma unroll
                 for (int s = 0; s < NS; s++) TAPE(n_acc, 2 + s) = y[s];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    TAPE(n_acc, kSuppTapeHead + 2 * q) = yin[q][0];
+                    TAPE(n_acc, kSuppTapeHead + 2 * q + 1) = yin[q][1];
+                }
                 n_acc++;
             } else {
                 failed = true;                    // more accepted steps than the tape holds
@@ -220,10 +226,9 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
         double acc[Net::NACC];
 #pragma unroll
         for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
-        double lam[NS], wsum = 0.0;
-        double k1_next[NS], kcar[NS];
+        double lam[NS], kcar[NS], wsum = 0.0;
 #pragma unroll
-        for (int s = 0; s < NS; s++) { k1_next[s] = 0.0; kcar[s] = 0.0; lam[s] = 0.0; }
+        for (int s = 0; s < NS; s++) { kcar[s] = 0.0; lam[s] = 0.0; }
         const double gs = a.inv_n;
         int hi = n_out;                            // observations [hi, n_out) are already accounted for
         int n_max = n_acc;
@@ -231,58 +236,43 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
         for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
         // a lane with fewer accepted steps idles on its last entry with zero adjoints until its own steps come up
         auto entry = [&](int n) { return n < n_acc ? n : (n_acc > 0 ? n_acc - 1 : 0); };
-        double e_ahead[TROWS];                     // the tape entry of the next iteration, requested one iteration ahead
+        // (t_n, dt_n, y_1(t_n)) of the next iteration are requested one iteration ahead; the stage inputs of a step are
+        // requested at its top, each is first used one VJP later than the one before
+        double e_ahead[3];
 #pragma unroll
-        for (int r = 0; r < TROWS; r++) e_ahead[r] = n_max > 0 ? TAPE(entry(n_max - 1), r) : 0.0;
+        for (int r = 0; r < 3; r++) e_ahead[r] = n_max > 0 ? TAPE(entry(n_max - 1), r) : 0.0;
 #pragma unroll 1
         for (int n = n_max - 1; n >= 0; n--) {
             const bool on = n < n_acc;
-            const double tn = e_ahead[0], h = e_ahead[1];
+            const int64_t e = entry(n);
+            const double tn = e_ahead[0], h = e_ahead[1], y1 = e_ahead[2];
+            double yin[6][2];
 #pragma unroll
-            for (int s = 0; s < NS; s++) y[s] = e_ahead[2 + s];
+            for (int q = 5; q >= 0; q--) {
+                yin[q][0] = TAPE(e, kSuppTapeHead + 2 * q);
+                yin[q][1] = TAPE(e, kSuppTapeHead + 2 * q + 1);
+            }
             if (n > 0) {
 #pragma unroll
-                for (int r = 0; r < TROWS; r++) e_ahead[r] = TAPE(entry(n - 1), r);
+                for (int r = 0; r < 3; r++) e_ahead[r] = TAPE(entry(n - 1), r);
             }
-            // ---- re-run the stages of the step: k_1 .. k_6 and Y_7 = y_{n+1}.  k_7 = f(y_{n+1}) is k_1 of the step after
-            // this one (FSAL), which the sweep has just re-run: it is carried over (k1_next), and so is the adjoint of
-            // that k_1 (kcar), applied together with k_7's at the shared linearisation point.  A lane's LAST step (and
-            // an idling lane) has no later step: the seventh evaluation is made whenever some lane of the wave needs it.
-            const bool last = !(n + 1 < n_acc);
-            const bool need7 = __any(last);
-            StageRows<NS, KY_LDS> Kr(smem, lane), Yr(smem + 7 * NS * kBlock, lane);
+            // state 1 at the stages: du1 = -0.4 u1 re-integrated from y_1(t_n) -- the forward sweep's own operations
+            double k1s[6], u1[7];
+            u1[0] = y1;
+#pragma unroll
+            for (int sq = 1; sq <= 6; sq++) {
+                k1s[sq - 1] = -0.4 * u1[sq - 1];
+                double t1s = 0.0;
+#pragma unroll
+                for (int j = 0; j < sq; j++) t1s = fma(TS_A[sq][j], k1s[j], t1s);
+                u1[sq] = fma(h, t1s, y1);
+            }
             StageRows<NS, false> B(nullptr, lane);
 #pragma unroll
-            for (int sq = 0; sq <= 6; sq++) {
-                double uu[NS], dd[NS];
+            for (int j = 0; j < 7; j++) {
 #pragma unroll
-                for (int s = 0; s < NS; s++) uu[s] = 0.0;
-#pragma unroll
-                for (int j = 0; j < sq; j++) {
-#pragma unroll
-                    for (int s = 0; s < NS; s++) uu[s] = fma(TS_A[sq][j], Kr.get(j, s), uu[s]);
-                }
-#pragma unroll
-                for (int s = 0; s < NS; s++) uu[s] = sq == 0 ? y[s] : fma(h, uu[s], y[s]);
-#pragma unroll
-                for (int s = 0; s < NS; s++) Yr.set(sq, s, uu[s]);
-                if (sq < 6) {
-                    rhs(uu, dd);
-                } else {
-                    if (need7) rhs(uu, dd);
-                    if (!last) {
-#pragma unroll
-                        for (int s = 0; s < NS; s++) dd[s] = k1_next[s];
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < NS; s++) {
-                    Kr.set(sq, s, dd[s]);
-                    B.set(sq, s, 0.0);
-                }
+                for (int s = 0; s < NS; s++) B.set(j, s, 0.0);
             }
-#pragma unroll
-            for (int s = 0; s < NS; s++) k1_next[s] = Kr.get(0, s);
             // ---- the observations that were saved from this step: adjoint of o = y_n + h sum_j w_j(theta) k_j
             double yb[NS];
 #pragma unroll
@@ -293,30 +283,24 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
                     const int oi = hi - 1;
                     const double th = fmin(1.0, (tout[oi] - tn) / h);
                     const bool at_end = fabs(th - 1.0) < 1e-12;
-                    double w[7], o[NS], ob[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; s++) o[s] = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 7; j++) {
-                        w[j] = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
-                                      : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
-#pragma unroll
-                        for (int s = 0; s < NS; s++) o[s] = fma(w[j], Kr.get(j, s), o[s]);
-                    }
-#pragma unroll
-                    for (int s = 0; s < NS; s++) o[s] = fma(h, o[s], y[s]);
-                    m.residual_bar(a, oi, i, o, ob);
+                    double ob[NS];
+                    ob[0] = 0.0;
+                    ob[1] = SEED(oi, 0);
+                    ob[2] = SEED(oi, 1);
 #pragma unroll
                     for (int s = A0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
 #pragma unroll
                     for (int j = 0; j < 7; j++) {
+                        const double w = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
+                                                : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
 #pragma unroll
-                        for (int s = A0; s < NS; s++) B.set(j, s, fma(w[j], ob[s], B.get(j, s)));
+                        for (int s = A0; s < NS; s++) B.set(j, s, fma(w, ob[s], B.get(j, s)));
                     }
                     hi--;
                 }
             }
-            // ---- stage VJPs, last stage first
+            // ---- stage VJPs, last stage first.  k_7 = f(y_{n+1}) is k_1 of the step after this one (FSAL): the adjoint of
+            // that k_1 (kcar) is applied together with k_7's at the shared linearisation point.
 #pragma unroll
             for (int sq = 6; sq >= 1; sq--) {
                 double kb[NS], ub[NS], uu[NS];
@@ -324,8 +308,10 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
                 for (int s = 0; s < NS; s++) {
                     kb[s] = s >= A0 ? B.get(sq, s) + (sq == 6 ? kcar[s] : 0.0) : 0.0;
                     ub[s] = (s >= A0 && sq == 6) ? lam[s] : 0.0;    // Y_7 = y_{n+1}
-                    uu[s] = Yr.get(sq, s);
                 }
+                uu[0] = u1[sq];
+                uu[1] = yin[sq - 1][0];
+                uu[2] = yin[sq - 1][1];
                 m.vjp(0.0, uu, kb, ub, acc, wsum);
 #pragma unroll
                 for (int s = A0; s < NS; s++) yb[s] += ub[s];
@@ -351,26 +337,25 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
         }
         double cst[M::NCST];
         m.finish_grad(a, i, set, acc, wsum, 0.0, cst);
-        __syncthreads();                   // the reduction scratch aliases the stage rows
+        __syncthreads();
         if (active) a.g_cond[set * a.set_stride_cond + i] = Net::grad_cond(m.p, acc, cst);
         block_reduce_expand<Net, M::NCST>(acc, cst, active ? 1.0 : 0.0, active ? sse : 0.0, (active && bad) ? 1.0 : 0.0,
                                           smem, out, lane);
     }
 #undef TAPE
+#undef SEED
 }
 
 template <class M>
 static hipError_t launch_unrolled_supp(const SuppArgs& a, bool grad, hipStream_t s) {
-    constexpr bool KY_LDS = CUDE_ADAPT_SUPP_KY_LDS != 0;
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
+    const size_t lds = sizeof(double) * (size_t)kRedRows * kBlock;      // the final reduction's scratch
     if (grad) {
         if (a.tape == nullptr || a.tape_cap < 1 || a.g_cond == nullptr) return hipErrorInvalidValue;
-        const size_t lds = sizeof(double) * (size_t)unrolled_supp_rows<true, KY_LDS>() * kBlock;
-        hipLaunchKernelGGL((adaptive_unrolled_supp_kernel<M, true, KY_LDS>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+        hipLaunchKernelGGL((adaptive_unrolled_supp_kernel<M, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     } else {
-        const size_t lds = sizeof(double) * (size_t)unrolled_supp_rows<false, KY_LDS>() * kBlock;
-        hipLaunchKernelGGL((adaptive_unrolled_supp_kernel<M, false, KY_LDS>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
+        hipLaunchKernelGGL((adaptive_unrolled_supp_kernel<M, false>), dim3((unsigned)nblocks, n_sets), dim3(kBlock), lds, s, a);
     }
     return hipGetLastError();
 }

@@ -185,13 +185,18 @@ int supp_grad_waves_per_cu(const NetShape& net);
 // route here when args.S == 0
 hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
 hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
-// rows of N doubles per accepted step on the adaptive gradient's tape: (t_n, dt_n, y_n) for the suppression model
-// (3 states: the reverse sweep re-runs the stages from y_n), dt_n alone for the c-peptide models (2 states, constant
-// Jacobian: the reverse sweep needs the stage times only and steps back from the final time)
-inline __host__ __device__ int adaptive_tape_rows(int n_state) { return n_state == 3 ? 2 + n_state : 1; }
-// ... and of one parameter set's tape: the steps, then T saved outputs
+// rows of N doubles per accepted step on the adaptive gradient's tape.  Suppression model (3 states): (t_n, dt_n, y_n) and
+// the inputs of stages 2..7 (states 2 and 3; state 1's follow from y_n in closed arithmetic) -- the linearisation points
+// of the reverse sweep, which then needs no network evaluation of its own (the one-body kernel of cude_adaptive.hip
+// re-runs the stages from y_n and leaves those rows unused).  C-peptide models (2 states, constant Jacobian): dt_n
+// alone -- the reverse sweep needs the stage times only and steps back from the final time.
+constexpr int kSuppTapeHead = 5;                   // t_n, dt_n, y_n[3]
+constexpr int kSuppTapeRows = kSuppTapeHead + 6 * 2;
+inline __host__ __device__ int adaptive_tape_rows(int n_state) { return n_state == 3 ? kSuppTapeRows : 1; }
+// ... and of one parameter set's tape: the steps, then per observation the saved output (c-peptide: state 1) or the
+// residual's derivative with respect to states 2 and 3 (suppression)
 inline __host__ __device__ int64_t adaptive_tape_rows(int n_state, int cap, int T) {
-    return (int64_t)cap * adaptive_tape_rows(n_state) + T;
+    return (int64_t)cap * adaptive_tape_rows(n_state) + (n_state == 3 ? 2 : 1) * T;
 }
 
 // common kernels

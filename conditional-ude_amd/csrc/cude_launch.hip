@@ -77,8 +77,8 @@ cude::SuppArgs supp_args(const cude_ctx* c) {
     return a;
 }
 
-// Tape of the adaptive gradient: per accepted step and subject the step size (c-peptide models: 8 B) or (t, dt, y) (the
-// suppression model: 40 B), + T saved outputs.  The reference's
+// Tape of the adaptive gradient: per accepted step and subject the step size (c-peptide models: 8 B) or (t, dt, y) and the
+// inputs of stages 2..7 (the suppression model: 136 B), + T saved outputs / 2 T residual derivatives.  The reference's
 // problems take 10-40 steps at its tolerances; the capacity is what ~4 GB hold, between 64 and 1024 steps
 // (option "tape_steps" overrides).  A subject with more accepted steps fails its gradient evaluation (+Inf), not the
 // process.  Allocated by the first gradient evaluation (forward-only users of the adaptive mode never pay for it), never
