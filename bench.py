@@ -594,6 +594,29 @@ def extras(Engine, device, steps=20, warm=40):
                        "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
                        "roofline": hbm, "roofline_valu": valu}
     eng.close()
+    # ---- the same instance as the reference solves it (Tsit5 adaptive, EnsembleThreads: suppression_model.jl:113,123)
+    eng = Engine("supp", arch, n_steps=0, lam=0.01, device=device)
+    eng.set_population_supp(tp, data)
+    eng.set_params(glorot(arch, 1234), theta)
+    eng.adam_init(1e-3)
+    eng.loss_grad(want_cond_grad=False)
+    spread = eng.adaptive_regroup()
+    dt, ms, launches = timed_adam(eng, n, steps, 10)
+    acc_steps = np.array([len(eng.adaptive_steps(i)[0]) for i in range(0, n, n // 500)])
+    asrec, _ = pmc_record("adaptive_supp_grad", n)
+    out["supp_1e5_adaptive"] = {
+        "config": "suppression cUDE, 4x3x3x3x3x3x1, 3 states, T=8, 1e5 subjects, ADAPTIVE Tsit5 forward (the reference's "
+                  "solver) + adjoint of the accepted steps + Adam, lambda=0.01",
+        "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
+        "kernel": "adaptive_unrolled_supp_kernel<SuppAd<3,5>,grad>", "kernel_ms": ms, "launches": launches,
+        "accepted_steps_per_subject": {"min": int(acc_steps.min()), "median": float(np.median(acc_steps)),
+                                       "max": int(acc_steps.max())},
+        "mean_step_spread_within_a_wave": {"before": spread[0], "after": spread[1]},
+        "hbm_traffic_per_launch": asrec.get("hbm_bytes_per_launch") if asrec else None,
+        "kernel_ms_rocprof": rocprof_figures(asrec),
+        "note": "6 network evaluations per trial step forward, 6 VJPs per accepted step in reverse at the stage inputs the "
+                "forward sweep left on the tape (136 B per step and subject); data-dependent work: no roofline fraction"}
+    eng.close()
     # ---- configs[4] on one GPU: SAEM E-step, 1e4 subjects x 100 Metropolis steps
     n, n_mc, arch = 10000, 100, (2, 4, 2)
     eng, pop = cpep_engine(Engine, arch, 2, n, 780, device, nn4)

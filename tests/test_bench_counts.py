@@ -131,5 +131,6 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 100 * c["value"]
-    for k in ("forward_only_1e4", "train_step_1e5", "cpep2_4_1e5", "cpep2_4_1e5_adaptive", "supp_1e5", "saem_estep_1e4x100"):
+    for k in ("forward_only_1e4", "train_step_1e5", "cpep2_4_1e5", "cpep2_4_1e5_adaptive", "supp_1e5", "supp_1e5_adaptive",
+              "saem_estep_1e4x100"):
         assert k in d["extra"], k

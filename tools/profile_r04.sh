@@ -53,6 +53,8 @@ echo "adaptive sq rc=$?"
 # ... and of the suppression model (the reference's EnsembleThreads solve, suppression_model.jl:113,123)
 ADAPTS="python3 $ROOT/tools/bench_adaptive_supp.py 100000"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/adaptive_supp_stats -o stats -- $ADAPTS > $OUT/adaptive_supp.log 2> $OUT/adaptive_supp.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/adaptive_supp_fetch -o fetch -- $ADAPTS > /dev/null 2>> $OUT/adaptive_supp.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/adaptive_supp_write -o write -- $ADAPTS > /dev/null 2>> $OUT/adaptive_supp.err
 echo "adaptive supp rc=$?"
 cd $ROOT
 python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1

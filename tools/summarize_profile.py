@@ -159,7 +159,18 @@ try:
     print(open(os.path.join(out, "adaptive.log")).read().strip())
 except Exception:
     pass
-kernel_stats("adaptive_supp_stats")
+asst = kernel_stats("adaptive_supp_stats")
+ASGRAD = "adaptive_unrolled_supp_kernel<cude::SuppAd<3, 5, 0, 0>, true>"
+f, nf = mean_ctr("adaptive_supp_fetch", ASGRAD, "FETCH_SIZE", skip=3)
+w, nw = mean_ctr("adaptive_supp_write", ASGRAD, "WRITE_SIZE", skip=3)
+if f is not None and w is not None:
+    rec["kernels"]["adaptive_supp_grad"] = {"kernel": "adaptive_unrolled_supp_kernel<SuppAd<3,5>,grad>", "subjects_per_gpu": 100000,
+                                            "launches": nf, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                                            "source_sha": rec["source_sha"],
+                                            "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024,
+                                            "note": "tape: 136 B per accepted step and subject written and read back (24 steps "
+                                                    "typical) + 16 B per observation each way"}
+    rec["kernels"]["adaptive_supp_grad"].update(rocprof_avg(asst, ASGRAD, "adaptive_supp_stats"))
 try:
     print(open(os.path.join(out, "adaptive_supp.log")).read().strip())
 except Exception:
