@@ -4,7 +4,7 @@ order of the shared gradient -- what the reference's serial loop fixes by constr
 import numpy as np
 import pytest
 
-from conftest import make_cpep_case
+from conftest import make_cpep_case, make_supp_case
 
 pytestmark = pytest.mark.gpu
 
@@ -125,3 +125,49 @@ def test_forward_launches_tell_the_step_counts_and_the_other_entry_points_regrou
     assert np.array_equal(out[False][2], out[True][2])                                   # dL/dbeta: per subject
     assert np.allclose(out[False][0], out[True][0], rtol=1e-13)
     assert np.allclose(out[False][1], out[True][1], rtol=0, atol=1e-12 * np.max(np.abs(out[False][1])))
+
+
+@pytest.mark.parametrize("model", ["cpep", "supp"])
+def test_a_tape_too_short_fails_the_gradient_not_the_process(model):
+    """The adaptive gradient's tape holds a fixed number of accepted steps per subject (option tape_steps; by default
+    what 4 GB hold, at least 64).  A subject that takes more fails ITS evaluation the way a failed solve does -- the loss
+    is +Inf with status 0 (reference: parameter-estimation.jl:61-64) -- while forward launches, which keep no tape, are
+    not affected; with room for the steps the same engine data give a finite gradient."""
+    from cude.engine import Engine
+    if model == "cpep":
+        arch = (2, 4, 2)
+        c = make_cpep_case(200, arch)
+
+        def make(steps):
+            eng = Engine("cpep", arch, n_steps=0, n_state=2)
+            if steps:
+                eng.set_option("tape_steps", steps)
+            eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+            eng.set_params(c["nn"], c["beta"])
+            return eng
+    else:
+        arch = (4, 3, 5)
+        c = make_supp_case(90, arch)
+
+        def make(steps):
+            eng = Engine("supp", arch, n_steps=0, lam=0.01)
+            if steps:
+                eng.set_option("tape_steps", steps)
+            eng.set_population_supp(c["tp"], c["data"])
+            eng.set_params(c["nn"], c["theta"])
+            return eng
+    eng = make(0)
+    loss, g_nn, g_c = eng.loss_grad()
+    n_steps = max(len(eng.adaptive_steps(i)[0]) for i in range(0, 90, 7))
+    assert np.isfinite(loss) and np.all(np.isfinite(g_nn)) and n_steps > 6
+    eng.close()
+    short = make(n_steps - 3)
+    fwd = short.forward()["loss"]
+    assert abs(fwd - loss) <= 1e-14 * loss                 # no tape in a forward launch
+    loss_short = short.loss_grad()[0]
+    assert np.isinf(loss_short) and loss_short > 0
+    short.close()
+    enough = make(n_steps + 8)
+    loss2, g2, _ = enough.loss_grad()
+    assert loss2 == loss and np.array_equal(g2, g_nn)
+    enough.close()
