@@ -215,6 +215,36 @@ constexpr int adaptive_waves() {
     return !GRAD ? 2 : (M::NetT::NACC <= (M::NEED_Y ? 24 : CUDE_ADAPT_2W_NACC) ? 2 : 1);
 }
 
+// ---------------------------------------------------------------------------------- shared by the integrators
+// weight of stage derivative j in the `saveat` output at theta = (t_out - t_n) / dt_n: Tsit5's free 4th-order interpolant,
+// or -- at the end of the step -- the last tableau row (y_{n+1} itself)
+__device__ __forceinline__ double saveat_weight(int j, double th, bool at_end) {
+    return at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
+                  : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+}
+
+// OrdinaryDiffEq's PI controller (beta1 = 7/50, beta2 = 2/25, gamma = 0.9, qmin = 0.2, qmax = 10) on the scaled error
+// estimate of a trial step.  q = est^(7/50) / qold^(2/25) with qold = max(previous est, 1e-4): both powers come from ONE
+// logarithm per trial step -- est^(7/50) = exp(0.14 log est) now, and, when the step is accepted, qold^(2/25) of the
+// NEXT step = exp(0.08 max(log est, log 1e-4)), carried in qold_pow (the two pow() calls per trial step were ~10 % of the
+// forward sweep's instructions in round 2)
+struct StepController {
+    double qold_pow = 0.47863009232263831;         // (1e-4)^(2/25)
+    double log_est = 0.0, q11 = 0.0;
+    __device__ __forceinline__ bool judge(double est) {            // true: the step is accepted
+        log_est = est > 0.0 ? log(est) : -1e3;                      // (est = 0: qold = 1e-4 below)
+        q11 = est > 0.0 ? exp((7.0 / 50.0) * log_est) : 1e-12;
+        return est <= 1.0;
+    }
+    __device__ __forceinline__ double after_accept(double dt) {    // the next step's size
+        double q = q11 / qold_pow;
+        q = fmax(1.0 / 10.0, fmin(1.0 / 0.2, q / 0.9));
+        qold_pow = exp((2.0 / 25.0) * fmax(log_est, -9.21034037197618273607));     // log 1e-4
+        return dt / q;
+    }
+    __device__ __forceinline__ double after_reject(double dt) const { return dt / fmin(1.0 / 0.2, q11 / 0.9); }
+};
+
 // a step's seven stage rows (derivatives, inputs or adjoints) in the unrolled kernels: registers (indices are literals
 // after unrolling), or one LDS row each at a constant offset
 template <int NS, bool IN_LDS>

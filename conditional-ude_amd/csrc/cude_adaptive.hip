@@ -85,8 +85,8 @@ void adaptive_kernel(typename M::Args a) {
     const double t0 = a.t_begin, t1 = a.t_end;
     const double t_stop = t1 - 1e-14 * fmax(1.0, fabs(t1));
 
-    double t = t0, dt = 0.0, qold = 1e-4, sse = chk;
-    double qold_pow = 0.47863009232263831;          // (1e-4)^(2/25)
+    double t = t0, dt = 0.0, sse = chk;
+    StepController ctl;
     double sk[NS], d0 = 0.0, d1 = 0.0;
     int nxt = 0;
     bool failed = false;
@@ -196,17 +196,7 @@ void adaptive_kernel(typename M::Args a) {
         const double est = rms(ev, NS);
         const bool live = !done && !failed;
         if (live && !(fabs(est) <= 1.79769313486231570815e308)) failed = true;     // NaN / Inf: the solve fails
-        // PI controller: q = est^(7/50) / qold^(2/25) with qold = max(previous est, 1e-4).  Both powers come from ONE
-        // logarithm per trial step, log(est): est^(7/50) = exp(0.14 log est) now, and -- when this step is accepted --
-        // qold^(2/25) of the NEXT step = exp(0.08 max(log est, log 1e-4)), kept in qold_pow (round 3; the two pow()
-        // calls per trial step were ~10 % of the forward sweep's instructions)
-#ifndef CUDE_ADAPT_POW
-        const double log_est = est > 0.0 ? log(est) : -1e3;                          // (est = 0: qold = 1e-4 below)
-        const double q11 = est > 0.0 ? exp((7.0 / 50.0) * log_est) : 1e-12;
-#else
-        const double q11 = est > 0.0 ? pow(est, 7.0 / 50.0) : 1e-12;
-#endif
-        const bool accept = est <= 1.0;
+        const bool accept = ctl.judge(est);
         if (live && !failed) {
             n_steps++;
             if (n_steps >= kAdaptiveMaxSteps) failed = true;
@@ -223,8 +213,7 @@ void adaptive_kernel(typename M::Args a) {
                     const bool at_end = fabs(th - 1.0) < 1e-12;
 #pragma unroll 1
                     for (int j = 0; j < 7; j++) {
-                        const double w = at_end ? (j < 6 ? TS_A[6][j] : 0.0)
-                                                : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+                        const double w = saveat_weight(j, th, at_end);
 #pragma unroll
                         for (int s = 0; s < NS; s++) o[s] = fma(w, KROW(j, s), o[s]);
                     }
@@ -254,23 +243,13 @@ void adaptive_kernel(typename M::Args a) {
         if (!GRAD && live && !failed && accept) n_acc++;      // (forward launches report the count too: cude_adaptive_regroup)
         if (live && !failed) {
             if (accept) {
-#ifndef CUDE_ADAPT_POW
-                double q = q11 / qold_pow;
-#else
-                double q = q11 / pow(qold, 2.0 / 25.0);
-#endif
-                q = fmax(1.0 / 10.0, fmin(1.0 / 0.2, q / 0.9));
                 t = t + dt;
 #pragma unroll
                 for (int s = 0; s < NS; s++) { y[s] = ynew[s]; KROW(0, s) = KROW(6, s); }
-                qold = fmax(est, 1e-4);
-#ifndef CUDE_ADAPT_POW
-                qold_pow = exp((2.0 / 25.0) * fmax(log_est, -9.21034037197618273607));     // log 1e-4
-#endif
-                dt = dt / q;
+                dt = ctl.after_accept(dt);
                 if (!(t < t_stop)) done = true;
             } else {
-                dt = dt / fmin(1.0 / 0.2, q11 / 0.9);
+                dt = ctl.after_reject(dt);
             }
         }
         if (done || failed) dt = 0.0;                 // parked lane: harmless arithmetic until the wave leaves
@@ -357,8 +336,7 @@ void adaptive_kernel(typename M::Args a) {
                         for (int s = 0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
 #pragma unroll 1
                         for (int j = 0; j < 7; j++) {
-                            const double w = at_end ? (j < 6 ? TS_A[6][j] : 0.0)
-                                                    : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+                            const double w = saveat_weight(j, th, at_end);
 #pragma unroll
                             for (int s = 0; s < NS; s++) BROW(j, s) = fma(w, ob[s], BROW(j, s));
                         }
@@ -461,8 +439,7 @@ void adaptive_kernel(typename M::Args a) {
                     for (int s = 0; s < NS; s++) o[s] = 0.0;
 #pragma unroll 1
                     for (int j = 0; j < 7; j++) {
-                        w[j] = at_end ? (j < 6 ? TS_A[6][j] : 0.0)
-                                      : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+                        w[j] = saveat_weight(j, th, at_end);
 #pragma unroll
                         for (int s = 0; s < NS; s++) o[s] = fma(w[j], KROW(j, s), o[s]);
                     }

@@ -58,7 +58,7 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
     const double t0 = a.t_begin, t1 = a.t_end;
     const double t_stop = t1 - 1e-14 * fmax(1.0, fabs(t1));
     double t = t0, dt = 0.0, sse = chk;
-    double qold_pow = 0.47863009232263831;          // (1e-4)^(2/25)
+    StepController ctl;
     int nxt = 0;
     bool failed = false;
     while (nxt < n_out && tout[nxt] <= t0 + 1e-12) {
@@ -142,9 +142,7 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
         const double est = rms(ev, NS);
         const bool live = !done && !failed;
         if (live && !(fabs(est) <= 1.79769313486231570815e308)) failed = true;
-        const double log_est = est > 0.0 ? log(est) : -1e3;
-        const double q11 = est > 0.0 ? exp((7.0 / 50.0) * log_est) : 1e-12;
-        const bool accept = est <= 1.0;
+        const bool accept = ctl.judge(est);
         if (live && !failed) {
             n_steps++;
             if (n_steps >= kAdaptiveMaxSteps) failed = true;
@@ -160,8 +158,7 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
                     const bool at_end = fabs(th - 1.0) < 1e-12;
 #pragma unroll
                     for (int j = 0; j < 7; j++) {
-                        const double w = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
-                                                : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+                        const double w = saveat_weight(j, th, at_end);
 #pragma unroll
                         for (int s = 0; s < NS; s++) o[s] = fma(w, K[j][s], o[s]);
                     }
@@ -197,16 +194,13 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
         if (!GRAD && live && !failed && accept) n_acc++;
         if (live && !failed) {
             if (accept) {
-                double q = q11 / qold_pow;
-                q = fmax(1.0 / 10.0, fmin(1.0 / 0.2, q / 0.9));
                 t = t + dt;
 #pragma unroll
                 for (int s = 0; s < NS; s++) { y[s] = ynew[s]; K[0][s] = K[6][s]; }
-                qold_pow = exp((2.0 / 25.0) * fmax(log_est, -9.21034037197618273607));     // log 1e-4
-                dt = dt / q;
+                dt = ctl.after_accept(dt);
                 if (!(t < t_stop)) done = true;
             } else {
-                dt = dt / fmin(1.0 / 0.2, q11 / 0.9);
+                dt = ctl.after_reject(dt);
             }
         }
         if (done || failed) dt = 0.0;
@@ -291,8 +285,7 @@ void adaptive_unrolled_supp_kernel(SuppArgs a) {
                     for (int s = A0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
 #pragma unroll
                     for (int j = 0; j < 7; j++) {
-                        const double w = at_end ? (j < 6 ? TS_A[6][j < 6 ? j : 0] : 0.0)
-                                                : fma(fma(fma(TS_R[j][3], th, TS_R[j][2]), th, TS_R[j][1]) * th, th, TS_R[j][0] * th);
+                        const double w = saveat_weight(j, th, at_end);
 #pragma unroll
                         for (int s = A0; s < NS; s++) B.set(j, s, fma(w, ob[s], B.get(j, s)));
                     }
