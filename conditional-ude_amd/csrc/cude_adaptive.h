@@ -264,7 +264,7 @@ struct StageRows<NS, true> {
 
 constexpr int kUnrolledKnots = 5;                  // the reference's five sampling times (c-peptide/02-conditional.jl)
 #define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
-// cude_adaptive_unrolled.hip: the c-peptide MLP shapes above on grids of at most kUnrolledKnots times; hipErrorNotSupported
+// cude_adaptive_unrolled.hip: the c-peptide MLP shapes above and the symbolic model on grids of at most kUnrolledKnots times; hipErrorNotSupported
 // for any other shape (the caller then runs the phase-machine kernel)
 hipError_t launch_cpep_adaptive_unrolled(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
 // cude_adaptive_unrolled_supp.hip: the suppression model, shapes of the reference's experiments

@@ -545,7 +545,7 @@ hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& 
     if (a.TG < 2 || a.TG > kMaxObs || a.T < 1) return hipErrorInvalidValue;
     if (grad && a.obs == nullptr) return hipErrorInvalidValue;
 #ifndef CUDE_ADAPT_ONE_BODY                        /* (A/B builds: tools/abl_adaptive_bits.py) */
-    if (!net.symbolic() && !net.general() && a.TG <= kUnrolledKnots) {
+    if (!net.general() && a.TG <= kUnrolledKnots) {
         const hipError_t e = launch_cpep_adaptive_unrolled(net, grad, a, s);
         if (e != hipErrorNotSupported) return e;
     }

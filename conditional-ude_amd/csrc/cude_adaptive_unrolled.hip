@@ -350,9 +350,11 @@ static hipError_t launch_unrolled(const typename M::Args& a, bool grad, hipStrea
 }
 
 hipError_t launch_cpep_adaptive_unrolled(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
-    if (net.symbolic() || net.general()) return hipErrorNotSupported;
+    if (net.general()) return hipErrorNotSupported;
     if (a.TG < 2 || a.TG > kUnrolledKnots || a.T < 1) return hipErrorNotSupported;
     if (grad && a.obs == nullptr) return hipErrorInvalidValue;
+    if (net.symbolic())
+        return a.cond_raw ? launch_unrolled<CpepAd<MmProd<true>>>(a, grad, s) : launch_unrolled<CpepAd<MmProd<false>>>(a, grad, s);
 #define X(NIN, W, D) \
     if (net.nin == NIN && net.width == W && net.depth == D) return launch_unrolled<CpepAd<Mlp<NIN, W, D, 1>>>(a, grad, s);
     CUDE_CPEP_AD_SHAPES(X)
