@@ -15,6 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("conditional-ude_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import cude_oracle as o  # noqa: E402
+if os.environ.get("CUDE_ABL"):                       # A/B runs: a library variant from tools/abl_so/
+    from cude import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "abl_so", os.environ["CUDE_ABL"] + ".so")
+    _lib.STRICT = False
 from cude.engine import Engine  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
