@@ -295,3 +295,80 @@ def test_suppression_full_size_properties_1e5_subjects():
     assert not np.array_equal(sse_sub, sse_big_scale) or np.allclose(s_sub, scale)
     sub.close()
     eng.close()
+
+
+def test_suppression_adaptive_gradient_at_1e5_subjects_properties():
+    """The suppression cUDE in the reference's own solver mode (Tsit5 adaptive, suppression_model.jl:113,123) at 1e5
+    subjects, through the kernel with unrolled stages that keeps the stage inputs on its tape
+    (csrc/cude_adaptive_unrolled_supp.hip): bitwise repeatable, the forward half of the gradient launch is the forward
+    launch, per-subject results independent of the launch order (cude_adaptive_regroup), additive over two ragged shards,
+    the directional derivative against central differences of the adaptive objective, one failing subject fails the
+    evaluation and nothing else, and the C oracle's adaptive solve on 200 subjects (solver-tolerance level: two correct
+    controllers do not always accept the same steps)."""
+    import c_oracle as co
+    from conftest import make_supp_case
+    from cude.engine import Engine
+    N, lam = 100_000, 0.01
+    c = make_supp_case(N)
+    arch = c["arch"]
+    eng = Engine("supp", arch, n_steps=0, lam=lam)
+    eng.set_option("auto_regroup", 0)
+    eng.set_population_supp(c["tp"], c["data"])
+    eng.set_params(c["nn"], c["theta"])
+    loss, g_nn, g_th = eng.loss_grad()
+    loss2, g_nn2, g_th2 = eng.loss_grad()
+    assert np.isfinite(loss) and loss == loss2 and np.array_equal(g_nn, g_nn2) and np.array_equal(g_th, g_th2)
+    fwd = eng.forward(want_sse=True)
+    assert abs(fwd["loss"] - loss) <= 1e-14 * loss
+    assert abs(fwd["sse"].sum() / N + lam * float(c["nn"] @ c["nn"]) - loss) < 1e-12 * loss
+    n_steps = np.array([len(eng.adaptive_steps(i)[0]) for i in range(0, N, 997)])
+    assert 8 <= n_steps.min() and n_steps.max() <= 64
+    scale, _ = eng.get_scale()
+    # launch ordered by accepted-step count: per-subject results bit for bit, the shared gradient to rounding
+    before, after = eng.adaptive_regroup()
+    assert after <= before
+    l3, gn3, gt3 = eng.loss_grad()
+    assert np.array_equal(gt3, g_th) and abs(l3 - loss) < 1e-12 * loss
+    assert np.max(np.abs(gn3 - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
+    # two ragged shards with the whole population's scale and subject count
+    cut, parts = 41_007, []
+    for lo, hi in ((0, cut), (cut, N)):
+        e2 = Engine("supp", arch, n_steps=0, lam=lam)
+        e2.set_population_supp(c["tp"], c["data"][:, :, lo:hi])
+        e2.set_global_subjects(N, scale)
+        e2.set_params(c["nn"], c["theta"][lo:hi])
+        parts.append(e2.loss_grad_partial(want_cond_grad=True))
+        e2.close()
+    P = g_nn.size
+    tot = parts[0][0] + parts[1][0]
+    assert tot[P + 1] == 0
+    assert abs(tot[P] / N + lam * float(c["nn"] @ c["nn"]) - loss) < 1e-12 * loss
+    assert np.max(np.abs(tot[:P] + 2 * lam * c["nn"] - g_nn)) < 1e-11 * np.max(np.abs(g_nn))
+    assert np.array_equal(np.concatenate([parts[0][1], parts[1][1]]), g_th)
+    # directional derivative of the adaptive objective (accepted steps move with the parameters: solver-tolerance level)
+    rng = np.random.default_rng(3)
+    d_nn, d_t = rng.standard_normal(P), rng.standard_normal(N)
+    eps = 1e-5
+    eng.set_params(c["nn"] + eps * d_nn, c["theta"] + eps * d_t); lp = eng.forward()["loss"]
+    eng.set_params(c["nn"] - eps * d_nn, c["theta"] - eps * d_t); lm = eng.forward()["loss"]
+    dd = g_nn @ d_nn + g_th @ d_t
+    assert abs((lp - lm) / (2 * eps) - dd) < 5e-3 * abs(dd)
+    # one failing subject
+    bad = c["theta"].copy()
+    bad[54_321] = np.inf
+    eng.set_params(c["nn"], bad)
+    l4, _, gt4 = eng.loss_grad()
+    assert np.isinf(l4) and eng.n_failed() == 1
+    ok = np.ones(N, bool)
+    ok[54_321] = False
+    assert np.array_equal(gt4[ok], g_th[ok])
+    eng.close()
+    # the C oracle's adaptive solve on 200 subjects (its own scale: the engine holds the same subset)
+    idx = np.sort(rng.choice(N, 200, replace=False))
+    sub = Engine("supp", arch, n_steps=0, lam=0.0)
+    sub.set_population_supp(c["tp"], c["data"][:, :, idx])
+    sub.set_params(c["nn"], c["theta"][idx])
+    traj = sub.forward(want_traj=True)["traj"]
+    ref = co.supp_adaptive(c["tp"], c["data"][:, :, idx], arch, c["nn"], c["theta"][idx])      # 3 x T x N, as simul
+    assert traj.shape == ref.shape and np.max(np.abs(traj - ref)) < 5e-7 * np.max(np.abs(ref))
+    sub.close()
