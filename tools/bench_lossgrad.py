@@ -11,6 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "conditional-ude_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import cude_oracle as o  # noqa: E402
+if os.environ.get("CUDE_ABL"):                       # A/B runs: a library variant from tools/abl_so/
+    from cude import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "abl_so", os.environ["CUDE_ABL"] + ".so")
+    _lib.STRICT = False
 from cude.engine import Engine  # noqa: E402
 
 for N in [int(v) for v in sys.argv[1:]] or [57, 1000, 10000]:
