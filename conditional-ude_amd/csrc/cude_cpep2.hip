@@ -521,10 +521,10 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     constexpr bool no_vw = false;
 #endif
     // the weights move into VGPRs (VWR) while the grid fits two waves per SIMD at once
-    const bool vwr = Net::HAS_VW && !no_vw && nblocks * a.L * n_sets <= 2 * 1024;
+    const bool vwr = Net::HAS_VW_SMALL && !no_vw && nblocks * a.L * n_sets <= 2 * 1024;
     const size_t lds_b = sizeof(double) * (size_t)a.base.T * kBlock;
     if (vwr) {
-        if constexpr (Net::HAS_VW) {
+        if constexpr (Net::HAS_VW_SMALL) {
             if (n_state == 3) hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 3, true>), grid2, dim3(kBlock), lds_b, s, a);
             else hipLaunchKernelGGL((cpep2_fwd_kernel<NIN, W, D, 2, true>), grid2, dim3(kBlock), lds_b, s, a);
         }

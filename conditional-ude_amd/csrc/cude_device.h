@@ -440,6 +440,9 @@ struct Mlp {
     // at 151 VGPRs = 3 waves per SIMD and would drop to 2.
     static constexpr int NVW = (D - 1) * LH + W + 1;
     static constexpr bool HAS_VW = (NV == 1 && NVW <= 49 && (W >= 6 || D >= 3)) && !GENERAL;
+    // ... and in the launches that leave registers idle anyway (time-split forward chunks of a small population: at most
+    // two waves per SIMD), also for the narrow networks
+    static constexpr bool HAS_VW_SMALL = (NV == 1 && NVW <= 49) && !GENERAL;
     struct VW {
         double w[NVW];
     };
@@ -966,6 +969,7 @@ struct MmProd {
     static constexpr int NACC = 2;                  // [d/dp0, d/dk]
     static constexpr bool HAS_TAB = false;          // one division per evaluation: nothing to tabulate
     static constexpr bool HAS_VW = false;
+    static constexpr bool HAS_VW_SMALL = false;
     static constexpr int DEPTH = 0, WIDTH = 1, NKEEP = 1;
     struct VW {};
     struct Exps {
