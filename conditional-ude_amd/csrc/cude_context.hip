@@ -176,6 +176,7 @@ const OptionEntry kOptions[] = {
     {"tape_steps", "CUDE_TAPE_STEPS", &Options::tape_steps, false, false},
     {"exp_table", "CUDE_NO_EXPTAB", &Options::exp_table, true, false},
     {"ms_split", "CUDE_NO_MS_SPLIT", &Options::ms_split, true, false},
+    {"train_host", "CUDE_TRAIN_HOST", &Options::train_host, false, false},
     {"auto_regroup", "CUDE_NO_AUTO_REGROUP", &Options::auto_regroup, true, false},
     {"poll_pinned", "CUDE_NO_POLL_PINNED", &Options::poll_pinned, true, false},
     {"debug_selector", "CUDE_DEBUG_SELECTOR", &Options::debug_selector, false, false},
@@ -440,6 +441,7 @@ int32_t cude_destroy(cude_ctx* c) {
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_pairs) (void)hipHostFree(c->pinned_pairs);
+    if (c->tr_pinned) (void)hipHostFree(c->tr_pinned);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);

@@ -1,7 +1,8 @@
 // Internal header of libcude_hip.so's host side: the context, its helpers and what the translation units share.
 //   cude_context.hip   contexts, populations, parameters, solver tables, run-time options
 //   cude_launch.hip    launch selection (one-lane / time-split / mixed), ensemble launches and every entry point built on them
-//   cude_optimise.hip  Adam (single steps and captured runs), L-BFGS, restarts trained side by side
+//   cude_optimise.hip  Adam (single steps and captured runs), L-BFGS on host vectors
+//   cude_train.hip     restarts trained side by side with their optimiser state on the device (cude_train_restarts)
 //   cude_comm.hip      multi-GPU: RCCL (dlopen) and the peer-write exchange over IPC-mapped mailboxes
 #pragma once
 #include <dlfcn.h>
@@ -65,6 +66,8 @@ struct Options {
     int tape_steps = 0;         // "tape_steps" / CUDE_TAPE_STEPS: capacity of the adaptive gradient tape (0 = sized to ~4 GB)
     int exp_table = 1;          // "exp_table" / CUDE_NO_EXPTAB: layer-1 exponent recurrence along glucose pieces
     int ms_split = 1;           // "ms_split" / CUDE_NO_MS_SPLIT: restarts of a small population on the time-split kernels
+    int train_host = 0;         // "train_host" / CUDE_TRAIN_HOST: 1 = cude_train_restarts keeps the L-BFGS vectors on the host
+                                //   (what a sharded population always does), 2 = the Adam stage on the host as well
     int auto_regroup = 1;       // "auto_regroup" / CUDE_NO_AUTO_REGROUP: adaptive launches re-ordered by accepted-step count
     int poll_pinned = 1;        // "poll_pinned" / CUDE_NO_POLL_PINNED: watch page-locked result slots instead of the stream wait
     int debug_selector = 0;     // "debug_selector" / CUDE_DEBUG_SELECTOR: print the launch-path decision
@@ -201,7 +204,15 @@ struct cude_ctx {
     bool have_counts = false;       // tape_n holds every subject's accepted-step count of some adaptive evaluation
     int64_t evals_since_regroup = 0;
     cude::api::DevBuf<double> red_tmp; // staging of small host vectors reduced through the communicator
-    std::vector<double> ms_host;
+    cude::api::DevBuf<double> ms_f;    // per-set loss values of a multi-set evaluation
+    double scratch_budget = 0.0;       // bytes of scratch one multi-set launch may use (sets_scratch_budget)
+    // cude_train_restarts (cude_train.hip): the restarts' optimiser state, resident between iterations
+    cude::api::DevBuf<double> tr_m_nn, tr_v_nn, tr_m_cond, tr_v_cond, tr_trace;     // Adam moments [K][P] / [K][N], loss trace
+    cude::api::DevBuf<int32_t> tr_alive, tr_act;
+    cude::api::DevBuf<double> tr_x, tr_g, tr_d, tr_s, tr_y, tr_trial, tr_gtrial;    // L-BFGS vectors [R][N + P], history [R][m][N + P]
+    cude::api::DevBuf<unsigned char> tr_state;
+    void* tr_pinned = nullptr;         // page-locked copy of the L-BFGS states / alive flags the host reads once per round
+    size_t tr_pinned_bytes = 0;
 #ifdef CUDE_WAVE_TIMING
     cude::api::DevBuf<long long> dbg;
 #endif
@@ -240,6 +251,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only =
 int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host);
 int32_t adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after);
 int32_t maybe_regroup(cude_ctx* c);
+int32_t eval_sets_device(cude_ctx* c, int64_t n_sets, const double* nn, int64_t stride_nn, const double* cond,
+                         int64_t stride_cond, double* g_cond, double* out);
 // ---- cude_optimise.hip
 void drop_graph(cude_ctx* c);
 int32_t ensure_trace(cude_ctx* c, int64_t n);

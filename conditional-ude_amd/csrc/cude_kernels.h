@@ -253,6 +253,60 @@ struct AdamArgs {
     double* state;                    // device: {b1^t, b2^t, steps done, trace position}, ALREADY advanced to this step
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
+
+// ---- restarts trained side by side with their optimiser state on the device (cude_train.hip)
+// Behind a multi-set gradient evaluation (eval_sets_device): per set k the L2 term in l2_term_kernel's arithmetic,
+// the loss value, and -- for the Adam stage -- the set's liveness and its loss-trace entry.
+struct FinishSetsArgs {
+    int P;
+    double* out;             // [K][P+2]: in [masked g_nn; sum SSE; failures]; g_nn gets its L2 term in place (g_dst == nullptr)
+    const double* nn;        // set k's network parameters at nn + k * stride_nn
+    int64_t stride_nn;
+    double lambda, n_global;
+    const double* mask;      // [P] or nullptr
+    double* f;               // [K] loss values, +Inf for a set with a failed subject
+    double* g_dst;           // optional: the finished network gradient goes to g_dst + k * g_stride instead
+    int64_t g_stride;
+    int32_t* alive;          // optional [K]: cleared for a set whose loss is not finite (the reference drops that restart)
+    double* trace;           // optional [K][trace_len]: trace[k][trace_pos] = loss of a live set
+    int64_t trace_len, trace_pos;
+};
+hipError_t launch_finish_sets(const FinishSetsArgs& a, int n_sets, hipStream_t s);
+// Optimisers.Adam for K sets at once, in the arithmetic of cude::adam_update (cude_optim.h; no contraction): dead sets skipped
+struct AdamSetsArgs {
+    int64_t N; int P;
+    double* cond; double* nn;                       // [K][N], [K][P]
+    double* m_cond; double* v_cond; double* m_nn; double* v_nn;
+    const double* g_cond;                           // [K][N]
+    const double* out;                              // [K][P+2] (network gradients)
+    const int32_t* alive;                           // [K]
+    double lr, b1, b2, eps, c1, c2;                 // c = 1 - b^t of this step (host: std::pow)
+};
+hipError_t launch_adam_sets(const AdamSetsArgs& a, int n_sets, hipStream_t s);
+// Optim's L-BFGS + BackTracking (cude_optim.h) with the vectors of R restarts on the device: one state per restart,
+// one workgroup per restart and round.  Vector layout [conditional (N); network (P)].
+constexpr int kLbfgsM = 10;
+constexpr int kLbfgsFirst = 0, kLbfgsFinite = 1, kLbfgsArmijo = 2, kLbfgsDone = 3;
+struct LbfgsState {
+    int32_t phase, pseudo, it, calls, accepted, f_flat, converged, ls_it, n_eval, maxiters, line_search_failed, pad_;
+    double f, f0, dphi0, a1, a2, phi1, g_tol;
+    double rho[kLbfgsM];
+};
+struct LbfgsArgs {
+    int64_t n;               // N + P
+    LbfgsState* state;       // [R]
+    const int32_t* act;      // [A]: restart of every active slot
+    double* X; double* G; double* D;        // [R][n]: iterate, its gradient, search direction
+    double* S; double* Y;                   // [R][kLbfgsM][n]: history ring
+    double* trial;           // [A][n]: the points the next evaluation is asked for
+    const double* g_trial;   // [A][n]: gradient at the trial points
+    const double* f_trial;   // [A]
+    double* trace;           // optional [.][trace_len]: row owner[r], entry trace_off + (accepted iterations before) = f
+    const int32_t* owner;    // [R]
+    int64_t trace_len, trace_off;
+};
+hipError_t launch_lbfgs_trial(const LbfgsArgs& a, int n_active, hipStream_t s);
+hipError_t launch_lbfgs_feed(const LbfgsArgs& a, int n_active, hipStream_t s);
 // SAEM E-step (Metropolis-Hastings) helper kernels
 hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, RngKey key, double proposal_std, double* prop,
                              hipStream_t s);

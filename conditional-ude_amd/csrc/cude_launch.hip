@@ -585,6 +585,102 @@ int32_t adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_af
     return CUDE_OK;
 }
 
+// Bytes of scratch one multi-set launch may use (partial rows, stage inputs, tapes): sets per launch = this / the
+// scratch of one set.  More sets per launch fill the chip better (25 sets of 1e5 subjects: 39 000 waves in one grid
+// instead of 25 grids that each end in a part-filled round), and the per-set results do not depend on it.
+double sets_scratch_budget(cude_ctx* c) {
+    if (c->scratch_budget > 0.0) return c->scratch_budget;
+    size_t free_b = 0, total_b = 0;
+    c->scratch_budget = 512e6;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b >= ((size_t)64 << 30))
+        c->scratch_budget = std::min(16e9, std::max(512e6, 0.25 * (double)free_b));
+    else
+        (void)hipGetLastError();
+    return c->scratch_budget;
+}
+
+// Loss sums and gradients of n_sets parameter sets that are ALREADY on the device (set k: nn + k * stride_nn,
+// cond + k * stride_cond), everything queued on the context's stream, no synchronisation, no host copy:
+//   g_cond + k * stride_cond   <- dL/dcond of set k                               [N]
+//   out + k * (P + 2)          <- [masked network gradient (P); sum of SSE; failed subjects], summed over the ranks
+// (the L2 term and the loss value are the caller's: launch_finish_sets).  The set index is the grid's second dimension
+// (third on the time-split path); sets are launched in groups as large as the scratch budget allows.
+int32_t eval_sets_device(cude_ctx* c, int64_t n_sets, const double* nn, int64_t stride_nn, const double* cond,
+                         int64_t stride_cond, double* g_cond, double* out) {
+    int32_t rc = CUDE_OK;
+    const int P = c->P, S = c->cfg.n_steps;
+    const int64_t N = c->N, nb = c->nblocks;
+    const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
+    // Small populations: K restarts of a few dozen subjects are K single-wave chains on the one-lane kernel (25 waves on
+    // 1024 SIMDs, each paying the full single-wave latency).  When the population itself runs time-split (chunks > 1) and
+    // the sets do not fill the chip either, the time-split kernels take the set index as a third grid dimension: K x L
+    // short waves instead.  Same kernels as cude_loss_grad on this context, so a set's result is bit-identical to it.
+    const int L = c->chunks;
+    const bool split = !supp && L > 1 && c->blk0 == 0 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 &&
+                       c->opt.ms_split;
+    if ((rc = ensure_tape(c))) return rc;                 // (fixes the capacity the per-set tapes share)
+    if ((rc = maybe_regroup(c))) return rc;
+    const int64_t tape_rows = adaptive(c) ? cude::adaptive_tape_rows(supp ? 3 : 2, c->tape_cap, c->T) : 0;
+    const double per_set = 8.0 * ((double)nb * (P + 2) + (double)tape_rows * N +
+                                  (supp && !adaptive(c) ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
+                                  (split ? (double)L * (3 + c->T) * N + 5.0 * S * N + (double)L * N + (double)L * nb * P : 0.0));
+    // sets per launch: bounded by the grid's y / z dimension and the scratch budget
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_sets, split ? 16384 : 32768),
+                                                                 (int64_t)(sets_scratch_budget(c) / per_set)));
+    if (split) {
+        HIP_TRY(c->ms_fsum.reserve((size_t)chunk * L * (3 + c->T) * N));
+        HIP_TRY(c->ms_wts.reserve((size_t)chunk * 5 * S * N));
+        HIP_TRY(c->ms_gcp.reserve((size_t)chunk * L * N));
+        HIP_TRY(c->ms_p2.reserve((size_t)chunk * L * nb * P));
+    }
+    HIP_TRY(c->ms_part.reserve((size_t)chunk * nb * (P + 2)));
+    if (supp && !adaptive(c)) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * cude::supp_ckpt_rows(S, c->T) * N));
+    if (adaptive(c)) HIP_TRY(c->ms_tape.reserve((size_t)chunk * tape_rows * N));
+    for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
+        const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
+        const double* nn_k = nn + k0 * stride_nn;
+        const double* cond_k = cond + k0 * stride_cond;
+        double* g_cond_k = g_cond + k0 * stride_cond;
+        double* out_k = out + k0 * (P + 2);
+        if (split) {
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = cond_k; a.nn = nn_k;
+            a.g_cond = g_cond_k; a.partials = c->ms_part.p;
+            a.sse = nullptr; a.traj = nullptr; a.auc = nullptr;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = stride_nn; a.set_stride_cond = stride_cond;
+            cude::Cpep2Args a2 = chunk_args(c, a);
+            a2.fsum = c->ms_fsum.p; a2.wts = c->ms_wts.p; a2.g_cond_part = c->ms_gcp.p; a2.partials2 = c->ms_p2.p;
+            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, true, a2, c->stream));
+            // network gradient: the reverse chunks' partial rows; loss / failure columns: the scan's
+            HIP_TRY(cude::launch_reduce_cols(c->ms_p2.p, nb * L, P, 0, P, out_k, c->stream, (int)kn, c->param_mask.p, P, P + 2));
+            HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, P, 2, out_k, c->stream, (int)kn));
+        } else if (!supp) {
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = cond_k; a.nn = nn_k;
+            a.g_cond = g_cond_k; a.partials = c->ms_part.p;
+            a.n_sets = (int32_t)kn; a.set_stride_nn = stride_nn; a.set_stride_cond = stride_cond;
+            if (adaptive(c)) a.tape = c->ms_tape.p;     // (tape_n: the counts of set 0, for the re-ordering)
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));     // one-lane kernel: the sets fill the chip
+        } else {
+            cude::SuppArgs a = supp_args(c);
+            a.cond = cond_k; a.nn = nn_k;
+            a.ckpt = c->ms_ckpt.p; a.g_cond = g_cond_k; a.partials = c->ms_part.p;
+            if (adaptive(c)) a.tape = c->ms_tape.p;
+            if (!adaptive(c) && !a.ckpt_steps_only && supp_keep_activations(c, kn)) {
+                HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
+                a.act = c->ms_act.p;
+            }
+            a.n_sets = (int32_t)kn; a.set_stride_nn = stride_nn; a.set_stride_cond = stride_cond;
+            HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
+        }
+        if (adaptive(c)) c->have_counts = true;     // (the launch left the step counts of its first parameter set behind)
+        if (!split)
+            HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, out_k, c->stream, (int)kn, c->param_mask.p, P));
+        if (distributed(c) && (rc = allreduce_dev(c, out_k, (size_t)kn * (P + 2)))) return rc;
+    }
+    return CUDE_OK;
+}
+
 }  // namespace api
 }  // namespace cude
 
@@ -816,110 +912,28 @@ int32_t cude_multistart_loss_grad(cude_ctx* c, int32_t n_sets, const double* nn_
     if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
     if (n_sets < 1 || !nn_sets || !cond_sets || !losses || !g_nn_sets || !g_cond_sets)
         return fail(CUDE_ERR_ARG, "null/empty input");
-    const int P = c->P, S = c->cfg.n_steps;
-    const int64_t N = c->N, nb = c->nblocks;
-    const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
-    // Small populations: K restarts of a few dozen subjects are K single-wave chains on the one-lane kernel (25 waves on
-    // 1024 SIMDs, each paying the full single-wave latency).  When the population itself runs time-split (chunks > 1) and
-    // the sets do not fill the chip either, the time-split kernels take the set index as a third grid dimension: K x L
-    // short waves instead.  Same kernels as cude_loss_grad on this context, so a set's result is bit-identical to it.
-    const int L = c->chunks;
-    const bool split = !supp && L > 1 && c->blk0 == 0 && nb * (int64_t)std::min<int64_t>(n_sets, 64) <= 512 &&
-                       c->opt.ms_split;
-    // sets per launch: bounded by the grid's y / z dimension and ~512 MB of scratch
-    if ((rc = ensure_tape(c))) return rc;                 // (fixes the capacity the per-set tapes share)
-    if ((rc = maybe_regroup(c))) return rc;
-    const int64_t tape_rows = adaptive(c) ? cude::adaptive_tape_rows(supp ? 3 : 2, c->tape_cap, c->T) : 0;
-    const double per_set = 8.0 * ((double)nb * (P + 2) + 2.0 * N + P + (double)tape_rows * N +
-                                  (supp && !adaptive(c) ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
-                                  (split ? (double)L * (3 + c->T) * N + 5.0 * S * N + (double)L * N + (double)L * nb * P : 0.0));
-    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_sets, split ? 16384 : 32768), (int64_t)(512e6 / per_set)));
-    if (split) {
-        HIP_TRY(c->ms_fsum.reserve((size_t)chunk * L * (3 + c->T) * N));
-        HIP_TRY(c->ms_wts.reserve((size_t)chunk * 5 * S * N));
-        HIP_TRY(c->ms_gcp.reserve((size_t)chunk * L * N));
-        HIP_TRY(c->ms_p2.reserve((size_t)chunk * L * nb * P));
-    }
-    HIP_TRY(c->ms_nn.reserve((size_t)chunk * P));
-    HIP_TRY(c->ms_cond.reserve((size_t)chunk * N));
-    HIP_TRY(c->ms_gcond.reserve((size_t)chunk * N));
-    HIP_TRY(c->ms_part.reserve((size_t)chunk * nb * (P + 2)));
-    HIP_TRY(c->ms_out.reserve((size_t)chunk * (P + 2)));
-    if (supp && !adaptive(c)) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * cude::supp_ckpt_rows(S, c->T) * N));
-    if (adaptive(c)) HIP_TRY(c->ms_tape.reserve((size_t)chunk * tape_rows * N));
-    c->ms_host.resize((size_t)chunk * (P + 2));
-    for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
-        const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
-        HIP_TRY(hipMemcpyAsync(c->ms_nn.p, nn_sets + k0 * P, kn * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->ms_cond.p, cond_sets + k0 * N, kn * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (split) {
-            cude::CpepArgs a = cpep_args(c);
-            a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
-            a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
-            a.sse = nullptr; a.traj = nullptr; a.auc = nullptr;
-            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
-            cude::Cpep2Args a2 = chunk_args(c, a);
-            a2.fsum = c->ms_fsum.p; a2.wts = c->ms_wts.p; a2.g_cond_part = c->ms_gcp.p; a2.partials2 = c->ms_p2.p;
-            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, true, a2, c->stream));
-            // network gradient: the reverse chunks' partial rows; loss / failure columns: the scan's
-            HIP_TRY(cude::launch_reduce_cols(c->ms_p2.p, nb * L, P, 0, P, c->ms_out.p, c->stream, (int)kn, c->param_mask.p, P,
-                                             P + 2));
-            HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, P, 2, c->ms_out.p, c->stream, (int)kn));
-        } else if (!supp) {
-            cude::CpepArgs a = cpep_args(c);
-            a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
-            a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
-            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
-            if (adaptive(c)) a.tape = c->ms_tape.p;     // (tape_n: the counts of set 0, for the re-ordering below)
-            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));     // one-lane kernel: the sets fill the chip
-        } else {
-            cude::SuppArgs a = supp_args(c);
-            a.cond = c->ms_cond.p; a.nn = c->ms_nn.p;
-            a.ckpt = c->ms_ckpt.p; a.g_cond = c->ms_gcond.p; a.partials = c->ms_part.p;
-            if (adaptive(c)) a.tape = c->ms_tape.p;
-            if (!adaptive(c) && !a.ckpt_steps_only && supp_keep_activations(c, kn)) {
-                HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
-                a.act = c->ms_act.p;
-            }
-            a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
-            HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
-        }
-        if (adaptive(c)) c->have_counts = true;     // (the launch left the step counts of its first parameter set behind)
-        if (!split)
-            HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, c->ms_out.p, c->stream, (int)kn,
-                                             c->param_mask.p, P));
-        if (distributed(c) && (rc = allreduce_dev(c, c->ms_out.p, (size_t)kn * (P + 2)))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->ms_host.data(), c->ms_out.p, kn * (P + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(g_cond_sets + k0 * N, c->ms_gcond.p, kn * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int64_t k = 0; k < kn; k++) {
-            const double* r = c->ms_host.data() + k * (P + 2);
-            const double* w = nn_sets + (k0 + k) * P;
-            double* g = g_nn_sets + (k0 + k) * P;
-            // L2 term in the arithmetic of l2_term_kernel (64 strided partial sums, xor-butterfly, fma), so that a
-            // set's loss and gradient are bit-identical to cude_loss_grad at the same parameters
-            double sum = r[P];
-            if (c->cfg.lambda != 0.0) {
-                double part[64], tmp[64];
-                for (int l = 0; l < 64; l++) {
-                    part[l] = 0.0;
-                    for (int q = l; q < P; q += 64) part[l] = std::fma(w[q], w[q], part[l]);
-                }
-                for (int off = 32; off >= 1; off >>= 1) {
-                    for (int l = 0; l < 64; l++) tmp[l] = part[l] + part[l ^ off];
-                    std::memcpy(part, tmp, sizeof(part));
-                }
-                sum = std::fma(c->cfg.lambda * c->n_global, part[0], sum);
-                for (int q = 0; q < P; q++)
-                    g[q] = std::fma(2.0 * c->cfg.lambda * (c->mask_host.empty() ? 1.0 : c->mask_host[q]), w[q], r[q]);
-            } else {
-                for (int q = 0; q < P; q++) g[q] = r[q];
-            }
-            losses[k0 + k] = (r[P + 1] > 0.0 || !std::isfinite(sum)) ? std::numeric_limits<double>::infinity()
-                                                                    : sum / c->n_global;
-        }
-    }
-    return CUDE_OK;
+    const int P = c->P;
+    const int64_t N = c->N, K = n_sets;
+    HIP_TRY(c->ms_nn.reserve((size_t)K * P));
+    HIP_TRY(c->ms_cond.reserve((size_t)K * N));
+    HIP_TRY(c->ms_gcond.reserve((size_t)K * N));
+    HIP_TRY(c->ms_out.reserve((size_t)K * (P + 2)));
+    HIP_TRY(c->ms_f.reserve((size_t)K));
+    HIP_TRY(hipMemcpyAsync(c->ms_nn.p, nn_sets, (size_t)K * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ms_cond.p, cond_sets, (size_t)K * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = eval_sets_device(c, K, c->ms_nn.p, P, c->ms_cond.p, N, c->ms_gcond.p, c->ms_out.p))) return rc;
+    // loss and L2 term per set, in the arithmetic of l2_term_kernel: a set's loss and gradient are bit-identical to
+    // cude_loss_grad at the same parameters
+    cude::FinishSetsArgs fa{};
+    fa.P = P; fa.out = c->ms_out.p; fa.nn = c->ms_nn.p; fa.stride_nn = P; fa.lambda = c->cfg.lambda; fa.n_global = c->n_global;
+    fa.mask = c->param_mask.p; fa.f = c->ms_f.p;
+    HIP_TRY(cude::launch_finish_sets(fa, (int)K, c->stream));
+    HIP_TRY(hipMemcpyAsync(losses, c->ms_f.p, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(g_nn_sets, (size_t)P * sizeof(double), c->ms_out.p, (size_t)(P + 2) * sizeof(double),
+                             (size_t)P * sizeof(double), (size_t)K, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(g_cond_sets, c->ms_gcond.p, (size_t)K * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return c->xchg.ready ? xchg_check(c) : CUDE_OK;
 }
 
 int32_t cude_adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after) {

@@ -1,6 +1,6 @@
 // libcude_hip.so -- the optimisers of the reference's training loop on the device-resident state: Optimisers.Adam as
-// single steps and as captured runs (src/parameter-estimation.jl:176, suppression_model.jl:164, saem.jl:128), Optim's
-// L-BFGS + BackTracking (:179-180, :168) and the restarts trained side by side.
+// single steps and as captured runs (src/parameter-estimation.jl:176, suppression_model.jl:164, saem.jl:128) and Optim's
+// L-BFGS + BackTracking (:179-180, :168) on a caller's objective; the restarts trained side by side: cude_train.hip.
 #include "cude_ctx.h"
 
 namespace cude {
@@ -267,95 +267,6 @@ int32_t cude_lbfgs_minimize_sharded(int32_t n, int32_t n_shared, const double* x
     if (iterations) *iterations = r.iterations;
     if (f_calls) *f_calls = r.f_calls;
     if (converged) *converged = r.converged ? 1 : 0;
-    return CUDE_OK;
-}
-
-int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, const double* cond_sets,
-                            int32_t adam_iters, double learning_rate, int32_t lbfgs_iters, double* nn_out,
-                            double* cond_out, double* objective_out, double* loss_trace) {
-    int32_t rc = bind(c);
-    if (rc) return rc;
-    if (!c->have_pop) return fail(CUDE_ERR_STATE, "population not set");
-    if (n_sets < 1 || !nn_sets || !cond_sets || !nn_out || !cond_out || !objective_out || adam_iters < 0 ||
-        lbfgs_iters < 0 || !(learning_rate > 0))
-        return fail(CUDE_ERR_ARG, "bad argument");
-    // Adam is element-wise and shards with the subjects; L-BFGS takes inner products over [neural; conditional]: on a
-    // sharded population the conditional part of every inner product / max-norm is reduced over the ranks (a few
-    // doubles per iteration, cude::Lbfgs reducer), so every rank follows the same iterates
-    const int K = n_sets, P = c->P;
-    const int64_t N = c->N, n = P + N;
-    // working copies in the ABI's [K][P] / [K][N] layout
-    std::vector<double> nn(nn_sets, nn_sets + (size_t)K * P), cond(cond_sets, cond_sets + (size_t)K * N);
-    std::vector<double> f(K), g_nn((size_t)K * P), g_cond((size_t)K * N);
-    std::vector<char> alive(K, 1);
-    const int64_t trace_len = (int64_t)adam_iters + lbfgs_iters;
-    if (loss_trace)
-        for (int64_t q = 0; q < (int64_t)K * trace_len; q++) loss_trace[q] = std::numeric_limits<double>::quiet_NaN();
-    // ---- Adam, vectorised over the restarts; a restart whose loss becomes non-finite is dropped
-    {
-        std::vector<double> m_nn((size_t)K * P, 0.0), v_nn((size_t)K * P, 0.0), m_c((size_t)K * N, 0.0), v_c((size_t)K * N, 0.0);
-        for (int t = 1; t <= adam_iters; t++) {
-            if ((rc = cude_multistart_loss_grad(c, K, nn.data(), cond.data(), f.data(), g_nn.data(), g_cond.data()))) return rc;
-            for (int k = 0; k < K; k++) {
-                if (!std::isfinite(f[k])) alive[k] = 0;
-                if (!alive[k]) continue;
-                if (loss_trace) loss_trace[(int64_t)k * trace_len + (t - 1)] = f[k];
-                cude::adam_update(nn.data() + (size_t)k * P, g_nn.data() + (size_t)k * P, m_nn.data() + (size_t)k * P,
-                                  v_nn.data() + (size_t)k * P, P, t, learning_rate);
-                cude::adam_update(cond.data() + (size_t)k * N, g_cond.data() + (size_t)k * N, m_c.data() + (size_t)k * N,
-                                  v_c.data() + (size_t)k * N, N, t, learning_rate);
-            }
-        }
-    }
-    // ---- L-BFGS, one resumable state machine per surviving restart, advanced in lock step
-    std::vector<cude::Lbfgs> opt;
-    std::vector<int> owner;                               // restart index of each machine
-    std::vector<double> x0(n);
-    for (int k = 0; k < K; k++) {
-        if (!alive[k]) continue;
-        std::copy(nn.begin() + (size_t)k * P, nn.begin() + (size_t)(k + 1) * P, x0.begin());
-        std::copy(cond.begin() + (size_t)k * N, cond.begin() + (size_t)(k + 1) * N, x0.begin() + P);
-        if (distributed(c)) opt.emplace_back(x0.data(), (int)n, lbfgs_iters, 10, 1e-8, P, lbfgs_comm_reduce, c);
-        else opt.emplace_back(x0.data(), (int)n, lbfgs_iters);
-        owner.push_back(k);
-    }
-    std::vector<double> b_nn, b_cond, b_f, b_gnn, b_gcond, gfull(n);
-    std::vector<int> active;
-    while (true) {
-        active.clear();
-        for (size_t q = 0; q < opt.size(); q++)
-            if (!opt[q].done()) active.push_back((int)q);
-        if (active.empty()) break;
-        const int A = (int)active.size();
-        b_nn.resize((size_t)A * P); b_cond.resize((size_t)A * N); b_f.resize(A);
-        b_gnn.resize((size_t)A * P); b_gcond.resize((size_t)A * N);
-        for (int a = 0; a < A; a++) {
-            const double* x = opt[active[a]].pending();
-            std::copy(x, x + P, b_nn.begin() + (size_t)a * P);
-            std::copy(x + P, x + n, b_cond.begin() + (size_t)a * N);
-        }
-        if ((rc = cude_multistart_loss_grad(c, A, b_nn.data(), b_cond.data(), b_f.data(), b_gnn.data(), b_gcond.data()))) return rc;
-        for (int a = 0; a < A; a++) {
-            std::copy(b_gnn.begin() + (size_t)a * P, b_gnn.begin() + (size_t)(a + 1) * P, gfull.begin());
-            std::copy(b_gcond.begin() + (size_t)a * N, b_gcond.begin() + (size_t)(a + 1) * N, gfull.begin() + P);
-            cude::Lbfgs& o = opt[active[a]];
-            const int before = o.accepted_steps();
-            o.feed(b_f[a], gfull.data());
-            if (loss_trace && o.accepted_steps() > before && before < lbfgs_iters)     // where Optim's callback fires
-                loss_trace[(int64_t)owner[active[a]] * trace_len + adam_iters + before] = o.current_f();
-            if (o.comm_failed()) return CUDE_ERR_COMM;     // message already set by the reducer
-        }
-    }
-    for (int k = 0; k < K; k++) objective_out[k] = std::numeric_limits<double>::infinity();
-    for (size_t q = 0; q < opt.size(); q++) {
-        const int k = owner[q];
-        const std::vector<double>& x = opt[q].x();
-        std::copy(x.begin(), x.begin() + P, nn.begin() + (size_t)k * P);
-        std::copy(x.begin() + P, x.end(), cond.begin() + (size_t)k * N);
-        objective_out[k] = opt[q].result().f;
-    }
-    std::copy(nn.begin(), nn.end(), nn_out);
-    std::copy(cond.begin(), cond.end(), cond_out);
     return CUDE_OK;
 }
 
