@@ -304,6 +304,7 @@ struct LbfgsArgs {
     double* trace;           // optional [.][trace_len]: row owner[r], entry trace_off + (accepted iterations before) = f
     const int32_t* owner;    // [R]
     int64_t trace_len, trace_off;
+    int64_t lds_doubles;     // set by launch_lbfgs_feed: dynamic LDS of the launch, in doubles
 };
 hipError_t launch_lbfgs_trial(const LbfgsArgs& a, int n_active, hipStream_t s);
 hipError_t launch_lbfgs_feed(const LbfgsArgs& a, int n_active, hipStream_t s);

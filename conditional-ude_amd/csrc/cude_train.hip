@@ -6,10 +6,10 @@
 // vectors (iterate, gradient, direction, ten (s, y) pairs) never leave the GPU.
 //   Adam stage     eval_sets_device -> finish_sets_kernel (L2 term, loss, liveness, trace) -> adam_sets_kernel; no
 //                  synchronisation at all between iterations.
-//   L-BFGS stage   per round: lbfgs_trial_kernel (x + alpha d of every live restart) -> eval_sets_device ->
-//                  finish_sets_kernel -> lbfgs_feed_kernel (one workgroup per restart: the whole of cude::Lbfgs::feed --
-//                  line-search decision, history update, two-loop recursion, next direction) -> the restarts' phases
-//                  come back (a few hundred bytes) so that finished restarts drop out of the next evaluation.
+//   L-BFGS stage   per round: eval_sets_device at the restarts' trial points -> finish_sets_kernel -> lbfgs_feed_kernel
+//                  (one workgroup per restart: the whole of cude::Lbfgs::feed -- line-search decision, history update,
+//                  two-loop recursion, next direction, next trial point x + alpha d) -> the restarts' phases come back
+//                  (a few hundred bytes) so that finished restarts drop out of the next evaluation.
 // The element-wise arithmetic is that of cude_optim.h (compiled without contraction); inner products are summed by a
 // fixed tree per workgroup instead of left to right, which is the only difference from the host statement.
 // A sharded population keeps the L-BFGS vectors on the host (cude::Lbfgs with its reducer: the inner products'
@@ -155,12 +155,15 @@ template <int TPB>
 __global__ __launch_bounds__(TPB) void lbfgs_feed_kernel(LbfgsArgs a) {
 #pragma clang fp contract(off)
     __shared__ double sh[3 * (TPB / 64)];
+    extern __shared__ double lds[];     // a.lds_doubles of them (launch_lbfgs_feed)
     const BlockRed<TPB> red{sh};
     constexpr int m = kLbfgsM, kMaxLs = 1000, kMaxFinite = 52;
     constexpr double kC1 = 1e-4, kRhoHi = 0.5, kRhoLo = 0.1;
     const int slot = blockIdx.x, r = a.act[slot], tid = threadIdx.x;
     LbfgsState st = a.state[r];
     if (st.phase == kLbfgsDone) return;
+    __syncthreads();            // every wave has the state before thread 0 can store the new one (a rejected trial step
+                                // reaches the end of this kernel without another barrier)
     const int64_t n = a.n;
     double* X = a.X + (int64_t)r * n;
     double* G = a.G + (int64_t)r * n;
@@ -274,15 +277,33 @@ __global__ __launch_bounds__(TPB) void lbfgs_feed_kernel(LbfgsArgs a) {
             const int upper = st.pseudo - 1, lower = st.pseudo - m > 1 ? st.pseudo - m : 1;
             double dphi0 = 0.0;
             if (upper >= lower) {
-                // two-loop recursion over the pairs lower..upper on q = D; every pass also forms the inner product the
-                // next step needs (same products, same element order as a separate pass would take)
+                // two-loop recursion over the pairs lower..upper on q; every pass also forms the inner product the next
+                // step needs (same products, same element order as a separate pass would take).  A small problem (the
+                // reference's 57 + 37 unknowns) is a chain of ~25 dependent passes over a few hundred bytes each: there
+                // the pairs, g and q are staged in LDS by one batch of independent loads, so that the chain pays the
+                // memory latency once instead of once per pass (26 -> 8 us per round at n = 94).
                 double alpha[m];
-                const double* su = Sr + (int64_t)((upper - 1) % m) * n;
-                const double* yu = Yr + (int64_t)((upper - 1) % m) * n;
+                const bool staged = a.lds_doubles >= (int64_t)(2 * m + 2) * n;
+                double* q = staged ? lds + (int64_t)(2 * m) * n : D;
+                const double* gq = staged ? lds + (int64_t)(2 * m + 1) * n : G;
+                const double* Sq = staged ? lds : Sr;
+                const double* Yq = staged ? lds + (int64_t)m * n : Yr;
+                if (staged) {
+                    for (int k = lower; k <= upper; k++) {
+                        const int64_t o = (int64_t)((k - 1) % m) * n;
+                        for (int64_t i = tid; i < n; i += TPB) {
+                            lds[o + i] = Sr[o + i];
+                            lds[(int64_t)m * n + o + i] = Yr[o + i];
+                        }
+                    }
+                    for (int64_t i = tid; i < n; i += TPB) lds[(int64_t)(2 * m + 1) * n + i] = G[i];
+                }
+                const double* su = Sq + (int64_t)((upper - 1) % m) * n;
+                const double* yu = Yq + (int64_t)((upper - 1) % m) * n;
                 double acc = 0.0, sy = 0.0, yy = 0.0;
                 for (int64_t i = tid; i < n; i += TPB) {
-                    const double g = G[i], s = su[i], y = yu[i];
-                    D[i] = g;
+                    const double g = gq[i], s = su[i], y = yu[i];
+                    q[i] = g;
                     acc += s * g;
                     sy += s * y;
                     yy += y * y;
@@ -292,47 +313,47 @@ __global__ __launch_bounds__(TPB) void lbfgs_feed_kernel(LbfgsArgs a) {
                 for (int k = upper; k >= lower; k--) {
                     const double al = st.rho[(k - 1) % m] * dotv;
                     alpha[k - lower] = al;
-                    const double* yk = Yr + (int64_t)((k - 1) % m) * n;
+                    const double* yk = Yq + (int64_t)((k - 1) % m) * n;
                     if (k > lower) {
-                        const double* sn = Sr + (int64_t)((k - 2) % m) * n;
+                        const double* sn = Sq + (int64_t)((k - 2) % m) * n;
                         acc = 0.0;
                         for (int64_t i = tid; i < n; i += TPB) {
-                            const double q = D[i] - al * yk[i];
-                            D[i] = q;
-                            acc += sn[i] * q;
+                            const double v = q[i] - al * yk[i];
+                            q[i] = v;
+                            acc += sn[i] * v;
                         }
                         dotv = red.sum(acc);
                     } else {
-                        for (int64_t i = tid; i < n; i += TPB) D[i] = D[i] - al * yk[i];
+                        for (int64_t i = tid; i < n; i += TPB) q[i] = q[i] - al * yk[i];
                     }
                 }
                 const double sc = sy / yy;                  // scaleinvH0
-                const double* yl = Yr + (int64_t)((lower - 1) % m) * n;
+                const double* yl = Yq + (int64_t)((lower - 1) % m) * n;
                 acc = 0.0;
                 for (int64_t i = tid; i < n; i += TPB) {
-                    const double q = D[i] * sc;
-                    D[i] = q;
-                    acc += yl[i] * q;
+                    const double v = q[i] * sc;
+                    q[i] = v;
+                    acc += yl[i] * v;
                 }
                 dotv = red.sum(acc);
                 for (int k = lower; k <= upper; k++) {
                     const double b = st.rho[(k - 1) % m] * dotv;
                     const double coef = alpha[k - lower] - b;
-                    const double* sk = Sr + (int64_t)((k - 1) % m) * n;
+                    const double* sk = Sq + (int64_t)((k - 1) % m) * n;
                     acc = 0.0;
                     if (k < upper) {
-                        const double* yn = Yr + (int64_t)(k % m) * n;
+                        const double* yn = Yq + (int64_t)(k % m) * n;
                         for (int64_t i = tid; i < n; i += TPB) {
-                            const double q = D[i] + coef * sk[i];
-                            D[i] = q;
-                            acc += yn[i] * q;
+                            const double v = q[i] + coef * sk[i];
+                            q[i] = v;
+                            acc += yn[i] * v;
                         }
                         dotv = red.sum(acc);
                     } else {
                         for (int64_t i = tid; i < n; i += TPB) {
-                            const double d = -(D[i] + coef * sk[i]);
+                            const double d = -(q[i] + coef * sk[i]);
                             D[i] = d;
-                            acc += G[i] * d;
+                            acc += gq[i] * d;
                         }
                         dphi0 = red.sum(acc);
                     }
@@ -370,11 +391,22 @@ __global__ __launch_bounds__(TPB) void lbfgs_feed_kernel(LbfgsArgs a) {
         }
     }
     if (tid == 0) a.state[r] = st;
+    // the point the next round evaluates (as lbfgs_trial_kernel, which runs only when the slots are re-assigned)
+    if (st.phase == kLbfgsFinite || st.phase == kLbfgsArmijo) {
+        double* t = a.trial + (int64_t)slot * n;
+        const double alpha = st.a2;
+        for (int64_t i = tid; i < n; i += TPB) t[i] = X[i] + alpha * D[i];
+    }
 }
 
-hipError_t launch_lbfgs_feed(const LbfgsArgs& a, int n_active, hipStream_t s) {
+hipError_t launch_lbfgs_feed(const LbfgsArgs& a_in, int n_active, hipStream_t s) {
+    LbfgsArgs a = a_in;
+    const int64_t stage = (int64_t)(2 * kLbfgsM + 2) * a.n;         // pairs, g and q in LDS when 60 KB hold them
+    a.lds_doubles = stage * 8 <= 60 * 1024 ? stage : 0;
+    const size_t lds = (size_t)a.lds_doubles * sizeof(double);
     if (a.n >= 16384) hipLaunchKernelGGL((lbfgs_feed_kernel<1024>), dim3((unsigned)n_active), dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL((lbfgs_feed_kernel<256>), dim3((unsigned)n_active), dim3(256), 0, s, a);
+    else if (a.n >= 2048) hipLaunchKernelGGL((lbfgs_feed_kernel<256>), dim3((unsigned)n_active), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lbfgs_feed_kernel<64>), dim3((unsigned)n_active), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -583,12 +615,28 @@ int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, 
             s0.phase = cude::kLbfgsFirst; s0.maxiters = lbfgs_iters; s0.g_tol = 1e-8;
             s0.f = std::numeric_limits<double>::quiet_NaN();
             st[(size_t)r] = s0;
-            const int k = owner[(size_t)r];
-            HIP_TRY(hipMemcpyAsync(c->tr_x.p + (size_t)r * n, c->ms_cond.p + (size_t)k * N, (size_t)N * sizeof(double),
-                                   hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->tr_x.p + (size_t)r * n + N, c->ms_nn.p + (size_t)k * P, (size_t)P * sizeof(double),
-                                   hipMemcpyDeviceToDevice, c->stream));
         }
+        // iterate r = [conditional; network] of restart owner[r]: runs of consecutive live restarts move in one strided copy
+        auto pack = [&](bool into_vectors) -> int32_t {
+            for (int r = 0; r < R;) {
+                int len = 1;
+                while (r + len < R && owner[(size_t)(r + len)] == owner[(size_t)r] + len) len++;
+                const int k = owner[(size_t)r];
+                double* xv = c->tr_x.p + (size_t)r * n;
+                double* cs = c->ms_cond.p + (size_t)k * N;
+                double* ns = c->ms_nn.p + (size_t)k * P;
+                if (into_vectors) {
+                    HIP_TRY(hipMemcpy2DAsync(xv, (size_t)n * 8, cs, (size_t)N * 8, (size_t)N * 8, (size_t)len, hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(hipMemcpy2DAsync(xv + N, (size_t)n * 8, ns, (size_t)P * 8, (size_t)P * 8, (size_t)len, hipMemcpyDeviceToDevice, c->stream));
+                } else {
+                    HIP_TRY(hipMemcpy2DAsync(cs, (size_t)N * 8, xv, (size_t)n * 8, (size_t)N * 8, (size_t)len, hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(hipMemcpy2DAsync(ns, (size_t)P * 8, xv + N, (size_t)n * 8, (size_t)P * 8, (size_t)len, hipMemcpyDeviceToDevice, c->stream));
+                }
+                r += len;
+            }
+            return CUDE_OK;
+        };
+        if ((rc = pack(true))) return rc;
         HIP_TRY(hipMemcpyAsync(c->tr_state.p, st.data(), (size_t)R * sizeof(cude::LbfgsState), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->tr_act.p + K, owner.data(), (size_t)R * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));       // st / owner are read by the copies above
@@ -611,8 +659,8 @@ int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, 
                 HIP_TRY(hipMemcpyAsync(c->tr_act.p, act.data(), (size_t)A * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));       // (pageable source: `act` is rebuilt below)
                 act_changed = false;
+                HIP_TRY(cude::launch_lbfgs_trial(la, A, c->stream));     // (otherwise the feed kernel has left the trial points)
             }
-            HIP_TRY(cude::launch_lbfgs_trial(la, A, c->stream));
             if ((rc = eval_sets_device(c, A, c->tr_trial.p + N, n, c->tr_trial.p, n, c->tr_gtrial.p, c->ms_out.p))) return rc;
             cude::FinishSetsArgs fa{};
             fa.P = P; fa.out = c->ms_out.p; fa.nn = c->tr_trial.p + N; fa.stride_nn = n; fa.lambda = c->cfg.lambda;
@@ -630,14 +678,7 @@ int32_t cude_train_restarts(cude_ctx* c, int32_t n_sets, const double* nn_sets, 
             act_changed = act.size() != before;
         }
         for (int r = 0; r < R; r++) objective_out[owner[(size_t)r]] = host_st[r].f;
-        // the iterates back into the [K][P] / [K][N] sets
-        for (int r = 0; r < R; r++) {
-            const int k = owner[(size_t)r];
-            HIP_TRY(hipMemcpyAsync(c->ms_cond.p + (size_t)k * N, c->tr_x.p + (size_t)r * n, (size_t)N * sizeof(double),
-                                   hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->ms_nn.p + (size_t)k * P, c->tr_x.p + (size_t)r * n + N, (size_t)P * sizeof(double),
-                                   hipMemcpyDeviceToDevice, c->stream));
-        }
+        if ((rc = pack(false))) return rc;      // the iterates back into the [K][P] / [K][N] sets
     }
     HIP_TRY(hipMemcpyAsync(nn_out, c->ms_nn.p, (size_t)K * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(cond_out, c->ms_cond.p, (size_t)K * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
