@@ -685,22 +685,49 @@ def extras(Engine, device, steps=20, warm=40):
     return out
 
 
-def saem_estep_sharded(Engine, device, world, rank, dist, torch, n_total=10000, n_mc=100, reps=5):
+def saem_estep_sharded(Engine, device, world, rank, dist, torch, coll, agreed, n_total=10000, n_mc=100, reps=5):
     """BASELINE configs[4] on N GPUs: the SAEM E-step (src/saem.jl:86-108,177-186) of n_total subjects x n_mc Metropolis
     steps, subjects sharded over the ranks (the E-step itself needs no communication), followed by the one exchange a
     SAEM iteration makes: the sum over ranks of [accepted, sum p, sum p^2, n] (acceptance rate, eta <- mean(p), Omega <-
-    var(p), saem.jl:196-205), timed inside the same region.  Returns this rank's view; the caller takes the max time."""
+    var(p), saem.jl:196-205), timed inside the same region.  The sum goes through the library's own transport
+    (cude_comm_allreduce_host: the peer-write exchange, else RCCL inside the library), torch.distributed only when
+    neither comes up.  Returns this rank's view; the caller takes the max time."""
+    from cude.parallel import ShardedTrainer, attach_exchange
     arch = (2, 4, 2)
     n = n_total // world + (1 if rank < n_total % world else 0)
     first = rank * (n_total // world) + min(rank, n_total % world)
     nn4 = glorot(arch, 4321)
     eng, pop = cpep_engine(Engine, arch, 2, n, 780 + rank, device, nn4)
+    transport, why = None, None
+    if os.environ.get("CUDE_BENCH_TRANSPORT", "xchg") == "xchg":
+        ok, why = attach_exchange(eng, coll, 30.0)
+        transport = "xchg" if ok else None
+    if transport is None and os.environ.get("CUDE_BENCH_TRANSPORT", "xchg") in ("xchg", "rccl"):
+        try:
+            ShardedTrainer.attach_rccl(Engine, eng, coll)
+            ok = True
+        except Exception as exc:  # noqa: BLE001
+            ok, why = False, f"{why}; cude_comm_init: {exc}"
+        if agreed(ok):
+            transport = "rccl"
+        elif ok:                   # up here, not everywhere: start again without it
+            eng.close()
+            eng, pop = cpep_engine(Engine, arch, 2, n, 780 + rank, device, nn4)
+    if transport is None:
+        transport = "torch"
     eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
     eng.set_params(nn4, pop["beta0"])
     eng.set_rng(20250905, first)               # one global stream of draws: the chain does not depend on the sharding
     eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
-    stats = torch.zeros(4, dtype=torch.float64, device=torch.device("cuda", device))
-    dist.all_reduce(stats)                     # warm the collective
+    ctl = torch.device("cuda", device)
+
+    def total(v):
+        if transport != "torch":
+            return eng.allreduce_host(v)
+        t = torch.tensor(v, dtype=torch.float64, device=ctl)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+    total([0.0, 0.0, 0.0, 0.0])                # warm the transport
     torch.cuda.synchronize()
     dist.barrier()
     t_red = 0.0
@@ -709,15 +736,14 @@ def saem_estep_sharded(Engine, device, world, rank, dist, torch, n_total=10000, 
         acc = eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=n_mc)
         _, p = eng.get_params()
         t1 = time.perf_counter()
-        stats = torch.tensor([float(acc.sum()), float(p.sum()), float(p @ p), float(n)], dtype=torch.float64,
-                             device=torch.device("cuda", device))
-        dist.all_reduce(stats)
-        tot = stats.cpu().numpy()
+        tot = total([float(acc.sum()), float(p.sum()), float(p @ p), float(n)])
         t_red += time.perf_counter() - t1
     dt = (time.perf_counter() - t0) / reps
+    lost = eng.xchg_info()[3] if transport == "xchg" else 0
     eng.close()
     return dict(dt=dt, dt_allreduce=t_red / reps, acceptance=float(tot[0]) / (tot[3] * n_mc), n_seen=float(tot[3]),
-                mean_p=float(tot[1] / tot[3]), subjects_per_gpu=n)
+                mean_p=float(tot[1] / tot[3]), subjects_per_gpu=n, transport=transport, transport_note=why,
+                timed_out_waits=lost)
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -791,37 +817,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return t.item() != 0
 
+    coll = None
+    xchg_attempts = []
     if dist_on:
-        # ---- the exchange: export the mailbox, all-gather the 128-byte handles, map the peers (self-test inside)
-        mine = bytes(128)
-        ok = want == "xchg"
-        if ok:
-            try:
-                mine = eng.xchg_export(world, rank)
-            except Exception as exc:
-                xchg_error = f"cude_xchg_export: {exc}"
-                ok = False
-        if agreed(ok):
-            h = torch.tensor(list(mine), dtype=torch.uint8, device=ctl)
-            hs = [torch.zeros_like(h) for _ in range(world)]
-            dist.all_gather(hs, h)
-            try:
-                eng.xchg_attach([bytes(t.cpu().tolist()) for t in hs], 30.0)
-                xchg_info = eng.xchg_info()
-            except Exception as exc:
-                xchg_error = f"cude_xchg_attach: {exc}"
-                print(f"[rank {rank}] peer-write exchange unavailable ({exc})", file=sys.stderr)
-                ok = False
-            if agreed(ok):
+        # ---- the exchange: export the mailbox, all-gather the 128-byte handles, map the peers (self-test inside), agree;
+        # a memory kind that fails on any rank is given up by all (cude/parallel.py attach_exchange, include/cude.h)
+        from cude.parallel import TorchCollective, attach_exchange
+        coll = TorchCollective(dist, None if rehearsal else torch.device("cuda", local_rank))
+        if agreed(want == "xchg"):
+            ok, why = attach_exchange(eng, coll, 30.0, log=xchg_attempts.append)
+            if ok:
                 transport = "xchg"
-            elif xchg_error is None:
-                xchg_error = "another rank could not attach the exchange"
-        elif xchg_error is None:
-            xchg_error = "CUDE_BENCH_TRANSPORT skipped it" if want != "xchg" else "another rank could not export its mailbox"
-        if transport is None and xchg_info is not None:   # attached here, not everywhere: start again without it
-            eng.close()
-            eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
-            xchg_info = None
+                xchg_info = eng.xchg_info()
+            else:
+                xchg_error = why
+                print(f"[rank {rank}] peer-write exchange unavailable ({why})", file=sys.stderr)
+        else:
+            xchg_error = "CUDE_BENCH_TRANSPORT skipped it"
         # ---- RCCL inside the library: the fallback, and (when the exchange is up) the second transport of `transports`
         my_id = bytes(128)
         ok = want in ("xchg", "rccl")
@@ -912,6 +924,12 @@ def main():
         t = torch.tensor([diff], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         allreduce_check = float(t.item())
+        # (the same verdict on every rank.)  An exchange that passed its self-test but forms other sums than
+        # torch.distributed does is not measured: the communicator takes over, and the line says why.
+        if transport == "xchg" and not allreduce_check <= 1e-9 and rccl_info is not None:
+            xchg_error = f"the exchange's step differs from torch.distributed's by {allreduce_check:.3g}: RCCL takes over"
+            eng.xchg_enable(False)
+            transport = "rccl"
 
     # ---- untimed: bring the GPU to its steady clock (same count on every rank: the collectives must pair up), then
     # the W warm-up steps of the contract
@@ -996,7 +1014,7 @@ def main():
     if dist_on and not rehearsal and not args.no_extra:
         eng.close()
         eng = None
-        saem = saem_estep_sharded(Engine, local_rank, world, rank, dist, torch)
+        saem = saem_estep_sharded(Engine, local_rank, world, rank, dist, torch, coll, agreed)
         t = torch.tensor([saem["dt"], saem["dt_allreduce"]], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         saem["dt"], saem["dt_allreduce"] = float(t[0]), float(t[1])
@@ -1044,14 +1062,18 @@ def main():
             out["allreduce_check"] = allreduce_check
             out["rccl_error"] = rccl_error
             out["xchg"] = ({"ranks": xchg_info[0], "memory_kind": {3: "uncached", 1: "fine-grained", 0: "device"}[xchg_info[2]],
-                            "timed_out_waits": xchg_info[3]} if xchg_info else None)
+                            "timed_out_waits": xchg_info[3], "attach_attempts": len(xchg_attempts) + 1,
+                            "attempts_given_up": xchg_attempts} if xchg_info else None)
             out["xchg_error"] = xchg_error
             out["transports"] = transports
             if saem is not None:
                 out["saem_estep_1e4x100_sharded"] = {
                     "config": f"BASELINE configs[4]: SAEM E-step, 1e4 subjects x 100 Metropolis steps sharded over "
                               f"{world} GPUs ({saem['subjects_per_gpu']} subjects on rank 0), 2x4x4x1, device-side draws, "
-                              f"+ the 4-double all-reduce of a SAEM iteration (RCCL through torch.distributed)",
+                              f"+ the 4-double sum of a SAEM iteration through the library's transport "
+                              f"(cude_comm_allreduce_host: {saem['transport']})",
+                    "transport": saem["transport"], "transport_note": saem["transport_note"],
+                    "timed_out_waits": saem["timed_out_waits"],
                     "value": 10000 * 100 / saem["dt"], "unit": "Metropolis draws/s", "ms_per_estep": saem["dt"] * 1e3,
                     "ms_allreduce_and_readback": saem["dt_allreduce"] * 1e3, "acceptance_rate": saem["acceptance"],
                     "subjects_seen": saem["n_seen"]}

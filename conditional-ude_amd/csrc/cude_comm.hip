@@ -86,15 +86,15 @@ cude::XchgArgs xchg_args(const cude_ctx* c) {
     return x;
 }
 
-// after a synchronisation of the context's stream: did a device-side wait of the exchange give up?
+// After a synchronisation of the context's stream: did a device-side wait of the exchange give up?  The status word
+// lives in page-locked coherent host memory (the kernels hold its device address): reading it is a host load, so every
+// call that synchronises behind an exchange launch asks -- not only those whose loss came back NaN.
 int32_t xchg_check(cude_ctx* c) {
-    if (!c->xchg.attached) return CUDE_OK;
-    int32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, c->xchg.status, sizeof(st), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (st == 0) return CUDE_OK;
+    if (!c->xchg.attached || !c->xchg.status_host) return CUDE_OK;
+    volatile int32_t* st = c->xchg.status_host;
+    if (*st == 0) return CUDE_OK;
     c->xchg_timeouts += 1;
-    HIP_TRY(hipMemsetAsync(c->xchg.status, 0, sizeof(int32_t), c->stream));
+    *st = 0;
     return fail(CUDE_ERR_COMM, "peer-write exchange: a rank's contribution did not arrive within the time limit "
                                "(a peer died, or the ranks are not making the same sequence of calls)");
 }
@@ -138,6 +138,30 @@ int32_t comm_self_test(cude_ctx* c) {
     return CUDE_OK;
 }
 
+// The exchange's own self-test: kXchgTestRounds sum rounds over MORE values than the mailbox has columns (every column,
+// both parities, every slot written at least twice: a stale word from the previous round would be a wrong sum, since the
+// values change with the round), then one max round.  Rank r contributes (r + 1) * (j + 1) + round to value j.
+constexpr int kXchgTestRounds = 4;
+int32_t xchg_self_test(cude_ctx* c) {
+    const double n = (double)c->n_ranks;
+    const int count = 2 * c->xchg.cols + 1;
+    std::vector<double> v((size_t)count);
+    for (int round = 0; round < kXchgTestRounds; round++) {
+        for (int j = 0; j < count; j++) v[(size_t)j] = ((double)c->rank + 1.0) * (j + 1) + round;
+        int32_t rc = comm_reduce_host(c, v.data(), count, 0);
+        if (rc) return rc;
+        for (int j = 0; j < count; j++)
+            if (v[(size_t)j] != 0.5 * n * (n + 1.0) * (j + 1) + n * round)
+                return fail(CUDE_ERR_COMM, "round " + std::to_string(round) + ", value " + std::to_string(j) +
+                                               ": the sum over the ranks came back wrong (stale or torn mailbox words)");
+    }
+    double w[3] = {1.0, 2.0, (double)c->rank + 1.0};
+    int32_t rc = comm_reduce_host(c, w, 3, 1);
+    if (rc) return rc;
+    if (w[0] != 1.0 || w[1] != 2.0 || w[2] != n) return fail(CUDE_ERR_COMM, "the max over the ranks came back wrong");
+    return CUDE_OK;
+}
+
 // Multi-process RCCL and HIP IPC need dmabuf IPC on hosts whose driver has no legacy IPC: without
 // HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the first HIP call, ncclCommInitRank / hipIpcGetMemHandle die
 // much later with "invalid argument".  Too late to set it when a communicator is asked for, so it is checked then.
@@ -162,6 +186,8 @@ struct XchgHandle {
     uint64_t address;           // of the mailbox in the exporting process
     int32_t n_ranks, rank, cols, device;
     hipIpcMemHandle_t ipc;      // 64 bytes
+    int32_t pci[3];             // domain, bus, device of the GPU the mailbox lives on (device ordinals are per process)
+    int32_t kind_index;         // 0 uncached, 1 fine-grained, 2 ordinary device memory
 };
 static_assert(sizeof(XchgHandle) <= CUDE_XCHG_HANDLE_BYTES, "handle layout");
 constexpr uint64_t kXchgMagic = 0x3148435845445543ull;
@@ -175,7 +201,7 @@ void xchg_release(cude_ctx* c) {
     }
     if (e.box) (void)hipFree(e.box);
     if (e.seq) (void)hipFree(e.seq);
-    if (e.status) (void)hipFree(e.status);
+    if (e.status_host) (void)hipHostFree(e.status_host);
     e = Exchange{};
 }
 
@@ -237,49 +263,92 @@ int32_t cude_comm_allreduce_host(cude_ctx* c, double* values, int32_t count) {
     return comm_reduce_host(c, values, count, 0);   // single rank: identity
 }
 
+// The kinds of memory a mailbox can live in, in order of preference: uncached device memory (what RCCL keeps its flags
+// in: peers' writes and the owner's polls meet in HBM, not in an L2), fine-grained device memory, ordinary device memory
+// + system-scope accesses (all three measured equal on ONE GPU, tools/ubench/xchg_ipc.hip; the last is refused when a
+// peer sits on another device: its owner's polls may be served from an L2 that the peers' xGMI writes do not pass).
+constexpr unsigned kXchgKinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, 0u};
+
 int32_t cude_xchg_export(cude_ctx* c, int32_t n_ranks, int32_t rank, uint8_t handle[CUDE_XCHG_HANDLE_BYTES]) {
     int32_t rc = bind(c);
     if (rc) return rc;
     if (n_ranks < 1 || n_ranks > CUDE_XCHG_MAX_RANKS || rank < 0 || rank >= n_ranks || !handle)
         return fail(CUDE_ERR_ARG, "bad exchange arguments (1 <= n_ranks <= 16)");
-    if (c->xchg.box) return fail(CUDE_ERR_STATE, "exchange already exported on this context");
+    if (c->xchg.box) return fail(CUDE_ERR_STATE, "exchange already exported on this context (cude_xchg_detach releases it)");
     if (c->comm && (c->n_ranks != n_ranks || c->rank != rank))
         return fail(CUDE_ERR_ARG, "the exchange must span the same ranks as the attached communicator");
     if (n_ranks > 1 && !ipc_mode_ok()) return CUDE_ERR_COMM;
+    if (c->xchg_next_kind > 2)
+        return fail(CUDE_ERR_COMM, "exchange mailbox: every kind of device memory has been tried on this context");
     Exchange& e = c->xchg;
     e.cols = c->P + 2;
     e.box_words = (size_t)2 * n_ranks * e.cols * 2;
-    // uncached device memory (what RCCL keeps its flags in): peers' writes and the owner's polls meet in HBM, not in
-    // an L2; fine-grained, then ordinary memory + system-scope accesses as fall-backs (all three measured equal on
-    // one GPU, tools/ubench/xchg_ipc.hip)
-    const unsigned kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, 0u};
-    hipError_t he = hipErrorOutOfMemory;
-    for (unsigned k : kinds) {
-        void* p = nullptr;
-        he = k ? hipExtMallocWithFlags(&p, e.box_words * 8, k) : hipMalloc(&p, e.box_words * 8);
-        if (he == hipSuccess) { e.box = static_cast<uint64_t*>(p); e.kind = (int)k; break; }
-        (void)hipGetLastError();
-    }
-    if (he != hipSuccess) return fail(CUDE_ERR_HIP, std::string("exchange mailbox: ") + hipGetErrorString(he));
     XchgHandle h{};
+    // a kind counts only if the block can be allocated AND cleared AND exported: a failure of any of the three moves on
+    // to the next kind (the clearing is ordered on the context's stream, which does not wait for the null stream)
+    std::string why;
+    for (int k = c->xchg_next_kind; k < 3 && !e.box; k++) {
+        void* p = nullptr;
+        hipError_t he = kXchgKinds[k] ? hipExtMallocWithFlags(&p, e.box_words * 8, kXchgKinds[k]) : hipMalloc(&p, e.box_words * 8);
+        const char* step = "allocation";
+        if (he == hipSuccess) {
+            step = "clearing";
+            he = hipMemsetAsync(p, 0, e.box_words * 8, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        }
+        if (he == hipSuccess) {
+            step = "hipIpcGetMemHandle";
+            he = hipIpcGetMemHandle(&h.ipc, p);
+        }
+        if (he == hipSuccess) {
+            e.box = static_cast<uint64_t*>(p);
+            e.kind = (int)kXchgKinds[k];
+            e.kind_index = k;
+        } else {
+            why += std::string(why.empty() ? "" : "; ") + "kind " + std::to_string(k) + ": " + step + ": " + hipGetErrorString(he);
+            if (p) (void)hipFree(p);
+            (void)hipGetLastError();
+        }
+    }
+    if (!e.box) {
+        c->xchg_next_kind = 3;
+        e = Exchange{};
+        return fail(CUDE_ERR_HIP, "exchange mailbox: " + why);
+    }
+    hipError_t he;
     if ((he = hipMalloc((void**)&e.seq, e.cols * sizeof(uint32_t))) != hipSuccess ||
-        (he = hipMalloc((void**)&e.status, sizeof(int32_t))) != hipSuccess ||
-        (he = hipMemset(e.box, 0, e.box_words * 8)) != hipSuccess ||
-        (he = hipMemset(e.seq, 0, e.cols * sizeof(uint32_t))) != hipSuccess ||
-        (he = hipMemset(e.status, 0, sizeof(int32_t))) != hipSuccess ||
-        (he = hipIpcGetMemHandle(&h.ipc, e.box)) != hipSuccess) {
+        (he = hipHostMalloc((void**)&e.status_host, sizeof(int32_t), hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess ||
+        (he = hipHostGetDevicePointer((void**)&e.status, e.status_host, 0)) != hipSuccess ||
+        (he = hipMemsetAsync(e.seq, 0, e.cols * sizeof(uint32_t), c->stream)) != hipSuccess ||
+        (he = hipStreamSynchronize(c->stream)) != hipSuccess) {
         xchg_release(c);
         return fail(CUDE_ERR_HIP, std::string("exchange mailbox: ") + hipGetErrorString(he));
     }
+    *e.status_host = 0;
     h.magic = kXchgMagic;
     h.pid = (int64_t)getpid();
     h.address = (uint64_t)(uintptr_t)e.box;
     h.n_ranks = n_ranks; h.rank = rank; h.cols = e.cols; h.device = c->cfg.device;
+    h.kind_index = e.kind_index;
+    int v = 0;
+    h.pci[0] = hipDeviceGetAttribute(&v, hipDeviceAttributePciDomainID, c->cfg.device) == hipSuccess ? v : -1;
+    h.pci[1] = hipDeviceGetAttribute(&v, hipDeviceAttributePciBusId, c->cfg.device) == hipSuccess ? v : -1;
+    h.pci[2] = hipDeviceGetAttribute(&v, hipDeviceAttributePciDeviceId, c->cfg.device) == hipSuccess ? v : -1;
+    (void)hipGetLastError();
     std::memset(handle, 0, CUDE_XCHG_HANDLE_BYTES);
     std::memcpy(handle, &h, sizeof(h));
     c->n_ranks = n_ranks;
     c->rank = rank;
     return CUDE_OK;
+}
+
+// a failed attach: everything released, the next export starts with the kind after the one that was tried
+static int32_t xchg_attach_failed(cude_ctx* c, int32_t code, const std::string& msg) {
+    c->xchg_next_kind = c->xchg.kind_index + 1;
+    (void)hipStreamSynchronize(c->stream);
+    xchg_release(c);
+    if (!c->comm) { c->n_ranks = 1; c->rank = 0; }
+    return fail(code, msg);
 }
 
 int32_t cude_xchg_attach(cude_ctx* c, const uint8_t* handles, double timeout_s) {
@@ -290,49 +359,77 @@ int32_t cude_xchg_attach(cude_ctx* c, const uint8_t* handles, double timeout_s) 
     if (e.attached) return fail(CUDE_ERR_STATE, "exchange already attached");
     if (!handles || !(timeout_s > 0) || !(timeout_s <= 3600)) return fail(CUDE_ERR_ARG, "null handles / bad time limit");
     const int n = c->n_ranks;
+    XchgHandle own;
+    std::memcpy(&own, handles + (size_t)c->rank * CUDE_XCHG_HANDLE_BYTES, sizeof(own));
+    bool other_device = false;
+    int same_device_same_process = 0;
     for (int r = 0; r < n; r++) {
         XchgHandle h;
         std::memcpy(&h, handles + (size_t)r * CUDE_XCHG_HANDLE_BYTES, sizeof(h));
-        if (h.magic != kXchgMagic || h.n_ranks != n || h.rank != r || h.cols != e.cols) {
-            xchg_release(c);
-            return fail(CUDE_ERR_ARG, "exchange handle " + std::to_string(r) + " does not describe rank " + std::to_string(r) +
-                                          " of " + std::to_string(n) + " with the same network shape");
-        }
+        if (h.magic != kXchgMagic || h.n_ranks != n || h.rank != r || h.cols != e.cols)
+            return xchg_attach_failed(c, CUDE_ERR_ARG, "exchange handle " + std::to_string(r) + " does not describe rank " +
+                                                           std::to_string(r) + " of " + std::to_string(n) +
+                                                           " with the same network shape (a rank whose export failed sends zeros)");
+        const bool same_gpu = h.pci[0] == own.pci[0] && h.pci[1] == own.pci[1] && h.pci[2] == own.pci[2] && h.pci[1] >= 0;
+        if (!same_gpu) other_device = true;
         if (r == c->rank) {
             e.peers[r] = e.box;
         } else if (h.pid == (int64_t)getpid()) {
             // a context of this process: its address is ours too (another device of the node: peer access)
             if (h.device != c->cfg.device) {
                 hipError_t pe = hipDeviceEnablePeerAccess(h.device, 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
-                    xchg_release(c);
-                    return fail(CUDE_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
-                }
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return xchg_attach_failed(c, CUDE_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
                 (void)hipGetLastError();
+            } else {
+                same_device_same_process++;
             }
             e.peers[r] = reinterpret_cast<uint64_t*>((uintptr_t)h.address);
         } else {
             void* p = nullptr;
             hipError_t oe = hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess);
             if (oe != hipSuccess) {
-                xchg_release(c);
-                return fail(CUDE_ERR_HIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " +
-                                              hipGetErrorString(oe));
+                (void)hipGetLastError();
+                return xchg_attach_failed(c, CUDE_ERR_HIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) +
+                                                               ", memory kind " + std::to_string(h.kind_index) + "): " +
+                                                               hipGetErrorString(oe));
             }
             e.peers[r] = static_cast<uint64_t*>(p);
             e.opened[r] = true;
         }
     }
+    // Ranks of ONE process on ONE device wait for each other in spinning kernels on separate streams: the runtime maps
+    // streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a peer's kernels queued behind a spinning
+    // one never run.  A rehearsal configuration; bounded so that it cannot stall until the time limit.
+    if (same_device_same_process + 1 > 4)
+        return xchg_attach_failed(c, CUDE_ERR_UNSUPPORTED, "more than 4 ranks of one process on one device: their spinning "
+                                                           "reduction kernels would share hardware queues (one rank per device "
+                                                           "is the supported configuration)");
+    if (other_device && e.kind_index == 2 && !c->opt.xchg_allow_plain)
+        return xchg_attach_failed(c, CUDE_ERR_COMM, "only ordinary device memory was left for the mailbox and peers sit on other "
+                                                    "devices: the owner's polls could be served from its L2 (option "
+                                                    "\"xchg_allow_plain\" / CUDE_ALLOW_PLAIN_MAILBOX=1 to try all the same)");
     e.timeout_s = timeout_s;
     e.attached = true;
     e.ready = true;
     drop_graph(c);                              // captured iterations carry the reduction kernels' arguments
-    if ((rc = comm_self_test(c))) {             // (collective: every rank runs it; a rank whose peers never write times out)
-        const std::string why = cude_last_error();
-        xchg_release(c);
-        if (!c->comm) { c->n_ranks = 1; c->rank = 0; }
-        return fail(rc, "exchange self-test: " + why);
-    }
+    rc = xchg_self_test(c);                     // (collective: every rank runs it; a rank whose peers never write times out)
+    if (rc == CUDE_OK && ((c->opt.xchg_fail_kinds >> e.kind_index) & 1))
+        rc = fail(CUDE_ERR_COMM, "failure of memory kind " + std::to_string(e.kind_index) + " forced by option xchg_fail_kinds");
+    if (rc) return xchg_attach_failed(c, rc, "exchange self-test (memory kind " + std::to_string(e.kind_index) + "): " +
+                                                 cude_last_error());
+    return CUDE_OK;
+}
+
+int32_t cude_xchg_detach(cude_ctx* c) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (!c->xchg.box) return CUDE_OK;           // (a failed attach has released it and moved on to the next kind already)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    c->xchg_next_kind = c->xchg.kind_index + 1;
+    xchg_release(c);
+    if (!c->comm) { c->n_ranks = 1; c->rank = 0; }
     return CUDE_OK;
 }
 

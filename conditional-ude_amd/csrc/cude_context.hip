@@ -180,6 +180,8 @@ const OptionEntry kOptions[] = {
     {"auto_regroup", "CUDE_NO_AUTO_REGROUP", &Options::auto_regroup, true, false},
     {"poll_pinned", "CUDE_NO_POLL_PINNED", &Options::poll_pinned, true, false},
     {"debug_selector", "CUDE_DEBUG_SELECTOR", &Options::debug_selector, false, false},
+    {"xchg_allow_plain", "CUDE_ALLOW_PLAIN_MAILBOX", &Options::xchg_allow_plain, false, false},
+    {"xchg_fail_kinds", "CUDE_XCHG_FAIL_KINDS", &Options::xchg_fail_kinds, false, false},
     {"mixed", "CUDE_NO_MIXED", &Options::mixed, true, true},
     {"mixed_one_stream", "CUDE_MIXED_ONE_STREAM", &Options::mixed_one_stream, false, true},
     {"fwd_split", "CUDE_NO_FWD_SPLIT", &Options::fwd_split, true, true},

@@ -71,6 +71,10 @@ struct Options {
     int auto_regroup = 1;       // "auto_regroup" / CUDE_NO_AUTO_REGROUP: adaptive launches re-ordered by accepted-step count
     int poll_pinned = 1;        // "poll_pinned" / CUDE_NO_POLL_PINNED: watch page-locked result slots instead of the stream wait
     int debug_selector = 0;     // "debug_selector" / CUDE_DEBUG_SELECTOR: print the launch-path decision
+    int xchg_allow_plain = 0;   // "xchg_allow_plain" / CUDE_ALLOW_PLAIN_MAILBOX: ordinary device memory as a mailbox although
+                                //   peers sit on other devices (the owner's polls may then be served from its L2)
+    int xchg_fail_kinds = 0;    // "xchg_fail_kinds" / CUDE_XCHG_FAIL_KINDS (tests): bit k set = this rank's cude_xchg_attach
+                                //   reports a failure when its mailbox is of the k-th memory kind (0 uncached, 1 fine-grained, 2 plain)
     // ("hidden_activation" = tanh | relu | sigmoid, "output_activation" = softplus | identity: kept in cude_ctx::net)
     // ---- ablation
     int mixed = 1;              // CUDE_NO_MIXED
@@ -89,13 +93,15 @@ struct Exchange {
     bool ready = false;         // the reductions of run_ensemble go through it
     bool attached = false;
     int kind = 0;               // how the mailbox was allocated: 3 uncached, 1 fine-grained, 0 plain device memory
+    int kind_index = 0;         // position of `kind` in the order of preference (0 uncached, 1 fine-grained, 2 plain)
     uint64_t* box = nullptr;    // own mailbox [2][n_ranks][cols][2] words
     size_t box_words = 0;
     int cols = 0;
     uint64_t* peers[CUDE_XCHG_MAX_RANKS] = {};
     bool opened[CUDE_XCHG_MAX_RANKS] = {};      // mapped through hipIpcOpenMemHandle (to be closed)
     uint32_t* seq = nullptr;    // [cols]
-    int32_t* status = nullptr;  // device word: set by a wait that ran out of time
+    int32_t* status = nullptr;  // set by a wait that ran out of time: the device's address of status_host
+    int32_t* status_host = nullptr;     // page-locked, coherent: the host reads it after any synchronisation, no copy
     double timeout_s = 20.0;
 };
 
@@ -170,6 +176,7 @@ struct cude_ctx {
     int n_ranks = 1, rank = 0;
     cude::api::Exchange xchg;
     int32_t xchg_timeouts = 0;      // device-side waits of the exchange that gave up so far (cude_xchg_info)
+    int xchg_next_kind = 0;         // first memory kind the next cude_xchg_export tries (advanced by a failed attach / a detach)
     // timing of the dominant kernel
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -413,7 +413,8 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only, 
     // the page-locked result buffer too, and finish_loss watches it arrive instead of queueing a copy and waiting for the stream
     double* host_tail = nullptr;
     {
-        if (c->opt.poll_pinned && c->poll_ok && watch && c->pinned && !rccl && c->cfg.lambda == 0.0 && !c->capturing &&
+        // (not with the exchange: a wait that gave up is reported through the status word, read after the stream's end)
+        if (c->opt.poll_pinned && c->poll_ok && watch && c->pinned && !rccl && !xc && c->cfg.lambda == 0.0 && !c->capturing &&
             !local_only && !fused_final) {
             host_tail = c->pinned + P;
             volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(host_tail);
@@ -522,7 +523,8 @@ int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
         }
     }
     c->loss_in_pinned = false;
-    if (c->xchg.ready && std::isnan(tmp[P])) {     // what a wait of the exchange that ran out of time leaves behind
+    if (c->xchg.ready) {        // a wait of the exchange that ran out of time (in ANY column, not only the loss's)
+        if (arrived) HIP_TRY(hipStreamSynchronize(c->stream));
         const int32_t xrc = xchg_check(c);
         if (xrc) return xrc;
     }
@@ -817,6 +819,7 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
         if (distributed(c) && (rc = allreduce_dev(c, d_out.p, (size_t)kn * 2))) return rc;
         HIP_TRY(hipMemcpyAsync(h_out.data(), d_out.p, kn * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->xchg.ready && (rc = xchg_check(c))) return rc;
         for (int64_t k = 0; k < kn; k++) {
             reg = 0.0;
             if (c->cfg.lambda != 0.0) {
@@ -894,6 +897,7 @@ int32_t cude_screen_candidates(cude_ctx* c, int64_t n_candidates, int32_t n_keep
         have = (int)std::min<int64_t>(n_keep, have + kn);
         cur = 1 - cur;
         HIP_TRY(hipStreamSynchronize(c->stream));            // the host chunk buffers are refilled by the next gen()
+        if (c->xchg.ready && (rc = xchg_check(c))) return rc;
     }
     std::vector<long long> idx(n_keep);
     HIP_TRY(hipMemcpyAsync(idx.data(), b_idx[cur].p, n_keep * sizeof(long long), hipMemcpyDeviceToHost, c->stream));

@@ -188,11 +188,7 @@ int32_t cude_adam_run(cude_ctx* c, int32_t n_iters, double* losses) {
     std::vector<double> tr((size_t)n_iters * 2);
     HIP_TRY(hipMemcpyAsync(tr.data(), c->adam_trace.p, tr.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->xchg.ready) {
-        bool lost = false;
-        for (int k = 0; k < n_iters && !lost; k++) lost = std::isnan(tr[2 * k]);
-        if (lost && (rc = xchg_check(c))) return rc;
-    }
+    if (c->xchg.ready && (rc = xchg_check(c))) return rc;     // (a wait that gave up in any column of any iteration)
     c->last_failed = (int64_t)std::llround(tr[(size_t)(n_iters - 1) * 2 + 1]);
     if (losses)
         for (int k = 0; k < n_iters; k++)

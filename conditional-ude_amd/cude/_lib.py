@@ -91,6 +91,7 @@ _SIGNATURES = {
     "cude_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cude_xchg_export": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "cude_xchg_attach": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double]),
+    "cude_xchg_detach": (C.c_int32, [C.c_void_p]),
     "cude_xchg_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cude_xchg_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),

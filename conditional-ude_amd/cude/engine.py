@@ -503,6 +503,10 @@ class Engine:
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         check(self._lib.cude_xchg_attach(self._h, buf, float(timeout_s)))
 
+    def xchg_detach(self):
+        """Releases the exported / attached exchange; the next xchg_export offers the next kind of mailbox memory."""
+        check(self._lib.cude_xchg_detach(self._h))
+
     def xchg_enable(self, enabled=True):
         check(self._lib.cude_xchg_enable(self._h, 1 if enabled else 0))
 

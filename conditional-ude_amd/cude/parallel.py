@@ -18,6 +18,8 @@ over the gloo backend; production uses cude.engine.Engine).
 """
 import numpy as np
 
+from ._lib import XCHG_HANDLE_BYTES, CudeError
+
 
 def shard_bounds(n_subjects, world_size, rank):
     """Contiguous block partition: the first (n mod world) ranks get one extra subject."""
@@ -83,6 +85,40 @@ class TorchCollective:
         return bytes(buf.cpu().tolist())
 
 
+def attach_exchange(engine, collective, timeout_s=20.0, log=None):
+    """The attach protocol of include/cude.h "cude_xchg_*": every rank exports its mailbox, the handles are all-gathered
+    through the host collective, every rank maps its peers (collective: ends with a self-test), and the ranks AGREE on
+    the outcome -- if any rank failed, all detach and go again with the next kind of mailbox memory (uncached ->
+    fine-grained -> ordinary device memory).  Whether a peer on another device can open and write a given kind is only
+    known at attach, and only to the rank that tried.  Returns (True, None) with the exchange attached on every rank, or
+    (False, reason) with it released on every rank (the caller falls back to RCCL).  Every rank makes the same sequence
+    of collective calls whatever fails locally."""
+    why = None
+    for _ in range(3):
+        mine, err = bytes(XCHG_HANDLE_BYTES), None
+        try:
+            mine = engine.xchg_export(collective.world_size, collective.rank)
+        except CudeError as exc:       # (no kind left, or none could be allocated / exported: peers get zeros)
+            err = f"cude_xchg_export: {exc}"
+        handles = collective.allgather_bytes(mine)
+        if err is None:
+            try:
+                engine.xchg_attach(handles, timeout_s)
+            except CudeError as exc:
+                err = f"cude_xchg_attach: {exc}"
+        exhausted = err is not None and err.startswith("cude_xchg_export")
+        flags = collective.allreduce([0.0 if err is None else 1.0, 1.0 if exhausted else 0.0], op=1)
+        if flags[0] == 0.0:
+            return True, None
+        why = err or why or "another rank could not attach"
+        if log is not None:
+            log(f"rank {collective.rank}: exchange attempt failed ({err or 'on another rank'})")
+        engine.xchg_detach()
+        if flags[1] != 0.0:
+            break
+    return False, why
+
+
 class ShardedTrainer:
     """Data-parallel Adam training of one cUDE over subject shards.
 
@@ -103,11 +139,11 @@ class ShardedTrainer:
 
     @staticmethod
     def attach_xchg(engine, collective, timeout_s=20.0):
-        """Bootstrap the peer-write exchange: every rank exports its mailbox, the handles are all-gathered through the
-        host collective, every rank maps its peers (collective: ends with a self-test).  Before the population is
-        uploaded, as attach_rccl."""
-        mine = engine.xchg_export(collective.world_size, collective.rank)
-        engine.xchg_attach(collective.allgather_bytes(mine), timeout_s)
+        """Bootstrap the peer-write exchange (attach_exchange below); raises if no kind of mailbox memory works on every
+        rank.  Before the population is uploaded, as attach_rccl."""
+        ok, why = attach_exchange(engine, collective, timeout_s)
+        if not ok:
+            raise CudeError(f"peer-write exchange unavailable: {why}")
 
     def sync_population_statistics(self, scale_sums=None):
         """host transport: establish the global subject count (and SUPP's scale = mean_i max_t data)."""

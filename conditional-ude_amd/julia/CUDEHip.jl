@@ -335,6 +335,40 @@ function xchg_attach!(c::Ctx, handles::Vector{Vector{UInt8}}; timeout_s = 20.0)
     GC.@preserve all check(ccall((:cude_xchg_attach, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Float64), c.h, all, timeout_s))
 end
 
+# releases the exported / attached exchange; the next xchg_export offers the next kind of mailbox memory
+xchg_detach!(c::Ctx) = check(ccall((:cude_xchg_detach, LIB), Int32, (Ptr{Cvoid},), c.h))
+
+# The attach protocol of include/cude.h (mirror of cude/parallel.py `attach_exchange`): export, all-gather the handles,
+# attach, AGREE on the outcome; if any rank failed all detach and go again with the next kind of mailbox memory.
+# `allgather(bytes) -> Vector{Vector{UInt8}}` and `anyfailed(flag::Bool) -> Bool` are the caller's channel (MPI.Allgather /
+# MPI.Allreduce(|), Distributed.jl fetches).  Returns true with the exchange attached on every rank, false with it
+# released on every rank (fall back to comm_init!).
+function attach_exchange!(c::Ctx, n_ranks, rank, allgather, anyfailed; timeout_s = 20.0)
+    for attempt in 1:3
+        mine = zeros(UInt8, 128)
+        failed = false
+        exhausted = false
+        try
+            mine = xchg_export(c, n_ranks, rank)
+        catch
+            failed = true
+            exhausted = true
+        end
+        handles = allgather(mine)
+        if !failed
+            try
+                xchg_attach!(c, handles; timeout_s = timeout_s)
+            catch
+                failed = true
+            end
+        end
+        anyfailed(failed) || return true
+        xchg_detach!(c)
+        anyfailed(exhausted) && break
+    end
+    false
+end
+
 xchg_enable!(c::Ctx, on::Bool) = check(ccall((:cude_xchg_enable, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, on ? 1 : 0))
 
 function xchg_info(c::Ctx)

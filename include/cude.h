@@ -373,12 +373,29 @@ int32_t cude_comm_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* 
  *   every rank:  cude_xchg_export(ctx, n_ranks, rank, mine)        -> 128 bytes describing its mailbox
  *   the host:    all-gather of those bytes (any channel: torch.distributed, MPI.jl, a file)
  *   every rank:  cude_xchg_attach(ctx, all[n_ranks][128], timeout_s)   (collective: ends with a self-test)
- * Ranks may live in one process (several contexts) or in several; all on ONE node.  Attach before the population is
+ *   the host:    do ALL ranks report CUDE_OK?  (one logical AND over the ranks, same channel)
+ *                no -> every rank, the successful ones too: cude_xchg_detach(ctx), and from the top: the next export
+ *                      offers the next kind of mailbox memory (uncached device memory, then fine-grained, then ordinary
+ *                      device memory -- the last only when all ranks share one device, or with option
+ *                      "xchg_allow_plain"); after the third kind cude_xchg_export fails and the caller falls back to
+ *                      cude_comm_init (RCCL).  cude/parallel.py `attach_exchange` and julia/CUDEHip.jl `attach_exchange!`
+ *                      are this loop.
+ * A kind is given up by the exporting rank itself when its allocation, clearing or hipIpcGetMemHandle fails; by all
+ * ranks when any rank cannot open a peer's handle or fails the self-test (4 sum rounds over every column and both
+ * parities with values that change per round, one max round) -- whether a peer ON ANOTHER DEVICE can write a given
+ * kind is only known then.  A rank whose export failed contributes 128 zero bytes, which fails everybody's attach.
+ * Ranks may live in one process (several contexts; at most 4 per device: their spinning reduction kernels share the
+ * device's hardware queues -- a rehearsal configuration) or in several; all on ONE node.  Attach before the population is
  * uploaded, as with cude_comm_init (the global subject count is summed there).  With an exchange attached every
  * reduction of the library goes through it and no RCCL communicator is needed; when both are attached the exchange
- * is used while enabled (cude_xchg_enable(ctx, 0) switches to the communicator, for comparisons). */
+ * is used while enabled (cude_xchg_enable(ctx, 0) switches to the communicator, for comparisons).  Every entry point
+ * that synchronises behind an exchange launch reads the exchange's status word (page-locked host memory) and returns
+ * CUDE_ERR_COMM if a wait gave up in ANY column. */
 int32_t cude_xchg_export(cude_ctx* ctx, int32_t n_ranks, int32_t rank, uint8_t handle[CUDE_XCHG_HANDLE_BYTES]);
 int32_t cude_xchg_attach(cude_ctx* ctx, const uint8_t* handles /* [n_ranks][CUDE_XCHG_HANDLE_BYTES] */, double timeout_s);
+/* Releases this context's exported or attached exchange (no-op when a failed cude_xchg_attach already has); the next
+ * cude_xchg_export starts with the memory kind after the one released. */
+int32_t cude_xchg_detach(cude_ctx* ctx);
 int32_t cude_xchg_enable(cude_ctx* ctx, int32_t enabled);
 /* n_ranks / rank of the attached exchange (1, 0 without), how its mailbox memory was allocated (3 = uncached, 1 =
  * fine-grained, 0 = ordinary device memory) and how many device-side waits have run out of time so far. */
@@ -392,9 +409,9 @@ int32_t cude_xchg_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* 
  * 2-4-4-1, 2-6-6-1, 3-4-4-1 (c-peptide) and 4-3x5-1, 4-3x3-1 (suppression): CUDE_ERR_UNSUPPORTED otherwise.
  * Implementation switches (cude_ctx.h `Options` lists them): launch-path override of the tests ("cpep_path" = "1" |
  * "2:L" | "3:B:L"), "cpep_keep", "supp_store", "supp_ckpt", "tape_steps", "exp_table", "ms_split", "auto_regroup",
- * "poll_pinned", "debug_selector".  Values are decimal integers as text unless noted.  Every option is also read once
+ * "poll_pinned", "debug_selector", "xchg_allow_plain", "xchg_fail_kinds" (tests).  Values are decimal integers as text unless noted.  Every option is also read once
  * at cude_create from its environment variable (CUDE_CPEP_PATH, CUDE_CPEP_KEEP, CUDE_SUPP_STORE, CUDE_SUPP_CKPT,
- * CUDE_TAPE_STEPS, CUDE_NO_EXPTAB, CUDE_NO_MS_SPLIT, CUDE_NO_AUTO_REGROUP, CUDE_NO_POLL_PINNED, CUDE_DEBUG_SELECTOR).
+ * CUDE_TAPE_STEPS, CUDE_NO_EXPTAB, CUDE_NO_MS_SPLIT, CUDE_NO_AUTO_REGROUP, CUDE_NO_POLL_PINNED, CUDE_DEBUG_SELECTOR, CUDE_ALLOW_PLAIN_MAILBOX, CUDE_XCHG_FAIL_KINDS).
  * Options that shape the launch path take effect at the next cude_set_population_*.  No reference line: these are
  * properties of this implementation. */
 int32_t cude_set_option(cude_ctx* ctx, const char* name, const char* value);

@@ -209,3 +209,103 @@ def test_a_missing_peer_ends_in_an_error_not_in_a_hang():
     assert np.isfinite(a.loss_grad()[0])
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------------------------------ the attach protocol's retry
+def _rank_retry(rank, world, port, masks, out_dir):
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.join(os.path.dirname(here), "conditional-ude_amd"), os.path.join(os.path.dirname(here), "oracle")]
+    from cude.parallel import TorchCollective, attach_exchange, shard_bounds
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    arch, n_total = (2, 6, 2), 333
+    c = make_cpep_case(n_total, arch)
+    lo, hi = shard_bounds(n_total, world, rank)
+    eng = _engine("cpep", arch, c, lo, hi)
+    eng.set_option("xchg_fail_kinds", masks[rank])        # (test hook: this rank reports the listed kinds as failed)
+    log = []
+    ok, why = attach_exchange(eng, TorchCollective(dist), timeout_s=30.0, log=log.append)
+    out = dict(ok=ok, why=str(why), attempts=len(log) + (1 if ok else 0), info=np.array(eng.xchg_info()))
+    if not ok:                                            # released everywhere: the context works on as a single rank
+        lo, hi = 0, n_total
+    _upload(eng, "cpep", c, lo, hi)
+    out.update(_train(eng))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("masks,kind,attempts", [((0, 1), 1, 2), ((3, 1), 0, 3), ((0, 0), 3, 1)],
+                         ids=["second-kind", "third-kind", "first-kind"])
+def test_a_failing_memory_kind_moves_every_rank_to_the_next(masks, kind, attempts, tmp_path):
+    """One rank cannot use a kind of mailbox memory (forced through option xchg_fail_kinds; on a real node: a peer on
+    another device that cannot open or write it): the ranks agree, ALL detach -- the one whose attach succeeded too -- and
+    attach again with the next kind.  Afterwards they train as in test_processes_sharing_one_gpu_train_as_one_engine."""
+    import torch.multiprocessing as mp
+    from cude.engine import Engine  # noqa: F401
+    port = free_port()
+    mp.spawn(_rank_retry, args=(2, port, masks, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+    for k in range(2):
+        assert r[k]["ok"] and r[k]["attempts"] == attempts
+        assert tuple(r[k]["info"][:2]) == (2, k) and r[k]["info"][2] == kind and r[k]["info"][3] == 0
+    for k in ("fwd", "loss", "g_nn", "losses", "nn"):
+        assert np.array_equal(r[0][k], r[1][k]), k
+    arch, n_total = (2, 6, 2), 333
+    c = make_cpep_case(n_total, arch)
+    eng = _engine("cpep", arch, c, 0, n_total)
+    _upload(eng, "cpep", c, 0, n_total)
+    ref = _train(eng)
+    eng.close()
+    assert np.allclose(r[0]["losses"], ref["losses"], rtol=1e-10)
+
+
+def test_no_usable_memory_kind_releases_the_exchange_on_every_rank(tmp_path):
+    """All three kinds fail on one rank: attach_exchange returns False on BOTH ranks with nothing attached (the caller's
+    cue to fall back to RCCL), and the contexts work on as single ranks."""
+    import torch.multiprocessing as mp
+    from cude.engine import Engine  # noqa: F401
+    port = free_port()
+    mp.spawn(_rank_retry, args=(2, port, (7, 0), str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+    for k in range(2):
+        assert not r[k]["ok"] and r[k]["info"][0] == 1 and r[k]["attempts"] == 3
+    assert "xchg_fail_kinds" in str(r[0]["why"])
+    assert np.array_equal(r[0]["losses"], r[1]["losses"]) and np.all(np.isfinite(r[0]["losses"]))
+
+
+def test_a_wait_that_gives_up_fails_the_call_that_synchronises_behind_it():
+    """A peer stops calling (here: rank 1 simply does not make the call): rank 0's screening call -- whose result carries
+    no NaN-able loss of its own but per-set sums -- returns CUDE_ERR_COMM instead of scoring the sets +Inf."""
+    from cude.engine import Engine, CudeError
+    arch, n_total = (2, 4, 2), 200
+    c = make_cpep_case(n_total, arch)
+    engs = [Engine("cpep", arch, n_steps=30, n_state=2) for _ in range(2)]
+    handles = [e.xchg_export(2, k) for k, e in enumerate(engs)]
+    err = []
+
+    def attach(k):
+        try:
+            engs[k].xchg_attach(handles, 0.5)
+            lo, hi = (0, 100) if k == 0 else (100, n_total)
+            _upload(engs[k], "cpep", c, lo, hi)
+        except Exception as exc:  # noqa: BLE001
+            err.append(exc)
+    th = [threading.Thread(target=attach, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not err, err
+    nn_sets = np.repeat(c["nn"][None, :], 3, axis=0)
+    with pytest.raises(CudeError) as ei:
+        engs[0].multistart_forward(nn_sets, np.repeat(c["beta"][None, :100], 3, axis=0))
+    assert ei.value.status == -5 and engs[0].xchg_info()[3] == 1
+    with pytest.raises(CudeError):                      # ... and a gradient evaluation alike
+        engs[0].loss_grad()
+    for e in engs:
+        e.close()
