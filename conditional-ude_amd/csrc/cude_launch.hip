@@ -394,7 +394,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only, 
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
     if (adaptive(c)) {
         c->have_counts = true;              // (adaptive launches leave every subject's accepted-step count behind)
-        if (grad) c->have_tape = true;
+        c->have_tape = grad;                // (a forward launch overwrites the counts cude_adaptive_steps pairs the tape with)
     }
     if (sse_ov) return CUDE_OK;
     const int P = c->P;
@@ -675,7 +675,7 @@ int32_t eval_sets_device(cude_ctx* c, int64_t n_sets, const double* nn, int64_t 
             a.n_sets = (int32_t)kn; a.set_stride_nn = stride_nn; a.set_stride_cond = stride_cond;
             HIP_TRY(cude::launch_supp(c->net, true, a, c->stream));
         }
-        if (adaptive(c)) c->have_counts = true;     // (the launch left the step counts of its first parameter set behind)
+        if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }   // (step counts of the first set; its tape is ms_tape)
         if (!split)
             HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, 0, P + 2, out_k, c->stream, (int)kn, c->param_mask.p, P));
         if (distributed(c) && (rc = allreduce_dev(c, out_k, (size_t)kn * (P + 2)))) return rc;
@@ -765,6 +765,7 @@ int32_t cude_simulate(cude_ctx* c, int32_t n_times, const double* times, double*
         a.T = (int32_t)kn;
         a.traj = d_traj.p; a.partials = c->partials.p;
         HIP_TRY(cude::launch_cpep(c->net, NS, false, a, c->stream));
+        if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }
         // device chunk [NS x kn x N] -> rows k0..k0+kn of the caller's [NS x n_times x N]
         HIP_TRY(hipMemcpy2DAsync(traj + (size_t)NS * k0, (size_t)NS * n_times * sizeof(double), d_traj.p,
                                  (size_t)NS * kn * sizeof(double), (size_t)NS * kn * sizeof(double), (size_t)N,
@@ -815,6 +816,7 @@ int32_t cude_multistart_forward(cude_ctx* c, int32_t n_sets, const double* nn_se
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
         }
+        if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }
         HIP_TRY(cude::launch_reduce_sets(d_part.p, (int)kn, nb, P + 2, P, d_out.p, c->stream));
         if (distributed(c) && (rc = allreduce_dev(c, d_out.p, (size_t)kn * 2))) return rc;
         HIP_TRY(hipMemcpyAsync(h_out.data(), d_out.p, kn * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -885,6 +887,7 @@ int32_t cude_screen_candidates(cude_ctx* c, int64_t n_candidates, int32_t n_keep
             a.n_sets = (int32_t)kn; a.set_stride_nn = P; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
         }
+        if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }
         HIP_TRY(cude::launch_reduce_sets(d_part.p, (int)kn, nb, P + 2, P, d_sums.p, c->stream));
         if (distributed(c) && (rc = allreduce_dev(c, d_sums.p, (size_t)kn * 2))) return rc;
         HIP_TRY(cude::launch_set_losses((int)kn, d_sums.p, d_nn.p, P, c->cfg.lambda, c->n_global, d_loss.p, c->stream));
@@ -1014,6 +1017,7 @@ int32_t cude_profile_conditional(cude_ctx* c, int32_t n_points, const double* va
             a.n_sets = (int32_t)kn; a.set_stride_nn = 0; a.set_stride_cond = N;
             HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
         }
+        if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }
         HIP_TRY(hipMemcpyAsync(sse_out + k0 * N, d_sse.p, kn * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }

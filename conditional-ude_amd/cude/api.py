@@ -20,12 +20,15 @@ Reference items mirrored (paths relative to the reference repo):
   CPeptideODEModel / production (symbolic) src/c-peptide-models.jl:68-75,118-142; c-peptide/03-symreg.jl:37-40
   train_symbolic (per-subject k, sigma)    c-peptide/03-symreg.jl:94-106
   SAEM_symbolic                            src/saem-symreg.jl:31-66,86-131,134-229
-Differences that are deliberate and documented in DESIGN.md: by default the ODE is solved with FIXED-step Tsit5
-(`n_steps`; default for the c-peptide model: 8 steps per observation interval, see default_steps; 30 for the
-suppression model): a smooth loss with an exact discrete adjoint and the fastest kernels; `n_steps=ADAPTIVE` (0) runs
-the reference's own adaptive Tsit5 on the device in every function of this module, training included -- its gradient
-is that of the accepted step sequence taken as fixed arithmetic, which is what ForwardDiff through `solve` yields.
-Gradients are a discrete adjoint instead of ForwardDiff; the per-subject 1-D fits use a bracketing search instead of
+Discretisation: every function here solves, like the reference, with ADAPTIVE Tsit5 at OrdinaryDiffEq's default
+tolerances unless told otherwise (`default_steps`; the gradient is that of the accepted step sequence taken as fixed
+arithmetic, which is what ForwardDiff through `solve` yields up to the controller's weighting of the partials,
+INTEGRATION.md).  The fixed-step mode -- a smooth loss with an exact discrete adjoint and the time-split kernels for small
+populations, 1e-4 ... 1e-3 away from the reference's values -- is the explicit fast option: `n_steps=
+fixed_steps(timepoints)` (c-peptide: 8 steps per observation interval; suppression: 30) per call, or
+`set_default_steps("fixed")` for the module.  julia/CUDEHip.jl has the same default and the same functions.
+Deliberate differences, documented in DESIGN.md: gradients are a discrete adjoint instead of ForwardDiff; the
+per-subject 1-D fits use a bracketing search instead of
 Fminbox(LBFGS).
 """
 import hashlib
@@ -40,18 +43,46 @@ from .lbfgs import lbfgs, lbfgs_batched
 
 DEFAULT_STEPS = 30
 ADAPTIVE = 0      # n_steps = ADAPTIVE: the reference's own adaptive Tsit5 (abstol 1e-6, reltol 1e-3)
+_DEFAULT_MODE = [ADAPTIVE]      # what default_steps returns: ADAPTIVE, "fixed" or a step count (set_default_steps)
 
 
-def default_steps(timepoints, per_interval=8):
-    """Step count used when the caller gives none: `per_interval` fixed Tsit5 steps per observation interval
-    when the observation times are equidistant, so that every step boundary coincides with a knot of the
-    piecewise-linear glucose forcing (on the Ohashi data S=32 is ~8x more accurate than S=30, whose steps
-    straddle the knots at 30 and 90 min: max rel. trajectory error 6e-6 vs 5e-5); otherwise DEFAULT_STEPS."""
+def fixed_steps(timepoints, per_interval=8):
+    """The fixed-step grid of the fast mode (`n_steps=fixed_steps(timepoints)`): `per_interval` Tsit5 steps per
+    observation interval when the observation times are equidistant, so that every step boundary coincides with a knot
+    of the piecewise-linear glucose forcing (on the Ohashi data S=32 is ~8x more accurate than S=30, whose steps
+    straddle the knots at 30 and 90 min: max rel. trajectory error 6e-6 vs 5e-5); otherwise DEFAULT_STEPS.
+    julia/CUDEHip.jl `fixed_steps` is the same rule."""
     tp = np.asarray(timepoints, dtype=np.float64)
     d = np.diff(tp)
     if tp.size >= 2 and np.allclose(d, d[0], rtol=1e-12, atol=0.0):
         return per_interval * (tp.size - 1)
     return DEFAULT_STEPS
+
+
+def default_steps(timepoints=None, per_interval=8):
+    """Discretisation of every function of this module whose caller passes no `n_steps`: ADAPTIVE -- the reference's
+    `solve(prob, Tsit5())` at OrdinaryDiffEq's default tolerances (src/parameter-estimation.jl:59,
+    suppression_model.jl:113,123, saem.jl:52), the mode that reproduces the reference's stored numbers (2e-9 on its 75
+    stored suppression objectives).  The fixed-step mode (a smooth loss, exact discrete adjoint, time-split kernels for
+    small populations; 1e-4 ... 1e-3 away from the reference's values) is asked for explicitly: `n_steps=
+    fixed_steps(timepoints)` per call or `set_default_steps("fixed")` for the module.  julia/CUDEHip.jl
+    `default_steps` / `set_default_steps!` are the same functions (tests/test_julia_shim.py compares the mirrors)."""
+    mode = _DEFAULT_MODE[0]
+    if mode == "fixed":
+        if timepoints is None:
+            return DEFAULT_STEPS
+        return fixed_steps(timepoints, per_interval)
+    return int(mode)
+
+
+def set_default_steps(mode):
+    """mode: ADAPTIVE (0, the default), "fixed" (fixed_steps(timepoints) per population; 30 for the suppression model)
+    or a positive step count.  Returns the previous mode."""
+    if not (mode == "fixed" or (isinstance(mode, (int, np.integer)) and mode >= 0)):
+        raise ValueError('set_default_steps: ADAPTIVE (0), "fixed" or a positive step count')
+    prev = _DEFAULT_MODE[0]
+    _DEFAULT_MODE[0] = mode if mode == "fixed" else int(mode)
+    return prev
 
 
 # ----------------------------------------------------------------------------- network
@@ -415,7 +446,7 @@ def _population(models, timepoints, cpeptide_data, n_steps=None, n_state=2, cond
     model's data (a fresh list of the same models -- `[model]`, `[model] * steps` -- is the same population), of the
     time grid and of all observations, so that calling `loss` in a loop neither rebuilds nor leaks engines, and
     changed data is never answered from a stale population."""
-    if n_steps is None:       # the analytic production has a kink at dG = 0: twice the steps of the smooth model
+    if n_steps is None:       # (fixed mode: the analytic production has a kink at dG = 0: twice the steps of the smooth model)
         n_steps = default_steps(timepoints, 16 if isinstance(models[0], CPeptideODEModel) else 8)
     cp = np.asarray(cpeptide_data, dtype=np.float64)
     h = hashlib.blake2b(digest_size=16)
@@ -798,7 +829,7 @@ class _SuppPop:
 
 
 def _supp_population(prob, data, timepoints, lam, n_steps=None):
-    n_steps = DEFAULT_STEPS if n_steps is None else n_steps
+    n_steps = default_steps() if n_steps is None else n_steps       # (fixed mode: DEFAULT_STEPS = 30)
     data = np.asarray(data, dtype=np.float64)
     key = ("supp", prob.network.key, float(lam), int(n_steps), _digest(timepoints, data))
     return _cached(key, lambda: _SuppPop(data, timepoints, prob.network, lam, n_steps, _DEVICE))

@@ -30,7 +30,8 @@ export chain, neural_network_model, CPeptideConditionalUDEModel, CPeptideCUDEMod
 
 const LIB = get(ENV, "CUDE_HIP_LIB", "libcude_hip.so")
 const MODEL_CPEP, MODEL_SUPP, MODEL_CPEP_SYM = Int32(0), Int32(1), Int32(2)
-const ADAPTIVE = 0                       # n_steps = ADAPTIVE: the reference's own adaptive Tsit5 (forward-only calls)
+const ADAPTIVE = 0                       # n_steps = ADAPTIVE: the reference's own adaptive Tsit5 (the default, default_steps)
+const DEFAULT_STEPS = 30
 
 struct Config
     model::Int32; n_state::Int32; nn_in::Int32; nn_width::Int32; nn_depth::Int32
@@ -541,12 +542,30 @@ struct Solution{U}               # the fields of Optimization.jl's solution that
 end
 
 # ----------------------------------------------------------------------------------------------- population cache
-const N_STEPS_DEFAULT = Ref(0)   # 0 = automatic: 8 fixed Tsit5 steps per observation interval (step_count)
-step_count(timepoints) = N_STEPS_DEFAULT[] > 0 ? N_STEPS_DEFAULT[] : 8 * (length(timepoints) - 1)
+# Discretisation of every method below whose caller passes no `n_steps` (cude/api.py `default_steps`, the same rule):
+# ADAPTIVE -- the reference's `solve(prob, Tsit5())` at OrdinaryDiffEq's default tolerances (src/parameter-estimation.jl:59),
+# the mode that reproduces the reference's stored numbers.  The fixed-step mode (smooth loss, exact discrete adjoint,
+# time-split kernels for small populations; 1e-4 ... 1e-3 away from the reference's values) is asked for explicitly:
+# `n_steps = fixed_steps(timepoints)` per call or `set_default_steps!(:fixed)` for the module.
+const DEFAULT_MODE = Ref{Union{Symbol,Int}}(ADAPTIVE)
+function fixed_steps(timepoints; per_interval = 8)
+    d = diff(Vector{Float64}(timepoints))
+    length(d) >= 1 && all(x -> isapprox(x, d[1]; rtol = 1e-12, atol = 0.0), d) ? per_interval * length(d) : DEFAULT_STEPS
+end
+function default_steps(timepoints = nothing; per_interval = 8)
+    DEFAULT_MODE[] === :fixed || return Int(DEFAULT_MODE[])
+    timepoints === nothing ? DEFAULT_STEPS : fixed_steps(timepoints; per_interval = per_interval)
+end
+function set_default_steps!(mode)
+    (mode === :fixed || (mode isa Integer && mode >= 0)) || error("set_default_steps!: ADAPTIVE (0), :fixed or a positive step count")
+    prev = DEFAULT_MODE[]
+    DEFAULT_MODE[] = mode === :fixed ? :fixed : Int(mode)
+    prev
+end
 const POPULATIONS = Dict{UInt64,Ctx}()
 
 function population(models::AbstractVector{CPeptideConditionalUDEModel}, timepoints, cpeptide_data; n_steps = nothing)
-    S = n_steps === nothing ? step_count(timepoints) : n_steps
+    S = n_steps === nothing ? default_steps(timepoints) : n_steps
     data = cpeptide_data isa AbstractVector ? reshape(Vector{Float64}(cpeptide_data), 1, :) : Matrix{Float64}(cpeptide_data)
     key = hash((S, Vector{Float64}(timepoints), data, [(m.glucose, m.age, m.t2dm, m.chain) for m in models]))
     get!(POPULATIONS, key) do
@@ -561,7 +580,7 @@ function population(models::AbstractVector{CPeptideConditionalUDEModel}, timepoi
     end
 end
 function population(models::AbstractVector{CPeptideUDEModel}, timepoints, cpeptide_data; n_steps = nothing)
-    S = n_steps === nothing ? step_count(timepoints) : n_steps
+    S = n_steps === nothing ? default_steps(timepoints) : n_steps
     data = cpeptide_data isa AbstractVector ? reshape(Vector{Float64}(cpeptide_data), 1, :) : Matrix{Float64}(cpeptide_data)
     key = hash((:ude, S, Vector{Float64}(timepoints), data, [(m.glucose, m.age, m.t2dm, m.chain) for m in models]))
     get!(POPULATIONS, key) do
@@ -728,7 +747,8 @@ struct SuppressionProblem          # stands in for ODEProblem(ude_lsup!, u0, tsp
     network::Chain
 end
 const SUPP_POPULATIONS = Dict{UInt64,Ctx}()
-function supp_population(prob::SuppressionProblem, data::AbstractArray{<:Real,3}, timepoints, λ; n_steps = 30)
+function supp_population(prob::SuppressionProblem, data::AbstractArray{<:Real,3}, timepoints, λ; n_steps = nothing)
+    n_steps = n_steps === nothing ? default_steps() : n_steps       # (fixed mode: DEFAULT_STEPS = 30)
     d = Array{Float64,3}(data)
     key = hash((n_steps, prob.network, Vector{Float64}(timepoints), d, Float64(λ)))
     get!(SUPP_POPULATIONS, key) do

@@ -90,7 +90,9 @@ int32_t cude_set_tolerances(cude_ctx* ctx, double abstol, double reltol);
 /* Adaptive mode: the accepted steps (t_n, dt_n) `subject` took in the last gradient evaluation of the context's own
  * parameters (cude_loss_grad, cude_loss_grad_partial, cude_adam_step ...) -- `sol.t` of the reference's solve.
  * *n_steps = number of accepted steps; at most `cap` of them are written to t_out / dt_out (either may be NULL).
- * CUDE_ERR_STATE before the first such evaluation or outside the adaptive mode. */
+ * CUDE_ERR_STATE before the first such evaluation, outside the adaptive mode, and when any other adaptive launch
+ * (cude_forward, a fit, a likelihood profile, a multi-set evaluation, a re-ordering) has run on the context since: those
+ * overwrite the step counts the tape is read with. */
 int32_t cude_adaptive_steps(cude_ctx* ctx, int64_t subject, int32_t cap, double* t_out, double* dt_out, int32_t* n_steps);
 /* Adaptive mode, large populations: order the launch by accepted-step count.  A wave's 64 lanes run until the slowest of
  * them has finished, and subjects differ in how many steps the controller grants them (8 ... 23 on the c-peptide data).

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import make_cpep_case, make_supp_case
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fixed_step_default")]
 COMBOS = [("tanh", "identity"), ("relu", "softplus"), ("relu", "identity"), ("sigmoid", "softplus"), ("sigmoid", "identity")]
 
 

@@ -9,7 +9,7 @@ import torch  # noqa: F401  (first: shared HIP runtime)
 
 from conftest import make_cpep_case, make_supp_case, free_port
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fixed_step_default")]
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -35,7 +35,7 @@ def test_population_loss_and_gradient_on_ohashi_data():
     val = api.loss(theta, args)
     ref = co.cpep(g["timepoints"], g["glucose"], g["cpeptide"], g["ages"], g["t2dm"], (2, 4, 2), theta.neural,
                   theta.conditional[:, 0], api.default_steps(g["timepoints"]), 2)
-    assert api.default_steps(g["timepoints"]) == 32          # 8 steps per 30-min interval: knots on step boundaries
+    assert api.default_steps(g["timepoints"]) == api.fixed_steps(g["timepoints"]) == 32   # 8 steps per 30-min interval
     assert abs(val - ref["loss"]) < 1e-10 * ref["loss"]
     val2, grad = api.loss_and_gradient(theta, args)
     assert abs(val2 - ref["loss"]) < 1e-10 * ref["loss"]

@@ -12,7 +12,7 @@ import pytest
 
 import test_figure_pins as F
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fixed_step_default")]
 FINE = np.round(np.arange(1201) * 0.1, 10)          # sol_timepoints = 0:0.1:120
 
 

@@ -65,7 +65,7 @@ def test_adaptive_gradient_at_1e5_subjects_properties():
     how the population is sharded or ordered, loss / network gradient additive over shards, one failing subject fails
     the evaluation and nothing else."""
     import cude_oracle as o
-    from cude.engine import Engine
+    from cude.engine import CudeError, Engine
     arch, N = (2, 4, 2), 100_000
     tp, G, obs, age, t2, beta = _population(N, 7)
     nn = o.glorot_params(arch, 5)
@@ -75,10 +75,12 @@ def test_adaptive_gradient_at_1e5_subjects_properties():
     loss, g_nn, g_cond = whole.loss_grad()
     again = whole.loss_grad()
     assert np.isfinite(loss) and again[0] == loss and np.array_equal(again[1], g_nn) and np.array_equal(again[2], g_cond)
-    fwd = whole.forward(want_sse=True)
-    assert abs(fwd["loss"] - loss) <= 1e-14 * loss
     n_steps = np.array([len(whole.adaptive_steps(i)[0]) for i in range(0, N, 997)])
     assert 5 <= n_steps.min() and n_steps.max() <= 64
+    fwd = whole.forward(want_sse=True)
+    assert abs(fwd["loss"] - loss) <= 1e-14 * loss
+    with pytest.raises(CudeError):          # a forward launch overwrites the step counts the gradient's tape is read with
+        whole.adaptive_steps(0)
     P = g_nn.size
     part_sum, g_parts = np.zeros(P + 2), []
     for s in (slice(0, 37_003), slice(37_003, N)):                # ragged shards: neither a multiple of the wave size

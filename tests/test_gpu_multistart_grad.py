@@ -6,7 +6,7 @@ import torch  # noqa: F401
 
 from conftest import make_cpep_case, make_supp_case
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fixed_step_default")]
 
 
 @pytest.mark.parametrize("model", ["cpep", "cpep4", "supp", "sym"])

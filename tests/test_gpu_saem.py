@@ -9,7 +9,7 @@ import torch  # noqa: F401
 
 from conftest import make_cpep_case
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fixed_step_default")]
 
 
 def _engine(c, arch):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch  # noqa: F401  (one HIP runtime for the process)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fixed_step_default")]
 
 
 def _case(N, seed=11, n_steps=30, noise=0.05):

@@ -192,3 +192,98 @@ def test_reference_signatures_are_present():
         assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
     opens = len(re.findall(r"(?m)^\s*(?:function|struct|mutable struct|module|for|if|begin|try|let)\b|\bdo\b(?=[^\n]*$)", code))
     assert opens > 0
+
+
+# ----------------------------------------------------------------------------- the two mirrors have the same defaults
+def _julia_keywords():
+    """name -> list (one per method) of {keyword: default source text} of every `function name(...; kw = v, ...)`."""
+    src = re.sub(r"#[^\n]*", "", open(JL).read())
+    out = {}
+    for m in re.finditer(r"(?m)^function\s+([\w!]+)\(", src):
+        end = _balanced(src, m.end() - 1)
+        sig = src[m.end():end - 1]
+        depth, cut = 0, None
+        for i, ch in enumerate(sig):
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            if ch == ";" and depth == 0:
+                cut = i
+                break
+        kws = {}
+        if cut is not None:
+            for part in _split_top(sig[cut + 1:]):
+                if "=" in part:
+                    k, v = part.split("=", 1)
+                    kws[re.sub(r"::.*", "", k).strip()] = v.strip()
+        out.setdefault(m.group(1), []).append(kws)
+    return out
+
+
+def _jl_value(text):
+    t = text.strip().replace("_", "")
+    if t == "nothing":
+        return None
+    if t in ("true", "false"):
+        return t == "true"
+    if t.startswith("(") and t.endswith(")"):
+        return tuple(_jl_value(x) for x in _split_top(t[1:-1]))
+    try:
+        return float(t)
+    except ValueError:
+        return text.strip()                      # a symbol / expression: compared as text
+
+
+# Julia keyword -> Python keyword where the spelling differs (Greek letters of the reference's signatures)
+_GREEK = {"σ": "sigma", "prior_η": "prior_eta", "prior_Ω": "prior_omega", "α": "alpha", "Ω_learning_rate": "omega_learning_rate"}
+
+
+def test_layer_two_defaults_agree_between_the_mirrors():
+    """Every default keyword value of the reference-facing layer in julia/CUDEHip.jl against cude/api.py -- the
+    executable mirror the GPU tests run through -- including the default discretisation (`n_steps = nothing` / None in
+    every function, resolved by `default_steps` in both: the reference's adaptive solve)."""
+    import inspect
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "conditional-ude_amd"))
+    from cude import api
+    jl = _julia_keywords()
+    checked = 0
+    for name in ("train_with_sigma", "likelihood_profile", "fit_suppression_model", "validate_suppression_model_sigma",
+                 "compute_individual_maps", "SAEM", "fixed_steps", "default_steps", "train"):
+        py = {k: v.default for k, v in inspect.signature(getattr(api, name)).parameters.items()
+              if v.default is not inspect.Parameter.empty}
+        assert name in jl, name
+        for kws in jl[name]:
+            for k, text in kws.items():
+                pk = _GREEK.get(k, k)
+                assert pk in py, f"{name}: Julia keyword {k} has no counterpart in cude/api.py"
+                want, got = _jl_value(text), py[pk]
+                if name == "train" and pk in ("initial_guesses", "selected_initials"):
+                    # one Python function for the reference's three methods: None = the method's own default
+                    assert got is None and want in (25000.0, 25.0, 10000.0, 10.0)
+                    src = inspect.getsource(api.train)
+                    assert f"{int(want):_}" in src or str(int(want)) in src
+                elif pk == "initial_mcmc_steps":
+                    assert got is None and want == "n_mcmc_steps"          # both: "as n_mcmc_steps"
+                elif isinstance(want, float):
+                    assert float(got) == want, (name, k, text, got)
+                else:
+                    assert got == want, (name, k, text, got)
+                checked += 1
+    assert checked >= 45
+    # the discretisation: no layer-2 function of either mirror hard-codes a step count
+    for name, methods in jl.items():
+        for kws in methods:
+            if "n_steps" in kws:
+                assert kws["n_steps"] == "nothing", (name, kws["n_steps"])
+    for name, fn in inspect.getmembers(api, inspect.isfunction):
+        p = inspect.signature(fn).parameters.get("n_steps")
+        if p is not None and not name.startswith("_"):
+            assert p.default is None, name
+    src = open(JL).read()
+    assert "const ADAPTIVE = 0" in src and "const DEFAULT_MODE = Ref{Union{Symbol,Int}}(ADAPTIVE)" in src
+    assert api.ADAPTIVE == 0 and api.default_steps([0.0, 30.0, 60.0]) == api.ADAPTIVE and api.DEFAULT_STEPS == 30
+    assert "const DEFAULT_STEPS = 30" in src
+    # the fast mode's rule, restated here from the Julia text: per_interval steps per interval if equidistant, else 30
+    assert "per_interval * length(d) : DEFAULT_STEPS" in src
+    assert api.fixed_steps([0.0, 30.0, 60.0, 90.0, 120.0]) == 32 and api.fixed_steps([0.0, 10.0, 30.0]) == 30
+    assert api.fixed_steps([0.0, 1.0], per_interval=16) == 16

@@ -56,6 +56,7 @@ def test_oracle_single_input_production_equals_the_carrier_with_a_zero_column():
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("fixed_step_default")
 def test_ude_loss_gradient_and_simulation_against_the_oracle():
     import torch  # noqa: F401
     import cude_oracle as o
@@ -85,6 +86,7 @@ def test_ude_loss_gradient_and_simulation_against_the_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("fixed_step_default")
 def test_train_ude_model_as_the_reference_script_does():
     """`optsols = train(model_train, timepoints, mean_c_peptide, rng)` (c-peptide/01-non-conditional.jl:25-29) at reduced
     counts: solutions carry the 1-input parameter vector, objectives are the SSE at it, the best one fits the mean
