@@ -621,6 +621,23 @@ def extras(Engine, device, steps=20, warm=40):
                        "value": n / dt, "unit": "subject-trajectories/s", "ms_per_step": dt * 1e3,
                        "roofline": hbm, "roofline_valu": valu}
     eng.close()
+    # the same kernel at a size that fills the chip exactly: 131 072 subjects = 2 048 waves on 2 048 wave slots (256 CUs x
+    # 4 SIMDs x 2 resident waves), where 1e5 subjects are 1 563 waves = 76 % of one fill -- the fraction of the vector
+    # peak at 1e5 mixes the kernel's own efficiency with that idle quarter
+    n_fill = 131072
+    tp_f, data_f, theta_f = synthetic_suppression(n_fill, 779)
+    eng = Engine("supp", arch, n_steps=N_STEPS, lam=0.01, device=device)
+    eng.set_population_supp(tp_f, data_f)
+    eng.set_params(glorot(arch, 1234), theta_f)
+    eng.adam_init(1e-3)
+    dt_f, ms_f, launches_f = timed_adam(eng, n_fill, steps, 10)
+    _, valu_f = rooflines("supp_kernel<3,5,grad>", ms_f, launches_f, n_fill, supp_algo_bytes(8, True),
+                          supp_ops(arch, N_STEPS, 8, True))
+    out["supp_1e5"]["at_one_full_fill"] = {
+        "subjects": n_fill, "waves": n_fill // 64, "wave_slots": 2048, "fill_at_1e5": (n + 63) // 64 / 2048.0,
+        "value": n_fill / dt_f, "ms_per_step": dt_f * 1e3, "kernel_ms": ms_f,
+        "roofline_valu_frac": valu_f["frac"], "achieved_tflops": valu_f["achieved"]}
+    eng.close()
     # ---- the same instance as the reference solves it (Tsit5 adaptive, EnsembleThreads: suppression_model.jl:113,123)
     eng = Engine("supp", arch, n_steps=0, lam=0.01, device=device)
     eng.set_population_supp(tp, data)
@@ -775,6 +792,11 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # stdout carries ONE line, the JSON: libraries that print banners there (RCCL 2.26 announces its version, host name
+    # and library path on stdout at communicator creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
         raise SystemExit("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for multi-process RCCL on this pool")
     # CUDE_BENCH_REHEARSAL=1 (development only): several ranks share the GPUs that exist and torch.distributed uses
@@ -1090,7 +1112,9 @@ def main():
             eng.close()
             eng = None
             out["extra"] = extras(Engine, local_rank)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        with os.fdopen(json_fd, "w") as real_stdout:
+            real_stdout.write(json.dumps(out) + "\n")
     if eng is not None:
         eng.close()
     if dist_on:

@@ -69,6 +69,29 @@ struct SuppRhs {
     }
 };
 
+// reverse sweep: the adjoint ub of stage input Y_ST = y_n + h sum_{j<ST} a(ST,j) k_j into the stage adjoints (rows j < ST
+// of s_K, [stage][state][lane]); the same fma per term as a rolled loop over j (aj = h * a(ST,j) formed the same way), but
+// the ST tableau entries arrive in one scalar round trip and the ST rows in one LDS round trip.  (The entries come from
+// the constant table, not from literals: a 64-bit literal needs a VGPR pair, 21 of them are hoisted out of the time loop
+// and the kernel -- 128 VGPRs of accumulators -- spills.)
+template <int ST>
+__device__ __forceinline__ void supp_propagate(double* s_K, int lane, double h, const double (&ub)[2]) {
+    double kk[ST][2], aj[ST];
+    cptr_t row = launder(as_const(&TS_A[ST][0]));      // (laundered: known entries would be folded back into literals)
+#pragma unroll
+    for (int j = 0; j < ST; j++) {
+        aj[j] = row[j];
+#pragma unroll
+        for (int s = 0; s < 2; s++) kk[j][s] = s_K[(j * 2 + s) * kBlock + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < ST; j++) {
+        const double haj = h * aj[j];
+#pragma unroll
+        for (int s = 0; s < 2; s++) s_K[(j * 2 + s) * kBlock + lane] = fma(haj, ub[s], kk[j][s]);
+    }
+}
+
 // LDS rows of kBlock doubles (one per lane), states 2 and 3 only:
 //   s_K [7][2]  stage derivatives k_i (forward) / their adjoints (reverse); after the time loops: reduction scratch
 //   s_Y [7][2]  stage inputs Y_i of the step being reversed (YONLY only)
@@ -343,12 +366,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
                         YB(s) += g;
                         hg[s] = h * g;
                     }
+#ifdef CUDE_SUPP_ROLLED_REVERSE
 #pragma unroll 1
                     for (int j = 0; j < 7; j++) {
                         const double w = obs_w[oi * 7 + j];
 #pragma unroll
                         for (int s = 0; s < 2; s++) KROW(j, s) = fma(w, hg[s], KROW(j, s));
                     }
+#else
+                    {   // the seven interpolation weights in one scalar round trip, the rows in one LDS round trip
+                        double w[7], kk[7][2];
+#pragma unroll
+                        for (int j = 0; j < 7; j++) {
+                            w[j] = obs_w[oi * 7 + j];
+#pragma unroll
+                            for (int s = 0; s < 2; s++) kk[j][s] = KROW(j, s);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 7; j++)
+#pragma unroll
+                            for (int s = 0; s < 2; s++) KROW(j, s) = fma(w[j], hg[s], kk[j][s]);
+                    }
+#endif
                     oi--;
                 }
             }
@@ -393,6 +432,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
             // propagate ub through  Y_st = y_n + h sum_{j<st} a(st,j) k_j
 #pragma unroll
             for (int s = 0; s < 2; s++) YB(s) += ub[s];
+#ifdef CUDE_SUPP_ROLLED_REVERSE
             const int nj = st < 6 ? st : 6;
 #pragma unroll 1
             for (int j = 0; j < nj; j++) {
@@ -400,6 +440,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(supp_wav
 #pragma unroll
                 for (int s = 0; s < 2; s++) KROW(j, s) = fma(aj, ub[s], KROW(j, s));
             }
+#else
+            // one body per stage (st is wave-uniform): the st rows read together, the tableau row as literals, the rows
+            // written together -- one LDS round trip and no scalar load per evaluation instead of one pair per term
+            switch (st) {
+                case 1: supp_propagate<1>(s_K, lane, h, ub); break;
+                case 2: supp_propagate<2>(s_K, lane, h, ub); break;
+                case 3: supp_propagate<3>(s_K, lane, h, ub); break;
+                case 4: supp_propagate<4>(s_K, lane, h, ub); break;
+                case 5: supp_propagate<5>(s_K, lane, h, ub); break;
+                default: supp_propagate<6>(s_K, lane, h, ub); break;
+            }
+#endif
             if (st > 1) {
                 st--;
             } else {

@@ -63,7 +63,7 @@ def test_cpeptide_loss_without_n_steps_is_the_adaptive_solve():
         api.set_default_steps(prev)
     assert api.default_steps(tp) == api.ADAPTIVE
     val2, grad = api.loss_and_gradient(theta, args)                         # gradients in the default mode as well
-    assert val2 == val
+    assert abs(val2 - val) <= 1e-14 * val                                   # (the gradient launch sums in another order)
     assert np.max(np.abs(grad.neural - g_nn_ref)) <= 5e-3 * np.max(np.abs(g_nn_ref))
     assert np.median(np.abs(grad.conditional[:, 0] - g_b_ref)) <= 1e-7 * np.max(np.abs(g_b_ref))
     api.clear_cache()

@@ -320,11 +320,11 @@ def test_suppression_adaptive_gradient_at_1e5_subjects_properties():
     loss, g_nn, g_th = eng.loss_grad()
     loss2, g_nn2, g_th2 = eng.loss_grad()
     assert np.isfinite(loss) and loss == loss2 and np.array_equal(g_nn, g_nn2) and np.array_equal(g_th, g_th2)
+    n_steps = np.array([len(eng.adaptive_steps(i)[0]) for i in range(0, N, 997)])     # (the gradient's: before any forward launch)
+    assert 8 <= n_steps.min() and n_steps.max() <= 64
     fwd = eng.forward(want_sse=True)
     assert abs(fwd["loss"] - loss) <= 1e-14 * loss
     assert abs(fwd["sse"].sum() / N + lam * float(c["nn"] @ c["nn"]) - loss) < 1e-12 * loss
-    n_steps = np.array([len(eng.adaptive_steps(i)[0]) for i in range(0, N, 997)])
-    assert 8 <= n_steps.min() and n_steps.max() <= 64
     scale, _ = eng.get_scale()
     # launch ordered by accepted-step count: per-subject results bit for bit, the shared gradient to rounding
     before, after = eng.adaptive_regroup()

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Builds a variant of libcude_hip.so with extra compiler flags into tools/abl_so/<name>.so (A/B runs on the GPU box:
-# tools/abl_bench.py <name> ...).  usage: tools/build_variant.sh <name> [extra hipcc flags...]
-# CUDE_SRC_ROOT=<checkout> builds another checkout's sources (e.g. a `git worktree` of the previous round's HEAD).
+# tools/abl_bench.py <name> ...).  usage: [ONLY="cude_supp ..."] tools/build_variant.sh <name> [extra hipcc flags...]
+# ONLY: recompile just these sources with the flags and take the other objects from the default build in csrc/ (for a
+# flag that touches one file).  CUDE_SRC_ROOT=<checkout> builds another checkout's sources (e.g. a `git worktree` of the
+# previous round's HEAD).
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -9,7 +11,15 @@ SRC=${CUDE_SRC_ROOT:-$ROOT}/conditional-ude_amd/csrc
 OUT=$ROOT/tools/abl_so
 TMP=$(mktemp -d)
 mkdir -p $OUT
-for f in cude_api cude_common cude_cpep cude_cpep2 cude_supp cude_adaptive; do
+ALL=$(sed -n 's/^SRCS *= *//p' $SRC/Makefile | sed 's/\.hip//g')
+if [ -n "$ONLY" ]; then
+  make -s -C $SRC -j8
+  for f in $ALL; do cp $SRC/$f.o $TMP/$f.o; done
+  LIST=$ONLY
+else
+  LIST=$ALL
+fi
+for f in $LIST; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable "$@" -c $SRC/$f.hip -o $TMP/$f.o &
 done
 wait
