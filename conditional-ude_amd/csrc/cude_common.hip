@@ -313,6 +313,25 @@ __global__ void mh_accept_kernel(MhArgs a) {
     mh_accept_one(a, i, a.prop[i], a.sse_new[i]);
 }
 
+// One lane per subject: walks the candidate heap of the round just evaluated (depth_resolve levels), leaves the chain
+// where the sequential steps would have left it, and writes the next round's candidates (MhSpecArgs, cude_kernels.h).
+// Everything that does not depend on the path -- the draws, log(u), every candidate's prior term and tempered
+// log-likelihood -- is formed first, for all nodes side by side (mh_spec_resolve, cude_rng.h); the walk itself is d
+// compare-and-select steps.
+__global__ void mh_spec_kernel(MhSpecArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.mh.N) return;
+    mh_spec_resolve(a, i);
+}
+
+hipError_t launch_mh_spec(const MhSpecArgs& a, hipStream_t s) {
+    if (a.depth_resolve < 0 || a.depth_resolve > kMhSpecMaxDepth || a.depth_next < 0 || a.depth_next > kMhSpecMaxDepth)
+        return hipErrorInvalidValue;
+    const int bs = 64;
+    hipLaunchKernelGGL(mh_spec_kernel, dim3((unsigned)((a.mh.N + bs - 1) / bs)), dim3(bs), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, RngKey key, double proposal_std, double* prop,
                              hipStream_t s) {
     const int bs = 256;

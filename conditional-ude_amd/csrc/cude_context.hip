@@ -177,6 +177,7 @@ const OptionEntry kOptions[] = {
     {"exp_table", "CUDE_NO_EXPTAB", &Options::exp_table, true, false},
     {"ms_split", "CUDE_NO_MS_SPLIT", &Options::ms_split, true, false},
     {"train_host", "CUDE_TRAIN_HOST", &Options::train_host, false, false},
+    {"mh_spec", "CUDE_MH_SPEC", &Options::mh_spec, false, false},
     {"auto_regroup", "CUDE_NO_AUTO_REGROUP", &Options::auto_regroup, true, false},
     {"poll_pinned", "CUDE_NO_POLL_PINNED", &Options::poll_pinned, true, false},
     {"debug_selector", "CUDE_DEBUG_SELECTOR", &Options::debug_selector, false, false},

@@ -230,19 +230,24 @@ __device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, 
 // Stitches the chunks (affine maps), forms residuals / SSE, and -- for the gradient -- runs the network-free
 // stage-adjoint recursion ONCE per subject, storing the 5 network weights of every step (wts[5S][N]) so that
 // the reverse lanes of all chunks only have to read theirs.
-template <int P>
+// SPEC (speculative Metropolis round, Cpep2Args::spec_slots): a workgroup holds every candidate set of its 64 / slots
+// subjects; behind the SSEs the slot-0 lanes resolve the round and write the next one's candidates (mh_spec_resolve).
+template <int P, bool SPEC = false>
 __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     extern __shared__ double smem[];
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x;
-    const int64_t gid = ((int64_t)blockIdx.x + b.blk0) * kBlock + lane;      // (blk0: mixed launch, see CpepArgs)
-    const bool active = gid < b.N;
-    const int64_t i = active ? gid : b.N - 1;
+    const int spb = SPEC ? kBlock / a.spec_slots : kBlock;                   // subjects per workgroup
+    const int64_t gid = SPEC ? (int64_t)blockIdx.x * spb + lane % spb
+                             : ((int64_t)blockIdx.x + b.blk0) * kBlock + lane;      // (blk0: mixed launch, see CpepArgs)
     const int64_t N = b.N;
     ciptr_t obs_step = as_const(b.obs_step);
     ciptr_t cs = as_const(a.chunk_start);
     const int T = b.T;
-    const int64_t set = blockIdx.y;             // parameter set (see cpep2_fwd_kernel)
+    const int64_t set_raw = SPEC ? lane / spb : blockIdx.y;                  // parameter set (see cpep2_fwd_kernel)
+    const bool active = gid < N && (!SPEC || set_raw < b.n_sets);
+    const int64_t i = gid < N ? gid : N - 1;
+    const int64_t set = SPEC && set_raw >= b.n_sets ? 0 : set_raw;           // (the idle slot re-reads set 0, writes nothing)
     const double* const fsum = a.fsum + set * ((int64_t)a.L * (3 + T) * N);
     double* const wts = a.wts != nullptr ? a.wts + set * ((int64_t)5 * b.S * N) : nullptr;
     double* s_res = smem + kRedRows * kBlock;   // [T][kBlock]
@@ -303,6 +308,12 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
                 for (int j = 0; j < 5; j++) wts[(int64_t)(5 * n + j) * N + i] = w[j];
             }
         }
+    }
+    if constexpr (SPEC) {
+        // the workgroup's own stores of the candidates' SSEs (global memory) are visible to it behind the barrier
+        __syncthreads();
+        if (lane < spb && gid < N) mh_spec_resolve(a.spec, gid);
+        return;
     }
     const double v2[2] = {active ? sse : 0.0, (active && failed) ? 1.0 : 0.0};
     block_reduce_store<2>(v2, smem, b.partials + (set * gridDim.x + blockIdx.x + b.blk0) * (P + 2) + P, lane,
@@ -535,6 +546,14 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     }
     Cpep2Args as = a;
     if (!grad) as.wts = nullptr;
+    if (a.spec_slots > 0) {
+        if (grad || a.spec_slots > kBlock || (int)n_sets >= a.spec_slots || (a.spec_slots & (a.spec_slots - 1)))
+            return hipErrorInvalidValue;
+        const int spb = kBlock / a.spec_slots;
+        hipLaunchKernelGGL((cpep2_scan_kernel<Net::P, true>), dim3((unsigned)((a.base.N + spb - 1) / spb)), dim3(kBlock),
+                           sizeof(double) * (size_t)(kRedRows + a.base.T) * kBlock, s, as);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kBlock),
                        sizeof(double) * (size_t)(kRedRows + a.base.T) * kBlock, s, as);
     if (!grad) return hipGetLastError();

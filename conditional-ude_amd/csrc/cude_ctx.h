@@ -68,6 +68,8 @@ struct Options {
     int ms_split = 1;           // "ms_split" / CUDE_NO_MS_SPLIT: restarts of a small population on the time-split kernels
     int train_host = 0;         // "train_host" / CUDE_TRAIN_HOST: 1 = cude_train_restarts keeps the L-BFGS vectors on the host
                                 //   (what a sharded population always does), 2 = the Adam stage on the host as well
+    int mh_spec = -1;           // "mh_spec" / CUDE_MH_SPEC: speculative Metropolis steps per launch chain (cude_mh_estep, gamma == 1,
+                                //   time-split forward path): 0 = off, 2 ... 4 = that many, -1 = by population size (mh_spec_depth)
     int auto_regroup = 1;       // "auto_regroup" / CUDE_NO_AUTO_REGROUP: adaptive launches re-ordered by accepted-step count
     int poll_pinned = 1;        // "poll_pinned" / CUDE_NO_POLL_PINNED: watch page-locked result slots instead of the stream wait
     int debug_selector = 0;     // "debug_selector" / CUDE_DEBUG_SELECTOR: print the launch-path decision

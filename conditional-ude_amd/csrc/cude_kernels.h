@@ -106,6 +106,27 @@ struct MhArgs {
     RngKey key;                // used when u == nullptr
 };
 
+// Speculative Metropolis (gamma == 1, carried SSE): the chain state after a step is one of two values and the draws are
+// known in advance (counter-based on (seed, subject, step), or the caller's rows), so the 2^d - 1 proposals that d
+// consecutive steps CAN make are evaluated in ONE ensemble launch (candidate = parameter set) and the accept / reject
+// decisions resolved afterwards: the same chain bit for bit, one dependent launch chain per d steps instead of per step.
+// Candidates form a binary heap: node v (1-based; level l = floor(log2 v)) proposes q(v) = s(v) + std * z_l from its
+// state s(v); s(1) = the chain state, s(2v) = s(v) (rejected), s(2v + 1) = q(v) (accepted).  cand / sse_sets: [v - 1][N].
+constexpr int kMhSpecMaxDepth = 4;
+struct MhSpecArgs {
+    MhArgs mh;                 // p, sse_cur, accepted, the prior and likelihood constants; key.step is NOT used (steps below)
+    int32_t depth_resolve;     // levels of `cand` / `sse_sets` to resolve into the chain now (0: none -- the first call)
+    int32_t depth_next;        // levels of candidates to write for the next round (0: none -- the last call)
+    int64_t step_resolve, step_next;   // Metropolis step index of level 0 of either (device draws: the counter's step)
+    const double* sse_sets;    // SSE of the candidates being resolved
+    double* cand;              // read (resolve), then overwritten with the next round's
+    const double* z_rows;      // caller's normals of the NEXT round's steps, row l at z_rows + l * N; nullptr = device draws
+    const double* u_rows;      // caller's uniforms of the steps being RESOLVED, likewise
+    double proposal_std;
+    double* samples;           // chain state after every resolved step, row l at samples + l * N; or nullptr
+};
+hipError_t launch_mh_spec(const MhSpecArgs& a, hipStream_t s);
+
 // chunked loss+gradient path (cude_cpep2.hip): the S steps of every subject are split into L chunks
 struct Cpep2Args {
     CpepArgs base;
@@ -129,6 +150,11 @@ struct Cpep2Args {
     const double* mh_z;          // [N] normals of this step, or nullptr = device stream (mh.key)
     double mh_std;
     MhArgs mh;
+    // speculative Metropolis round (MhSpecArgs): spec_slots = 2^d > 0 makes the scan launch hold ALL candidate sets of a
+    // subject in one workgroup (lane = slot * (64 / spec_slots) + local subject; slot = candidate set, the last slot
+    // idles) and resolve the round right behind the SSEs -- no reduction, no resolver launch
+    int32_t spec_slots;
+    MhSpecArgs spec;
 };
 bool cpep2_shape_supported(const NetShape& net, int n_state);
 int cpep2_rev_waves_per_cu(const NetShape& net);

@@ -1071,6 +1071,30 @@ int32_t cude_fit_conditional(cude_ctx* c, double lower, double upper, int32_t n_
     return CUDE_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// Steps per speculative round of cude_mh_chain (0 = one step per launch pair, the plain fused path).  Option "mh_spec":
+// 0 off, 2 ... 4 forced; -1 (default) by size: a round of depth d evaluates 2^d - 1 candidates per subject in one launch,
+// which is nearly free while the candidates' forward chunks run side by side on otherwise idle SIMDs and costs their
+// full multiple once the chip is filled.  Rule = waves of the round's forward launch (candidates x workgroups x chunks of
+// the forward split), fitted to profiles/r05/estep_speculative.txt (one MI355X, 2-4-4-1, 100 steps, us per step plain ->
+// speculative): 625 subjects 25.2 -> 12.3 (depth 3), 1 250: 25.3 -> 14.6 (3; 14.1 with 2), 1 600: 24.1 -> 14.2 (3), 2 500:
+// 25.1 -> 17.2 (2), 5 000: 26.8 -> 23.7 (2), 1e4: 31.5 -> 29.7 (2), 12 000 and above: slower, off.
+int mh_spec_depth(const cude_ctx* c, int n_mc) {
+    int d = c->opt.mh_spec;
+    if (d < 0) {
+        const int64_t waves1 = c->nblocks * (c->chunks_f > 1 ? c->chunks_f : c->chunks);
+        d = 7 * waves1 <= 2700 ? 3 : (3 * waves1 <= 3000 ? 2 : 0);
+    }
+    d = std::min(d, cude::kMhSpecMaxDepth);
+    if (d > n_mc) d = n_mc;
+    return d >= 2 ? d : 0;
+}
+}  // namespace
+
+extern "C" {
+
 int32_t cude_mh_estep(cude_ctx* c, int32_t n_mc, const double* normals, const double* uniforms, double sigma,
                       double prior_mean, double prior_sd, double proposal_std, double temperature, double gamma,
                       int64_t* accepted) {
@@ -1114,6 +1138,70 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
     // Time-split forward path + carried SSE: the proposal is formed inside the forward chunks and accepted inside the
     // scan (Cpep2Args::mh_fused) -- two launches per Metropolis step instead of four, same bits.
     const bool fused = m.carry_sse && is_cpep(c) && !adaptive(c) && c->chunks > 1 && c->opt.mh_fuse;
+    // Speculative steps (MhSpecArgs, cude_kernels.h): d steps per dependent launch pair -- forward chunks of the 2^d - 1
+    // candidate states as parameter sets of ONE launch, then a scan launch that holds a subject's candidates in one
+    // workgroup and resolves the d decisions behind their SSEs -- instead of one pair per step.
+    // Pays while the candidates still fit the chip beside each other (a shard of an E-step spread over 8 GPUs).
+    const int spec = fused ? mh_spec_depth(c, n_mc) : 0;
+    if (spec >= 2) {
+        const int P = c->P, Lf = (c->chunks_f > 1 ? c->chunks_f : c->chunks), T = c->T;
+        const int64_t nb = c->nblocks, max_sets = (1 << spec) - 1;
+        DevBuf<double> d_cand, d_sse_sets;
+        HIP_TRY(d_cand.resize((size_t)max_sets * N));
+        HIP_TRY(d_sse_sets.resize((size_t)max_sets * N));
+        HIP_TRY(c->ms_fsum.reserve((size_t)max_sets * Lf * (3 + T) * N));
+        HIP_TRY(c->ms_part.reserve((size_t)max_sets * nb * (P + 2)));
+        cude::MhSpecArgs sa{};
+        sa.mh = m;
+        sa.mh.key = cude::RngKey{c->rng_seed, c->rng_offset, 0};
+        sa.cand = d_cand.p; sa.sse_sets = d_sse_sets.p; sa.proposal_std = proposal_std;
+        sa.depth_resolve = 0; sa.depth_next = std::min(spec, n_mc);
+        sa.step_resolve = sa.step_next = c->rng_step;
+        sa.z_rows = device_rng ? nullptr : d_z.p;
+        HIP_TRY(cude::launch_mh_spec(sa, c->stream));                 // the first round's candidates
+        int round = 0;
+        for (int k = 0; k < n_mc; round++) {
+            const int d = std::min(spec, n_mc - k), sets = (1 << d) - 1;
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = d_cand.p; a.nn = c->nn.p; a.sse = d_sse_sets.p; a.traj = nullptr; a.auc = nullptr;
+            a.g_cond = c->g_cond.p; a.partials = c->ms_part.p;
+            a.n_sets = sets; a.set_stride_nn = 0; a.set_stride_cond = N;       // one network, `sets` candidate states
+            cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true, /*forward_only=*/true);
+            a2.fsum = c->ms_fsum.p;
+            sa.depth_resolve = d;
+            sa.depth_next = std::min(spec, n_mc - k - d);
+            sa.step_resolve = c->rng_step + k;
+            sa.step_next = c->rng_step + k + d;
+            sa.u_rows = device_rng ? nullptr : d_u.p + (size_t)k * N;
+            sa.z_rows = device_rng ? nullptr : d_z.p + (size_t)(k + d) * N;
+            // (caller's draws + samples: the states of steps k .. k+d-1 overwrite the normals of those steps, which the
+            //  PREVIOUS resolver consumed; the next round's normals are rows k+d ...)
+            sa.samples = samples ? d_z.p + (size_t)k * N : nullptr;
+            a2.spec_slots = 1 << d;             // the scan launch resolves the round itself
+            a2.spec = sa;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->timing && round % 4 == 0) {
+                if (c->ev_used == c->ev_pool.size()) {
+                    hipEvent_t ea, eb;
+                    HIP_TRY(hipEventCreate(&ea));
+                    HIP_TRY(hipEventCreate(&eb));
+                    c->ev_pool.emplace_back(ea, eb);
+                }
+                e0 = c->ev_pool[c->ev_used].first; e1 = c->ev_pool[c->ev_used].second;
+                c->ev_used++;
+                HIP_TRY(hipEventRecord(e0, c->stream));
+            }
+            HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, false, a2, c->stream));
+            if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+            k += d;
+        }
+        if (samples)
+            HIP_TRY(hipMemcpyAsync(samples, d_z.p, (size_t)n_mc * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (device_rng) c->rng_step += n_mc;
+        return CUDE_OK;
+    }
     for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
         m.key = cude::RngKey{c->rng_seed, c->rng_offset, c->rng_step + k};
         if (fused) {

@@ -55,25 +55,115 @@ __device__ __forceinline__ double mh_proposal(const double* __restrict__ p, cons
     return fma(z != nullptr ? z[i] : rng_normal(key, i), proposal_std, p[i]);
 }
 
+// The decision of one Metropolis-Hastings step (src/saem.jl:86-108): proposal q with SSE sn against state p with SSE sc,
+// uniform draw u.  Its two per-state terms are written so that their bits do not depend on whether the compiler
+// contracts a multiply-add (halving is exact; the likelihood's multiply-add is an explicit fma): the stand-alone kernel,
+// the fused scan and the speculative resolver -- which forms the terms of all candidates before it walks them -- agree
+// bit for bit.
+__device__ __forceinline__ double mh_prior_term(const MhArgs& a, double x) {        // -logpdf(Normal(mu, sd), x) + const
+    const double z = (x - a.prior_mean) / a.prior_sd;
+    return 0.5 * (z * z);
+}
+__device__ __forceinline__ double mh_tempered_ll(const MhArgs& a, double sse) {     // -Inf on solver failure (:59-62)
+    const bool ok = fabs(sse) <= 1.79769313486231570815e308;
+    return (ok ? fma(-sse, a.inv_2s2, a.ll_const) : -__builtin_huge_val()) / a.temperature;
+}
+__device__ __forceinline__ bool mh_decide_terms(double logu, double prior_p, double prior_q, double llt_cur, double llt_new) {
+    return logu < (prior_p - prior_q) + (llt_new - llt_cur);            // NaN compares false
+}
+__device__ __forceinline__ bool mh_decide(const MhArgs& a, double p, double q, double sc, double sn, double u) {
+    return mh_decide_terms(log(u), mh_prior_term(a, p), mh_prior_term(a, q), mh_tempered_ll(a, sc), mh_tempered_ll(a, sn));
+}
+
 // accept / reject of one Metropolis-Hastings step for subject i (src/saem.jl:86-108 and the stochastic-approximation
 // update :177-186): q = proposal, sn = its SSE
 __device__ __forceinline__ void mh_accept_one(const MhArgs& a, int64_t i, double q, double sn) {
     const double p = a.p[i];
-    // logpdf(Normal(mu, sd), x) differences: the normalisation cancels
-    const double zq = (q - a.prior_mean) / a.prior_sd, zp = (p - a.prior_mean) / a.prior_sd;
-    const double prior_ratio = -0.5 * zq * zq + 0.5 * zp * zp;
-    const double inf = __builtin_huge_val();
-    const double sc = a.sse_cur[i];
-    const bool okn = fabs(sn) <= 1.79769313486231570815e308, okc = fabs(sc) <= 1.79769313486231570815e308;
-    const double ll_new = okn ? a.ll_const - sn * a.inv_2s2 : -inf;     // -Inf on solver failure (:59-62)
-    const double ll_cur = okc ? a.ll_const - sc * a.inv_2s2 : -inf;
-    const double ratio = ll_new / a.temperature - ll_cur / a.temperature;
     const double u = a.u != nullptr ? a.u[i] : rng_uniform(a.key, i);
-    const bool acc = log(u) < prior_ratio + ratio;                      // NaN compares false
+    const bool acc = mh_decide(a, p, q, a.sse_cur[i], sn, u);
     a.p[i] = (1.0 - a.gamma) * p + a.gamma * (acc ? q : p);
     if (acc) {
         a.accepted[i] += 1;
         if (a.carry_sse) a.sse_cur[i] = sn;
+    }
+}
+
+// Resolver of a speculative round for subject i (MhSpecArgs, cude_kernels.h): the decisions of mh_decide /
+// mh_accept_one, with the path-independent parts of every node hoisted out of the walk -- same expressions on the same
+// values, hence the same bits as d sequential steps.
+__device__ __forceinline__ void mh_spec_resolve(const MhSpecArgs& a, int64_t i) {
+    constexpr int D = kMhSpecMaxDepth, NODES = (1 << D) - 1;
+    const int64_t N = a.mh.N;
+    const MhArgs& m = a.mh;
+    // draws of both rounds first: they depend on (seed, subject, step) only
+    double logu[D], zn[D];
+#pragma unroll
+    for (int l = 0; l < D; l++) {
+        RngKey key = m.key;
+        if (l < a.depth_resolve) {
+            key.step = a.step_resolve + l;
+            logu[l] = log(a.u_rows != nullptr ? a.u_rows[(int64_t)l * N + i] : rng_uniform(key, i));
+        }
+        if (l < a.depth_next) {
+            key.step = a.step_next + l;
+            zn[l] = a.z_rows != nullptr ? a.z_rows[(int64_t)l * N + i] : rng_normal(key, i);
+        }
+    }
+    double s = m.p[i];
+    if (a.depth_resolve > 0) {
+        const int nodes = (1 << a.depth_resolve) - 1;
+        double q[NODES], sn[NODES], pri[NODES], llt[NODES];      // per node: proposal, its SSE, -0.5 zq^2 parts, ll / T
+#pragma unroll
+        for (int v = 0; v < NODES; v++) {
+            if (v < nodes) {
+                q[v] = a.cand[(int64_t)v * N + i];
+                sn[v] = a.sse_sets[(int64_t)v * N + i];
+            }
+        }
+        double sc = m.sse_cur[i];
+        // the state's own terms, then every candidate's (what mh_decide forms per step)
+        double pri_s = mh_prior_term(m, s), llt_s = mh_tempered_ll(m, sc);
+#pragma unroll
+        for (int v = 0; v < NODES; v++) {
+            if (v < nodes) {
+                pri[v] = mh_prior_term(m, q[v]);
+                llt[v] = mh_tempered_ll(m, sn[v]);
+            }
+        }
+        int v = 1, nacc = 0;
+#pragma unroll
+        for (int l = 0; l < D; l++) {
+            if (l < a.depth_resolve) {
+                // (select the node's values without dynamic register indexing: a chain of compares over the level)
+                double qv = 0.0, snv = 0.0, priv = 0.0, lltv = 0.0;
+#pragma unroll
+                for (int w = (1 << l); w < (2 << l); w++)
+                    if (w == v) { qv = q[w - 1]; snv = sn[w - 1]; priv = pri[w - 1]; lltv = llt[w - 1]; }
+                const bool acc = mh_decide_terms(logu[l], pri_s, priv, llt_s, lltv);
+                s = (1.0 - m.gamma) * s + m.gamma * (acc ? qv : s);      // (gamma == 1: the statement of mh_accept_one)
+                if (acc) { nacc++; sc = snv; pri_s = priv; llt_s = lltv; }
+                v = 2 * v + (acc ? 1 : 0);
+                if (a.samples != nullptr) a.samples[(int64_t)l * N + i] = s;
+            }
+        }
+        m.p[i] = s;
+        m.sse_cur[i] = sc;
+        if (nacc) m.accepted[i] += nacc;
+    }
+    if (a.depth_next > 0) {
+        double st[1 << D];                          // st[v]: state of node v
+        st[1] = s;
+#pragma unroll
+        for (int l = 0; l < D; l++) {
+            if (l < a.depth_next) {
+#pragma unroll
+                for (int v = 1 << l; v < (2 << l); v++) {
+                    const double qn = fma(zn[l], a.proposal_std, st[v]);      // (= mh_proposal from that state)
+                    a.cand[(int64_t)(v - 1) * N + i] = qn;
+                    if (l + 1 < D) { st[2 * v] = st[v]; st[2 * v + 1] = qn; }
+                }
+            }
+        }
     }
 }
 

@@ -222,3 +222,43 @@ def test_saem_loop_with_device_draws_equals_the_same_loop_fed_those_draws():
     assert np.array_equal(a.acceptance_rates, b.acceptance_rates) and np.array_equal(a.p_individuals, b.p_individuals)
     assert np.array_equal(a.p_neural, b.p_neural) and a.sigma == b.sigma and a.Omega == b.Omega
     assert 0.0 < a.acceptance_rates[-1] < 1.0
+
+
+@pytest.mark.parametrize("N", [48, 1300])
+def test_speculative_metropolis_is_the_same_chain_bit_for_bit(N):
+    """Option "mh_spec" (csrc/cude_kernels.h MhSpecArgs): d steps of every subject's chain per dependent launch chain --
+    the 2^d - 1 states the d steps can propose from are evaluated as parameter sets of one launch and the decisions
+    resolved afterwards.  Same draws (the caller's rows, or the counter-based device stream: a draw depends on (seed,
+    subject, step) only), same arithmetic per decision: states, acceptance counts and every intermediate sample equal
+    the step-by-step path's (src/saem.jl:86-108,177-186) bit for bit, for every depth, when the step count is not a
+    multiple of the depth, and with a subject whose solve fails."""
+    from cude.engine import Engine
+    arch, steps = (2, 4, 2), 11
+    c = make_cpep_case(N, arch)
+    rng = np.random.default_rng(5)
+    normals, uniforms = rng.standard_normal((steps, N)), rng.random((steps, N))
+    start = c["beta"].copy()
+    start[N // 3] = 800.0                      # exp overflows: this subject's likelihood is -Inf throughout
+
+    def run(depth, device_draws):
+        eng = Engine("cpep", arch, n_steps=30)
+        eng.set_option("mh_spec", depth)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], start)
+        eng.set_rng(1234, 77)
+        if device_draws:
+            acc, samples = eng.mh_chain(None, None, 0.4, -0.6, 0.9, 0.3, n_mc=steps)
+            acc2 = eng.mh_estep(None, None, 0.4, -0.6, 0.9, 0.3, n_mc=5)        # the stream of draws continues
+        else:
+            acc, samples = eng.mh_chain(normals, uniforms, 0.4, -0.6, 0.9, 0.3)
+            acc2 = eng.mh_estep(normals[:5], uniforms[:5], 0.4, -0.6, 0.9, 0.3)
+        _, p = eng.get_params()
+        eng.close()
+        return acc, samples, acc2, p
+    for device_draws in (False, True):
+        ref = run(0, device_draws)
+        assert 0 < ref[0].sum() < steps * N and ref[0][N // 3] == 0
+        for depth in (2, 3, 4, -1):
+            got = run(depth, device_draws)
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), (depth, device_draws)
