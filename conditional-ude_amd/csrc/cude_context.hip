@@ -180,6 +180,7 @@ const OptionEntry kOptions[] = {
     {"mh_spec", "CUDE_MH_SPEC", &Options::mh_spec, false, false},
     {"auto_regroup", "CUDE_NO_AUTO_REGROUP", &Options::auto_regroup, true, false},
     {"poll_pinned", "CUDE_NO_POLL_PINNED", &Options::poll_pinned, true, false},
+    {"force_fallback", "CUDE_FORCE_FALLBACK", &Options::force_fallback, false, false},
     {"debug_selector", "CUDE_DEBUG_SELECTOR", &Options::debug_selector, false, false},
     {"xchg_allow_plain", "CUDE_ALLOW_PLAIN_MAILBOX", &Options::xchg_allow_plain, false, false},
     {"xchg_fail_kinds", "CUDE_XCHG_FAIL_KINDS", &Options::xchg_fail_kinds, false, false},
@@ -193,6 +194,48 @@ const OptionEntry kOptions[] = {
     {"prio_shift", "CUDE_PRIO_SHIFT", &Options::prio_shift, false, true},
 };
 }  // namespace
+
+// `chain(widths, activation_functions; input_dims, output_activation)` (src/neural-network.jl:42-58) as the fallback
+// kernel's network: n_hidden widths, n_hidden + 1 activation codes (CUDE_ACT_*; the last one is the output layer's)
+int32_t make_general_network(int32_t model, int32_t nin, int32_t n_hidden, const int32_t* widths, const int32_t* acts,
+                             cude::GenNet* out) {
+    if (n_hidden < 1 || !widths || !acts) return fail(CUDE_ERR_ARG, "a network needs at least one hidden layer");
+    if (n_hidden + 1 > cude::kGenMaxLayers)
+        return fail(CUDE_ERR_UNSUPPORTED, "more than " + std::to_string(cude::kGenMaxLayers - 1) + " hidden layers");
+    const int want_in = model == CUDE_MODEL_SUPP ? 4 : nin;
+    if (model == CUDE_MODEL_SUPP ? nin != 4 : (nin != 2 && nin != 3))
+        return fail(CUDE_ERR_ARG, "network inputs: 2 (glucose, conditional) or 3 (+ age) for the c-peptide model, 4 for the suppression model");
+    cude::GenNet g;
+    g.nin = want_in;
+    g.n_layers = n_hidden + 1;
+    for (int l = 0; l <= n_hidden; l++) {
+        g.width[l] = l < n_hidden ? widths[l] : 1;
+        g.act[l] = acts[l];
+        if (g.width[l] < 1 || g.width[l] > 4096) return fail(CUDE_ERR_ARG, "layer widths must lie in 1 ... 4096");
+        if (acts[l] < cude::kGenActTanh || acts[l] > cude::kGenActIdentity)
+            return fail(CUDE_ERR_ARG, "activation codes: 0 tanh, 1 relu, 2 sigmoid, 3 softplus, 4 identity");
+    }
+    if (cude::gen_lds_bytes(g) > cude::kGenMaxLds)
+        return fail(CUDE_ERR_UNSUPPORTED, "this network needs " + std::to_string(cude::gen_lds_bytes(g) / 1024) +
+                                              " KB of LDS per workgroup (weights + one activation column per lane); 160 KB fit");
+    *out = g;
+    return CUDE_OK;
+}
+
+// P-sized buffers of a context (cude_create; again when cude_set_network changes the network)
+int32_t alloc_network_buffers(cude_ctx* c) {
+    const int P = c->P;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    if (hipHostMalloc((void**)&c->pinned, (size_t)(P + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+        c->pinned = nullptr;
+    (void)hipGetLastError();
+    if (c->nn.resize(P) || c->g_nn.resize(P + 2) || c->m_nn.resize(P) || c->v_nn.resize(P)) return fail(CUDE_ERR_HIP, "hipMalloc failed");
+    (void)hipMemsetAsync(c->g_nn.p, 0, (P + 2) * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->m_nn.p, 0, P * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->v_nn.p, 0, P * sizeof(double), c->stream);
+    return CUDE_OK;
+}
 
 int32_t apply_option(cude_ctx* c, const char* name, const char* value) {
     if (!name || !value) return fail(CUDE_ERR_ARG, "null option name / value");
@@ -217,9 +260,20 @@ int32_t apply_option(cude_ctx* c, const char* name, const char* value) {
         }
         const bool ok = c->cfg.model == CUDE_MODEL_SUPP ? cude::supp_shape_supported(net)
                                                         : cude::cpep_shape_supported(net, c->cfg.n_state);
-        if (!ok)
-            return fail(CUDE_ERR_UNSUPPORTED, "activation functions other than tanh / softplus are compiled for the networks "
-                                              "2-4-4-1, 2-6-6-1, 3-4-4-1 (c-peptide) and 4-3x5-1, 4-3x3-1 (suppression)");
+        if (!ok) {          // no tuned kernel for this shape with these functions: the fallback kernel
+            const int Dh = net.generic() ? net.gen.n_layers - 1 : net.depth;
+            std::vector<int32_t> w((size_t)Dh), act((size_t)Dh + 1);
+            const int hcode = net.hact == cude::kActHiddenRelu ? cude::kGenActRelu
+                              : (net.hact == cude::kActHiddenSigmoid ? cude::kGenActSigmoid : cude::kGenActTanh);
+            for (int l = 0; l < Dh; l++) {
+                w[(size_t)l] = net.generic() ? net.gen.width[l] : net.width;
+                act[(size_t)l] = hidden || !net.generic() ? hcode : net.gen.act[l];
+            }
+            act[(size_t)Dh] = !hidden || !net.generic() ? (net.oact == cude::kActOutIdentity ? cude::kGenActIdentity : cude::kGenActSoftplus)
+                                                        : net.gen.act[Dh];
+            int32_t rc = make_general_network(c->cfg.model, c->cfg.nn_in, Dh, w.data(), act.data(), &net.gen);
+            if (rc) return rc;
+        }
         c->net = net;
         drop_graph(c);
         return CUDE_OK;
@@ -292,6 +346,7 @@ int32_t alloc_common(cude_ctx* c) {
     HIP_TRY(c->perm.resize(0));          // a new population starts in its own order
     c->slot_of.clear();
     HIP_TRY(c->tape.resize(0));          // adaptive gradient tape: allocated by the first gradient evaluation
+    HIP_TRY(c->gen_acc.resize(0));
     c->tape_cap = 0;
     HIP_TRY(c->tape_n.resize(adaptive(c) ? (size_t)N : 0));      // accepted-step counts: written by every adaptive launch
     c->have_tape = false;
@@ -402,10 +457,16 @@ int32_t cude_create(const cude_config* cfg, cude_ctx** out) {
         if (cfg->nn_in < 1 || cfg->nn_width < 1 || cfg->nn_depth < 1) return fail(CUDE_ERR_ARG, "bad network shape");
         if (cfg->cond_space != CUDE_COND_LOG)
             return fail(CUDE_ERR_ARG, "cond_space must be CUDE_COND_LOG for the network models");
-        if (cfg->model == CUDE_MODEL_CPEP && !cude::cpep_shape_supported(net, cfg->n_state))
-            return fail(CUDE_ERR_UNSUPPORTED, "c-peptide kernel not compiled for this (nn_in,width,depth,n_state)");
-        if (cfg->model == CUDE_MODEL_SUPP && (cfg->n_state != 3 || !cude::supp_shape_supported(net)))
-            return fail(CUDE_ERR_UNSUPPORTED, "suppression kernel not compiled for this (width,depth)");
+        if (cfg->model == CUDE_MODEL_CPEP && cfg->n_state != 2 && cfg->n_state != 3) return fail(CUDE_ERR_UNSUPPORTED, "n_state must be 2 or 3");
+        if (cfg->model == CUDE_MODEL_SUPP && cfg->n_state != 3) return fail(CUDE_ERR_UNSUPPORTED, "the suppression model has 3 states");
+        const bool tuned = cfg->model == CUDE_MODEL_CPEP ? cude::cpep_shape_supported(net, cfg->n_state)
+                                                         : cude::supp_shape_supported(net);
+        if (!tuned) {       // no tuned kernel for this width / depth: the fallback kernel (cude_generic.hip), tanh / softplus
+            std::vector<int32_t> w((size_t)cfg->nn_depth, cfg->nn_width), act((size_t)cfg->nn_depth + 1, cude::kGenActTanh);
+            act.back() = cude::kGenActSoftplus;
+            int32_t rc = make_general_network(cfg->model, cfg->nn_in, cfg->nn_depth, w.data(), act.data(), &net.gen);
+            if (rc) return rc;
+        }
     } else {
         return fail(CUDE_ERR_ARG, "unknown model id");
     }
@@ -421,16 +482,43 @@ int32_t cude_create(const cude_config* cfg, cude_ctx** out) {
     c->P = net.n_params();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(CUDE_ERR_HIP, hipGetErrorString(e)); }
-    const int P = c->P;
-    if (hipHostMalloc((void**)&c->pinned, (size_t)(P + 2) * sizeof(double), kWatchedHostFlags) != hipSuccess) c->pinned = nullptr;
-    if (c->nn.resize(P) || c->g_nn.resize(P + 2) || c->m_nn.resize(P) || c->v_nn.resize(P)) {
+    if (alloc_network_buffers(c)) {
         cude_destroy(c);
         return fail(CUDE_ERR_HIP, "hipMalloc failed");
     }
-    (void)hipMemsetAsync(c->g_nn.p, 0, (P + 2) * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->m_nn.p, 0, P * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->v_nn.p, 0, P * sizeof(double), c->stream);
     *out = c;
+    return CUDE_OK;
+}
+
+int32_t cude_set_network(cude_ctx* c, int32_t n_hidden, const int32_t* widths, const int32_t* activations) {
+    int32_t rc = bind(c);
+    if (rc) return rc;
+    if (c->cfg.model != CUDE_MODEL_CPEP && c->cfg.model != CUDE_MODEL_SUPP) return fail(CUDE_ERR_ARG, "the symbolic model has no network");
+    if (c->have_pop) return fail(CUDE_ERR_STATE, "set the network before the population");
+    if (n_hidden < 1 || !widths || !activations) return fail(CUDE_ERR_ARG, "a network needs at least one hidden layer");
+    cude::NetShape net{c->cfg.nn_in, widths[0], n_hidden};
+    // one width, tanh in every hidden layer, softplus at the output, and a kernel compiled for it: the tuned path
+    bool plain = activations[n_hidden] == cude::kGenActSoftplus;
+    for (int l = 0; l < n_hidden; l++) plain = plain && widths[l] == widths[0] && activations[l] == cude::kGenActTanh;
+    const bool tuned = plain && !c->opt.force_fallback &&
+                       (c->cfg.model == CUDE_MODEL_CPEP ? cude::cpep_shape_supported(net, c->cfg.n_state)
+                                                        : cude::supp_shape_supported(net));
+    if (!tuned && (rc = make_general_network(c->cfg.model, c->cfg.nn_in, n_hidden, widths, activations, &net.gen))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    c->net = net;
+    c->cfg.nn_width = net.generic() ? net.gen.max_width() : widths[0];
+    c->cfg.nn_depth = n_hidden;
+    c->P = net.n_params();
+    c->have_nn = false;
+    HIP_TRY(c->param_mask.resize(0));
+    return alloc_network_buffers(c);
+}
+
+int32_t cude_network_info(cude_ctx* c, int32_t* n_params, int32_t* fallback_kernel) {
+    if (!c || !n_params || !fallback_kernel) return fail(CUDE_ERR_ARG, "null argument");
+    *n_params = c->P;
+    *fallback_kernel = c->net.generic() ? 1 : 0;
     return CUDE_OK;
 }
 

@@ -502,6 +502,7 @@ static bool general_shape(const NetShape& net) {
 
 // resident waves per CU of the one-lane-per-subject gradient kernel (0 = unknown)
 int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T) {
+    if (net.generic()) return 1;
     if (net.symbolic()) return grad_occupancy<MmProd<false>>(n_state, T);
     if (net.general()) return 4;             // (not tuned: the path selector only needs "at least one wave per SIMD")
 #define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return grad_occupancy<CpepNet<NIN, W, D>>(n_state, T);
@@ -512,7 +513,7 @@ int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T) {
 
 // kept values per evaluation of the gradient kernel's kept-activation variant (0: the shape has none)
 int cpep_keep_values(const NetShape& net) {
-    if (net.symbolic() || net.general()) return 0;
+    if (net.symbolic() || net.general() || net.generic()) return 0;
 #define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return cpep_can_keep<CpepNet<NIN, W, D>>() ? CpepNet<NIN, W, D>::NKEEP : 0;
     CUDE_CPEP_SHAPES(X)
 #undef X
@@ -520,6 +521,7 @@ int cpep_keep_values(const NetShape& net) {
 }
 
 bool cpep_shape_supported(const NetShape& net, int n_state) {
+    if (net.generic()) return false;         // (the tuned kernels; the fallback kernel takes what they do not)
     if (n_state != 2 && n_state != 3) return false;
     if (net.symbolic()) return true;
     if (net.general()) return general_shape(net) && general_acts_compiled(net.hact, net.oact);
@@ -530,6 +532,7 @@ bool cpep_shape_supported(const NetShape& net, int n_state) {
 }
 
 hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepArgs& a, hipStream_t s) {
+    if (net.generic()) return launch_cpep_generic(net, n_state, grad, a, s);       // fixed-step and adaptive alike
     if (a.S == 0) return n_state != 2 ? hipErrorInvalidValue : launch_cpep_adaptive(net, grad, a, s);
     if (net.symbolic())
         return a.cond_raw ? launch_shape<MmProd<true>>(n_state, grad, a, s) : launch_shape<MmProd<false>>(n_state, grad, a, s);

@@ -570,7 +570,7 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
 #define CUDE_CPEP2_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
 
 bool cpep2_shape_supported(const NetShape& net, int n_state) {
-    if (net.general()) return false;         // other activation functions: the one-lane kernels only
+    if (net.general() || net.generic()) return false;         // other activation functions / shapes: the one-lane kernels only
     if (n_state != 2 && n_state != 3) return false;
 #define X(NIN, W, D) if (net.nin == NIN && net.width == W && net.depth == D) return true;
     CUDE_CPEP2_SHAPES(X)

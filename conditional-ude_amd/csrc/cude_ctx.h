@@ -72,6 +72,8 @@ struct Options {
                                 //   time-split forward path): 0 = off, 2 ... 4 = that many, -1 = by population size (mh_spec_depth)
     int auto_regroup = 1;       // "auto_regroup" / CUDE_NO_AUTO_REGROUP: adaptive launches re-ordered by accepted-step count
     int poll_pinned = 1;        // "poll_pinned" / CUDE_NO_POLL_PINNED: watch page-locked result slots instead of the stream wait
+    int force_fallback = 0;     // "force_fallback" / CUDE_FORCE_FALLBACK (tests): cude_set_network takes the fallback kernel also
+                                //   for shapes a tuned kernel is compiled for
     int debug_selector = 0;     // "debug_selector" / CUDE_DEBUG_SELECTOR: print the launch-path decision
     int xchg_allow_plain = 0;   // "xchg_allow_plain" / CUDE_ALLOW_PLAIN_MAILBOX: ordinary device memory as a mailbox although
                                 //   peers sit on other devices (the owner's polls may then be served from its L2)
@@ -203,6 +205,7 @@ struct cude_ctx {
     cude::api::DevBuf<double> ms_fsum, ms_wts, ms_gcp, ms_p2;   // time-split path with parameter sets (small populations)
     cude::api::DevBuf<double> act;     // SUPP: kept network activations of the gradient launch (small populations only)
     cude::api::DevBuf<double> tape, ms_tape;   // adaptive mode: accepted steps of the forward sweep, walked back by the adjoint
+    cude::api::DevBuf<double> gen_acc, ms_gacc;    // general network (cude_generic.hip): [P][N] gradient accumulators per set
     cude::api::DevBuf<int32_t> tape_n;
     cude::api::DevBuf<int32_t> perm;                           // adaptive kernels: subject of every launch position (cude_adaptive_regroup)
     std::vector<int32_t> slot_of;                   // its inverse on the host (empty = identity)

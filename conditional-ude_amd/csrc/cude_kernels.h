@@ -15,12 +15,43 @@ constexpr int kMaxObs = 32;
 constexpr int kActHiddenTanh = 0, kActHiddenRelu = 1, kActHiddenSigmoid = 2, kActHiddenIdentity = 3;
 constexpr int kActOutSoftplus = 0, kActOutIdentity = 1;
 
+// The general network (cude_generic.hip): per-layer widths and activation functions, evaluated by the fallback kernel
+// when no tuned kernel is compiled for the shape.  Activation codes = CUDE_ACT_* of include/cude.h.
+constexpr int kGenMaxLayers = 9;                 // hidden layers + the output layer
+constexpr int kGenActTanh = 0, kGenActRelu = 1, kGenActSigmoid = 2, kGenActSoftplus = 3, kGenActIdentity = 4;
+constexpr size_t kGenMaxLds = 160 * 1024;        // a workgroup's LDS on gfx950
+struct GenNet {
+    int32_t n_layers = 0;                        // 0 = not a general network
+    int32_t nin = 0;
+    int32_t width[kGenMaxLayers] = {};           // units of layer l (the last layer: 1)
+    int32_t act[kGenMaxLayers] = {};
+    __host__ __device__ int n_params() const {
+        int p = 0, fan = nin;
+        for (int l = 0; l < n_layers; l++) { p += width[l] * fan + width[l]; fan = width[l]; }
+        return p;
+    }
+    __host__ __device__ int n_units() const {
+        int u = 0;
+        for (int l = 0; l < n_layers; l++) u += width[l];
+        return u;
+    }
+    __host__ __device__ int max_width() const {
+        int m = 0;
+        for (int l = 0; l < n_layers; l++) m = width[l] > m ? width[l] : m;
+        return m;
+    }
+};
+size_t gen_lds_bytes(const GenNet& net);         // LDS of one workgroup of the fallback kernel
+
 struct NetShape {
     int nin, width, depth;
     int hact = kActHiddenTanh, oact = kActOutSoftplus;
+    GenNet gen;                                  // gen.n_layers > 0: the fallback kernel evaluates THIS network
+    bool generic() const { return gen.n_layers > 0; }
     bool general() const { return hact != kActHiddenTanh || oact != kActOutSoftplus; }
-    bool symbolic() const { return width == 0; }   // analytic production p0*dG/(dG+k): P = 1
+    bool symbolic() const { return width == 0 && !generic(); }   // analytic production p0*dG/(dG+k): P = 1
     int n_params() const {
+        if (generic()) return gen.n_params();
         if (symbolic()) return 1;
         int p = 0, fan = nin;
         for (int l = 0; l < depth; l++) { p += width * fan + width; fan = width; }
@@ -79,6 +110,8 @@ struct CpepArgs {
     double* tape;            // adaptive gradient: [n_sets][tape_cap][N] step sizes dt_n of the accepted steps (+ T saved outputs)
     int32_t tape_cap;
     int32_t* tape_n;         // [N] accepted steps per subject of parameter set 0 (forward and gradient launches), or nullptr
+    double* gen_acc;         // fallback kernel (cude_generic.hip), gradient: [n_sets][P][N] per-lane accumulators; its tape
+                             // (CpepArgs::tape) is [n_sets][steps][2 + n_state][N] with steps = S, or tape_cap when S == 0
     const int32_t* perm;     // adaptive kernels: lane `gid` works on subject perm[gid] (nullptr = identity).  Lanes of a wave
                              // run as long as the slowest of them: cude_adaptive_regroup orders the subjects by their
                              // accepted-step counts so that a wave's lanes finish together.  The tape is kept in LANE order.
@@ -198,9 +231,13 @@ struct SuppArgs {
     double* tape;            // adaptive gradient, as CpepArgs
     int32_t tape_cap;
     int32_t* tape_n;
+    double* gen_acc;         // as CpepArgs
     const int32_t* perm;     // as CpepArgs
 };
 
+// the fallback kernel for networks no tuned kernel is compiled for (net.generic(); cude_generic.hip)
+hipError_t launch_cpep_generic(const NetShape& net, int n_state, bool grad, const CpepArgs& a, hipStream_t s);
+hipError_t launch_supp_generic(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);
 // returns hipSuccess, or hipErrorInvalidValue when the shape is not compiled in
 hipError_t launch_cpep(const NetShape& net, int n_state, bool grad, const CpepArgs& a, hipStream_t s);
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);

@@ -14,7 +14,7 @@ size_t supp_act_doubles(const cude_ctx* c) {
     return (size_t)(6 * c->cfg.n_steps + 1) * (size_t)(c->net.depth * c->net.width + 1) * (size_t)c->N;
 }
 bool supp_keep_activations(const cude_ctx* c, int64_t n_sets) {
-    if (c->net.general()) return false;      // (other activation functions: the plain stage-input kernels only)
+    if (c->net.general() || c->net.generic()) return false;      // (other activation functions / shapes: no kept activations)
     if (c->opt.supp_store == 0 || c->opt.supp_store == 1) return c->opt.supp_store == 1;
     return (double)n_sets * (double)supp_act_doubles(c) * 8.0 <= 256e6;
 }
@@ -52,6 +52,7 @@ cude::CpepArgs cpep_args(const cude_ctx* c) {
     a.t_begin = c->tp.front(); a.t_end = c->tp.back();
     a.abstol = c->abstol; a.reltol = c->reltol;
     a.tape = c->tape.p; a.tape_cap = c->tape_cap; a.tape_n = c->tape_n.p;
+    a.gen_acc = c->gen_acc.p;
     a.perm = (adaptive(c) && !c->slot_of.empty()) ? c->perm.p : nullptr;
     return a;
 }
@@ -73,6 +74,7 @@ cude::SuppArgs supp_args(const cude_ctx* c) {
     a.t_begin = c->tp.front(); a.t_end = c->tp.back();
     a.abstol = c->abstol; a.reltol = c->reltol;
     a.tape = c->tape.p; a.tape_cap = c->tape_cap; a.tape_n = c->tape_n.p;
+    a.gen_acc = c->gen_acc.p;
     a.perm = (adaptive(c) && !c->slot_of.empty()) ? c->perm.p : nullptr;
     return a;
 }
@@ -83,7 +85,27 @@ cude::SuppArgs supp_args(const cude_ctx* c) {
 // (option "tape_steps" overrides).  A subject with more accepted steps fails its gradient evaluation (+Inf), not the
 // process.  Allocated by the first gradient evaluation (forward-only users of the adaptive mode never pay for it), never
 // under stream capture.
+// The fallback kernel of a general network (cude_generic.hip) keeps (t_n, dt_n, y_n) of EVERY step -- in the fixed-step
+// mode too -- and a lane's P gradient accumulators in HBM: both are allocated here as well.
+int64_t tape_doubles_per_set(const cude_ctx* c) {        // (after ensure_tape)
+    const int n_state = c->cfg.model == CUDE_MODEL_SUPP ? 3 : (c->net.generic() ? c->cfg.n_state : 2);
+    if (c->net.generic()) return (int64_t)(adaptive(c) ? c->tape_cap : c->cfg.n_steps) * (2 + n_state) * c->N;
+    return adaptive(c) ? cude::adaptive_tape_rows(n_state, c->tape_cap, c->T) * c->N : 0;
+}
+
 int32_t ensure_tape(cude_ctx* c) {
+    if (c->net.generic()) {
+        if (c->tape.p && c->gen_acc.p) return CUDE_OK;
+        if (c->capturing) return fail(CUDE_ERR_STATE, "gradient scratch of the general network not allocated before stream capture");
+        const int rows = 2 + (c->cfg.model == CUDE_MODEL_SUPP ? 3 : c->cfg.n_state);
+        int64_t cap = (int64_t)(4e9 / (8.0 * rows * (double)c->N));
+        cap = std::max<int64_t>(64, std::min<int64_t>(1024, cap));
+        if (c->opt.tape_steps > 0) cap = c->opt.tape_steps;
+        c->tape_cap = (int)cap;
+        HIP_TRY(c->tape.resize((size_t)tape_doubles_per_set(c)));
+        HIP_TRY(c->gen_acc.resize((size_t)c->P * c->N));
+        return CUDE_OK;
+    }
     if (!adaptive(c) || c->tape.p) return CUDE_OK;
     if (c->capturing) return fail(CUDE_ERR_STATE, "adaptive gradient tape not allocated before stream capture");
     const int64_t N = c->N;
@@ -542,12 +564,13 @@ int32_t finish_loss(cude_ctx* c, double* loss, double* g_nn_host) {
 // results do not depend on the order; the shared gradient's summation order does (rounding).
 int32_t maybe_regroup(cude_ctx* c) {
     constexpr int64_t kRegroupEvals = 200;
-    if (!adaptive(c) || c->N < 8192 || !c->opt.auto_regroup || !c->have_counts || c->capturing) return CUDE_OK;
+    if (!adaptive(c) || c->N < 8192 || !c->opt.auto_regroup || !c->have_counts || c->capturing || c->net.generic()) return CUDE_OK;
     if (!c->slot_of.empty() && c->evals_since_regroup < kRegroupEvals) { c->evals_since_regroup++; return CUDE_OK; }
     return adaptive_regroup(c, nullptr, nullptr);
 }
 
 int32_t adaptive_regroup(cude_ctx* c, int32_t* spread_before, int32_t* spread_after) {
+    if (c->net.generic()) return fail(CUDE_ERR_UNSUPPORTED, "the fallback kernel of a general network runs in the caller's order");
     if (!adaptive(c) || !c->have_counts) return fail(CUDE_ERR_STATE, "no adaptive evaluation on this context yet");
     const int64_t N = c->N;
     std::vector<int32_t> n_acc((size_t)N);
@@ -622,8 +645,9 @@ int32_t eval_sets_device(cude_ctx* c, int64_t n_sets, const double* nn, int64_t 
                        c->opt.ms_split;
     if ((rc = ensure_tape(c))) return rc;                 // (fixes the capacity the per-set tapes share)
     if ((rc = maybe_regroup(c))) return rc;
-    const int64_t tape_rows = adaptive(c) ? cude::adaptive_tape_rows(supp ? 3 : 2, c->tape_cap, c->T) : 0;
-    const double per_set = 8.0 * ((double)nb * (P + 2) + (double)tape_rows * N +
+    const bool gen = c->net.generic();
+    const int64_t tape_rows = tape_doubles_per_set(c) / N;
+    const double per_set = 8.0 * ((double)nb * (P + 2) + (double)tape_rows * N + (gen ? (double)P * N : 0.0) +
                                   (supp && !adaptive(c) ? (double)cude::supp_ckpt_rows(S, c->T) * N : 0.0) +
                                   (split ? (double)L * (3 + c->T) * N + 5.0 * S * N + (double)L * N + (double)L * nb * P : 0.0));
     // sets per launch: bounded by the grid's y / z dimension and the scratch budget
@@ -636,8 +660,9 @@ int32_t eval_sets_device(cude_ctx* c, int64_t n_sets, const double* nn, int64_t 
         HIP_TRY(c->ms_p2.reserve((size_t)chunk * L * nb * P));
     }
     HIP_TRY(c->ms_part.reserve((size_t)chunk * nb * (P + 2)));
-    if (supp && !adaptive(c)) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * cude::supp_ckpt_rows(S, c->T) * N));
-    if (adaptive(c)) HIP_TRY(c->ms_tape.reserve((size_t)chunk * tape_rows * N));
+    if (supp && !adaptive(c) && !gen) HIP_TRY(c->ms_ckpt.reserve((size_t)chunk * cude::supp_ckpt_rows(S, c->T) * N));
+    if (adaptive(c) || gen) HIP_TRY(c->ms_tape.reserve((size_t)chunk * tape_rows * N));
+    if (gen) HIP_TRY(c->ms_gacc.reserve((size_t)chunk * P * N));
     for (int64_t k0 = 0; k0 < n_sets; k0 += chunk) {
         const int64_t kn = std::min<int64_t>(chunk, n_sets - k0);
         const double* nn_k = nn + k0 * stride_nn;
@@ -661,13 +686,15 @@ int32_t eval_sets_device(cude_ctx* c, int64_t n_sets, const double* nn, int64_t 
             a.cond = cond_k; a.nn = nn_k;
             a.g_cond = g_cond_k; a.partials = c->ms_part.p;
             a.n_sets = (int32_t)kn; a.set_stride_nn = stride_nn; a.set_stride_cond = stride_cond;
-            if (adaptive(c)) a.tape = c->ms_tape.p;     // (tape_n: the counts of set 0, for the re-ordering)
+            if (adaptive(c) || gen) a.tape = c->ms_tape.p;     // (tape_n: the counts of set 0, for the re-ordering)
+            if (gen) a.gen_acc = c->ms_gacc.p;
             HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, true, a, c->stream));     // one-lane kernel: the sets fill the chip
         } else {
             cude::SuppArgs a = supp_args(c);
             a.cond = cond_k; a.nn = nn_k;
             a.ckpt = c->ms_ckpt.p; a.g_cond = g_cond_k; a.partials = c->ms_part.p;
-            if (adaptive(c)) a.tape = c->ms_tape.p;
+            if (adaptive(c) || gen) a.tape = c->ms_tape.p;
+            if (gen) a.gen_acc = c->ms_gacc.p;
             if (!adaptive(c) && !a.ckpt_steps_only && supp_keep_activations(c, kn)) {
                 HIP_TRY(c->ms_act.reserve((size_t)kn * supp_act_doubles(c)));
                 a.act = c->ms_act.p;
@@ -959,8 +986,10 @@ int32_t cude_adaptive_steps(cude_ctx* c, int64_t subject, int32_t cap, double* t
     HIP_TRY(hipMemcpyAsync(&n, c->tape_n.p + subject, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *n_steps = n;
-    const bool supp = c->cfg.model == CUDE_MODEL_SUPP;
-    const int rows = cude::adaptive_tape_rows(supp ? 3 : 2);
+    // (the fallback kernel of a general network keeps (t_n, dt_n, y_n) for either model, as the suppression kernels do)
+    const bool supp = c->cfg.model == CUDE_MODEL_SUPP || c->net.generic();
+    const int rows = c->net.generic() ? 2 + (c->cfg.model == CUDE_MODEL_SUPP ? 3 : c->cfg.n_state)
+                                      : cude::adaptive_tape_rows(supp ? 3 : 2);
     const int m = std::min(std::min(n, cap), c->tape_cap);
     const int64_t slot = c->slot_of.empty() ? subject : c->slot_of[(size_t)subject];      // the tape is in launch order
     if (m < 1) return CUDE_OK;

@@ -508,6 +508,7 @@ static int supp_grad_occupancy() {
     return n;
 }
 int supp_grad_waves_per_cu(const NetShape& net) {
+    if (net.generic()) return 1;
     if (net.general()) return 4;
 #define X(W, D) if (net.width == W && net.depth == D) return supp_grad_occupancy<W, D>();
     CUDE_SUPP_SHAPES(X)
@@ -516,7 +517,7 @@ int supp_grad_waves_per_cu(const NetShape& net) {
 }
 
 bool supp_shape_supported(const NetShape& net) {
-    if (net.nin != 4) return false;
+    if (net.nin != 4 || net.generic()) return false;
     if (net.general()) {
         if (!general_acts_compiled(net.hact, net.oact)) return false;
 #define X(W, D) if (net.width == W && net.depth == D) return true;
@@ -531,6 +532,7 @@ bool supp_shape_supported(const NetShape& net) {
 }
 
 hipError_t launch_supp(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
+    if (net.generic()) return launch_supp_generic(net, grad, a, s);                 // fixed-step and adaptive alike
     if (net.nin != 4) return hipErrorInvalidValue;
     if (a.S == 0) return launch_supp_adaptive(net, grad, a, s);
     if (net.general()) {

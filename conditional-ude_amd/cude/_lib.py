@@ -38,6 +38,8 @@ _SIGNATURES = {
     "cude_n_params": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "cude_create": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "cude_destroy": (C.c_int32, [C.c_void_p]),
+    "cude_set_network": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cude_network_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cude_set_tolerances": (C.c_int32, [C.c_void_p, C.c_double, C.c_double]),
     "cude_adaptive_steps": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "cude_set_rng": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64]),

@@ -98,31 +98,47 @@ class Chain:
     (cude_set_param_mask): parameter vectors have THAT layout (n_params entries, `mask` marks the live ones;
     pad_network / unpad_network convert to and from SimpleChains' own layout)."""
 
-    def __init__(self, input_dims, width, depth, widths=None, activation="tanh", output_activation="softplus"):
+    def __init__(self, input_dims, width, depth, widths=None, activation="tanh", output_activation="softplus",
+                 layer_activations=None):
         self.input_dims, self.width, self.depth = int(input_dims), int(width), int(depth)
         self.widths = None if widths is None else [int(w) for w in widths]
-        # hidden tanh | relu | sigmoid, output softplus | identity: what libcude_hip.so compiles (the reference's
+        # hidden tanh | relu | sigmoid, output softplus | identity: what the tuned kernels compile (the reference's
         # scripts build tanh / softplus networks only; src/neural-network.jl:42-58 accepts any function)
         self.activation, self.output_activation = activation, output_activation
+        # the general form -- one activation function PER hidden layer, any of ACTIVATIONS, any widths: evaluated by the
+        # library's fallback kernel (cude_set_network); parameter vectors then have SimpleChains' own layout, unpadded
+        self.layer_activations = None if layer_activations is None else [str(a) for a in layer_activations]
+        if self.layer_activations is not None and self.widths is None:
+            self.widths = [self.width] * self.depth
+
+    @property
+    def general(self):
+        return self.layer_activations is not None
 
     @property
     def mask(self):
         """1 for the live entries of the padded parameter vector, 0 for the padding; None for equal widths."""
-        if self.widths is None:
+        if self.widths is None or self.general:
             return None
         n = sum(w * f + w for w, f in zip(self.widths + [1], [self.input_dims] + self.widths))
         return (pad_network(self.widths, np.ones(n), input_dims=self.input_dims)[1] != 0.0).astype(np.float64)
 
     @property
     def arch(self):
+        if self.general:        # (Engine: (nn_in, [widths], [activation per hidden layer], output activation))
+            return (self.input_dims, tuple(self.widths), tuple(self.layer_activations), self.output_activation)
         return (self.input_dims, self.width, self.depth)
 
     @property
     def key(self):
+        if self.general:
+            return self.arch
         return self.arch + (tuple(self.widths) if self.widths else ()) + (self.activation, self.output_activation)
 
     def configure(self, engine):
         """tell a fresh engine the activation functions (before the population is uploaded)"""
+        if self.general:        # (the engine was built from `arch`: cude_set_network has been called)
+            return
         if self.activation != "tanh":
             engine.set_option("hidden_activation", self.activation)
         if self.output_activation != "softplus":
@@ -130,6 +146,8 @@ class Chain:
 
     @property
     def n_params(self):
+        if self.general:
+            return _layer_slices(self.input_dims, self.widths)[1]
         p, fan = 0, self.input_dims
         for _ in range(self.depth):
             p += self.width * fan + self.width
@@ -139,6 +157,7 @@ class Chain:
 
 _HIDDEN = ("tanh", "relu", "sigmoid")
 _OUTPUT = ("softplus", "identity")
+ACTIVATIONS = ("tanh", "relu", "sigmoid", "softplus", "identity")       # the fallback kernel: any of these in any layer
 
 
 def chain(width, depth=None, activation="tanh", *, input_dims=2, output_dims=1, output_activation="softplus"):
@@ -152,22 +171,36 @@ def chain(width, depth=None, activation="tanh", *, input_dims=2, output_dims=1, 
             activation = depth
         if len(widths) == 0:
             raise ValueError("Input widths must be non-empty.")
+        if output_dims != 1:
+            raise NotImplementedError("the models of the reference use ONE network output (output_dims = 1)")
+        per_layer = None
         if isinstance(activation, (list, tuple)):
             if len(activation) != len(widths):
                 raise ValueError("The number of widths must match the number of activation functions.")
-            if len({_act_name(a) for a in activation}) != 1:
-                raise NotImplementedError("one activation function for all hidden layers is what the HIP kernels implement")
-            activation = activation[0]
-        act, out = _act_name(activation), _act_name(output_activation)
+            per_layer = [_act_name(a) for a in activation]
+            if len(set(per_layer)) == 1:
+                activation, per_layer = per_layer[0], None
+        out = _act_name(output_activation)
+        act = None if per_layer is not None else _act_name(activation)
+        # what only the fallback kernel evaluates: different functions per layer, softplus / identity hidden layers, other
+        # output functions, unequal widths with anything but tanh / softplus
+        if (per_layer is not None or act not in _HIDDEN or out not in _OUTPUT
+                or (len(set(widths)) != 1 and (act != "tanh" or out != "softplus"))):
+            names = per_layer if per_layer is not None else [act] * len(widths)
+            bad = [a for a in names + [out] if a not in ACTIVATIONS]
+            if bad:
+                raise NotImplementedError(f"activation functions of the library: {ACTIVATIONS} (got {bad})")
+            return Chain(input_dims, max(widths), len(widths), widths=widths, output_activation=out, layer_activations=names)
         if len(set(widths)) != 1:
-            if act != "tanh" or out != "softplus" or output_dims != 1:
-                raise NotImplementedError("unequal hidden widths are compiled for tanh hidden layers with one softplus output")
             return Chain(input_dims, max(widths), len(widths), widths=widths)     # zero-padded + masked (class Chain)
         width, depth = widths[0], len(widths)
     act, out = _act_name(activation), _act_name(output_activation)
-    if act not in _HIDDEN or out not in _OUTPUT or output_dims != 1:
-        raise NotImplementedError(f"compiled into the HIP kernels: hidden activation in {_HIDDEN}, ONE output with "
-                                  f"activation in {_OUTPUT} (got {act!r}, {out!r}, {output_dims} outputs)")
+    if output_dims != 1:
+        raise NotImplementedError("the models of the reference use ONE network output (output_dims = 1)")
+    if act not in _HIDDEN or out not in _OUTPUT:
+        if act not in ACTIVATIONS or out not in ACTIVATIONS:
+            raise NotImplementedError(f"activation functions of the library: {ACTIVATIONS} (got {act!r}, {out!r})")
+        return Chain(input_dims, width, depth, output_activation=out, layer_activations=[act] * int(depth))
     return Chain(input_dims, width, depth, activation=act, output_activation=out)
 
 
@@ -244,6 +277,8 @@ def init_params(net, rng=None):
         parts += [rng.standard_normal(out * fan) * sigma, rng.standard_normal(out) * sigma]
         fan = out
     p = np.concatenate(parts)
+    if getattr(net, "general", False):
+        return p
     return pad_network(net.widths, p, input_dims=net.input_dims)[1] if getattr(net, "widths", None) else p
 
 

@@ -112,7 +112,18 @@ class Engine:
     def __init__(self, model, arch=(1, 0, 0), n_steps=30, n_state=None, lam=0.0, device=0, cond_space="log"):
         self._lib = _lib.load()
         self.model = {"cpep": MODEL_CPEP, "supp": MODEL_SUPP, "cpep_sym": MODEL_CPEP_SYM}[model]
-        self.arch = tuple(int(v) for v in arch)
+        # the general form `chain(widths, activation_functions; input_dims, output_activation)`: arch = (nn_in, [widths],
+        # [one activation per hidden layer], output activation), names as in ACTIVATIONS (cude_set_network)
+        general = None
+        if len(arch) >= 2 and isinstance(arch[1], (list, tuple)):
+            widths = [int(w) for w in arch[1]]
+            hidden = arch[2] if len(arch) > 2 else "tanh"
+            hidden = [hidden] * len(widths) if isinstance(hidden, str) else list(hidden)
+            if len(hidden) != len(widths):
+                raise ValueError("The number of widths must match the number of activation functions.")
+            general = (widths, hidden + [arch[3] if len(arch) > 3 else "softplus"])
+            arch = (arch[0], max(widths), len(widths))
+        self.arch = tuple(int(v) for v in arch[:3])
         if n_state is None:
             n_state = 3 if self.model == MODEL_SUPP else 2
         space = {"log": COND_LOG, "raw": COND_RAW}[cond_space]
@@ -123,9 +134,29 @@ class Engine:
         self._h = h
         self.n_state = n_state
         self.lam = float(lam)
-        self.P = n_params(*self.arch)
         self.N = 0
         self.T = 0
+        if general is not None:
+            self.set_network(*general)
+        self.P, self.fallback_kernel = self.network_info()
+
+    ACTIVATIONS = {"tanh": 0, "relu": 1, "sigmoid": 2, "softplus": 3, "identity": 4}
+
+    def set_network(self, widths, activations):
+        """cude_set_network: per-layer widths and activation names (hidden layers, then the output layer's).  Before the
+        population is uploaded.  Shapes without a tuned kernel run on the fallback kernel (csrc/cude_generic.hip)."""
+        w = (C.c_int32 * len(widths))(*[int(v) for v in widths])
+        a = (C.c_int32 * len(activations))(*[self.ACTIVATIONS[str(v)] for v in activations])
+        if len(activations) != len(widths) + 1:
+            raise ValueError("one activation per hidden layer and one for the output layer")
+        check(self._lib.cude_set_network(self._h, len(widths), w, a))
+        self.P, self.fallback_kernel = self.network_info()
+
+    def network_info(self):
+        """(number of shared parameters, True if the network runs on the fallback kernel)."""
+        p, g = C.c_int32(), C.c_int32()
+        check(self._lib.cude_network_info(self._h, C.byref(p), C.byref(g)))
+        return p.value, bool(g.value)
 
     # -- lifetime
     def close(self):

@@ -378,6 +378,22 @@ function xchg_info(c::Ctx)
     (ranks = Int(n[]), rank = Int(r[]), memory_kind = Int(k[]), timed_out_waits = Int(t[]))
 end
 
+# the general form of `chain(widths, activation_functions; ...)` (src/neural-network.jl:42-58): per-layer widths and one
+# activation code per hidden layer + the output layer's (include/cude.h CUDE_ACT_*); before the population is uploaded
+const ACTIVATION_CODES = Dict(:tanh => 0, :relu => 1, :sigmoid => 2, :softplus => 3, :identity => 4)
+function set_network!(c::Ctx, widths::AbstractVector{<:Integer}, activations::AbstractVector{Symbol})
+    length(activations) == length(widths) + 1 || throw(ArgumentError("one activation per hidden layer and one for the output layer"))
+    w = Int32.(widths); a = Int32[ACTIVATION_CODES[f] for f in activations]
+    GC.@preserve w a check(ccall((:cude_set_network, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}), c.h, length(w), w, a))
+    c.P = network_info(c).n_params
+    c
+end
+function network_info(c::Ctx)
+    p = Ref{Int32}(); g = Ref{Int32}()
+    check(ccall((:cude_network_info, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), c.h, p, g))
+    (n_params = Int(p[]), fallback_kernel = g[] != 0)
+end
+
 # run-time options of a context (launch-path override, auto_regroup, poll_pinned ...: include/cude.h)
 set_option!(c::Ctx, name::AbstractString, value) =
     check(ccall((:cude_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Cstring), c.h, name, string(value)))

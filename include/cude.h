@@ -81,7 +81,28 @@ int32_t cude_device_count(int32_t* count);
  * model (CUDE_MODEL_CPEP_SYM): 1 shared parameter. */
 int32_t cude_n_params(int32_t nn_in, int32_t nn_width, int32_t nn_depth);
 
+/* Any (nn_in, nn_width, nn_depth) is accepted for the network models: shapes a tuned kernel is compiled for (24 c-peptide
+ * + 16 suppression shapes, widths <= 8) run on it, every other on the fallback kernel of cude_set_network below. */
 int32_t cude_create(const cude_config* cfg, cude_ctx** out);
+/* The general form of `chain(widths, activation_functions; input_dims, output_dims = 1, output_activation)`,
+ * src/neural-network.jl:42-58 (the docstring's example: chain([10, 20, 30], [tanh, relu, softplus]; input_dims = 4)):
+ * n_hidden layer widths and n_hidden + 1 activation codes, one per hidden layer and the output layer's last.  Replaces the
+ * network of the context (cfg.nn_in stays; call it after cude_create and before the population is uploaded); the parameter
+ * vector is SimpleChains' [vec_colmajor(W); b] per layer and cude_network_info tells its length.  One width, tanh in every
+ * hidden layer, softplus at the output and a tuned kernel compiled for it: that kernel; anything else runs on the
+ * fallback kernel (csrc/cude_generic.hip: run-time shape, weights staged once per workgroup in LDS, one lane per
+ * subject, fixed-step and adaptive, forward and adjoint, both network models) -- every entry point of this header works
+ * on it except cude_adaptive_regroup; built for generality, not for speed.  CUDE_ERR_UNSUPPORTED only when the weights
+ * and one activation column per lane exceed the 160 KB of LDS of a workgroup (sum of widths around 250) or for more
+ * than 8 hidden layers. */
+#define CUDE_ACT_TANH 0
+#define CUDE_ACT_RELU 1
+#define CUDE_ACT_SIGMOID 2
+#define CUDE_ACT_SOFTPLUS 3
+#define CUDE_ACT_IDENTITY 4
+int32_t cude_set_network(cude_ctx* ctx, int32_t n_hidden, const int32_t* widths, const int32_t* activations);
+/* Length of the context's shared parameter vector and whether its network runs on the fallback kernel (1) or a tuned one (0). */
+int32_t cude_network_info(cude_ctx* ctx, int32_t* n_params, int32_t* fallback_kernel);
 int32_t cude_destroy(cude_ctx* ctx);
 /* Tolerances of the adaptive mode (cude_config.n_steps = 0): `solve(...; abstol, reltol)`; the defaults 1e-6 / 1e-3
  * are OrdinaryDiffEq's, which every solve call of the reference uses (src/parameter-estimation.jl:59, src/saem.jl:52,
@@ -411,9 +432,10 @@ int32_t cude_xchg_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* 
  * 2-4-4-1, 2-6-6-1, 3-4-4-1 (c-peptide) and 4-3x5-1, 4-3x3-1 (suppression): CUDE_ERR_UNSUPPORTED otherwise.
  * Implementation switches (cude_ctx.h `Options` lists them): launch-path override of the tests ("cpep_path" = "1" |
  * "2:L" | "3:B:L"), "cpep_keep", "supp_store", "supp_ckpt", "tape_steps", "exp_table", "ms_split", "auto_regroup",
- * "poll_pinned", "debug_selector", "xchg_allow_plain", "xchg_fail_kinds" (tests).  Values are decimal integers as text unless noted.  Every option is also read once
+ * "poll_pinned", "debug_selector", "xchg_allow_plain", "xchg_fail_kinds" (tests), "force_fallback" (tests: cude_set_network takes the fallback kernel for tuned shapes too), "mh_spec" (speculative Metropolis steps per
+ * launch pair in cude_mh_estep / cude_mh_chain: 0 off, 2 ... 4, -1 = by population size; the chain is the same bit for bit).  Values are decimal integers as text unless noted.  Every option is also read once
  * at cude_create from its environment variable (CUDE_CPEP_PATH, CUDE_CPEP_KEEP, CUDE_SUPP_STORE, CUDE_SUPP_CKPT,
- * CUDE_TAPE_STEPS, CUDE_NO_EXPTAB, CUDE_NO_MS_SPLIT, CUDE_NO_AUTO_REGROUP, CUDE_NO_POLL_PINNED, CUDE_DEBUG_SELECTOR, CUDE_ALLOW_PLAIN_MAILBOX, CUDE_XCHG_FAIL_KINDS).
+ * CUDE_TAPE_STEPS, CUDE_NO_EXPTAB, CUDE_NO_MS_SPLIT, CUDE_NO_AUTO_REGROUP, CUDE_NO_POLL_PINNED, CUDE_DEBUG_SELECTOR, CUDE_ALLOW_PLAIN_MAILBOX, CUDE_XCHG_FAIL_KINDS, CUDE_MH_SPEC).
  * Options that shape the launch path take effect at the next cude_set_population_*.  No reference line: these are
  * properties of this implementation. */
 int32_t cude_set_option(cude_ctx* ctx, const char* name, const char* value);

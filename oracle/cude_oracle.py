@@ -110,7 +110,19 @@ def locate_observations(timepoints, n_steps):
 SYMBOLIC = (1, 0, 0)     # "architecture" of the analytic production model: one shared parameter p0
 
 
+def general_arch(arch):
+    """`chain(widths, activation_functions; input_dims, output_activation)` in its general form (src/neural-network.jl:
+    42-58): arch = (nin, (w1, w2, ...), (act1, act2, ...), output_act) -- widths and activation names per hidden layer."""
+    return len(arch) >= 2 and isinstance(arch[1], (list, tuple))
+
+
 def n_params(arch):
+    if general_arch(arch):
+        p, fan = 0, arch[0]
+        for w in list(arch[1]) + [1]:
+            p += w * fan + w
+            fan = w
+        return p
     nin, width, depth = arch[:3]
     if width == 0:
         return 1
@@ -139,19 +151,26 @@ def _relu(xp, z):
 # reference's scripts pass tanh and softplus.  An `arch` tuple may name others behind its three sizes:
 # (nin, width, depth, hidden, output) with hidden in HIDDEN_ACTS and output in OUTPUT_ACTS.
 HIDDEN_ACTS = {"tanh": lambda xp, z: xp.tanh(z), "relu": _relu,
-               "sigmoid": lambda xp, z: 1.0 / (1.0 + xp.exp(-z)), "identity": lambda xp, z: z}
+               "sigmoid": lambda xp, z: 1.0 / (1.0 + xp.exp(-z)), "identity": lambda xp, z: z, "softplus": softplus}
 OUTPUT_ACTS = {"softplus": softplus, "identity": lambda xp, z: z}
 
 
 def mlp(xp, inputs, p, arch):
     """inputs: list of nin arrays (N,) or scalars; p: (P,) parameter vector.
     Returns the scalar network output per subject (N,)."""
-    nin, width, depth = arch[:3]
-    act = HIDDEN_ACTS[arch[3] if len(arch) > 3 else "tanh"]
-    out = OUTPUT_ACTS[arch[4] if len(arch) > 4 else "softplus"]
+    if general_arch(arch):
+        nin, widths = arch[0], list(arch[1])
+        names = arch[2] if len(arch) > 2 else "tanh"
+        acts = [HIDDEN_ACTS[names]] * len(widths) if isinstance(names, str) else [HIDDEN_ACTS[a] for a in names]
+        out = HIDDEN_ACTS[arch[3] if len(arch) > 3 else "softplus"]
+    else:
+        nin, width, depth = arch[:3]
+        widths = [width] * depth
+        acts = [HIDDEN_ACTS[arch[3] if len(arch) > 3 else "tanh"]] * depth
+        out = OUTPUT_ACTS[arch[4] if len(arch) > 4 else "softplus"]
     h = list(inputs)
     off, fan_in = 0, nin
-    for _ in range(depth):
+    for width, act in zip(widths, acts):
         nxt = []
         for j in range(width):
             z = p[off + fan_in * width + j]                      # bias
@@ -691,6 +710,13 @@ def synthetic_cpep_population(N, seed=20250905):
 
 def glorot_params(arch, seed):
     rng = np.random.default_rng(seed)
+    if general_arch(arch):
+        parts, fan_in = [], arch[0]
+        for width in list(arch[1]) + [1]:
+            parts.append(rng.standard_normal(width * fan_in) * math.sqrt(2.0 / (fan_in + width)))
+            parts.append(0.1 * rng.standard_normal(width))       # (non-zero biases: every entry of the gradient is exercised)
+            fan_in = width
+        return np.concatenate(parts)
     nin, width, depth = arch[:3]
     parts, fan_in = [], nin
     for _ in range(depth):
