@@ -263,10 +263,19 @@ struct StageRows<NS, true> {
 };
 
 constexpr int kUnrolledKnots = 5;                  // the reference's five sampling times (c-peptide/02-conditional.jl)
-#define CUDE_CPEP_AD_SHAPES(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
+// (three groups: the two integrators compile them as separate translation units, cude_adaptive*.hip + -DCUDE_AD_PART=k)
+#define CUDE_CPEP_AD_SHAPES_0(X) X(2, 4, 2) X(2, 6, 2) X(3, 4, 2) X(2, 8, 2) X(2, 4, 3) X(2, 3, 2) X(2, 5, 2) X(2, 7, 2)
+#define CUDE_CPEP_AD_SHAPES_1(X) X(3, 6, 2) X(2, 4, 1) X(2, 6, 1) X(2, 6, 3) X(2, 8, 1) X(2, 8, 3) X(3, 8, 2) X(2, 3, 1)
+#define CUDE_CPEP_AD_SHAPES_2(X) X(2, 5, 1) X(2, 7, 1) X(2, 3, 3) X(2, 5, 3) X(2, 7, 3) X(3, 4, 1) X(3, 6, 1) X(3, 4, 3)
+#define CUDE_CPEP_AD_SHAPES(X) CUDE_CPEP_AD_SHAPES_0(X) CUDE_CPEP_AD_SHAPES_1(X) CUDE_CPEP_AD_SHAPES_2(X)
 // cude_adaptive_unrolled.hip: the c-peptide MLP shapes above and the symbolic model on grids of at most kUnrolledKnots times; hipErrorNotSupported
 // for any other shape (the caller then runs the phase-machine kernel)
 hipError_t launch_cpep_adaptive_unrolled(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
+// shape groups 1 and 2 of either integrator (their own translation units); hipErrorNotSupported = not in this group
+hipError_t launch_cpep_adaptive_unrolled_part1(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
+hipError_t launch_cpep_adaptive_unrolled_part2(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
+hipError_t launch_cpep_adaptive_part1(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
+hipError_t launch_cpep_adaptive_part2(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
 // cude_adaptive_unrolled_supp.hip: the suppression model, shapes of the reference's experiments
 #define CUDE_SUPP_AD_UNROLLED(X) X(3, 5) X(3, 3) X(3, 4) X(3, 2)
 hipError_t launch_supp_adaptive_unrolled(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s);

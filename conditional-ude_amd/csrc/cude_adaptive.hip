@@ -522,7 +522,17 @@ static hipError_t launch_adaptive(const typename M::Args& a, int extra_rows, boo
     return hipGetLastError();
 }
 
+#ifndef CUDE_AD_PART
+#define CUDE_AD_PART 0
+#endif
+#if CUDE_AD_PART == 0
+// the one-body kernel of the suppression shapes the unrolled kernel does not cover (cude_adaptive.h CUDE_SUPP_AD_UNROLLED
+// lists those it does; A/B builds with -DCUDE_ADAPT_ONE_BODY compile them here as well)
+#ifdef CUDE_ADAPT_ONE_BODY
 #define CUDE_SUPP_AD_SHAPES(X) X(3, 5) X(3, 2) X(4, 2) X(6, 2) X(5, 2) X(3, 3) X(8, 2) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
+#else
+#define CUDE_SUPP_AD_SHAPES(X) X(4, 2) X(6, 2) X(5, 2) X(8, 2) X(4, 3) X(4, 4) X(5, 3) X(6, 3) X(3, 1) X(4, 1) X(6, 1) X(8, 1)
+#endif
 
 // (the shapes compiled with the other activation functions: as CUDE_CPEP_GENERAL_SHAPES / CUDE_SUPP_GENERAL_SHAPES)
 template <int NIN, int W, int D>
@@ -561,9 +571,11 @@ hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& 
     }
 #define X(NIN, W, D) \
     if (net.nin == NIN && net.width == W && net.depth == D) return launch_adaptive<CpepAd<Mlp<NIN, W, D, 1>>, true>(a, a.TG, grad, s);
-    CUDE_CPEP_AD_SHAPES(X)
+    CUDE_CPEP_AD_SHAPES_0(X)
 #undef X
-    return hipErrorInvalidValue;
+    hipError_t e = launch_cpep_adaptive_part1(net, grad, a, s);
+    if (e == hipErrorNotSupported) e = launch_cpep_adaptive_part2(net, grad, a, s);
+    return e == hipErrorNotSupported ? hipErrorInvalidValue : e;
 }
 
 hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& a, hipStream_t s) {
@@ -585,5 +597,22 @@ hipError_t launch_supp_adaptive(const NetShape& net, bool grad, const SuppArgs& 
 #undef X
     return hipErrorInvalidValue;
 }
+#elif CUDE_AD_PART == 1
+hipError_t launch_cpep_adaptive_part1(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
+#define X(NIN, W, D) \
+    if (net.nin == NIN && net.width == W && net.depth == D) return launch_adaptive<CpepAd<Mlp<NIN, W, D, 1>>, true>(a, a.TG, grad, s);
+    CUDE_CPEP_AD_SHAPES_1(X)
+#undef X
+    return hipErrorNotSupported;
+}
+#else
+hipError_t launch_cpep_adaptive_part2(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
+#define X(NIN, W, D) \
+    if (net.nin == NIN && net.width == W && net.depth == D) return launch_adaptive<CpepAd<Mlp<NIN, W, D, 1>>, true>(a, a.TG, grad, s);
+    CUDE_CPEP_AD_SHAPES_2(X)
+#undef X
+    return hipErrorNotSupported;
+}
+#endif
 
 }  // namespace cude

@@ -349,6 +349,10 @@ static hipError_t launch_unrolled(const typename M::Args& a, bool grad, hipStrea
     return hipGetLastError();
 }
 
+#ifndef CUDE_AD_PART
+#define CUDE_AD_PART 0
+#endif
+#if CUDE_AD_PART == 0
 hipError_t launch_cpep_adaptive_unrolled(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
     if (net.general()) return hipErrorNotSupported;
     if (a.TG < 2 || a.TG > kUnrolledKnots || a.T < 1) return hipErrorNotSupported;
@@ -357,9 +361,27 @@ hipError_t launch_cpep_adaptive_unrolled(const NetShape& net, bool grad, const C
         return a.cond_raw ? launch_unrolled<CpepAd<MmProd<true>>>(a, grad, s) : launch_unrolled<CpepAd<MmProd<false>>>(a, grad, s);
 #define X(NIN, W, D) \
     if (net.nin == NIN && net.width == W && net.depth == D) return launch_unrolled<CpepAd<Mlp<NIN, W, D, 1>>>(a, grad, s);
-    CUDE_CPEP_AD_SHAPES(X)
+    CUDE_CPEP_AD_SHAPES_0(X)
+#undef X
+    const hipError_t e = launch_cpep_adaptive_unrolled_part1(net, grad, a, s);
+    return e != hipErrorNotSupported ? e : launch_cpep_adaptive_unrolled_part2(net, grad, a, s);
+}
+#elif CUDE_AD_PART == 1
+hipError_t launch_cpep_adaptive_unrolled_part1(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
+#define X(NIN, W, D) \
+    if (net.nin == NIN && net.width == W && net.depth == D) return launch_unrolled<CpepAd<Mlp<NIN, W, D, 1>>>(a, grad, s);
+    CUDE_CPEP_AD_SHAPES_1(X)
 #undef X
     return hipErrorNotSupported;
 }
+#else
+hipError_t launch_cpep_adaptive_unrolled_part2(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
+#define X(NIN, W, D) \
+    if (net.nin == NIN && net.width == W && net.depth == D) return launch_unrolled<CpepAd<Mlp<NIN, W, D, 1>>>(a, grad, s);
+    CUDE_CPEP_AD_SHAPES_2(X)
+#undef X
+    return hipErrorNotSupported;
+}
+#endif
 
 }  // namespace cude

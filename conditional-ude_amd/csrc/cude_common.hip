@@ -69,14 +69,11 @@ __device__ __forceinline__ void adam_advance(const TailAdvance& a, double loss_s
 // before it is stored, so that `out` holds the sum over ALL ranks' subjects -- no collective launch behind this one,
 // and the tail workgroup advances the optimiser state with the GLOBAL pair.  With adv the tail workgroup exchanges the
 // loss column as well and the loss column's own workgroup stores nothing.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
-                                                              int stride, int col0, double* __restrict__ out,
-                                                              const double* __restrict__ mask, int n_mask, int out_stride,
-                                                              int accumulate, TailAdvance adv, double* host_tail,
-                                                              XchgArgs xchg) {
-    __shared__ double s[256];
-    __shared__ double s2[256];
-    const int q = col0 + blockIdx.x;
+// (the body of reduce_partials_kernel for column q; shared with chunked_tail_kernel so that both form the same bits)
+__device__ __forceinline__ void reduce_column(const double* __restrict__ partials, int64_t nblocks, int stride, int q,
+                                              double* __restrict__ out, const double* __restrict__ mask, int n_mask,
+                                              int out_stride, int accumulate, const TailAdvance& adv, double* host_tail,
+                                              const XchgArgs& xchg, double* s, double* s2) {
     const bool tail = adv.state != nullptr && q == stride - 1 && blockIdx.y == 0;      // wave-uniform
     const bool xc = xchg.seq != nullptr && blockIdx.y == 0;
     if (xc && adv.state != nullptr && q == stride - 2) return;     // the tail workgroup exchanges and stores this column
@@ -117,6 +114,48 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
         if (host_tail != nullptr && q >= stride - 2 && blockIdx.y == 0) host_tail[q - (stride - 2)] = vq;
         if (tail) adam_advance(adv, loss, vq);
     }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t nblocks,
+                                                              int stride, int col0, double* __restrict__ out,
+                                                              const double* __restrict__ mask, int n_mask, int out_stride,
+                                                              int accumulate, TailAdvance adv, double* host_tail,
+                                                              XchgArgs xchg) {
+    __shared__ double s[256];
+    __shared__ double s2[256];
+    reduce_column(partials, nblocks, stride, col0 + blockIdx.x, out, mask, n_mask, out_stride, accumulate, adv, host_tail, xchg,
+                  s, s2);
+}
+
+// Tail of a time-split gradient evaluation in ONE launch (round 5; three before: at the reference's population sizes every
+// launch of the dependent chain costs ~5 us whatever it does): workgroups [0, P) reduce the network-gradient columns over
+// the reverse chunks' rows (partials2, stride P), workgroups P and P + 1 the loss / failure columns over the scan's rows
+// (partials, stride P + 2; tail work as in reduce_partials_kernel), the workgroups behind them add up the chunks' shares
+// of d loss / d conditional (what cpep2_sum_chunks_kernel does).  Each output is formed by the code that formed it before.
+__global__ __launch_bounds__(256) void chunked_tail_kernel(ChunkedTailArgs a) {
+    __shared__ double s[256];
+    __shared__ double s2[256];
+    const int q = blockIdx.x;
+    if (q < a.P) {
+        reduce_column(a.partials2, a.rows2, a.P, q, a.out, a.mask, a.n_mask, a.out_stride, 0, TailAdvance{}, nullptr, a.xchg, s, s2);
+    } else if (q < a.P + 2) {
+        reduce_column(a.partials, a.rows, a.P + 2, q, a.out, nullptr, 0, a.out_stride, 0, a.adv, a.host_tail, a.xchg, s, s2);
+    } else {
+        const int64_t i = ((int64_t)(q - a.P - 2)) * 256 + threadIdx.x;
+        if (i >= a.N) return;
+        const double* part = a.g_cond_part + (int64_t)blockIdx.y * a.L * a.N;
+        double v = 0.0;
+        for (int c = 0; c < a.L; c++) v += part[(int64_t)c * a.N + i];
+        a.g_cond[(int64_t)blockIdx.y * a.g_cond_set_stride + i] = v;
+    }
+}
+
+hipError_t launch_chunked_tail(const ChunkedTailArgs& a, int n_sets, hipStream_t s) {
+    if (a.P < 1 || a.out_stride < a.P + 2 || n_sets < 1) return hipErrorInvalidValue;
+    if (a.xchg.seq != nullptr && (n_sets != 1 || a.P + 2 > a.xchg.cols)) return hipErrorInvalidValue;
+    const unsigned gblocks = a.g_cond_part != nullptr ? (unsigned)((a.N + 255) / 256) : 0u;
+    hipLaunchKernelGGL(chunked_tail_kernel, dim3((unsigned)a.P + 2u + gblocks, (unsigned)n_sets), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 // reduces columns [col0, col0+ncol) of partials[nblocks][stride] into out[col0..]

@@ -188,6 +188,7 @@ const OptionEntry kOptions[] = {
     {"mixed_one_stream", "CUDE_MIXED_ONE_STREAM", &Options::mixed_one_stream, false, true},
     {"fwd_split", "CUDE_NO_FWD_SPLIT", &Options::fwd_split, true, true},
     {"fused_final", "CUDE_NO_FUSED_FINAL", &Options::fused_final, true, true},
+    {"fused_tail", "CUDE_NO_FUSED_TAIL", &Options::fused_tail, true, true},
     {"mh_fuse", "CUDE_NO_MH_FUSE", &Options::mh_fuse, true, true},
     {"graph", "CUDE_NO_GRAPH", &Options::graph, true, true},
     {"graph_unroll", "CUDE_GRAPH_UNROLL", &Options::graph_unroll, false, true},

@@ -224,8 +224,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
 
 // ---------------------------------------------------------------------------------- scan + residuals
 __device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, cptr_t obs_w, ciptr_t obs_step,
-                                         const double* s_res, int lane, int n, int& oi, double& lam1, double& lam2,
-                                         double& kap1, double& kap2, double (&w)[5]);
+                                         const double* s_res, int lane, int n, int& oi, int& oi_step, double& lam1,
+                                         double& lam2, double& kap1, double& kap2, double (&w)[5]);
 
 // Stitches the chunks (affine maps), forms residuals / SSE, and -- for the gradient -- runs the network-free
 // stage-adjoint recursion ONCE per subject, storing the 5 network weights of every step (wts[5S][N]) so that
@@ -300,9 +300,10 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
         double lam1 = 0.0, lam2 = 0.0, kap1 = 0.0, kap2 = 0.0, w[5];
         const double gscale = 2.0 * b.inv_n;
         oi = T - 1;
+        int oi_step = obs_step[oi];
 #pragma unroll 1
         for (int n = b.S - 1; n >= 0; n--) {
-            adj_step(kin, b.h, gscale, obs_w, obs_step, s_res, lane, n, oi, lam1, lam2, kap1, kap2, w);
+            adj_step(kin, b.h, gscale, obs_w, obs_step, s_res, lane, n, oi, oi_step, lam1, lam2, kap1, kap2, w);
             if (active) {
 #pragma unroll
                 for (int j = 0; j < 5; j++) wts[(int64_t)(5 * n + j) * N + i] = w[j];
@@ -323,22 +324,25 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
 // ---------------------------------------------------------------------------------- reverse sweep
 // Stage-adjoint algebra of one step (J_f = A): consumes the adjoint (lam, kap) of (y_{n+1}, k_7), the
 // observation seeds of the step, and returns the adjoint of (y_n, k_1) plus the 5 network weights.
+// oi_step = obs_step[oi] (-1 when oi < 0), kept in a register by the caller: the step index is compared against it, and
+// the table is read again only when an observation has been consumed (a scalar round trip per STEP before)
 __device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, cptr_t obs_w, ciptr_t obs_step,
-                                         const double* s_res, int lane, int n, int& oi, double& lam1, double& lam2,
-                                         double& kap1, double& kap2, double (&w)[5]) {
+                                         const double* s_res, int lane, int n, int& oi, int& oi_step, double& lam1,
+                                         double& lam2, double& kap1, double& kap2, double (&w)[5]) {
     double kb[7][2];
 #pragma unroll
     for (int j = 0; j < 6; j++) { kb[j][0] = 0.0; kb[j][1] = 0.0; }
     kb[6][0] = kap1;
     kb[6][1] = kap2;
     double yb1 = 0.0, yb2 = 0.0;
-    while (oi >= 0 && obs_step[oi] == n) {
+    while (oi_step == n) {
         const double g = gscale * s_res[oi * kBlock + lane];
         yb1 += g;
         const double hg = h * g;
 #pragma unroll
         for (int j = 0; j < 7; j++) kb[j][0] = fma(obs_w[oi * 7 + j], hg, kb[j][0]);
         oi--;
+        oi_step = oi >= 0 ? obs_step[oi] : -1;
     }
     lam1 = fma(k.a11, kb[6][0], fma(k.a21, kb[6][1], lam1));
     lam2 = fma(k.a12, kb[6][0], fma(k.a22, kb[6][1], lam2));
@@ -560,6 +564,7 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     constexpr int TABROWS = Net::HAS_TAB ? 5 * W : 0;
     const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;
     hipLaunchKernelGGL((cpep2_rev_kernel<NIN, W, D>), grid2, dim3(kBlock), lds_r, s, a);
+    if (a.defer_chunk_sum && a.base.blk0 == 0) return hipGetLastError();
     const int bs = 256;
     const int64_t i0 = a.base.blk0 * kBlock;
     hipLaunchKernelGGL(cpep2_sum_chunks_kernel, dim3((unsigned)((a.base.N - i0 + bs - 1) / bs), n_sets), dim3(bs), 0, s,

@@ -85,6 +85,7 @@ struct Options {
     int mixed_one_stream = 0;   // CUDE_MIXED_ONE_STREAM
     int fwd_split = 1;          // CUDE_NO_FWD_SPLIT
     int fused_final = 1;        // CUDE_NO_FUSED_FINAL
+    int fused_tail = 1;         // CUDE_NO_FUSED_TAIL: tail of a time-split gradient evaluation in one launch (round 5)
     int mh_fuse = 1;            // CUDE_NO_MH_FUSE
     int graph = 1;              // CUDE_NO_GRAPH
     int graph_unroll = 8;       // CUDE_GRAPH_UNROLL

@@ -188,6 +188,7 @@ struct Cpep2Args {
     // idles) and resolve the round right behind the SSEs -- no reduction, no resolver launch
     int32_t spec_slots;
     MhSpecArgs spec;
+    int32_t defer_chunk_sum;     // gradient launches: leave g_cond_part to the caller's launch_chunked_tail (no sum_chunks launch)
 };
 bool cpep2_shape_supported(const NetShape& net, int n_state);
 int cpep2_rev_waves_per_cu(const NetShape& net);
@@ -285,6 +286,19 @@ hipError_t launch_reduce_cols(const double* partials, int64_t nblocks, int strid
                               const TailAdvance* adv = nullptr,
                               double* host_tail = nullptr /* page-locked [2]: the sums of the last two columns as well */,
                               const XchgArgs* xchg = nullptr);
+// The whole tail of a time-split gradient evaluation as ONE launch (chunked_tail_kernel, cude_common.hip): the network
+// gradient from the reverse chunks' rows, the loss / failure columns from the scan's rows (with the tail work of
+// launch_reduce_cols), and the chunks' shares of d loss / d conditional added up (g_cond_part == nullptr: not that part).
+struct ChunkedTailArgs {
+    const double* partials2; int64_t rows2;    // [n_sets][rows2][P]
+    const double* partials; int64_t rows;      // [n_sets][rows][P + 2]
+    int P;
+    double* out; int out_stride;               // [n_sets][out_stride >= P + 2]
+    const double* mask; int n_mask;
+    TailAdvance adv; double* host_tail; XchgArgs xchg;
+    const double* g_cond_part; int L; int64_t N; double* g_cond; int64_t g_cond_set_stride;
+};
+hipError_t launch_chunked_tail(const ChunkedTailArgs& a, int n_sets, hipStream_t s);
 // buf[0..count) <- sum (op 0) / max (op 1) over the ranks, in place, through the exchange (any count: columns in turn)
 hipError_t launch_xchg_allreduce(const XchgArgs& x, double* buf, int64_t count, int op, hipStream_t s);
 hipError_t launch_adam_advance(const TailAdvance& adv, const double* g_tail, hipStream_t s);

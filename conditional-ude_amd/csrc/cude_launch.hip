@@ -394,6 +394,7 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only, 
                     for (int64_t q = 0; q < 2 * c->nblocks; q++) w[q] = kPairSentinel;
                 }
             }
+            a2.defer_chunk_sum = grad && c->blk0 == 0 && c->opt.fused_tail;      // (summed by the one tail launch below)
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, grad, a2, c->stream));
         } else {
             if (grad && !adaptive(c)) a.prio_shift = prio_shift_for(c, c->nblocks);
@@ -450,6 +451,19 @@ int32_t run_ensemble(cude_ctx* c, bool grad, double* traj_dev, bool local_only, 
                                          c->param_mask.p, P, 0, /*accumulate=*/true, nullptr, nullptr, xq));
         HIP_TRY(cude::launch_reduce_cols(c->partials.p, c->nblocks, P + 2, P, 2, c->g_nn.p, c->stream, 1, nullptr, 0, 0, false,
                                          adv_red, host_tail, xq));
+    } else if (grad && is_cpep(c) && c->chunks > 1 && c->opt.fused_tail) {
+        // one launch: the network gradient over the reverse chunks' rows, the loss / failure columns over the scan's rows
+        // (+ state advance, page-locked pair, exchange) and the chunks' shares of the conditional gradient
+        cude::ChunkedTailArgs ta{};
+        ta.partials2 = c->partials2.p; ta.rows2 = c->nblocks * c->chunks;
+        ta.partials = c->partials.p; ta.rows = c->nblocks;
+        ta.P = P; ta.out = c->g_nn.p; ta.out_stride = P + 2;
+        ta.mask = c->param_mask.p; ta.n_mask = P;
+        if (adv_red) ta.adv = *adv_red;
+        ta.host_tail = host_tail;
+        if (xq) ta.xchg = *xq;
+        ta.g_cond_part = c->g_cond_part.p; ta.L = c->chunks; ta.N = c->N; ta.g_cond = c->g_cond.p; ta.g_cond_set_stride = c->N;
+        HIP_TRY(cude::launch_chunked_tail(ta, 1, c->stream));
     } else if (grad && is_cpep(c) && c->chunks > 1) {
         HIP_TRY(cude::launch_reduce_cols(c->partials2.p, c->nblocks * c->chunks, P, 0, P, c->g_nn.p, c->stream, 1,
                                          c->param_mask.p, P, 0, false, nullptr, nullptr, xq));
@@ -677,10 +691,19 @@ int32_t eval_sets_device(cude_ctx* c, int64_t n_sets, const double* nn, int64_t 
             a.n_sets = (int32_t)kn; a.set_stride_nn = stride_nn; a.set_stride_cond = stride_cond;
             cude::Cpep2Args a2 = chunk_args(c, a);
             a2.fsum = c->ms_fsum.p; a2.wts = c->ms_wts.p; a2.g_cond_part = c->ms_gcp.p; a2.partials2 = c->ms_p2.p;
+            a2.defer_chunk_sum = c->opt.fused_tail;
             HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, true, a2, c->stream));
             // network gradient: the reverse chunks' partial rows; loss / failure columns: the scan's
-            HIP_TRY(cude::launch_reduce_cols(c->ms_p2.p, nb * L, P, 0, P, out_k, c->stream, (int)kn, c->param_mask.p, P, P + 2));
-            HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, P, 2, out_k, c->stream, (int)kn));
+            if (c->opt.fused_tail) {
+                cude::ChunkedTailArgs ta{};
+                ta.partials2 = c->ms_p2.p; ta.rows2 = nb * L; ta.partials = c->ms_part.p; ta.rows = nb;
+                ta.P = P; ta.out = out_k; ta.out_stride = P + 2; ta.mask = c->param_mask.p; ta.n_mask = P;
+                ta.g_cond_part = c->ms_gcp.p; ta.L = L; ta.N = N; ta.g_cond = g_cond_k; ta.g_cond_set_stride = stride_cond;
+                HIP_TRY(cude::launch_chunked_tail(ta, (int)kn, c->stream));
+            } else {
+                HIP_TRY(cude::launch_reduce_cols(c->ms_p2.p, nb * L, P, 0, P, out_k, c->stream, (int)kn, c->param_mask.p, P, P + 2));
+                HIP_TRY(cude::launch_reduce_cols(c->ms_part.p, nb, P + 2, P, 2, out_k, c->stream, (int)kn));
+            }
         } else if (!supp) {
             cude::CpepArgs a = cpep_args(c);
             a.cond = cond_k; a.nn = nn_k;

@@ -96,8 +96,20 @@ def test_adaptive_mode_and_the_api_with_other_activation_functions():
     with pytest.raises(NotImplementedError):
         api.chain(4, 2, "gelu")
     from cude.engine import Engine, CudeError
+    # a shape the other activation functions are not compiled for: the fallback kernel takes it (round 5; CUDE_ERR_UNSUPPORTED before)
+    eng = Engine("cpep", (2, 8, 2), n_steps=30, n_state=2)
+    assert not eng.fallback_kernel
+    eng.set_option("hidden_activation", "relu")
+    assert eng.network_info() == (eng.P, True)
+    arch8 = (2, 8, 2, "relu", "softplus")
+    nn8 = o.glorot_params((2, 8, 2), 3)
+    eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+    eng.set_params(nn8, c["beta"])
+    want8 = float(o.cpep_loss(np, nn8, c["beta"], pop, arch8, 30)[0])
+    assert abs(eng.forward()["loss"] - want8) <= 1e-10 * abs(want8)
+    eng.close()
     eng = Engine("cpep", (2, 8, 2), n_steps=30, n_state=2)
     with pytest.raises(CudeError) as ei:
-        eng.set_option("hidden_activation", "relu")               # compiled for the reference's shapes only
+        eng.set_option("hidden_activation", "gelu")
     assert ei.value.status == -4
     eng.close()

@@ -422,8 +422,13 @@ def test_size_limits_and_missing_values():
 def test_argument_errors_are_statuses():
     from cude.engine import Engine
     from cude._lib import CudeError
+    wide = Engine("cpep", (2, 9, 2))                   # no tuned kernel for width 9: the fallback kernel (round 5; an error before)
+    assert wide.fallback_kernel
+    wide.close()
     with pytest.raises(CudeError):
-        Engine("cpep", (2, 9, 2))                      # shape not compiled in -> CUDE_ERR_UNSUPPORTED
+        Engine("cpep", (2, 200, 4))                    # ... which refuses what does not fit a workgroup's LDS -> CUDE_ERR_UNSUPPORTED
+    with pytest.raises(CudeError):
+        Engine("cpep", (4, 4, 2))                      # four network inputs: not a c-peptide network
     eng = Engine("cpep", (2, 4, 2))
     with pytest.raises(CudeError):
         eng.forward()                                  # population not set
