@@ -250,43 +250,79 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
     const int64_t set = SPEC && set_raw >= b.n_sets ? 0 : set_raw;           // (the idle slot re-reads set 0, writes nothing)
     const double* const fsum = a.fsum + set * ((int64_t)a.L * (3 + T) * N);
     double* const wts = a.wts != nullptr ? a.wts + set * ((int64_t)5 * b.S * N) : nullptr;
-    double* s_res = smem + kRedRows * kBlock;   // [T][kBlock]
+    double* s_res = smem + kRedRows * kBlock;   // [T][kBlock] residuals, then [T][4][kBlock] what every observation needs
     const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i], c0 = b.c0[i];
     double y1 = c0, y2 = (k2 / k1) * c0, y3 = 0.0, sse = 0.0;
     int oi = 0;
-    // The scan is a chain of L dependent affine maps, but what it READS does not depend on the chain: the summary and
-    // the transfer matrix of chunk c + 1 are requested while chunk c is applied (left in program order every chunk paid
-    // a full HBM round trip: 17 us for L = 30, more than the forward chunks themselves at small populations).
-    double nx[7];
+    // The scan is a chain of L dependent affine maps, but what it READS does not depend on the chain.  Rounds 2-4 requested
+    // chunk c + 1's summary while chunk c was applied: a look-ahead of ONE short iteration, so every chunk still waited
+    // most of an HBM round trip (measured: the scan took 25 us for 57 subjects as for 1e4 -- L = 30 round trips).  Now
+    // (round 5): everything an observation needs (its two homogeneous responses, its forced part, its datum) is put into
+    // LDS rows up front with all loads in flight together, and the chunk summaries arrive kScanGroup chunks at a time,
+    // one group ahead.  Same operations in the same order on the same values.
+    double* s_obs = s_res + T * kBlock;         // [T][4][kBlock]
     {
-        const double* f = fsum + i;
-        const double* M = a.hom_M + i;
-        nx[0] = f[0]; nx[1] = f[N]; nx[2] = f[2 * N];
-        nx[3] = M[0]; nx[4] = M[N]; nx[5] = M[2 * N]; nx[6] = M[3 * N];
-    }
-    for (int c = 0; c < a.L; c++) {
-        const double* f = fsum + (int64_t)c * (3 + T) * N + i;
-        const int n1 = cs[c + 1];
-        double cu[7];
+        constexpr int kObsBatch = 4;                // observations whose loads are in flight together
+        int c_of = 0;
+        for (int o0 = 0; o0 < T; o0 += kObsBatch) {
+            double v[kObsBatch][4];
 #pragma unroll
-        for (int q = 0; q < 7; q++) cu[q] = nx[q];
-        if (c + 1 < a.L) {
-            const double* fn = f + (int64_t)(3 + T) * N;
-            const double* Mn = a.hom_M + (int64_t)(c + 1) * 4 * N + i;
-            nx[0] = fn[0]; nx[1] = fn[N]; nx[2] = fn[2 * N];
-            nx[3] = Mn[0]; nx[4] = Mn[N]; nx[5] = Mn[2 * N]; nx[6] = Mn[3 * N];
+            for (int k = 0; k < kObsBatch; k++) {
+                const int o = o0 + k < T ? o0 + k : T - 1;
+                const int st = obs_step[o];
+                while (c_of + 1 < a.L && cs[c_of + 1] <= st) c_of++;      // the chunk whose steps hold observation o
+                v[k][0] = a.hom_obs[((int64_t)o * 2) * N + i];
+                v[k][1] = a.hom_obs[((int64_t)o * 2 + 1) * N + i];
+                v[k][2] = fsum[((int64_t)c_of * (3 + T) + 3 + o) * N + i];
+                v[k][3] = b.obs[(int64_t)o * N + i];
+            }
+#pragma unroll
+            for (int k = 0; k < kObsBatch; k++) {
+                if (o0 + k < T) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) s_obs[(4 * (o0 + k) + q) * kBlock + lane] = v[k][q];
+                }
+            }
         }
-        while (oi < T && obs_step[oi] < n1) {
-            const double hy = fma(a.hom_obs[((int64_t)oi * 2) * N + i], y1, a.hom_obs[((int64_t)oi * 2 + 1) * N + i] * y2);
-            const double r = (f[(int64_t)(3 + oi) * N] + hy) - b.obs[(int64_t)oi * N + i];
-            sse = fma(r, r, sse);
-            s_res[oi * kBlock + lane] = r;
-            oi++;
+    }
+    constexpr int kScanGroup = 6;
+    double nx[kScanGroup][7];
+    auto request = [&](int c0) {                 // summaries and transfer matrices of chunks c0 ... c0 + kScanGroup - 1
+#pragma unroll
+        for (int k = 0; k < kScanGroup; k++) {
+            const int c = c0 + k < a.L ? c0 + k : a.L - 1;
+            const double* f = fsum + (int64_t)c * (3 + T) * N + i;
+            const double* M = a.hom_M + (int64_t)c * 4 * N + i;
+            nx[k][0] = f[0]; nx[k][1] = f[N]; nx[k][2] = f[2 * N];
+            nx[k][3] = M[0]; nx[k][4] = M[N]; nx[k][5] = M[2 * N]; nx[k][6] = M[3 * N];
         }
-        const double n1y = cu[0] + fma(cu[3], y1, cu[4] * y2);
-        const double n2y = cu[1] + fma(cu[5], y1, cu[6] * y2);
-        y1 = n1y; y2 = n2y;
-        y3 += cu[2];
+    };
+    request(0);
+    for (int c0 = 0; c0 < a.L; c0 += kScanGroup) {
+        double cu[kScanGroup][7];
+#pragma unroll
+        for (int k = 0; k < kScanGroup; k++)
+#pragma unroll
+            for (int q = 0; q < 7; q++) cu[k][q] = nx[k][q];
+        if (c0 + kScanGroup < a.L) request(c0 + kScanGroup);
+#pragma unroll
+        for (int k = 0; k < kScanGroup; k++) {
+            const int c = c0 + k;
+            if (c < a.L) {
+                const int n1 = cs[c + 1];
+                while (oi < T && obs_step[oi] < n1) {
+                    const double hy = fma(s_obs[(4 * oi + 0) * kBlock + lane], y1, s_obs[(4 * oi + 1) * kBlock + lane] * y2);
+                    const double r = (s_obs[(4 * oi + 2) * kBlock + lane] + hy) - s_obs[(4 * oi + 3) * kBlock + lane];
+                    sse = fma(r, r, sse);
+                    s_res[oi * kBlock + lane] = r;
+                    oi++;
+                }
+                const double n1y = cu[k][0] + fma(cu[k][3], y1, cu[k][4] * y2);
+                const double n2y = cu[k][1] + fma(cu[k][5], y1, cu[k][6] * y2);
+                y1 = n1y; y2 = n2y;
+                y3 += cu[k][2];
+            }
+        }
     }
     const bool failed = !(fabs(sse) <= 1.79769313486231570815e308);
     if (active) {
@@ -301,12 +337,53 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
         const double gscale = 2.0 * b.inv_n;
         oi = T - 1;
         int oi_step = obs_step[oi];
-#pragma unroll 1
-        for (int n = b.S - 1; n >= 0; n--) {
-            adj_step(kin, b.h, gscale, obs_w, obs_step, s_res, lane, n, oi, oi_step, lam1, lam2, kap1, kap2, w);
-            if (active) {
+        if (a.adj_map != nullptr) {
+            // the recursion as the subject's linear map (Cpep2Args::adj_map): 36 multiply-adds per step; the response of
+            // the NEXT observation to be met is requested while the steps before it run
+            const double* mp = a.adj_map + i;
+            double Phi[16], Wm[20], R[9];
 #pragma unroll
-                for (int j = 0; j < 5; j++) wts[(int64_t)(5 * n + j) * N + i] = w[j];
+            for (int q = 0; q < 16; q++) Phi[q] = mp[(int64_t)q * N];
+#pragma unroll
+            for (int q = 0; q < 20; q++) Wm[q] = mp[(int64_t)(16 + q) * N];
+#pragma unroll
+            for (int q = 0; q < 9; q++) R[q] = mp[(int64_t)(kAdjMapRows + 9 * oi + q) * N];
+#pragma unroll 1
+            for (int n = b.S - 1; n >= 0; n--) {
+                const double in[4] = {lam1, lam2, kap1, kap2};
+                double o[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    o[r] = fma(Phi[4 * r + 3], in[3], fma(Phi[4 * r + 2], in[2], fma(Phi[4 * r + 1], in[1], Phi[4 * r] * in[0])));
+#pragma unroll
+                for (int j = 0; j < 5; j++)
+                    w[j] = fma(Wm[4 * j + 3], in[3], fma(Wm[4 * j + 2], in[2], fma(Wm[4 * j + 1], in[1], Wm[4 * j] * in[0])));
+                while (oi_step == n) {
+                    const double g = gscale * s_res[oi * kBlock + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = fma(R[r], g, o[r]);
+#pragma unroll
+                    for (int j = 0; j < 5; j++) w[j] = fma(R[4 + j], g, w[j]);
+                    oi--;
+                    oi_step = oi >= 0 ? obs_step[oi] : -1;
+                    const int on = oi >= 0 ? oi : 0;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) R[q] = mp[(int64_t)(kAdjMapRows + 9 * on + q) * N];
+                }
+                lam1 = o[0]; lam2 = o[1]; kap1 = o[2]; kap2 = o[3];
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) wts[(int64_t)(5 * n + j) * N + i] = w[j];
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int n = b.S - 1; n >= 0; n--) {
+                adj_step(kin, b.h, gscale, obs_w, obs_step, s_res, lane, n, oi, oi_step, lam1, lam2, kap1, kap2, w);
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) wts[(int64_t)(5 * n + j) * N + i] = w[j];
+                }
             }
         }
     }
@@ -376,6 +453,49 @@ __device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, 
     lam2 = yb2;
     kap1 = kb[0][0];
     kap2 = kb[0][1];
+}
+
+// The step's adjoint algebra on unit inputs: the coefficients of Cpep2Args::adj_map, per subject, once per population.
+// (adj_step itself is run, so the map IS the algebra's linearisation point by point; sums over its entries round
+// differently from the stage-by-stage form: ~1e-16 per step.)
+__global__ __launch_bounds__(kBlock) void cpep2_adjmap_kernel(Cpep2Args a, double* __restrict__ map) {
+    extern __shared__ double s_res[];           // [T][kBlock]: unit residual of one observation, zeros for the others
+    const CpepArgs& b = a.base;
+    const int lane = threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
+    const bool active = gid < b.N;
+    const int64_t i = active ? gid : b.N - 1, N = b.N;
+    cptr_t obs_w = as_const(b.obs_w);
+    ciptr_t obs_step = as_const(b.obs_step);
+    const int T = b.T;
+    const double k0 = b.k0[i], k1 = b.k1[i], k2 = b.k2[i];
+    const Kin kin{-(k0 + k2), k1, k2, -k1, 0.0};
+    for (int c = 0; c < 4; c++) {
+        double lam1 = c == 0, lam2 = c == 1, kap1 = c == 2, kap2 = c == 3, w[5];
+        int oi = -1, oi_step = -1;
+        adj_step(kin, b.h, 1.0, obs_w, obs_step, s_res, lane, 0, oi, oi_step, lam1, lam2, kap1, kap2, w);
+        if (active) {
+            map[(int64_t)(0 + c) * N + i] = lam1;
+            map[(int64_t)(4 + c) * N + i] = lam2;
+            map[(int64_t)(8 + c) * N + i] = kap1;
+            map[(int64_t)(12 + c) * N + i] = kap2;
+            for (int j = 0; j < 5; j++) map[(int64_t)(16 + 4 * j + c) * N + i] = w[j];
+        }
+    }
+    for (int o = 0; o < T; o++) {
+        for (int q = 0; q < T; q++) s_res[q * kBlock + lane] = q == o ? 1.0 : 0.0;
+        const int n = obs_step[o];
+        int oi = o;
+        while (oi + 1 < T && obs_step[oi + 1] == n) oi++;       // the step's last observation: the recursion meets it first
+        int oi_step = n;
+        double lam1 = 0.0, lam2 = 0.0, kap1 = 0.0, kap2 = 0.0, w[5];
+        adj_step(kin, b.h, 1.0, obs_w, obs_step, s_res, lane, n, oi, oi_step, lam1, lam2, kap1, kap2, w);
+        if (active) {
+            double* r = map + (int64_t)(kAdjMapRows + 9 * o) * N + i;
+            r[0] = lam1; r[N] = lam2; r[2 * N] = kap1; r[3 * N] = kap2;
+            for (int j = 0; j < 5; j++) r[(int64_t)(4 + j) * N] = w[j];
+        }
+    }
 }
 
 template <int NIN, int W, int D>
@@ -555,11 +675,11 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
             return hipErrorInvalidValue;
         const int spb = kBlock / a.spec_slots;
         hipLaunchKernelGGL((cpep2_scan_kernel<Net::P, true>), dim3((unsigned)((a.base.N + spb - 1) / spb)), dim3(kBlock),
-                           sizeof(double) * (size_t)(kRedRows + a.base.T) * kBlock, s, as);
+                           sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kBlock),
-                       sizeof(double) * (size_t)(kRedRows + a.base.T) * kBlock, s, as);
+                       sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as);
     if (!grad) return hipGetLastError();
     constexpr int TABROWS = Net::HAS_TAB ? 5 * W : 0;
     const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;
@@ -602,6 +722,13 @@ int cpep2_rev_waves_per_cu(const NetShape& net) {
 hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s) {
     const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(cpep2_homog_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_cpep2_adjmap(const Cpep2Args& a, double* adj_map, hipStream_t s) {
+    const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(cpep2_adjmap_kernel, dim3((unsigned)nblocks), dim3(kBlock), sizeof(double) * (size_t)a.base.T * kBlock, s, a,
+                       adj_map);
     return hipGetLastError();
 }
 

@@ -86,6 +86,7 @@ struct Options {
     int fwd_split = 1;          // CUDE_NO_FWD_SPLIT
     int fused_final = 1;        // CUDE_NO_FUSED_FINAL
     int fused_tail = 1;         // CUDE_NO_FUSED_TAIL: tail of a time-split gradient evaluation in one launch (round 5)
+    int scan_map = 1;           // CUDE_NO_SCAN_MAP: the scan's adjoint recursion as a per-subject linear map (round 5)
     int mh_fuse = 1;            // CUDE_NO_MH_FUSE
     int graph = 1;              // CUDE_NO_GRAPH
     int graph_unroll = 8;       // CUDE_GRAPH_UNROLL
@@ -206,6 +207,7 @@ struct cude_ctx {
     cude::api::DevBuf<double> ms_fsum, ms_wts, ms_gcp, ms_p2;   // time-split path with parameter sets (small populations)
     cude::api::DevBuf<double> act;     // SUPP: kept network activations of the gradient launch (small populations only)
     cude::api::DevBuf<double> tape, ms_tape;   // adaptive mode: accepted steps of the forward sweep, walked back by the adjoint
+    cude::api::DevBuf<double> adj_map;             // time-split path: Cpep2Args::adj_map of the population
     cude::api::DevBuf<double> gen_acc, ms_gacc;    // general network (cude_generic.hip): [P][N] gradient accumulators per set
     cude::api::DevBuf<int32_t> tape_n;
     cude::api::DevBuf<int32_t> perm;                           // adaptive kernels: subject of every launch position (cude_adaptive_regroup)

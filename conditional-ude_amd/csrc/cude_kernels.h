@@ -189,7 +189,17 @@ struct Cpep2Args {
     int32_t spec_slots;
     MhSpecArgs spec;
     int32_t defer_chunk_sum;     // gradient launches: leave g_cond_part to the caller's launch_chunked_tail (no sum_chunks launch)
+    // The scan's adjoint recursion as a per-subject LINEAR MAP (round 5): the stage-adjoint algebra of a step (J_f = A, fixed
+    // h) maps (lam1, lam2, kap1, kap2) of step n + 1 and the residual seeds of step n to those of step n and to the step's
+    // five network weights with coefficients that depend on the subject's kinetics alone.  Rows of N doubles, computed once
+    // per population by running the algebra on unit inputs (cpep2_adjmap_kernel): [0, 16) Phi[out][in], [16, 36) W[weight][in],
+    // [36 + 9 oi, 36 + 9 oi + 9) response of (lam1, lam2, kap1, kap2, w0 ... w4) to a unit seed of observation oi.
+    // 36 multiply-adds of depth 4 per step instead of ~100 of depth ~25; nullptr = the stage-by-stage algebra.
+    const double* adj_map;
 };
+constexpr int kAdjMapRows = 36;
+inline int64_t adj_map_rows(int T) { return kAdjMapRows + 9 * (int64_t)T; }
+hipError_t launch_cpep2_adjmap(const Cpep2Args& a, double* adj_map, hipStream_t s);
 bool cpep2_shape_supported(const NetShape& net, int n_state);
 int cpep2_rev_waves_per_cu(const NetShape& net);
 int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T);

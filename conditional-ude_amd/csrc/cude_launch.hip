@@ -133,6 +133,7 @@ cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base, bool all_blo
         a2.hom_M = c->hom_M_f.p; a2.hom_obs = c->hom_obs_f.p; a2.fsum = c->fsum_f.p; a2.wts = nullptr;
     }
     a2.g_cond_part = c->g_cond_part.p; a2.partials2 = c->partials2.p;
+    a2.adj_map = (c->opt.scan_map && !forward_only) ? c->adj_map.p : nullptr;
     a2.base.blk0 = all_blocks ? 0 : c->blk0; a2.base.blk_count = 0;
     return a2;
 }
@@ -276,6 +277,8 @@ int32_t setup_chunks(cude_ctx* c) {
     cude::CpepArgs a = cpep_args(c);
     cude::Cpep2Args a2 = chunk_args(c, a);
     HIP_TRY(cude::launch_cpep2_homog(a2, c->stream));
+    HIP_TRY(c->adj_map.resize((size_t)cude::adj_map_rows(T) * N));          // the scan's adjoint recursion as a linear map
+    HIP_TRY(cude::launch_cpep2_adjmap(a2, c->adj_map.p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));   // cs (host vector) dies here
     // ---- the forward-only split.  Model (fitted to profiles/r03/forward_chunks.txt): a SIMD that holds w waves of e
     // evaluations each needs e * w / thr(w) evaluation times (thr = 1, 1.33, 1.36, 1.38 ... for 1, 2, 3, 4+ waves: the
