@@ -52,7 +52,7 @@ N_STEPS = 30
 T_OBS = 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
-TIMING_PERIOD = 4              # kernel time of the timed region: HIP events around every 4th gradient launch
+TIMING_PERIOD = 4              # kernel time of the timed region: HIP events around every 4th gradient launch (median quoted)
 PREWARM_STEPS = 64             # untimed launches before the W warm-up steps: the GPU needs ~30 launches (20 ms) to
                                # reach its steady clock after an idle period (profiles/r02/clock_ramp.txt)
 
@@ -981,16 +981,19 @@ def main():
             loss = train_step()
     barrier()
     dt = time.perf_counter() - t0
-    kern_ms, n_launch = eng.kernel_time_ms()
+    kern_mean, kern_ms, kern_min, n_launch = eng.kernel_time_stats()     # kern_ms = the MEDIAN of the sampled launches
     eng.set_kernel_timing(False)
 
     # the same K steps with the loss returned to the host after every step (reported as extra information)
     barrier()
+    eng.set_kernel_timing(1)              # (this untimed pass carries events on EVERY launch: K samples beside the timed region's K/4)
     t1 = time.perf_counter()
     for _ in range(args.steps):
         train_step()
     barrier()
     dt_sync = time.perf_counter() - t1
+    sync_mean, sync_median, sync_min, sync_n = eng.kernel_time_stats()
+    eng.set_kernel_timing(False)
 
     # the same K steps replayed from captured graphs (no kernel timing: cude_adam_run's production mode), and -- N > 1 --
     # through every other transport that came up, for the record (`transports`): all untimed by the contract's clock
@@ -1073,6 +1076,11 @@ def main():
                        "subjects_per_gpu": n_local, "parallelism": f"subject-shard x{world}",
                        "allreduce": transport if dist_on else None},
             "roofline": hbm, "roofline_valu": valu,
+            "kernel_ms_samples": {"median": kern_ms, "mean": kern_mean, "min": kern_min, "launches": n_launch,
+                                  "note": "HIP events around every TIMING_PERIOD-th gradient launch of the timed region; "
+                                          "roofline.achieved uses the median (this rank's; N > 1: the slowest rank's)",
+                                  "every_launch_of_the_read_back_pass": {"median": sync_median, "mean": sync_mean, "min": sync_min,
+                                                                         "launches": sync_n}},
             "value_with_loss_read_back_every_step": n_total * args.steps / dt_sync,
             "final_loss": loss, "prewarm_steps": PREWARM_STEPS, "kernel_source_sha": kernel_source_sha(),
             "launch_mode": f"plain+events/{TIMING_PERIOD}" if lib_transport else "host in every step",

@@ -1,6 +1,8 @@
 // libcude_hip.so -- host side of the C ABI declared in include/cude.h: contexts, populations, parameters.
 // Owns the device-resident population (subject-major SoA), the solver tables and the HIP stream; the launches are in
 // cude_launch.hip, the optimisers in cude_optimise.hip, the multi-GPU exchange in cude_comm.hip.
+#include <algorithm>
+
 #include "cude_ctx.h"
 
 namespace {
@@ -780,22 +782,31 @@ int32_t cude_set_kernel_timing(cude_ctx* c, int32_t enabled) {
     return CUDE_OK;
 }
 
-int32_t cude_kernel_time_ms(cude_ctx* c, double* avg_ms, int64_t* launches) {
+int32_t cude_kernel_time_stats(cude_ctx* c, double* avg_ms, double* median_ms, double* min_ms, int64_t* launches) {
     int32_t rc = bind(c);
     if (rc) return rc;
     if (!avg_ms) return fail(CUDE_ERR_ARG, "null output");
     HIP_TRY(hipStreamSynchronize(c->stream));
     double tot = 0.0;
+    std::vector<double> all(c->ev_used);
     for (size_t k = 0; k < c->ev_used; k++) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
         tot += ms;
+        all[k] = ms;
     }
+    std::sort(all.begin(), all.end());
     *avg_ms = c->ev_used ? tot / (double)c->ev_used : 0.0;
+    if (median_ms) *median_ms = all.empty() ? 0.0 : 0.5 * (all[(all.size() - 1) / 2] + all[all.size() / 2]);
+    if (min_ms) *min_ms = all.empty() ? 0.0 : all.front();
     if (launches) *launches = (int64_t)c->ev_used;
     c->ev_used = 0;
     c->timing_count = 0;            // (the first launch after a query is a timed one, whatever the period)
     return CUDE_OK;
+}
+
+int32_t cude_kernel_time_ms(cude_ctx* c, double* avg_ms, int64_t* launches) {
+    return cude_kernel_time_stats(c, avg_ms, nullptr, nullptr, launches);
 }
 
 }  // extern "C"

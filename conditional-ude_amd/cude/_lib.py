@@ -86,6 +86,8 @@ _SIGNATURES = {
     "cude_loss_grad_partial_device": (C.c_int32, [C.c_void_p]),
     "cude_adam_apply_device": (C.c_int32, [C.c_void_p, _dp]),
     "cude_kernel_time_ms": (C.c_int32, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
+    "cude_kernel_time_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(C.c_int64)]),
     "cude_set_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cude_comm_unique_id": (C.c_int32, [C.c_void_p]),
     "cude_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

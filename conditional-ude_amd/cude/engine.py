@@ -499,6 +499,13 @@ class Engine:
         check(self._lib.cude_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_time_stats(self):
+        """(mean, median, minimum in ms, launches timed) of the dominant kernel since the last query (cude_kernel_time_stats)."""
+        ms, med, mn = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int64()
+        check(self._lib.cude_kernel_time_stats(self._h, C.byref(ms), C.byref(med), C.byref(mn), C.byref(n)))
+        return ms.value, med.value, mn.value, n.value
+
     # -- communicator
     @staticmethod
     def comm_unique_id():

@@ -458,6 +458,11 @@ function kernel_time_ms(c::Ctx)
     check(ccall((:cude_kernel_time_ms, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}), c.h, ms, n))
     ms[], Int(n[])
 end
+function kernel_time_stats(c::Ctx)
+    ms = Ref{Float64}(); med = Ref{Float64}(); mn = Ref{Float64}(); n = Ref{Int64}()
+    check(ccall((:cude_kernel_time_stats, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}), c.h, ms, med, mn, n))
+    (mean = ms[], median = med[], minimum = mn[], launches = Int(n[]))
+end
 
 # ----------------------------------------------------------------------------------------------- reference API: models
 # chain(width, depth, act; input_dims = 2, output_activation = softplus): what the kernels compile -- equal widths, ONE
@@ -466,9 +471,15 @@ struct Chain
     input_dims::Int; width::Int; depth::Int
     widths::Vector{Int}     # empty = equal widths; otherwise the network is carried zero-padded to width = maximum(widths)
     activation::String; output_activation::String
+    # non-empty: the general form -- one activation name per hidden layer, any of ACTIVATION_CODES, `widths` holds every
+    # layer's own width and parameter vectors have SimpleChains' own (unpadded) layout; runs on the library's fallback kernel
+    layer_activations::Vector{String}
 end
+Chain(input_dims::Integer, width::Integer, depth::Integer, widths::Vector{Int}, a::String, o::String) =
+    Chain(input_dims, width, depth, widths, a, o, String[])
 Chain(input_dims::Integer, width::Integer, depth::Integer, widths::Vector{Int} = Int[]) =
     Chain(input_dims, width, depth, widths, "tanh", "softplus")
+is_general(c::Chain) = !isempty(c.layer_activations)
 softplus(x) = log(1 + exp(x))                                   # src/neural-network.jl:13-15
 act_name(f) = (n = string(nameof(f)); n in ("σ", "sigmoid_fast") ? "sigmoid" : n == "tanh_fast" ? "tanh" : n)
 function chain(width::Integer, depth::Integer, activation = tanh; input_dims::Integer = 2, output_dims::Integer = 1,
@@ -480,9 +491,24 @@ function chain(width::Integer, depth::Integer, activation = tanh; input_dims::In
 end
 # the activation functions travel to the library as options of the context, before the population is uploaded
 function configure!(c, net::Chain)
+    if is_general(net)
+        return set_network!(c, net.widths, Symbol.(vcat(net.layer_activations, net.output_activation)))
+    end
     net.activation == "tanh" || set_option!(c, "hidden_activation", net.activation)
     net.output_activation == "softplus" || set_option!(c, "output_activation", net.output_activation)
     c
+end
+# chain(widths, activation_functions; input_dims, output_activation) in its general form (src/neural-network.jl:42-58; the
+# docstring's chain([10, 20, 30], [tanh, relu, softplus]; input_dims = 4)): one function per hidden layer
+function chain(widths::AbstractVector{<:Integer}, activation_functions::AbstractVector; input_dims::Integer = 2,
+               output_dims::Integer = 1, output_activation = softplus)
+    isempty(widths) && throw(ArgumentError("Input widths must be non-empty."))
+    length(widths) == length(activation_functions) ||
+        throw(ArgumentError("The number of widths must match the number of activation functions."))
+    output_dims == 1 || error("the models of the reference use ONE network output")
+    names = [act_name(f) for f in activation_functions]; o = act_name(output_activation)
+    all(n -> haskey(ACTIVATION_CODES, Symbol(n)), vcat(names, o)) || error("activation functions of the library: $(keys(ACTIVATION_CODES))")
+    Chain(input_dims, maximum(widths), length(widths), collect(Int, widths), "tanh", o, names)
 end
 # chain(widths, tanh) (src/neural-network.jl:42-58): unequal widths = the equal-width network of width maximum(widths)
 # whose extra units have zero weights, frozen through cude_set_param_mask; parameter vectors carry THAT layout
@@ -493,7 +519,14 @@ function chain(widths::AbstractVector{<:Integer}, activation = tanh; input_dims:
                                  Chain(input_dims, maximum(widths), length(widths), collect(Int, widths))
 end
 neural_network_model(depth::Integer, width::Integer; input_dims::Integer = 2) = Chain(input_dims, width, depth)
-n_params(c::Chain) = Int(ccall((:cude_n_params, LIB), Int32, (Int32, Int32, Int32), c.input_dims, c.width, c.depth))
+function n_params(c::Chain)
+    if is_general(c)
+        p = 0; fan = c.input_dims
+        for w in vcat(c.widths, 1); p += w * fan + w; fan = w; end
+        return p
+    end
+    Int(ccall((:cude_n_params, LIB), Int32, (Int32, Int32, Int32), c.input_dims, c.width, c.depth))
+end
 
 # SimpleChains' layout of an unequal-width network -> the padded layout (and the 0 / 1 mask of its live entries)
 function pad_network(c::Chain, p::AbstractVector{<:Real})
@@ -591,7 +624,7 @@ function population(models::AbstractVector{CPeptideConditionalUDEModel}, timepoi
         G = Matrix{Float64}(undef, length(models), length(timepoints))
         for (i, m) in enumerate(models); G[i, :] .= m.glucose; end
         set_population!(c, Vector{Float64}(timepoints), G, data, [m.age for m in models], UInt8[m.t2dm for m in models])
-        isempty(net.widths) || set_param_mask!(c, param_mask(net))
+        (isempty(net.widths) || is_general(net)) || set_param_mask!(c, param_mask(net))
         c
     end
 end

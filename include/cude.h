@@ -362,6 +362,9 @@ int32_t cude_adam_apply_device(cude_ctx* ctx, double* loss);
 /* Average device time (ms) of the ensemble launches (forward, or forward+adjoint: whatever the calls since the last
  * query ran) measured with HIP events on the context's stream; resets the accumulator. */
 int32_t cude_kernel_time_ms(cude_ctx* ctx, double* avg_ms, int64_t* launches);
+/* The same samples with their median and minimum (the median is the sturdier figure when a few launches of the timed
+ * region ran before the GPU clock had settled); resets the accumulator as cude_kernel_time_ms does. */
+int32_t cude_kernel_time_stats(cude_ctx* ctx, double* avg_ms, double* median_ms, double* min_ms, int64_t* launches);
 /* Enable / disable (0) the event timing used by cude_kernel_time_ms: 1 = a pair of HIP events around every ensemble
  * launch, n > 1 = around every n-th launch (a pair costs ~4.5 us of stream time and keeps queued iterations from being
  * replayed as graphs: sampling keeps a live kernel time at a fraction of that). */

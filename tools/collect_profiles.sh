@@ -1,14 +1,18 @@
 #!/bin/bash
-# Copies what tools/profile_r04.sh left under gpurun_out/prof_r04 (scratch) into profiles/r04 (tracked) and installs the
-# PMC record bench.py reads.  usage: tools/collect_profiles.sh
+# Copies what tools/profile_rNN.sh left under gpurun_out/prof_rNN (scratch) into profiles/rNN (tracked) and installs the
+# PMC record bench.py reads.  usage: tools/collect_profiles.sh [r05]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-SRC=$ROOT/gpurun_out/prof_r04
-DST=$ROOT/profiles/r04
+R=${1:-r05}
+SRC=$ROOT/gpurun_out/prof_$R
+DST=$ROOT/profiles/$R
 mkdir -p $DST
 cp $SRC/stats/stats_kernel_stats.csv $DST/kernel_stats.csv
 cp $SRC/supp_stage_inputs_stats/stats_kernel_stats.csv $DST/kernel_stats_supp_stage_inputs.csv
-cp $SRC/supp_steps_stats/stats_kernel_stats.csv $DST/kernel_stats_supp_steps_only.csv
+[ -f $SRC/supp_steps_stats/stats_kernel_stats.csv ] && cp $SRC/supp_steps_stats/stats_kernel_stats.csv $DST/kernel_stats_supp_steps_only.csv
+for extra in supp_fill train estep smallgrad; do
+  [ -f $SRC/${extra}_stats/stats_kernel_stats.csv ] && cp $SRC/${extra}_stats/stats_kernel_stats.csv $DST/kernel_stats_$extra.csv
+done
 cp $SRC/adaptive_stats/stats_kernel_stats.csv $DST/kernel_stats_adaptive.csv
 cp $SRC/summary.txt $DST/rocprof_summary.txt
 cp $SRC/bench_stats.json $DST/bench_under_rocprof.json

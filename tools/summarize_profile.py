@@ -175,5 +175,12 @@ try:
     print(open(os.path.join(out, "adaptive_supp.log")).read().strip())
 except Exception:
     pass
+# round 5: the suppression kernel at one full fill, the restart trainer, the speculative E-step, the small-population gradient
+for tag in ("supp_fill", "train", "estep", "smallgrad"):
+    kernel_stats(f"{tag}_stats")
+    try:
+        print("\n".join(l for l in open(os.path.join(out, f"{tag}.log")).read().strip().splitlines() if "amdgpu.ids" not in l))
+    except Exception:
+        pass
 json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("== pmc_traffic.json", json.dumps(rec, indent=1))
