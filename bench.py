@@ -672,23 +672,40 @@ def extras(Engine, device, steps=20, warm=40):
     t0 = time.perf_counter()
     eng.mh_estep(z, u, 0.5, -0.6, 0.8, 0.3)          # host-supplied draws: 16 MB cross PCIe inside the call
     dt_host_draws = time.perf_counter() - t0
-    eng.set_params(nn4, pop["beta0"])
-    eng.set_rng(20250905)
+    def estep_best_of(e, reps=3):            # draws generated on the device (Philox4x32-10); the same chain every time
+        best, acc_ = 1e9, None
+        for _ in range(reps):
+            e.set_params(nn4, pop["beta0"])
+            e.set_rng(20250905)
+            t0_ = time.perf_counter()
+            acc_ = e.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=n_mc)
+            best = min(best, time.perf_counter() - t0_)
+        return best, acc_
     eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
-    t0 = time.perf_counter()
-    acc = eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=n_mc)    # draws generated on the device (Philox4x32-10)
-    dt = time.perf_counter() - t0
+    dt, acc = estep_best_of(eng)              # the library's default: speculative steps where the size rule says so (option "mh_spec")
+    _, state_spec = eng.get_params()
+    # the same E-step with one Metropolis step per launch pair (mh_spec = 0): the launches the roofline figures below count
+    eng.set_option("mh_spec", 0)
+    eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
+    dt_plain, acc_plain = estep_best_of(eng)
+    _, state_plain = eng.get_params()
+    same_chain = bool(np.array_equal(acc, acc_plain) and np.array_equal(state_spec, state_plain))
     eng.set_kernel_timing(True)                                        # kernel time: a second E-step with the events on
     eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=n_mc)
     ms, launches = eng.kernel_time_ms()
     eng.set_kernel_timing(False)
-    hbm, valu = rooflines("time-split forward launches <2,4,2,2> inside cude_mh_estep", ms, launches, n,
+    hbm, valu = rooflines("time-split forward launches <2,4,2,2> inside cude_mh_estep (mh_spec = 0)", ms, launches, n,
                           cpep_algo_bytes(T_OBS, 2, False), cpep_ops(arch, N_STEPS, T_OBS, 2, False))
     out["saem_estep_1e4x100"] = {"config": "BASELINE configs[4] on one GPU: SAEM E-step (saem.jl:86-108,177-186), 1e4 "
                                            "subjects x 100 Metropolis steps (gamma = 1: burn-in phase), 2x4x4x1, "
                                            "draws generated on the device (counter-based Philox4x32-10)",
                                  "ms_per_estep_with_host_supplied_draws": dt_host_draws * 1e3,
                                  "value": n * n_mc / dt, "unit": "Metropolis draws/s", "ms_per_estep": dt * 1e3,
+                                 "timing": "best of 3 E-steps",
+                                 "ms_per_estep_one_step_per_launch_pair": dt_plain * 1e3,
+                                 "speculative_steps": "library default (option mh_spec = -1: depth by population size; "
+                                                      "profiles/r05/estep_speculative.txt)",
+                                 "same_chain_as_one_step_per_launch_pair": same_chain,
                                  "forward_solves_per_s": n * (n_mc + 1) / dt,
                                  "reference_equivalent_solves_per_s": 2 * n * n_mc / dt,
                                  "solves_note": "the reference solves the proposal AND the current state in every "
@@ -698,6 +715,23 @@ def extras(Engine, device, steps=20, warm=40):
                                                 f"Metropolis step ({launches} launches timed)",
                                  "acceptance_rate": float(acc.sum()) / (n * n_mc),
                                  "roofline": hbm, "roofline_valu": valu}
+    eng.close()
+    # one GPU's share of the same E-step on 8 GPUs (1 250 subjects): what the sharded configs[4] will run per rank
+    n8 = n // 8
+    eng, pop8 = cpep_engine(Engine, arch, 2, n8, 780, device, nn4)
+    eng.set_population_cpep(pop8["tp"], pop8["G"], pop8["obs"], pop8["age"], pop8["t2dm"])
+    pop = pop8
+    eng.set_params(nn4, pop8["beta0"])
+    eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
+    dt8, acc8 = estep_best_of(eng)
+    eng.set_option("mh_spec", 0)
+    eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
+    dt8_plain, acc8_plain = estep_best_of(eng)
+    out["saem_estep_1e4x100"]["one_gpus_share_on_8_gpus"] = {
+        "subjects": n8, "ms_per_estep": dt8 * 1e3, "ms_per_estep_one_step_per_launch_pair": dt8_plain * 1e3,
+        "same_acceptance_counts": bool(np.array_equal(acc8, acc8_plain)),
+        "note": "the E-step is a chain of dependent launches whose cost is one wave's latency: sharding alone shortens it "
+                "only this much; speculative steps use the SIMDs a small shard leaves idle"}
     eng.close()
     return out
 

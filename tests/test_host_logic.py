@@ -21,15 +21,17 @@ def test_chain_mirrors_reference_argument_errors():
     with pytest.raises(ValueError):
         api.chain([4, 4], ["tanh"])
     assert api.chain([4, 5], "tanh").arch == (2, 5, 2)                 # unequal widths: zero-padded + masked (class Chain)
-    with pytest.raises(NotImplementedError):
-        api.chain([4, 5], ["tanh", "relu"])
+    mixed = api.chain([4, 5], ["tanh", "relu"])                        # (round 5) per-layer functions: the general form,
+    assert mixed.general and mixed.arch == (2, (4, 5), ("tanh", "relu"), "softplus")      # SimpleChains' own layout, no padding
+    assert mixed.n_params == 2 * 4 + 4 + 4 * 5 + 5 + 5 + 1 and mixed.mask is None
     relu = api.chain(4, 2, "relu", output_activation="identity")       # (round 4) relu / sigmoid, softplus / identity
     assert (relu.activation, relu.output_activation) == ("relu", "identity") and relu.key != api.chain(4, 2, "tanh").key
     assert api.chain([4, 4], ["sigmoid", "sigmoid"]).activation == "sigmoid"
     with pytest.raises(NotImplementedError):
         api.chain(4, 2, "gelu")
+    assert api.chain([4, 5], "relu").general                           # unequal widths with another function: general form too
     with pytest.raises(NotImplementedError):
-        api.chain([4, 5], "relu")                                      # unequal widths: tanh / softplus only
+        api.chain([4, 5], "tanh", output_dims=2)                       # one network output, as every model of the reference
     net = api.chain(4, 2, "tanh")
     with pytest.raises(ValueError):
         api.CPeptideConditionalUDEModel([1, 2, 3], [0, 1, 2], 40, net, [1, 2], False)
