@@ -473,8 +473,8 @@ def test_unequal_widths_are_the_zero_padded_equal_width_network():
     p0 = api.init_params(net, np.random.default_rng(1))
     assert p0.size == 67 and np.array_equal(p0 != 0.0, net.mask == 1.0)
     assert api.chain([4, 4], "tanh").mask is None and api.chain(4, 2, "tanh").widths is None
-    with pytest.raises(NotImplementedError):
-        api.chain([6, 3], "relu")
+    relu = api.chain([6, 3], "relu")            # (round 5) another function on unequal widths: the general form, UNPADDED layout
+    assert relu.general and relu.mask is None and relu.n_params == 43 and api.init_params(relu, np.random.default_rng(1)).size == 43
 
 
 def test_script_utilities_stratified_split_and_argmedian():
