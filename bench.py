@@ -930,6 +930,40 @@ def main():
             transport = "torch" if not rehearsal else "host"
             eng.close()
             eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
+    # ---- N > 1: the exchange's first real steps, BEFORE anything is measured.  The self-test at attach moves a few hundred
+    # doubles; a transport that passes it and then loses a word under load (a wait that runs out of time: CUDE_ERR_COMM)
+    # would otherwise end this run without a JSON line.  Every rank makes the same calls whatever happens locally; if any
+    # rank fails, all hand over to RCCL (or to torch.distributed on a fresh context) and the line says why.
+    if dist_on and transport == "xchg":
+        ok = True
+        try:
+            eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])
+            eng.set_params(nn, pop["beta0"])
+            eng.adam_init(1e-2)
+            for _ in range(4):
+                eng.adam_step()
+            eng.adam_run(16)                       # captured graphs
+            eng.synchronize()
+            ok = eng.xchg_info()[3] == 0
+            if not ok:
+                xchg_error = "a wait of the exchange ran out of time during its first steps"
+        except Exception as exc:  # noqa: BLE001
+            ok = False
+            xchg_error = f"the exchange failed during its first steps: {exc}"
+        if not agreed(ok):
+            xchg_error = xchg_error or "the exchange failed during its first steps on another rank"
+            print(f"[rank {rank}] {xchg_error}", file=sys.stderr)
+            xchg_info = None
+            if rccl_info is not None:
+                try:
+                    eng.xchg_enable(False)
+                except Exception:  # noqa: BLE001  (already released on this rank)
+                    pass
+                transport = "rccl"
+            else:
+                transport = "torch" if not rehearsal else "host"
+                eng.close()
+                eng = Engine("cpep", ARCH, n_steps=N_STEPS, n_state=N_STATE, device=local_rank)
     lib_transport = transport in ("xchg", "rccl") or not dist_on     # the step is the library's own (cude_adam_step / _run)
     eng.set_population_cpep(pop["tp"], pop["G"], pop["obs"], pop["age"], pop["t2dm"])   # global count all-reduced here
     if not lib_transport:

@@ -226,3 +226,42 @@ def test_limits_are_reported_not_crashed_into():
         eng.set_network([3, 3], ["tanh", "tanh", "softplus"])  # the network is part of the population's buffers
     assert e.value.status == -3
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_general_networks_against_the_oracle(seed):
+    """Shapes nobody wrote a case for: 1 ... 8 hidden layers of width 1 ... 12 (a layer of ONE unit, layers wider and
+    narrower than the inputs), a random activation function per layer and at the output, either model."""
+    import cude_oracle as o
+    from cude.engine import Engine
+    rng = np.random.default_rng(100 + seed)
+    depth = int(rng.integers(1, 9)) if seed else 8
+    widths = tuple(int(w) for w in rng.integers(1, 13, depth))
+    names = ("tanh", "relu", "sigmoid", "softplus", "identity")
+    acts = tuple(names[int(k)] for k in rng.integers(0, 5, depth))
+    out_act = names[int(rng.integers(0, 5))] if seed % 2 else "softplus"
+    supp = seed % 2 == 0
+    S, N = 8, 66
+    if supp:
+        arch = (4, widths, acts, out_act)
+        c = make_supp_case(N, (4, 3, 5))
+        nn = 0.7 * o.glorot_params(arch, seed)
+        eng = Engine("supp", arch, n_steps=S, lam=0.003)
+        eng.set_population_supp(c["tp"], c["data"])
+        eng.set_params(nn, c["theta"])
+        ref, rg, rc, _ = o.supp_loss_grad_torch(nn, c["theta"], c["data"], c["tp"], arch, S, 0.003)
+    else:
+        arch = (2, widths, acts, out_act)
+        c = make_cpep_case(N, (2, 4, 2))
+        nn = 0.7 * o.glorot_params(arch, seed)
+        pop = o.CPepPopulation(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng = Engine("cpep", arch, n_steps=S, n_state=2)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(nn, c["beta"])
+        ref, rg, rc, _ = o.cpep_loss_grad_torch(nn, c["beta"], pop, arch, S, 2)
+    assert eng.fallback_kernel and eng.P == nn.size
+    loss, g_nn, g_c = eng.loss_grad()
+    eng.close()
+    assert np.isfinite(ref) and abs(loss - ref) <= 1e-10 * abs(ref), (arch, loss, ref)
+    assert np.max(np.abs(g_nn - rg)) <= 1e-9 * max(np.max(np.abs(rg)), 1e-300), arch
+    assert np.max(np.abs(g_c - rc)) <= 1e-9 * max(np.max(np.abs(rc)), 1e-300), arch

@@ -287,3 +287,97 @@ def test_layer_two_defaults_agree_between_the_mirrors():
     assert "per_interval * length(d) : DEFAULT_STEPS" in src
     assert api.fixed_steps([0.0, 30.0, 60.0, 90.0, 120.0]) == 32 and api.fixed_steps([0.0, 10.0, 30.0]) == 30
     assert api.fixed_steps([0.0, 1.0], per_interval=16) == 16
+
+
+# ----------------------------------------------------------------------------- block structure (no Julia parser in the image)
+_OPENERS = {"function", "if", "for", "while", "let", "begin", "do", "try", "struct", "module", "macro", "quote", "baremodule"}
+
+
+def _julia_tokens(src):
+    """Code tokens of a Julia file with comments, strings, characters and `:symbol` quotes removed, each with the bracket
+    depth it sits at and whether it starts a statement (first token of its line or follows `;` / `=` / `(`-free keyword use)."""
+    out, i, n, depth = [], 0, len(src), 0
+    line_start = True
+    while i < n:
+        ch = src[i]
+        if ch == "#":
+            if src.startswith("#=", i):
+                i = src.index("=#", i) + 2
+            else:
+                while i < n and src[i] != "\n":
+                    i += 1
+            continue
+        if ch == '"':
+            if src.startswith('"""', i):
+                i = src.index('"""', i + 3) + 3
+            else:
+                i += 1
+                while src[i] != '"':
+                    i += 2 if src[i] == "\\" else 1
+                i += 1
+            line_start = False
+            continue
+        if ch == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")) \
+                and not (i > 0 and (src[i - 1].isalnum() or src[i - 1] in ")]_")):
+            i += 3 if src[i + 2] == "'" else 4                      # a character literal (not the adjoint operator)
+            continue
+        if ch == "\n":
+            line_start = True
+            i += 1
+            continue
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch.isalpha() or ch == "_":
+            j = i
+            while j < n and (src[j].isalnum() or src[j] in "_!"):
+                j += 1
+            word = src[i:j]
+            quoted = i > 0 and src[i - 1] == ":" and (i < 2 or src[i - 2] != ":")      # :end, :for ... are symbols
+            field = i > 0 and src[i - 1] == "."                                       # x.end cannot occur, x.begin neither: skip anyway
+            if not quoted and not field:
+                out.append((word, depth, line_start))
+            i = j
+            line_start = False
+            continue
+        if not ch.isspace():
+            line_start = False
+        i += 1
+    assert depth == 0, "unbalanced brackets"
+    return out
+
+
+def test_every_block_of_the_julia_module_is_closed():
+    """What a Julia front end would reject first: a `function` / `if` / `for` / `do` / `struct` ... without its `end`, or an
+    `end` too many.  Counted on the token stream: block keywords outside brackets (inside brackets `for` / `if` belong to
+    comprehensions and generators, `end` to indexing), `abstract type` / `primitive type` / `mutable struct` as one opener,
+    one-line `f(x) = ...` definitions open nothing."""
+    toks = _julia_tokens(open(JL).read())
+    stack, k = [], 0
+    while k < len(toks):
+        word, depth, first = toks[k]
+        nxt = toks[k + 1][0] if k + 1 < len(toks) else ""
+        if word in ("abstract", "primitive") and nxt == "type" and depth == 0:
+            stack.append((word + " type", k))
+            k += 2
+            continue
+        if word == "mutable" and nxt == "struct" and depth == 0:
+            stack.append(("mutable struct", k))
+            k += 2
+            continue
+        if word in _OPENERS and depth == 0:
+            stack.append((word, k))
+        elif word in _OPENERS and word in ("begin", "let", "quote", "function", "do", "try") and depth > 0:
+            stack.append((word, k))                       # (these open a block wherever they stand; `end` at the same depth closes)
+        elif word == "end":
+            inside_index = depth > 0 and not (stack and toks[stack[-1][1]][1] == depth)
+            if not inside_index:
+                assert stack, f"`end` without an opener near token {k}: {[t[0] for t in toks[max(0, k - 8):k + 1]]}"
+                stack.pop()
+        k += 1
+    assert not stack, f"unclosed blocks: {[(w, [t[0] for t in toks[p:p + 6]]) for w, p in stack[:5]]}"
+    # every function of the reference-facing layer is a complete definition: `function name(` ... `end` pairs were matched above;
+    # here: none of them is empty
+    src = re.sub(r"#[^\n]*", "", open(JL).read())
+    assert not re.search(r"function\s+[\w!.]+\([^)]*\)\s*\n\s*end", src)
