@@ -1133,14 +1133,15 @@ namespace {
 // 0 off, 2 ... 4 forced; -1 (default) by size: a round of depth d evaluates 2^d - 1 candidates per subject in one launch,
 // which is nearly free while the candidates' forward chunks run side by side on otherwise idle SIMDs and costs their
 // full multiple once the chip is filled.  Rule = waves of the round's forward launch (candidates x workgroups x chunks of
-// the forward split), fitted to profiles/r05/estep_speculative.txt (one MI355X, 2-4-4-1, 100 steps, us per step plain ->
-// speculative): 625 subjects 25.2 -> 12.3 (depth 3), 1 250: 25.3 -> 14.6 (3; 14.1 with 2), 1 600: 24.1 -> 14.2 (3), 2 500:
-// 25.1 -> 17.2 (2), 5 000: 26.8 -> 23.7 (2), 1e4: 31.5 -> 29.7 (2), 12 000 and above: slower, off.
+// the forward split): depth 3 while they fit two waves per SIMD (the resident-weights variant of the forward kernel),
+// depth 2 up to ~3 per SIMD.  profiles/r05/estep_speculative.txt (one MI355X, 2-4-4-1, 100 steps, us per step plain ->
+// speculative): 625 subjects 23.8 -> 12.2 (depth 3), 1 250: 23.9 -> 13.7 (2; 14.5 with 3), 1 600: 23.7 -> 16.0 (2; 14.6 with 3),
+// 2 500: 23.6 -> 16.5 (2), 5 000: 25.7 -> 23.5 (2), 1e4: 30.9 -> 29.6 (2), 12 000 and above: slower, off.
 int mh_spec_depth(const cude_ctx* c, int n_mc) {
     int d = c->opt.mh_spec;
     if (d < 0) {
         const int64_t waves1 = c->nblocks * (c->chunks_f > 1 ? c->chunks_f : c->chunks);
-        d = 7 * waves1 <= 2700 ? 3 : (3 * waves1 <= 3000 ? 2 : 0);
+        d = 7 * waves1 <= 2048 ? 3 : (3 * waves1 <= 3000 ? 2 : 0);
     }
     d = std::min(d, cude::kMhSpecMaxDepth);
     if (d > n_mc) d = n_mc;
