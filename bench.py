@@ -1025,6 +1025,30 @@ def main():
     # the W warm-up steps of the contract
     for _ in range(PREWARM_STEPS):
         train_step(want_loss=False)
+    # ---- N > 1 with both library transports up: the headline goes through the one that is faster HERE (a short untimed
+    # trial of each, the slowest rank's time; the exchange has never run across devices before this node).  `transports`
+    # below still reports both over the full K steps.
+    transport_trial = None
+    if dist_on and world > 1 and transport == "xchg" and rccl_info is not None and not rehearsal:
+        def trial(k=16):
+            eng.adam_run(k)
+            barrier()
+            tq = time.perf_counter()
+            eng.adam_run(k)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - tq) / k], dtype=torch.float64, device=ctl)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        t_x = trial()
+        eng.xchg_enable(False)
+        t_r = trial()
+        transport_trial = {"xchg_ms_per_step": t_x * 1e3, "rccl_ms_per_step": t_r * 1e3}
+        if t_r < 0.98 * t_x:
+            transport = "rccl"
+            transport_trial["chosen"] = "rccl"
+        else:
+            eng.xchg_enable(True)
+            transport_trial["chosen"] = "xchg"
     # HIP events around every TIMING_PERIOD-th gradient launch of the timed region (a pair costs ~4.5 us of stream time and
     # a gap on either side of the kernel: on every launch that is 2 % of the step being measured); the warm-up also
     # creates the events the timed steps will reuse
@@ -1085,6 +1109,10 @@ def main():
                 eng.xchg_enable(False)                   # RCCL on the context's stream; plain launches (not capturable)
                 transports["rccl"] = {"ms_per_step": timed_run(args.steps) * 1e3, "launch_mode": "plain"}
                 eng.xchg_enable(True)
+            elif transport == "rccl" and transport_trial is not None:      # (the trial preferred RCCL: the exchange is still attached)
+                eng.xchg_enable(True)
+                transports["xchg"] = {"ms_per_step": timed_run(args.steps) * 1e3, "launch_mode": "graph replay"}
+                eng.xchg_enable(False)
             if not rehearsal:
                 tw = time.perf_counter()
                 for _ in range(args.steps):
@@ -1163,6 +1191,7 @@ def main():
                             "timed_out_waits": xchg_info[3], "attach_attempts": len(xchg_attempts) + 1,
                             "attempts_given_up": xchg_attempts} if xchg_info else None)
             out["xchg_error"] = xchg_error
+            out["transport_trial"] = transport_trial
             out["transports"] = transports
             if saem is not None:
                 out["saem_estep_1e4x100_sharded"] = {
