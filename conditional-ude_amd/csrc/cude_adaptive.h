@@ -271,6 +271,10 @@ constexpr int kUnrolledKnots = 5;                  // the reference's five sampl
 // cude_adaptive_unrolled.hip: the c-peptide MLP shapes above and the symbolic model on grids of at most kUnrolledKnots times; hipErrorNotSupported
 // for any other shape (the caller then runs the phase-machine kernel)
 hipError_t launch_cpep_adaptive_unrolled(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
+// cude_adaptive_team.hip: the same solve with a step's five network evaluations on five waves, for launches of at most
+// kTeamMaxWaves single-wave workgroups (the reference's own population sizes); hipErrorNotSupported otherwise
+constexpr int kTeamMaxWaves = 256;
+hipError_t launch_cpep_adaptive_team(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
 // shape groups 1 and 2 of either integrator (their own translation units); hipErrorNotSupported = not in this group
 hipError_t launch_cpep_adaptive_unrolled_part1(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);
 hipError_t launch_cpep_adaptive_unrolled_part2(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s);

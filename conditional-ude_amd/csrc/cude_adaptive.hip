@@ -556,7 +556,9 @@ hipError_t launch_cpep_adaptive(const NetShape& net, bool grad, const CpepArgs& 
     if (grad && a.obs == nullptr) return hipErrorInvalidValue;
 #ifndef CUDE_ADAPT_ONE_BODY                        /* (A/B builds: tools/abl_adaptive_bits.py) */
     if (!net.general() && a.TG <= kUnrolledKnots) {
-        const hipError_t e = launch_cpep_adaptive_unrolled(net, grad, a, s);
+        hipError_t e = launch_cpep_adaptive_team(net, grad, a, s);      // small launches: five waves per 64 subjects
+        if (e != hipErrorNotSupported) return e;
+        e = launch_cpep_adaptive_unrolled(net, grad, a, s);
         if (e != hipErrorNotSupported) return e;
     }
 #endif

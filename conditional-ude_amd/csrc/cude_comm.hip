@@ -342,9 +342,11 @@ int32_t cude_xchg_export(cude_ctx* c, int32_t n_ranks, int32_t rank, uint8_t han
     return CUDE_OK;
 }
 
-// a failed attach: everything released, the next export starts with the kind after the one that was tried
+// a failed attach: everything released, the next export starts one kind further down the order of preference.  The
+// ranks move through these LEVELS in lock step (every rank detaches after a failed attempt); a rank whose own export had
+// to skip a kind simply offers the same kind again at the next level.
 static int32_t xchg_attach_failed(cude_ctx* c, int32_t code, const std::string& msg) {
-    c->xchg_next_kind = c->xchg.kind_index + 1;
+    c->xchg_next_kind += 1;         // (one LEVEL per attempt on every rank, whatever kind this rank's export had ended up with)
     (void)hipStreamSynchronize(c->stream);
     xchg_release(c);
     if (!c->comm) { c->n_ranks = 1; c->rank = 0; }
@@ -427,7 +429,7 @@ int32_t cude_xchg_detach(cude_ctx* c) {
     if (!c->xchg.box) return CUDE_OK;           // (a failed attach has released it and moved on to the next kind already)
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_graph(c);
-    c->xchg_next_kind = c->xchg.kind_index + 1;
+    c->xchg_next_kind += 1;
     xchg_release(c);
     if (!c->comm) { c->n_ranks = 1; c->rank = 0; }
     return CUDE_OK;

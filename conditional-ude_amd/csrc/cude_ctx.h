@@ -70,6 +70,8 @@ struct Options {
                                 //   (what a sharded population always does), 2 = the Adam stage on the host as well
     int mh_spec = -1;           // "mh_spec" / CUDE_MH_SPEC: speculative Metropolis steps per launch chain (cude_mh_estep, gamma == 1,
                                 //   time-split forward path): 0 = off, 2 ... 4 = that many, -1 = by population size (mh_spec_depth)
+    int adaptive_team = 1;      // "adaptive_team" / CUDE_NO_ADAPTIVE_TEAM: adaptive launches of small c-peptide populations put a
+                                //   step's five network evaluations on five waves (cude_adaptive_team.hip)
     int auto_regroup = 1;       // "auto_regroup" / CUDE_NO_AUTO_REGROUP: adaptive launches re-ordered by accepted-step count
     int poll_pinned = 1;        // "poll_pinned" / CUDE_NO_POLL_PINNED: watch page-locked result slots instead of the stream wait
     int force_fallback = 0;     // "force_fallback" / CUDE_FORCE_FALLBACK (tests): cude_set_network takes the fallback kernel also

@@ -110,6 +110,8 @@ struct CpepArgs {
     double* tape;            // adaptive gradient: [n_sets][tape_cap][N] step sizes dt_n of the accepted steps (+ T saved outputs)
     int32_t tape_cap;
     int32_t* tape_n;         // [N] accepted steps per subject of parameter set 0 (forward and gradient launches), or nullptr
+    int32_t team;            // adaptive mode, small launches: 0 = a step's five evaluations on five waves (cude_adaptive_team.hip)
+                             // where that kernel applies, -1 = never (option "adaptive_team" = 0)
     double* gen_acc;         // fallback kernel (cude_generic.hip), gradient: [n_sets][P][N] per-lane accumulators; its tape
                              // (CpepArgs::tape) is [n_sets][steps][2 + n_state][N] with steps = S, or tape_cap when S == 0
     const int32_t* perm;     // adaptive kernels: lane `gid` works on subject perm[gid] (nullptr = identity).  Lanes of a wave

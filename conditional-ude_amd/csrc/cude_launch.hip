@@ -53,6 +53,7 @@ cude::CpepArgs cpep_args(const cude_ctx* c) {
     a.abstol = c->abstol; a.reltol = c->reltol;
     a.tape = c->tape.p; a.tape_cap = c->tape_cap; a.tape_n = c->tape_n.p;
     a.gen_acc = c->gen_acc.p;
+    a.team = c->opt.adaptive_team ? 0 : -1;
     a.perm = (adaptive(c) && !c->slot_of.empty()) ? c->perm.p : nullptr;
     return a;
 }

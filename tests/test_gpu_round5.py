@@ -72,3 +72,47 @@ def test_scan_adjoint_recursion_as_a_linear_map(N, arch, n_state, tp):
     assert abs(l1 - ref["loss"]) <= 1e-10 * ref["loss"]
     assert np.max(np.abs(g1 - ref["g_nn"])) <= 1e-9 * np.max(np.abs(ref["g_nn"]))
     assert np.max(np.abs(b1 - ref["g_beta"])) <= 1e-9 * np.max(np.abs(ref["g_beta"]))
+
+
+@pytest.mark.parametrize("N,arch", [(57, (2, 4, 2)), (117, (3, 4, 2)), (200, (2, 6, 2)), (64, (2, 8, 2))])
+def test_adaptive_solve_of_a_small_population_on_a_team_of_waves(N, arch):
+    """csrc/cude_adaptive_team.hip: the reference's own population sizes in the reference's solver mode (the mirrors'
+    default since round 5) -- a step's five network evaluations on five waves, every wave carrying the integrator
+    redundantly.  Against the one-wave kernel (option "adaptive_team" = 0): loss, per-subject SSE, trajectories and accepted
+    steps bit for bit (the same arithmetic), gradients to 1e-13 (five partial sums in another association); the same for
+    side-by-side parameter sets; and the gradient against the oracle's replay of the device's own steps."""
+    import cude_oracle as o
+    from cude.engine import Engine
+    c = make_cpep_case(N, arch)
+    rng = np.random.default_rng(4)
+    nn_sets = c["nn"][None, :] * (1.0 + 0.05 * rng.standard_normal((3, c["nn"].size)))
+    b_sets = c["beta"][None, :] + 0.1 * rng.standard_normal((3, N))
+    out = []
+    for team in (1, 0):
+        eng = Engine("cpep", arch, n_steps=0, n_state=2)
+        eng.set_option("adaptive_team", team)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], c["beta"])
+        fwd = eng.forward(want_sse=True, want_traj=True)
+        loss, g_nn, g_b = eng.loss_grad()
+        steps = [eng.adaptive_steps(i) for i in range(N)]
+        ms = eng.multistart_loss_grad(nn_sets, b_sets)
+        msf = eng.multistart_forward(nn_sets, b_sets)
+        eng.adam_init(1e-2)
+        tr = np.array([eng.adam_step() for _ in range(2)] + list(eng.adam_run(9)))
+        out.append((fwd, loss, g_nn, g_b, steps, ms, msf, tr))
+        eng.close()
+    (f1, l1, g1, b1, s1, m1, mf1, t1), (f0, l0, g0, b0, s0, m0, mf0, t0) = out
+    assert f1["loss"] == f0["loss"] and np.array_equal(f1["sse"], f0["sse"]) and np.array_equal(f1["traj"], f0["traj"])
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(s1, s0))
+    assert abs(l1 - l0) <= 1e-14 * abs(l0)                       # (the workgroup's loss sum is formed by the same tree)
+    assert np.max(np.abs(g1 - g0)) <= 1e-13 * np.max(np.abs(g0)) and np.max(np.abs(b1 - b0)) <= 1e-13 * np.max(np.abs(b0))
+    assert np.allclose(m1[0], m0[0], rtol=1e-14) and np.max(np.abs(m1[1] - m0[1])) <= 1e-13 * np.max(np.abs(m0[1]))
+    assert np.max(np.abs(m1[2] - m0[2])) <= 1e-13 * np.max(np.abs(m0[2])) and np.allclose(mf1, mf0, rtol=1e-14)
+    # (along a training run step-size control amplifies last-place differences: the first iterations agree to rounding,
+    #  the later ones to the solver's tolerance)
+    assert np.allclose(t1[:1], t0[:1], rtol=1e-13) and np.allclose(t1, t0, rtol=2e-3) and np.all(np.isfinite(t1))
+    pop = o.CPepPopulation(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"], covariate=(arch[0] == 3))
+    rl, rg, rb, _ = o.cpep_replay_loss_grad(c["nn"], c["beta"], pop, arch, [list(zip(t, dt)) for t, dt in s1])
+    assert abs(l1 - rl) <= 1e-10 * rl
+    assert np.max(np.abs(g1 - rg)) <= 1e-8 * np.max(np.abs(rg)) and np.max(np.abs(b1 - rb)) <= 1e-8 * np.max(np.abs(rb))

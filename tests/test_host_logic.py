@@ -522,3 +522,78 @@ def test_generate_data_mirrors_the_reference_generator():
     assert np.array_equal(gt2, gt) and np.all(noisy >= 0.0)
     ratio = noisy[:, 1:] / data[:, 1:] - 1.0                                   # = 0.1 * randn wherever nothing was clamped
     assert 0.07 < np.std(ratio) < 0.13 and abs(np.mean(ratio)) < 0.03
+
+
+# ------------------------------------------------------------------ the exchange's attach protocol (host logic, no GPU)
+class _MailboxEngine:
+    """Stand-in for the three exchange entry points: kind k of this rank's mailbox memory 'works' unless listed in `bad`
+    (export fails: allocation / IPC export) or in `bad_attach` (a peer cannot use it: only attach finds out)."""
+
+    def __init__(self, rank, bad=(), bad_attach=()):
+        self.rank, self.bad, self.bad_attach = rank, set(bad), set(bad_attach)
+        self.level, self.kind, self.attached, self.log = 0, None, False, []      # level: csrc/cude_comm.hip xchg_next_kind
+
+    def xchg_export(self, n_ranks, rank):
+        from cude._lib import CudeError
+        k = self.level
+        while k in self.bad:
+            k += 1
+        if k > 2:
+            self.level = 3
+            raise CudeError(-5, "exchange mailbox: every kind of device memory has been tried on this context")
+        self.kind = k
+        self.log.append(("export", self.kind))
+        return bytes([0xC0 + self.kind]) * 128
+
+    def xchg_attach(self, handles, timeout_s):
+        from cude._lib import CudeError
+        assert len(handles) > 1 and all(len(h) == 128 for h in handles)
+        if any(h[0] == 0 for h in handles) or self.kind in self.bad_attach:
+            self.level, self.kind = self.level + 1, None          # (the library releases a failed attach and moves one level on)
+            raise CudeError(-1, "hipIpcOpenMemHandle / self-test failed")
+        self.attached = True
+
+    def xchg_detach(self):
+        if self.kind is not None:
+            self.level += 1
+        self.kind, self.attached = None, False
+        self.log.append(("detach",))
+
+
+def _attach_rank_main(rank, world, port, scenario, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "conditional-ude_amd"))
+    import torch.distributed as dist
+    from cude.parallel import TorchCollective, attach_exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bad, bad_attach = scenario[rank]
+    eng = _MailboxEngine(rank, bad, bad_attach)
+    ok, why = attach_exchange(eng, TorchCollective(dist), 1.0)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ok=ok, kind=-1 if eng.kind is None else eng.kind,
+             attached=eng.attached, exports=sum(1 for e in eng.log if e[0] == "export"), why=str(why))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario,ok,kinds,exports", [
+    ({0: ((), ()), 1: ((), ()), 2: ((), ())}, True, (0, 0, 0), (1, 1, 1)),              # first kind works everywhere
+    ({0: ((), ()), 1: ((), (0,)), 2: ((), ())}, True, (1, 1, 1), (2, 2, 2)),            # one rank cannot USE kind 0: all move on
+    ({0: ((0,), ()), 1: ((), (0, 1)), 2: ((), ())}, True, (2, 2, 2), None),             # mixed: export falls through, attach fails twice
+    ({0: ((), ()), 1: ((0, 1, 2), ()), 2: ((), ())}, False, (-1, -1, -1), None),        # a rank with no kind left: released everywhere
+    ({0: ((), (0, 1, 2)), 1: ((), ()), 2: ((), ())}, False, (-1, -1, -1), (3, 3, 3)),   # every kind fails at attach on one rank
+], ids=["first", "second", "mixed", "export-exhausted", "attach-exhausted"])
+def test_exchange_attach_protocol_agrees_over_the_ranks(tmp_path, scenario, ok, kinds, exports):
+    """cude/parallel.py attach_exchange (the loop bench.py and CUDEHip.jl attach_exchange! run; include/cude.h "cude_xchg_*"):
+    whatever fails on whichever rank, every rank makes the same sequence of collective calls, and they end either ALL
+    attached on their next common attempt or ALL released."""
+    import torch.multiprocessing as mp
+    world, port = 3, free_port()
+    mp.spawn(_attach_rank_main, args=(world, port, scenario, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    assert all(bool(x["ok"]) == ok and bool(x["attached"]) == ok for x in r)
+    assert tuple(int(x["kind"]) for x in r) == kinds
+    if exports is not None:
+        assert tuple(int(x["exports"]) for x in r) == exports
+    if not ok:
+        assert all(str(x["why"]) not in ("", "None") for x in r)
