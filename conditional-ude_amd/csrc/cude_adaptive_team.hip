@@ -52,7 +52,8 @@ __global__ __launch_bounds__(kBlock* kTeam) void adaptive_team_kernel(typename M
     double* const s_model = s_prod + 2 * kTeam * kBlock;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + lane;
     const bool active = gid < a.N;
-    const int64_t i = active ? gid : a.N - 1;
+    const int64_t slot = active ? gid : a.N - 1;                          // position in the launch (lane order) ...
+    const int64_t i = a.perm != nullptr ? (int64_t)a.perm[slot] : slot;   // ... and the subject that sits there
     const int64_t set = blockIdx.y;
     const bool lead = wave == 0;                   // the wave that writes what must be written once
     cptr_t tout = as_const(a.out_times);
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kBlock* kTeam) void adaptive_team_kernel(typename M
         }
         return fma(t - tlo, s_S[j * kBlock + lane], m.s_G[j * kBlock + lane]);
     };
-    double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + i : nullptr;
+    double* const tape = GRAD ? a.tape + (set * adaptive_tape_rows(NS, a.tape_cap, a.T)) * a.N + slot : nullptr;
 #define TAPE(n) tape[(int64_t)(n) * a.N]
 #define OUTV(oi) tape[((int64_t)a.tape_cap + (oi)) * a.N]
     int n_acc = 0;
@@ -385,10 +386,10 @@ static hipError_t launch_team(const typename M::Args& a, bool grad, hipStream_t 
 }
 
 // Small launches only (the team multiplies the waves by five: worth it while the one-wave-per-64-subjects grid leaves most
-// of the chip idle), in the caller's order, the network shapes of the reference's scripts and their neighbours (shape group
+// of the chip idle), the network shapes of the reference's scripts and their neighbours (shape group
 // 0 of cude_adaptive.h) on grids of at most kUnrolledKnots times; hipErrorNotSupported = not this kernel's case.
 hipError_t launch_cpep_adaptive_team(const NetShape& net, bool grad, const CpepArgs& a, hipStream_t s) {
-    if (net.general() || net.generic() || net.symbolic() || a.team < 0 || a.perm != nullptr) return hipErrorNotSupported;
+    if (net.general() || net.generic() || net.symbolic() || a.team < 0) return hipErrorNotSupported;
     if (a.TG < 2 || a.TG > kUnrolledKnots || a.T < 1) return hipErrorNotSupported;
     const int64_t waves1 = ((a.N + kBlock - 1) / kBlock) * (a.n_sets > 0 ? a.n_sets : 1);
     if (waves1 > kTeamMaxWaves) return hipErrorNotSupported;
