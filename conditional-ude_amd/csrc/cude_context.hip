@@ -193,6 +193,7 @@ const OptionEntry kOptions[] = {
     {"fused_final", "CUDE_NO_FUSED_FINAL", &Options::fused_final, true, true},
     {"fused_tail", "CUDE_NO_FUSED_TAIL", &Options::fused_tail, true, true},
     {"scan_map", "CUDE_NO_SCAN_MAP", &Options::scan_map, true, true},
+    {"scan_bulk", "CUDE_NO_SCAN_BULK", &Options::scan_bulk, true, true},
     {"mh_fuse", "CUDE_NO_MH_FUSE", &Options::mh_fuse, true, true},
     {"graph", "CUDE_NO_GRAPH", &Options::graph, true, true},
     {"graph_unroll", "CUDE_GRAPH_UNROLL", &Options::graph_unroll, false, true},

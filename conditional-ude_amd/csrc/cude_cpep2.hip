@@ -19,6 +19,8 @@
 //   * the reverse lane of chunk c evaluates the network reverse sweeps of its own stage times with those
 //     weights and accumulates its share of the gradient (cpep2_rev_kernel).
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 #include "cude_device.h"
 #include "cude_kernels.h"
@@ -398,6 +400,271 @@ __global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
                           a.final_host != nullptr ? a.final_host + 2 * (int64_t)blockIdx.x : nullptr);
 }
 
+// ---------------------------------------------------------------------------------- scan of a small launch
+// On a nearly empty chip the scan is a LONE wave, and a lone wave issues one instruction every ~5 cycles whatever the
+// instruction is (measured with s_memrealtime stamps, tools/scan_timing.py, 57 subjects, 32 chunks, 2.4 GHz: requesting its
+// ~200 rows 6.9 us although they arrive 0.2 us after the last request, stitching 4.6 us, the 32 steps of the adjoint
+// recursion 7.4 us = 550 cycles per step of ~100 instructions, the final sums 1.0 us: 20.5 us, none of it memory latency --
+// a first version that only moved every read to the top of the kernel ran exactly as long).  Hence, for launches of at
+// most one scan workgroup per compute unit, EIGHT waves share a block of 64 subjects:
+//   1. every row the scan reads is requested up front, each wave an eighth of them, by loads that write LDS directly
+//      (global_load_lds_dword: no destination registers, hundreds in flight; a lane's double travels as two dwords into
+//      rows 256 B apart);
+//   2. wave 0 stitches the chunks out of LDS (chunk boundaries by arithmetic, the next observation's step in a register:
+//      no scalar load per chunk) and runs the adjoint recursion's four STATE components alone through all steps (16 of
+//      the step's 36 multiply-adds, no stores), leaving the state at the head of every wave's segment of steps in LDS;
+//   3. every wave then runs the full recursion (weights + stores) over its own segment from that state.
+// The state components do not depend on the weights, so every number is produced by the same operations in the same
+// order as in cpep2_scan_kernel: same bits.  Needs chunks of equal length (then every chunk has chunk 0's transfer
+// matrix: 4 rows instead of 4 L) and the recursion as a linear map (Cpep2Args::adj_map).
+constexpr int kScanWaves = 8;
+// orders a wave's LDS writes against the reads of its other lanes (a wave's LDS operations execute in order: no s_barrier)
+__device__ __forceinline__ void stage_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ double lds_get_plain(const double* row, int lane) { return row[lane]; }
+__device__ __forceinline__ void lds_fetch(const double* g, double* row) {
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    const unsigned* gp = reinterpret_cast<const unsigned*>(g);
+    __builtin_amdgcn_global_load_lds(gp, (lds_ptr)row, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds(gp + 1, (lds_ptr)(row + kBlock / 2), 4, 0, 0);
+}
+__device__ __forceinline__ double lds_get(const double* row, int lane) {
+    const unsigned* r = reinterpret_cast<const unsigned*>(row);
+    return __hiloint2double((int)r[kBlock + lane], (int)r[lane]);
+}
+inline int scan_bulk_rows(int T, int L, bool grad) {
+    return kRedRows + 5 * T + 8 + 3 * L + (grad ? kAdjMapRows + 9 * T + 4 * kScanWaves : 0);
+}
+
+template <int P, bool SPEC = false>
+__global__ __launch_bounds__(kScanWaves* kBlock) void cpep2_scan_bulk_kernel(Cpep2Args a) {
+    extern __shared__ double smem[];
+    const CpepArgs& b = a.base;
+    const int lane = threadIdx.x & (kBlock - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int spb = SPEC ? kBlock / a.spec_slots : kBlock;                   // subjects per workgroup
+    const int64_t gid = SPEC ? (int64_t)blockIdx.x * spb + lane % spb : (int64_t)blockIdx.x * kBlock + lane;
+    const int64_t N = b.N;
+    ciptr_t obs_step = as_const(b.obs_step);
+    const int T = b.T, L = a.L, S = b.S;
+    const int len = S / L;                                                   // steps per chunk
+    const int64_t set_raw = SPEC ? lane / spb : blockIdx.y;                  // parameter set (see cpep2_fwd_kernel)
+    const bool active = gid < N && (!SPEC || set_raw < b.n_sets);
+    const int64_t i = gid < N ? gid : N - 1;
+    const int64_t set = SPEC && set_raw >= b.n_sets ? 0 : set_raw;           // (the idle slot re-reads set 0, writes nothing)
+    const double* const fsum = a.fsum + set * ((int64_t)L * (3 + T) * N);
+    double* const wts = a.wts != nullptr ? a.wts + set * ((int64_t)5 * S * N) : nullptr;
+    double* const s_res = smem + kRedRows * kBlock;     // [T] residuals
+    double* const s_obs = s_res + T * kBlock;           // [T][4] what every observation needs
+    double* const s_kin = s_obs + 4 * T * kBlock;       // k0, k1, k2, c0
+    double* const s_M = s_kin + 4 * kBlock;             // the chunks' transfer matrix
+    double* const s_f = s_M + 4 * kBlock;               // [L][3] chunk summaries
+    double* const s_map = s_f + 3 * L * kBlock;         // [36 + 9 T] the adjoint recursion's map (gradient)
+    double* const s_bnd = s_map + (kAdjMapRows + 9 * T) * kBlock;      // [kScanWaves][4] state at the head of a segment
+#ifdef CUDE_SCAN_TIMING
+    unsigned long long tk[8];
+    tk[0] = __builtin_amdgcn_s_memrealtime();
+#define TK(k) tk[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define TK(k)
+#endif
+    {
+        // every wave walks its own eighth of each group of rows (a wave that skipped the others' rows one by one still
+        // paid for their address arithmetic: 4.8 us for its 26 rows)
+        if (wv < 4) lds_fetch((wv == 0 ? b.k0 : wv == 1 ? b.k1 : wv == 2 ? b.k2 : b.c0) + i, s_kin + wv * kBlock);
+        else lds_fetch(a.hom_M + (int64_t)(wv - 4) * N + i, s_M + (wv - 4) * kBlock);
+        for (int r = wv; r < 4 * T; r += kScanWaves) {
+            const int o = r >> 2, q = r & 3;
+            const double* g = q < 2 ? a.hom_obs + ((int64_t)o * 2 + q) * N + i
+                                    : (q == 2 ? fsum + ((int64_t)(obs_step[o] / len) * (3 + T) + 3 + o) * N + i      // (the chunk whose steps hold o)
+                                              : b.obs + (int64_t)o * N + i);
+            lds_fetch(g, s_obs + r * kBlock);
+        }
+        for (int r = wv; r < 3 * L; r += kScanWaves) {
+            const int c = r / 3, q = r - 3 * c;
+            lds_fetch(fsum + ((int64_t)c * (3 + T) + q) * N + i, s_f + r * kBlock);
+        }
+        if (wts != nullptr) {
+            const int rows = kAdjMapRows + 9 * T;
+            for (int q = wv; q < rows; q += kScanWaves) lds_fetch(a.adj_map + (int64_t)q * N + i, s_map + q * kBlock);
+        }
+    }
+    TK(1);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    TK(2);
+    double sse = 0.0;
+    bool failed = false;
+    if (wv == 0) {
+        const double k1 = lds_get(s_kin + kBlock, lane), k2 = lds_get(s_kin + 2 * kBlock, lane), c0 = lds_get(s_kin + 3 * kBlock, lane);
+        double y1 = c0, y2 = (k2 / k1) * c0, y3 = 0.0;
+        int oi = 0;
+        int next_obs = obs_step[0];                     // step of the next observation to be met (ascending)
+        const double M0 = lds_get(s_M, lane), M1 = lds_get(s_M + kBlock, lane), M2 = lds_get(s_M + 2 * kBlock, lane),
+                     M3 = lds_get(s_M + 3 * kBlock, lane);
+        constexpr int kGroup = 4;                       // chunks whose summaries are read from LDS together
+        for (int cg = 0; cg < L; cg += kGroup) {
+            double f[kGroup][3];
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const int c = cg + k < L ? cg + k : L - 1;
+#pragma unroll
+                for (int q = 0; q < 3; q++) f[k][q] = lds_get(s_f + (3 * c + q) * kBlock, lane);
+            }
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const int c = cg + k;
+                if (c < L) {
+                    const int n1 = (c + 1) * len;
+                    while (oi < T && next_obs < n1) {
+                        const double hy = fma(lds_get(s_obs + (4 * oi + 0) * kBlock, lane), y1, lds_get(s_obs + (4 * oi + 1) * kBlock, lane) * y2);
+                        const double r = (lds_get(s_obs + (4 * oi + 2) * kBlock, lane) + hy) - lds_get(s_obs + (4 * oi + 3) * kBlock, lane);
+                        sse = fma(r, r, sse);
+                        s_res[oi * kBlock + lane] = r;
+                        oi++;
+                        next_obs = oi < T ? obs_step[oi] : 0x7fffffff;
+                    }
+                    const double n1y = f[k][0] + fma(M0, y1, M1 * y2);
+                    const double n2y = f[k][1] + fma(M2, y1, M3 * y2);
+                    y1 = n1y; y2 = n2y;
+                    y3 += f[k][2];
+                }
+            }
+        }
+        failed = !(fabs(sse) <= 1.79769313486231570815e308);
+        TK(3);
+        if (wts != nullptr) {
+            // the recursion's state alone, through all steps but the first segment's: what every wave starts from
+            stage_lds_sync();
+            const int seg = (S + kScanWaves - 1) / kScanWaves;
+            double st[4] = {0.0, 0.0, 0.0, 0.0};
+            const double gscale = 2.0 * b.inv_n;
+            int ob = T - 1;
+            int ob_step = obs_step[ob];
+            double Phi[16], R[4];
+#pragma unroll
+            for (int q = 0; q < 16; q++) Phi[q] = lds_get(s_map + q * kBlock, lane);
+#pragma unroll
+            for (int q = 0; q < 4; q++) R[q] = lds_get(s_map + (kAdjMapRows + 9 * ob + q) * kBlock, lane);
+#pragma unroll 1
+            for (int n = S - 1; n >= seg - 1; n--) {
+                if ((n + 1) % seg == 0 || n == S - 1) {
+                    const int k = n / seg;              // the segment whose first (highest) step is n
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s_bnd[(4 * k + r) * kBlock + lane] = st[r];
+                    if (n == seg - 1) break;
+                }
+                double o[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    o[r] = fma(Phi[4 * r + 3], st[3], fma(Phi[4 * r + 2], st[2], fma(Phi[4 * r + 1], st[1], Phi[4 * r] * st[0])));
+                while (ob_step == n) {
+                    const double g = gscale * s_res[ob * kBlock + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = fma(R[r], g, o[r]);
+                    ob--;
+                    ob_step = ob >= 0 ? obs_step[ob] : -1;
+                    const int on = ob >= 0 ? ob : 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) R[q] = lds_get(s_map + (kAdjMapRows + 9 * on + q) * kBlock, lane);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) st[r] = o[r];
+            }
+        }
+        TK(4);
+        if (active) {
+            if (b.sse != nullptr) b.sse[set * b.set_stride_cond + i] = sse;
+            if (b.auc != nullptr && set == 0) b.auc[i] = y3;
+            if (a.mh_fused) mh_accept_one(a.mh, i, mh_proposal(a.mh.p, a.mh_z, a.mh.key, a.mh_std, i), sse);
+        }
+    }
+    if (wts != nullptr) {
+        __syncthreads();
+        const int seg = (S + kScanWaves - 1) / kScanWaves;
+        const int n_hi = (wv + 1) * seg - 1 < S - 1 ? (wv + 1) * seg - 1 : S - 1, n_lo = wv * seg;
+        if (n_lo <= n_hi) {
+            double lam1 = lds_get_plain(s_bnd + (4 * wv + 0) * kBlock, lane), lam2 = lds_get_plain(s_bnd + (4 * wv + 1) * kBlock, lane),
+                   kap1 = lds_get_plain(s_bnd + (4 * wv + 2) * kBlock, lane), kap2 = lds_get_plain(s_bnd + (4 * wv + 3) * kBlock, lane), w[5];
+            const double gscale = 2.0 * b.inv_n;
+            int oi = T - 1;
+            while (oi >= 0 && obs_step[oi] > n_hi) oi--;        // the observations of later steps belong to other waves
+            int oi_step = oi >= 0 ? obs_step[oi] : -1;
+            const int o_first = oi >= 0 ? oi : 0;
+            double Phi[16], Wm[20], R[9];
+#pragma unroll
+            for (int q = 0; q < 16; q++) Phi[q] = lds_get(s_map + q * kBlock, lane);
+#pragma unroll
+            for (int q = 0; q < 20; q++) Wm[q] = lds_get(s_map + (16 + q) * kBlock, lane);
+#pragma unroll
+            for (int q = 0; q < 9; q++) R[q] = lds_get(s_map + (kAdjMapRows + 9 * o_first + q) * kBlock, lane);
+#pragma unroll 1
+            for (int n = n_hi; n >= n_lo; n--) {
+                const double in[4] = {lam1, lam2, kap1, kap2};
+                double o[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    o[r] = fma(Phi[4 * r + 3], in[3], fma(Phi[4 * r + 2], in[2], fma(Phi[4 * r + 1], in[1], Phi[4 * r] * in[0])));
+#pragma unroll
+                for (int j = 0; j < 5; j++)
+                    w[j] = fma(Wm[4 * j + 3], in[3], fma(Wm[4 * j + 2], in[2], fma(Wm[4 * j + 1], in[1], Wm[4 * j] * in[0])));
+                while (oi_step == n) {
+                    const double g = gscale * s_res[oi * kBlock + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = fma(R[r], g, o[r]);
+#pragma unroll
+                    for (int j = 0; j < 5; j++) w[j] = fma(R[4 + j], g, w[j]);
+                    oi--;
+                    oi_step = oi >= 0 ? obs_step[oi] : -1;
+                    const int on = oi >= 0 ? oi : 0;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) R[q] = lds_get(s_map + (kAdjMapRows + 9 * on + q) * kBlock, lane);
+                }
+                lam1 = o[0]; lam2 = o[1]; kap1 = o[2]; kap2 = o[3];
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) wts[(int64_t)(5 * n + j) * N + i] = w[j];
+                }
+            }
+        }
+    }
+    TK(5);
+    if (wv != 0) return;
+    if constexpr (SPEC) {
+        // the wave's own stores of the candidates' SSEs (global memory) are visible to it behind the fence
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < spb && gid < N) mh_spec_resolve(a.spec, gid);
+        return;
+    }
+    {   // (sum SSE, failures) over the wave: block_reduce_store<2> of cude_device.h for one wave of a larger workgroup
+        double* const out = b.partials + (set * gridDim.x + blockIdx.x) * (P + 2) + P;
+        double* const out2 = a.final_host != nullptr ? a.final_host + 2 * (int64_t)blockIdx.x : nullptr;
+        stage_lds_sync();
+        smem[lane] = active ? sse : 0.0;
+        smem[kBlockLanes + lane] = (active && failed) ? 1.0 : 0.0;
+        stage_lds_sync();
+        if (lane < 2) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < kBlockLanes; l++) acc += smem[lane * kBlockLanes + ((l + lane) & (kBlockLanes - 1))];
+            out[lane] = acc;
+            if (out2 != nullptr) out2[lane] = acc;
+        }
+    }
+#ifdef CUDE_SCAN_TIMING
+    TK(6);
+    __builtin_amdgcn_s_waitcnt(0);
+    TK(7);
+    if (lane == 0 && blockIdx.x == 0 && a.mh_fused == 0)
+        printf("scan L=%d grad=%d [10 ns]: issue %llu, arrive %llu, stitch %llu, state pass %llu, own segment %llu, reduce %llu, drain %llu\n",
+               L, wts != nullptr, tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5], tk[7] - tk[6]);
+#endif
+#undef TK
+}
+
 // ---------------------------------------------------------------------------------- reverse sweep
 // Stage-adjoint algebra of one step (J_f = A): consumes the adjoint (lam, kap) of (y_{n+1}, k_7), the
 // observation seeds of the step, and returns the adjoint of (y_n, k_1) plus the 5 network weights.
@@ -643,6 +910,19 @@ __global__ void cpep2_sum_chunks_kernel(const double* __restrict__ part, int L, 
 }
 
 // ---------------------------------------------------------------------------------- dispatch
+constexpr size_t kScanBulkMaxLds = 156 * 1024;      // (+ nothing static in the scan: 160 KB per compute unit)
+// dynamic LDS above 64 KB has to be allowed per kernel, once
+static hipError_t allow_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::set<const void*> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(kernel)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanBulkMaxLds);
+    if (e == hipSuccess) done.insert(kernel);
+    return e;
+}
+
 template <int NIN, int W, int D>
 static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStream_t s) {
     using Net = CpepNet<NIN, W, D>;
@@ -670,16 +950,34 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
     }
     Cpep2Args as = a;
     if (!grad) as.wts = nullptr;
+    // launches of at most one scan workgroup per compute unit: every row through LDS up front (cpep2_scan_bulk_kernel)
+    const size_t lds_bulk = sizeof(double) * (size_t)scan_bulk_rows(a.base.T, a.L, as.wts != nullptr) * kBlock;
+    const int64_t scan_blocks = a.spec_slots > 0 ? (a.base.N + kBlock / a.spec_slots - 1) / (kBlock / a.spec_slots) : nblocks * n_sets;
+    const bool bulk = a.scan_bulk_blocks > 0 && scan_blocks <= a.scan_bulk_blocks && a.base.blk0 == 0 && a.base.S % a.L == 0 &&
+                      (as.wts == nullptr || a.adj_map != nullptr) && lds_bulk <= kScanBulkMaxLds;
     if (a.spec_slots > 0) {
         if (grad || a.spec_slots > kBlock || (int)n_sets >= a.spec_slots || (a.spec_slots & (a.spec_slots - 1)))
             return hipErrorInvalidValue;
         const int spb = kBlock / a.spec_slots;
+        if (bulk) {
+            hipError_t e = allow_lds((const void*)cpep2_scan_bulk_kernel<Net::P, true>, lds_bulk);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((cpep2_scan_bulk_kernel<Net::P, true>), dim3((unsigned)((a.base.N + spb - 1) / spb)),
+                               dim3(kScanWaves * kBlock), lds_bulk, s, as);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL((cpep2_scan_kernel<Net::P, true>), dim3((unsigned)((a.base.N + spb - 1) / spb)), dim3(kBlock),
                            sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kBlock),
-                       sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as);
+    if (bulk) {
+        hipError_t e = allow_lds((const void*)cpep2_scan_bulk_kernel<Net::P, false>, lds_bulk);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((cpep2_scan_bulk_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kScanWaves * kBlock), lds_bulk, s, as);
+    } else {
+        hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kBlock),
+                           sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as);
+    }
     if (!grad) return hipGetLastError();
     constexpr int TABROWS = Net::HAS_TAB ? 5 * W : 0;
     const size_t lds_r = sizeof(double) * (size_t)(TABROWS > kRedRows ? TABROWS : kRedRows) * kBlock;

@@ -88,6 +88,7 @@ struct Options {
     int fwd_split = 1;          // CUDE_NO_FWD_SPLIT
     int fused_final = 1;        // CUDE_NO_FUSED_FINAL
     int fused_tail = 1;         // CUDE_NO_FUSED_TAIL: tail of a time-split gradient evaluation in one launch (round 5)
+    int scan_bulk = 1;          // CUDE_NO_SCAN_BULK: small scan launches fetch every row through LDS up front (round 5)
     int scan_map = 1;           // CUDE_NO_SCAN_MAP: the scan's adjoint recursion as a per-subject linear map (round 5)
     int mh_fuse = 1;            // CUDE_NO_MH_FUSE
     int graph = 1;              // CUDE_NO_GRAPH
@@ -145,6 +146,7 @@ struct cude_ctx {
     cude::api::DevBuf<double> nn, cond, g_nn, g_cond, sse, auc, partials, traj;
     // chunked gradient path (cude_cpep2.hip)
     int chunks = 1;
+    int n_cu = 256;         // compute units of the device (setup_chunks)
     int64_t blk0 = 0;       // > 0: mixed gradient launch -- blocks [0, blk0) on the one-lane kernel, the rest time-split
     int64_t slots_one = 0, half_slots = 0;          // resident-wave slots of the one-lane gradient kernel; one per SIMD
     hipStream_t stream2 = nullptr;                  // mixed launch: the time-split remainder runs beside the whole rounds

@@ -198,6 +198,9 @@ struct Cpep2Args {
     // [36 + 9 oi, 36 + 9 oi + 9) response of (lam1, lam2, kap1, kap2, w0 ... w4) to a unit seed of observation oi.
     // 36 multiply-adds of depth 4 per step instead of ~100 of depth ~25; nullptr = the stage-by-stage algebra.
     const double* adj_map;
+    // > 0: a scan launch of at most this many workgroups requests every row it will read up front, through LDS
+    // (cpep2_scan_bulk_kernel: one memory round trip instead of a dozen dependent ones); 0 = never
+    int64_t scan_bulk_blocks;
 };
 constexpr int kAdjMapRows = 36;
 inline int64_t adj_map_rows(int T) { return kAdjMapRows + 9 * (int64_t)T; }

@@ -135,6 +135,7 @@ cude::Cpep2Args chunk_args(cude_ctx* c, const cude::CpepArgs& base, bool all_blo
     }
     a2.g_cond_part = c->g_cond_part.p; a2.partials2 = c->partials2.p;
     a2.adj_map = (c->opt.scan_map && !forward_only) ? c->adj_map.p : nullptr;
+    a2.scan_bulk_blocks = c->opt.scan_bulk ? c->n_cu : 0;          // (one workgroup per compute unit: its LDS is the scan's)
     a2.base.blk0 = all_blocks ? 0 : c->blk0; a2.base.blk_count = 0;
     return a2;
 }
@@ -168,6 +169,7 @@ int32_t setup_chunks(cude_ctx* c) {
     c->slots_one = c->half_slots = 0;
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device);
+    c->n_cu = n_cu;
     c->half_slots = (int64_t)n_cu * 4;
     if (adaptive(c)) return CUDE_OK;
     c->slots_one = (int64_t)n_cu * std::max(1, cude::cpep_grad_waves_per_cu(c->net, c->cfg.n_state, c->T));

@@ -116,3 +116,50 @@ def test_adaptive_solve_of_a_small_population_on_a_team_of_waves(N, arch):
     rl, rg, rb, _ = o.cpep_replay_loss_grad(c["nn"], c["beta"], pop, arch, [list(zip(t, dt)) for t, dt in s1])
     assert abs(l1 - rl) <= 1e-10 * rl
     assert np.max(np.abs(g1 - rg)) <= 1e-8 * np.max(np.abs(rg)) and np.max(np.abs(b1 - rb)) <= 1e-8 * np.max(np.abs(rb))
+
+
+@pytest.mark.parametrize("N,arch,n_state,steps,tp", [(57, (2, 4, 2), 2, 32, None), (700, (2, 6, 2), 3, 30, None),
+                                                     (90, (2, 4, 2), 2, 30, [0.0, 0.0001, 30.0, 31.0, 31.5, 120.0]),
+                                                     (130, (3, 4, 2), 2, 20, None)],
+                         ids=["57", "700-three-states", "several-observations-in-one-step", "covariate-20-steps"])
+def test_scan_of_a_small_launch_on_eight_waves_is_bit_identical(N, arch, n_state, steps, tp):
+    """csrc/cude_cpep2.hip cpep2_scan_bulk_kernel (launches of at most one scan workgroup per compute unit; option
+    "scan_bulk" = 0: the one-wave scan): every row through LDS up front, the adjoint recursion's state in wave 0 and the
+    weights of a segment of steps in every wave.  The same operations on the same values: loss, gradients, per-subject
+    SSE, queued Adam iterations, side-by-side parameter sets and a Metropolis chain (plain and speculative) bit for bit,
+    also when several observations fall into one step and when the step count is not a multiple of eight."""
+    from cude.engine import Engine
+    c = make_cpep_case(N, arch)
+    if tp is not None:
+        t_old = c["tp"]
+        G = np.stack([np.interp(tp, t_old, c["G"][i]) for i in range(N)])
+        obs = np.stack([np.interp(tp, t_old, c["obs"][i]) for i in range(N)])
+        c = dict(c, tp=np.array(tp), G=G, obs=obs)
+    rng = np.random.default_rng(7)
+    nn_sets = c["nn"][None, :] * (1.0 + 0.05 * rng.standard_normal((3, c["nn"].size)))
+    b_sets = c["beta"][None, :] + 0.1 * rng.standard_normal((3, N))
+    normals, uniforms = rng.standard_normal((7, N)), rng.random((7, N))
+    out = []
+    for bulk in (1, 0):
+        r = []
+        for spec in (0, 3):
+            eng = Engine("cpep", arch, n_steps=steps, n_state=n_state)
+            eng.set_option("scan_bulk", bulk)
+            eng.set_option("mh_spec", spec)
+            eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+            eng.set_params(c["nn"], c["beta"])
+            if spec == 0:
+                f = eng.forward(want_sse=True)
+                r += [np.float64(f["loss"]), f["sse"]] + list(eng.loss_grad())
+                r += list(eng.multistart_loss_grad(nn_sets, b_sets)) + [eng.multistart_forward(nn_sets, b_sets)]
+                eng.adam_init(1e-2)
+                r.append(np.array(eng.adam_run(9)))
+                r += list(eng.get_params())
+                eng.set_params(c["nn"], c["beta"])
+            acc, samples = eng.mh_chain(normals, uniforms, 0.4, -0.6, 0.9, 0.3)
+            r += [acc, samples]
+            eng.close()
+        out.append(r)
+    assert np.isfinite(out[0][0]) and np.all(np.isfinite(out[0][3]))
+    for a, b in zip(*out):
+        assert np.array_equal(np.asarray(a), np.asarray(b))

@@ -15,6 +15,7 @@ ALL=$(sed -n 's/^SRCS *= *//p' $SRC/Makefile | sed 's/\.hip//g')
 if [ -n "$ONLY" ]; then
   make -s -C $SRC -j8
   for f in $ALL; do cp $SRC/$f.o $TMP/$f.o; done
+  cp $SRC/*_p[0-9].o $TMP/          # (shape groups compiled as translation units of their own: Makefile PARTS)
   LIST=$ONLY
 else
   LIST=$ALL
