@@ -119,6 +119,13 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     // side-by-side parameter sets (restarts trained together on a small population): grid z = set; every per-set array
     // is [set][...] with the strides of one set (single evaluations are set 0 of 1)
     const int64_t set = blockIdx.z;
+#ifdef CUDE_SCAN_TIMING
+    unsigned long long tk[8];
+    tk[0] = __builtin_amdgcn_s_memrealtime();
+#define TKF(k) tk[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define TKF(k)
+#endif
     cptr_t p = as_const(b.nn + set * b.set_stride_nn);
     cptr_t phi = as_const(b.phi);
     cptr_t obs_w = as_const(b.obs_w);
@@ -154,8 +161,11 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
         oi = (int)__popcll(__ballot(before));
     }
     int n = n0;
+    asm volatile("" ::"v"(chk), "v"(c[0]));
+    TKF(1);
     if constexpr (Net::USES_TANH) tanh_tab_init(lane, !Net::LDS_BIAS);    // (here: its global read travels with the subject's own loads)
     Net::bias_init(b.nn + set * b.set_stride_nn, lane);
+    TKF(2);
     {
         double* const s_G = smem;                         // [T][kBlock] glucose increments at the knots
         for (int m = 0; m < T; m++) {
@@ -163,6 +173,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             s_G[m * kBlock + lane] = gv;
             chk = fma(gv, 0.0, chk);
         }
+        asm volatile("" ::"v"(chk));
+        TKF(3);
         auto input_at = [&](int e) {
             const int sg = seg[e];
             const double lo = s_G[sg * kBlock + lane];
@@ -181,6 +193,8 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             K1a = kin.f0 + qprev;
             K1b = 0.0;
         }
+        asm volatile("" ::"v"(K1a));
+        TKF(4);
 #pragma unroll 1
         for (; n < n1; n++) {
             double xs[5], q[7], g[7];
@@ -216,12 +230,21 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             qprev = q[6];
         }
     }
+    asm volatile("" ::"v"(y1), "v"(y2));
+    TKF(5);
     if (active) {
         double* f = fsum + (int64_t)c_idx * (3 + T) * N + i;
         f[0] = y1 + chk;
         f[N] = y2;
         f[2 * N] = y3;
     }
+#ifdef CUDE_SCAN_TIMING
+    TKF(6);
+    if (lane == 0 && blockIdx.x == 0 && c_idx == 1 && a.mh_fused == 0)
+        printf("fwd chunk 1 of %d (%d steps) [10 ns]: subject loads + exp + first layer %llu, table fills %llu, glucose rows %llu, two evaluations %llu, steps %llu, stores %llu\n",
+               a.L, n1 - n0, tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
+#endif
+#undef TKF
 }
 
 // ---------------------------------------------------------------------------------- scan + residuals
@@ -234,8 +257,10 @@ __device__ __forceinline__ void adj_step(const Kin& k, double h, double gscale, 
 // the reverse lanes of all chunks only have to read theirs.
 // SPEC (speculative Metropolis round, Cpep2Args::spec_slots): a workgroup holds every candidate set of its 64 / slots
 // subjects; behind the SSEs the slot-0 lanes resolve the round and write the next one's candidates (mh_spec_resolve).
-template <int P, bool SPEC = false>
-__global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a) {
+// (P = the network's parameter count, a run-time argument: it only places the (loss, failures) pair in the partial-sum rows,
+//  and one instance per network shape was a third of this file's compile time)
+template <bool SPEC = false>
+__global__ __launch_bounds__(kBlock) void cpep2_scan_kernel(Cpep2Args a, int P) {
     extern __shared__ double smem[];
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x;
@@ -438,8 +463,8 @@ inline int scan_bulk_rows(int T, int L, bool grad) {
     return kRedRows + 5 * T + 8 + 3 * L + (grad ? kAdjMapRows + 9 * T + 4 * kScanWaves : 0);
 }
 
-template <int P, bool SPEC = false>
-__global__ __launch_bounds__(kScanWaves* kBlock) void cpep2_scan_bulk_kernel(Cpep2Args a) {
+template <bool SPEC = false>
+__global__ __launch_bounds__(kScanWaves* kBlock) void cpep2_scan_bulk_kernel(Cpep2Args a, int P) {
     extern __shared__ double smem[];
     const CpepArgs& b = a.base;
     const int lane = threadIdx.x & (kBlock - 1);
@@ -960,23 +985,24 @@ static hipError_t run_shape(int n_state, bool grad, const Cpep2Args& a, hipStrea
             return hipErrorInvalidValue;
         const int spb = kBlock / a.spec_slots;
         if (bulk) {
-            hipError_t e = allow_lds((const void*)cpep2_scan_bulk_kernel<Net::P, true>, lds_bulk);
+            hipError_t e = allow_lds((const void*)cpep2_scan_bulk_kernel<true>, lds_bulk);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((cpep2_scan_bulk_kernel<Net::P, true>), dim3((unsigned)((a.base.N + spb - 1) / spb)),
-                               dim3(kScanWaves * kBlock), lds_bulk, s, as);
+            hipLaunchKernelGGL((cpep2_scan_bulk_kernel<true>), dim3((unsigned)((a.base.N + spb - 1) / spb)),
+                               dim3(kScanWaves * kBlock), lds_bulk, s, as, (int)Net::P);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL((cpep2_scan_kernel<Net::P, true>), dim3((unsigned)((a.base.N + spb - 1) / spb)), dim3(kBlock),
-                           sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as);
+        hipLaunchKernelGGL((cpep2_scan_kernel<true>), dim3((unsigned)((a.base.N + spb - 1) / spb)), dim3(kBlock),
+                           sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as, (int)Net::P);
         return hipGetLastError();
     }
     if (bulk) {
-        hipError_t e = allow_lds((const void*)cpep2_scan_bulk_kernel<Net::P, false>, lds_bulk);
+        hipError_t e = allow_lds((const void*)cpep2_scan_bulk_kernel<false>, lds_bulk);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((cpep2_scan_bulk_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kScanWaves * kBlock), lds_bulk, s, as);
+        hipLaunchKernelGGL((cpep2_scan_bulk_kernel<false>), dim3((unsigned)nblocks, n_sets), dim3(kScanWaves * kBlock), lds_bulk, s, as,
+                           (int)Net::P);
     } else {
-        hipLaunchKernelGGL((cpep2_scan_kernel<Net::P>), dim3((unsigned)nblocks, n_sets), dim3(kBlock),
-                           sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as);
+        hipLaunchKernelGGL((cpep2_scan_kernel<false>), dim3((unsigned)nblocks, n_sets), dim3(kBlock),
+                           sizeof(double) * (size_t)(kRedRows + 5 * a.base.T) * kBlock, s, as, (int)Net::P);
     }
     if (!grad) return hipGetLastError();
     constexpr int TABROWS = Net::HAS_TAB ? 5 * W : 0;
