@@ -189,6 +189,24 @@ int32_t setup_chunks(cude_ctx* c) {
         const double cost = 1.10 * launch_cost((double)c->nblocks * d, (double)n_cu * occ_rev, 5.0 * S / d + 3.0);
         if (cost < best * (1.0 - 1e-3)) { best = cost; L = d; }
     }
+    // Small populations (at most two workgroups per compute unit before splitting): the slot model above takes every
+    // resident wave for full throughput, but a SIMD gives 1, 1.33, 1.36, 1.38 ... of a lone wave's rate to 1, 2, 3, 4+
+    // waves (profiles/r02/ubench_fma_latency.txt) -- it chose 15 chunks for 1e4 and 2e4 subjects where 6 are 5 % and 11 %
+    // faster, and 30 for 4 000 where 15 are 8 % faster (profiles/r05/sweep_chunks_small.txt).  Model fitted to that sweep:
+    // a wave of 5S/L + 3 evaluations at 1.36 us each, slowed by the waves it shares its SIMD with, + 0.25 us of scan per chunk.
+    if (c->nblocks <= 2 * (int64_t)n_cu) {
+        const double simds = (double)n_cu * 4.0;
+        int Ls = 0;
+        double best_s = 0.0;
+        for (int d = 2; d <= S; d++) {
+            if (S % d) continue;
+            const double w = std::ceil((double)c->nblocks * d / simds);
+            const double thr = w <= 1.0 ? 1.0 : (w <= 2.0 ? 1.33 : (w <= 3.0 ? 1.36 : 1.38));
+            const double cost = 1.36 * (5.0 * S / d + 3.0) * w / thr + 0.25 * d;
+            if (Ls == 0 || cost < best_s) { best_s = cost; Ls = d; }
+        }
+        if (Ls >= 2) L = Ls;
+    }
     // Mixed launch (more than one machine-fill of subjects): whole rounds of the one-lane kernel, the remainder --
     // which would otherwise be a second, mostly idle round -- time-split on its own.  Cost = the two parts one after
     // the other (they do overlap at the seam; not counted).
