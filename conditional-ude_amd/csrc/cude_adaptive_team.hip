@@ -15,9 +15,13 @@
 //     hence the same bits, hence the same accept / reject decisions without anybody telling anybody;
 //   * wave w evaluates the network at stage time w + 1 only and publishes the value in LDS (double-buffered by step
 //     parity: ONE workgroup barrier per trial step);
-//   * the reverse sweep needs no exchange at all: the adjoint recursion is network-free (every wave runs it), wave w
-//     applies the VJP of stage w + 1 of every reversed step to ITS OWN accumulators; at the end the five accumulator sets
-//     are added up in wave order through LDS and wave 0 finishes as the one-wave kernel does.
+//   * the reverse sweep: the adjoint recursion is network-free and sequential, the five VJPs of a reversed step need only
+//     the weights it leaves behind.  A SIXTH wave (the scribe; gradient launches only -- it carries the integrator forward
+//     like the others, evaluating nothing) runs the recursion and publishes a step's five weights, h and t_n in LDS
+//     (double-buffered, one barrier per step); wave w < 5 applies the VJP of stage w + 1 of the step published BEFORE to
+//     its own accumulators while the scribe is already on the next step (round 5, first form: every wave ran the
+//     recursion itself, recursion + VJP back to back: 3.3 us per reversed step; now the longer of the two).  At the end
+//     the five accumulator sets are added up in wave order through LDS and wave 0 finishes as the one-wave kernel does.
 // Forward values (trajectories, SSE, accepted steps) are bit-identical to adaptive_unrolled_kernel -- the same arithmetic
 // in the same order; gradients differ by the association of the five partial sums (1e-15).
 #include "cude_adaptive.h"
@@ -37,14 +41,15 @@ template <class M, bool GRAD>
 constexpr bool team_adjoints_in_lds() { return GRAD && M::NetT::NACC > 40; }
 
 template <class M, bool GRAD>
-__global__ __launch_bounds__(kBlock* kTeam) void adaptive_team_kernel(typename M::Args a) {
+__global__ __launch_bounds__(kBlock*(kTeam + (GRAD ? 1 : 0))) void adaptive_team_kernel(typename M::Args a) {
     static_assert(!M::NEED_Y, "constant-Jacobian models only");
     constexpr int NS = M::NS;
     constexpr int P = M::P;
     constexpr bool B_LDS = team_adjoints_in_lds<M, GRAD>();
     using Net = typename M::NetT;
     // LDS: [kRedRows] reduction scratch | [2][kTeam] published network values | TG glucose rows, TG - 1 slope rows |
-    // (GRAD) [NACC] accumulator rows for the sum over the waves, (wide networks) [kTeam][7 NS] stage-adjoint rows
+    // (GRAD) [NACC] accumulator rows for the sum over the waves, (wide networks) [7 NS] stage-adjoint rows of the scribe,
+    // [2][7] published weights / h / t_n of a reversed step + 2 rows for the recursion's closing sums
     extern __shared__ double smem[];
     const int lane = threadIdx.x % kBlock;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kBlock);
@@ -142,13 +147,13 @@ __global__ __launch_bounds__(kBlock* kTeam) void adaptive_team_kernel(typename M
             }
         }
     }
-    const double c_mine = TS_C[wave + 1];          // stage time of this wave's evaluation: t + c dt  (c_6 = 1: t + dt)
+    const double c_mine = TS_C[wave < kTeam ? wave + 1 : kTeam];   // stage time of this wave's evaluation: t + c dt  (c_6 = 1: t + dt)
     int par = 0;
 #pragma unroll 1
     while (true) {
         dt = fmin(dt, t1 - t);
         // ---- this wave's one network evaluation of the trial step, published for the team
-        s_prod[(par * kTeam + wave) * kBlock + lane] = m.production(forcing(fma(c_mine, dt, t)));
+        if (wave < kTeam) s_prod[(par * kTeam + wave) * kBlock + lane] = m.production(forcing(fma(c_mine, dt, t)));
         __syncthreads();
         double prod[kTeam];
 #pragma unroll
@@ -252,87 +257,115 @@ __global__ __launch_bounds__(kBlock* kTeam) void adaptive_team_kernel(typename M
         double acc[Net::NACC];
 #pragma unroll
         for (int q = 0; q < Net::NACC; q++) acc[q] = 0.0;
-        double lam[NS], wsum = 0.0, carry = 0.0;
-#pragma unroll
-        for (int s = 0; s < NS; s++) lam[s] = 0.0;
+        double wsum = 0.0, carry = 0.0;
         const double gs = a.inv_n;
-        int hi = n_out;
         int n_max = n_acc;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
-        double t_next = t;
-        double h_ahead = 0.0;
-        if (n_max > 0) h_ahead = TAPE(n_max - 1 < n_acc ? n_max - 1 : (n_acc > 0 ? n_acc - 1 : 0));
-        const int my = wave + 1;                   // the stage whose VJP this wave applies
+        double* const s_B = s_model + (2 * a.TG + Net::NACC) * kBlock;
+        double* const s_pub = s_B + (B_LDS ? 7 * NS : 0) * kBlock;
+        constexpr int kPub = 7;                    // five weights, h, t_n
+        if (wave == kTeam) {
+            // ---- the scribe: the network-free stage-adjoint recursion, a step ahead of the VJPs
+            double lam[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) lam[s] = 0.0;
+            int hi = n_out;
+            double t_next = t;
+            double h_ahead = 0.0;
+            if (n_max > 0) h_ahead = TAPE(n_max - 1 < n_acc ? n_max - 1 : (n_acc > 0 ? n_acc - 1 : 0));
+            int pb = 0;
 #pragma unroll 1
-        for (int n = n_max - 1; n >= 0; n--) {
-            const bool on = n < n_acc;
-            const double h = h_ahead;
-            if (n > 0) h_ahead = TAPE(n - 1 < n_acc ? n - 1 : (n_acc > 0 ? n_acc - 1 : 0));
-            const double tn = t_next - h;
-            if (on) t_next = tn;
-            StageRows<NS, B_LDS> B(s_model + (2 * a.TG + Net::NACC + wave * 7 * NS) * kBlock, lane);
-            double yb[NS];
+            for (int n = n_max - 1; n >= 0; n--) {
+                const bool on = n < n_acc;
+                const double h = h_ahead;
+                if (n > 0) h_ahead = TAPE(n - 1 < n_acc ? n - 1 : (n_acc > 0 ? n_acc - 1 : 0));
+                const double tn = t_next - h;
+                if (on) t_next = tn;
+                StageRows<NS, B_LDS> B(s_B, lane);
+                double yb[NS];
 #pragma unroll
-            for (int j = 0; j < 7; j++) {
+                for (int j = 0; j < 7; j++) {
 #pragma unroll
-                for (int s = 0; s < NS; s++) B.set(j, s, 0.0);
-            }
+                    for (int s = 0; s < NS; s++) B.set(j, s, 0.0);
+                }
 #pragma unroll
-            for (int s = 0; s < NS; s++) yb[s] = 0.0;
-            while (__any(on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12)) {
-                const bool mine = on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12;
-                if (mine) {
-                    const int oi = hi - 1;
-                    const double th = fmin(1.0, (tout[oi] - tn) / h);
-                    const bool at_end = fabs(th - 1.0) < 1e-12;
-                    double o[NS], ob[NS];
+                for (int s = 0; s < NS; s++) yb[s] = 0.0;
+                while (__any(on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12)) {
+                    const bool mine = on && hi > 0 && tout[hi > 0 ? hi - 1 : 0] > tn + 1e-12;
+                    if (mine) {
+                        const int oi = hi - 1;
+                        const double th = fmin(1.0, (tout[oi] - tn) / h);
+                        const bool at_end = fabs(th - 1.0) < 1e-12;
+                        double o[NS], ob[NS];
 #pragma unroll
-                    for (int s = 0; s < NS; s++) o[s] = 0.0;
-                    o[0] = OUTV(oi);
-                    m.residual_bar(a, oi, i, o, ob);
+                        for (int s = 0; s < NS; s++) o[s] = 0.0;
+                        o[0] = OUTV(oi);
+                        m.residual_bar(a, oi, i, o, ob);
 #pragma unroll
-                    for (int s = 0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
+                        for (int s = 0; s < NS; s++) { ob[s] *= gs; yb[s] += ob[s]; ob[s] *= h; }
 #pragma unroll
-                    for (int j = 0; j < 7; j++) {
-                        const double w = saveat_weight(j, th, at_end);
+                        for (int j = 0; j < 7; j++) {
+                            const double w = saveat_weight(j, th, at_end);
 #pragma unroll
-                        for (int s = 0; s < NS; s++) B.set(j, s, fma(w, ob[s], B.get(j, s)));
+                            for (int s = 0; s < NS; s++) B.set(j, s, fma(w, ob[s], B.get(j, s)));
+                        }
+                        hi--;
                     }
-                    hi--;
                 }
+                double wacc = carry, wst[kTeam];
+#pragma unroll
+                for (int sq = 6; sq >= 0; sq--) {
+                    double kb[NS], ub[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) { kb[s] = B.get(sq, s); ub[s] = sq == 6 ? lam[s] : 0.0; }
+                    m.vjp_linear(kb, ub);
+                    if (sq == 6) {
+                        wacc += kb[0];
+                    } else if (sq == 0) {
+                        carry = kb[0];
+                    } else {
+                        wst[sq - 1] = sq == 5 ? wacc + kb[0] : kb[0];      // the weight of stage sq's VJP (wave sq - 1)
+                    }
+                    wsum += kb[0];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) yb[s] += ub[s];
+#pragma unroll
+                    for (int j = 0; j < sq; j++) {
+                        const double aj = h * TS_A[sq][j];
+#pragma unroll
+                        for (int s = 0; s < NS; s++) B.set(j, s, fma(aj, ub[s], B.get(j, s)));
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; s++) lam[s] = yb[s];
+#pragma unroll
+                for (int q = 0; q < kTeam; q++) s_pub[(pb * kPub + q) * kBlock + lane] = wst[q];
+                s_pub[(pb * kPub + 5) * kBlock + lane] = h;
+                s_pub[(pb * kPub + 6) * kBlock + lane] = tn;
+                pb ^= 1;
+                __syncthreads();
             }
-            // ---- the network-free stage-adjoint recursion (every wave); the weight of this wave's stage is picked up on the way
-            double wacc = carry, my_w = 0.0;
-#pragma unroll
-            for (int sq = 6; sq >= 0; sq--) {
-                double kb[NS], ub[NS];
-#pragma unroll
-                for (int s = 0; s < NS; s++) { kb[s] = B.get(sq, s); ub[s] = sq == 6 ? lam[s] : 0.0; }
-                m.vjp_linear(kb, ub);
-                if (sq == 6) {
-                    wacc += kb[0];
-                } else if (sq == 0) {
-                    carry = kb[0];
-                } else if (sq == my) {
-                    my_w = sq == 5 ? wacc + kb[0] : kb[0];
-                }
-                wsum += kb[0];
-#pragma unroll
-                for (int s = 0; s < NS; s++) yb[s] += ub[s];
-#pragma unroll
-                for (int j = 0; j < sq; j++) {
-                    const double aj = h * TS_A[sq][j];
-#pragma unroll
-                    for (int s = 0; s < NS; s++) B.set(j, s, fma(aj, ub[s], B.get(j, s)));
-                }
+            s_pub[(2 * kPub) * kBlock + lane] = wsum;
+            s_pub[(2 * kPub + 1) * kBlock + lane] = carry;
+        } else {
+            // ---- wave w: the VJP of stage w + 1 of the step the scribe published last
+            int pb = 0;
+#pragma unroll 1
+            for (int n = n_max - 1; n >= 0; n--) {
+                __syncthreads();
+                const double my_w = s_pub[(pb * kPub + wave) * kBlock + lane];
+                const double h = s_pub[(pb * kPub + 5) * kBlock + lane], tn = s_pub[(pb * kPub + 6) * kBlock + lane];
+                pb ^= 1;
+                double dx[1] = {0.0};
+                const double xx[1] = {forcing(fma(c_mine, h, tn))};
+                Net::template eval_grad<false, decltype(acc), kAdaptivePin>(m.p, m.c, xx, my_w, acc, dx);
             }
-#pragma unroll
-            for (int s = 0; s < NS; s++) lam[s] = yb[s];
-            // ---- this wave's one VJP of the step
-            double dx[1] = {0.0};
-            const double xx[1] = {forcing(fma(c_mine, h, tn))};
-            Net::template eval_grad<false, decltype(acc), kAdaptivePin>(m.p, m.c, xx, my_w, acc, dx);
+        }
+        __syncthreads();                           // the recursion's closing sums are in LDS for the lead wave
+        if (lead) {
+            wsum = s_pub[(2 * kPub) * kBlock + lane];
+            carry = s_pub[(2 * kPub + 1) * kBlock + lane];
         }
         // ---- closing evaluations (k1 of the first step at t0, the baseline term): the lead wave; then the five accumulator
         // sets are added up in wave order
@@ -371,14 +404,14 @@ template <class M>
 static hipError_t launch_team(const typename M::Args& a, bool grad, hipStream_t s) {
     const int64_t nblocks = (a.N + kBlock - 1) / kBlock;
     const unsigned n_sets = a.n_sets > 0 ? (unsigned)a.n_sets : 1u;
-    const size_t lds = sizeof(double) * (size_t)(kRedRows + 2 * kTeam + 2 * a.TG + (grad ? M::NetT::NACC : 0) +
-                                                 (grad && team_adjoints_in_lds<M, true>() ? kTeam * 7 * M::NS : 0)) * kBlock;
+    const size_t lds = sizeof(double) * (size_t)(kRedRows + 2 * kTeam + 2 * a.TG + (grad ? M::NetT::NACC + 2 * 7 + 2 : 0) +
+                                                 (grad && team_adjoints_in_lds<M, true>() ? 7 * M::NS : 0)) * kBlock;
     if (grad) {
         if (a.tape == nullptr || a.tape_cap < 1 || a.g_cond == nullptr) return hipErrorInvalidValue;
         // (networks with more than 64 accumulators spill heavily at the two waves per SIMD a team of five needs: they keep
         // the one-wave kernel for the gradient)
         if constexpr (M::NetT::NACC > 64) return hipErrorNotSupported;
-        hipLaunchKernelGGL((adaptive_team_kernel<M, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock * kTeam), lds, s, a);
+        hipLaunchKernelGGL((adaptive_team_kernel<M, true>), dim3((unsigned)nblocks, n_sets), dim3(kBlock * (kTeam + 1)), lds, s, a);
     } else {
         hipLaunchKernelGGL((adaptive_team_kernel<M, false>), dim3((unsigned)nblocks, n_sets), dim3(kBlock * kTeam), lds, s, a);
     }
