@@ -1043,6 +1043,13 @@ int cpep2_rev_waves_per_cu(const NetShape& net) {
     return 0;
 }
 
+// once per context, outside any stream capture: the eight-wave scan may ask for more than 64 KB of LDS
+hipError_t cpep2_prepare() {
+    hipError_t e = allow_lds((const void*)cpep2_scan_bulk_kernel<false>, kScanBulkMaxLds);
+    if (e != hipSuccess) return e;
+    return allow_lds((const void*)cpep2_scan_bulk_kernel<true>, kScanBulkMaxLds);
+}
+
 hipError_t launch_cpep2_homog(const Cpep2Args& a, hipStream_t s) {
     const int64_t nblocks = (a.base.N + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(cpep2_homog_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, a);

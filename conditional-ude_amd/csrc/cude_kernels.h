@@ -205,6 +205,7 @@ struct Cpep2Args {
 constexpr int kAdjMapRows = 36;
 inline int64_t adj_map_rows(int T) { return kAdjMapRows + 9 * (int64_t)T; }
 hipError_t launch_cpep2_adjmap(const Cpep2Args& a, double* adj_map, hipStream_t s);
+hipError_t cpep2_prepare();
 bool cpep2_shape_supported(const NetShape& net, int n_state);
 int cpep2_rev_waves_per_cu(const NetShape& net);
 int cpep_grad_waves_per_cu(const NetShape& net, int n_state, int T);

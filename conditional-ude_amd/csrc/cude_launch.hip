@@ -297,6 +297,7 @@ int32_t setup_chunks(cude_ctx* c) {
     }
     cude::CpepArgs a = cpep_args(c);
     cude::Cpep2Args a2 = chunk_args(c, a);
+    HIP_TRY(cude::cpep2_prepare());
     HIP_TRY(cude::launch_cpep2_homog(a2, c->stream));
     HIP_TRY(c->adj_map.resize((size_t)cude::adj_map_rows(T) * N));          // the scan's adjoint recursion as a linear map
     HIP_TRY(cude::launch_cpep2_adjmap(a2, c->adj_map.p, c->stream));
