@@ -123,8 +123,10 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
     unsigned long long tk[8];
     tk[0] = __builtin_amdgcn_s_memrealtime();
 #define TKF(k) tk[k] = __builtin_amdgcn_s_memrealtime()
+#define TKF_PIN(x) x        // (the values a stamp stands behind have to exist by then)
 #else
 #define TKF(k)
+#define TKF_PIN(x)
 #endif
     cptr_t p = as_const(b.nn + set * b.set_stride_nn);
     cptr_t phi = as_const(b.phi);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
         oi = (int)__popcll(__ballot(before));
     }
     int n = n0;
-    asm volatile("" ::"v"(chk), "v"(c[0]));
+    TKF_PIN(asm volatile("" ::"v"(chk), "v"(c[0])));
     TKF(1);
     if constexpr (Net::USES_TANH) tanh_tab_init(lane, !Net::LDS_BIAS);    // (here: its global read travels with the subject's own loads)
     Net::bias_init(b.nn + set * b.set_stride_nn, lane);
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             s_G[m * kBlock + lane] = gv;
             chk = fma(gv, 0.0, chk);
         }
-        asm volatile("" ::"v"(chk));
+        TKF_PIN(asm volatile("" ::"v"(chk)));
         TKF(3);
         auto input_at = [&](int e) {
             const int sg = seg[e];
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             K1a = kin.f0 + qprev;
             K1b = 0.0;
         }
-        asm volatile("" ::"v"(K1a));
+        TKF_PIN(asm volatile("" ::"v"(K1a)));
         TKF(4);
 #pragma unroll 1
         for (; n < n1; n++) {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
             qprev = q[6];
         }
     }
-    asm volatile("" ::"v"(y1), "v"(y2));
+    TKF_PIN(asm volatile("" ::"v"(y1), "v"(y2)));
     TKF(5);
     if (active) {
         double* f = fsum + (int64_t)c_idx * (3 + T) * N + i;
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(kBlock) void cpep2_fwd_kernel(Cpep2Args a) {
                a.L, n1 - n0, tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
 #endif
 #undef TKF
+#undef TKF_PIN
 }
 
 // ---------------------------------------------------------------------------------- scan + residuals

@@ -314,7 +314,10 @@ int32_t setup_chunks(cude_ctx* c) {
             if (S % d) continue;
             const double w = std::ceil((double)c->nblocks * d / simds);
             const double thr = w <= 1.0 ? 1.0 : (w <= 2.0 ? 1.33 : (w <= 3.0 ? 1.36 : 1.38));
-            const double cost = (5.0 * S / d + 2.0) * w / thr + 0.6 * d;
+            // (the eight-wave scan of a small launch stitches a chunk in ~0.1 us: 57 ... 2 000 subjects 23.3 -> 22.0 us per
+            //  forward call with 30 chunks instead of 15, profiles/r05/sweep_chunks_small.txt)
+            const double per_chunk = (double)c->nblocks * S <= simds ? 0.25 : 0.6;     // (not a function of option "scan_bulk": an A/B of it keeps the split)
+            const double cost = (5.0 * S / d + 2.0) * w / thr + per_chunk * d;
             if (Lf == 0 || cost < best_f) { best_f = cost; Lf = d; }
         }
         if (Lf >= 2 && Lf != L) {
@@ -1158,12 +1161,14 @@ namespace {
 // the forward split): depth 3 while they fit two waves per SIMD (the resident-weights variant of the forward kernel),
 // depth 2 up to ~3 per SIMD.  profiles/r05/estep_speculative.txt (one MI355X, 2-4-4-1, 100 steps, us per step plain ->
 // speculative): 625 subjects 23.8 -> 12.2 (depth 3), 1 250: 23.9 -> 13.7 (2; 14.5 with 3), 1 600: 23.7 -> 16.0 (2; 14.6 with 3),
-// 2 500: 23.6 -> 16.5 (2), 5 000: 25.7 -> 23.5 (2), 1e4: 30.9 -> 29.6 (2), 12 000 and above: slower, off.
+// 2 500: 23.6 -> 16.5 (2), 5 000: 25.7 -> 23.5 (2), 1e4: 30.9 -> 29.6 (2), 12 000 and above: slower, off.  With the
+// eight-wave scan (which helps the plain step more) 1e4 is a draw (30.2 -> 29.6 in that tool, 30.1 -> 31.2 in bench.py's
+// 1e4 x 100): off from ~8 000 subjects.
 int mh_spec_depth(const cude_ctx* c, int n_mc) {
     int d = c->opt.mh_spec;
     if (d < 0) {
         const int64_t waves1 = c->nblocks * (c->chunks_f > 1 ? c->chunks_f : c->chunks);
-        d = 7 * waves1 <= 2048 ? 3 : (3 * waves1 <= 3000 ? 2 : 0);
+        d = 7 * waves1 <= 2048 ? 3 : (3 * waves1 <= 2400 ? 2 : 0);
     }
     d = std::min(d, cude::kMhSpecMaxDepth);
     if (d > n_mc) d = n_mc;
