@@ -314,10 +314,11 @@ int32_t setup_chunks(cude_ctx* c) {
             if (S % d) continue;
             const double w = std::ceil((double)c->nblocks * d / simds);
             const double thr = w <= 1.0 ? 1.0 : (w <= 2.0 ? 1.33 : (w <= 3.0 ? 1.36 : 1.38));
-            // (the eight-wave scan of a small launch stitches a chunk in ~0.1 us: 57 ... 2 000 subjects 23.3 -> 22.0 us per
-            //  forward call with 30 chunks instead of 15, profiles/r05/sweep_chunks_small.txt)
-            const double per_chunk = (double)c->nblocks * S <= simds ? 0.25 : 0.6;     // (not a function of option "scan_bulk": an A/B of it keeps the split)
-            const double cost = (5.0 * S / d + 2.0) * w / thr + per_chunk * d;
+            // (0.6 per chunk dates from the one-wave scan; the eight-wave scan stitches a chunk in ~0.1 us and plain forward
+            //  calls of <= 2 000 subjects would gain ~1 us from 30 chunks instead of 15 -- but the speculative Metropolis
+            //  rounds launch 3 or 7 parameter sets on this split, and with 30 chunks their waves no longer have a SIMD each:
+            //  1 250 subjects x 100 steps 1.25 -> 1.34 ms.  Kept.)
+            const double cost = (5.0 * S / d + 2.0) * w / thr + 0.6 * d;
             if (Lf == 0 || cost < best_f) { best_f = cost; Lf = d; }
         }
         if (Lf >= 2 && Lf != L) {
