@@ -733,6 +733,29 @@ def extras(Engine, device, steps=20, warm=40):
         "note": "the E-step is a chain of dependent launches whose cost is one wave's latency: sharding alone shortens it "
                 "only this much; speculative steps use the SIMDs a small shard leaves idle"}
     eng.close()
+    # the same E-steps in the API mirrors' DEFAULT discretisation (the reference's adaptive solve, n_steps = 0): a Metropolis
+    # step there is one wave's whole adaptive solve; the candidates of d steps run side by side as parameter sets of ONE
+    # launch (option "mh_spec", depth by population size) -- the same chain
+    ad = {}
+    for n_ad, popd in ((n, None), (n8, pop8)):
+        if popd is None:
+            e0, popd = cpep_engine(Engine, arch, 2, n_ad, 780, device, nn4)
+            e0.close()
+        pop = popd
+        res = {}
+        for depth in (-1, 0):
+            eng = Engine("cpep", arch, n_steps=0, n_state=2, device=device)
+            eng.set_option("mh_spec", depth)
+            eng.set_population_cpep(popd["tp"], popd["G"], popd["obs"], popd["age"], popd["t2dm"])
+            eng.set_params(nn4, popd["beta0"])
+            eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, n_mc=10)
+            res[depth] = estep_best_of(eng, reps=2)
+            eng.close()
+        ad[str(n_ad)] = {"ms_per_estep": res[-1][0] * 1e3, "ms_per_estep_one_step_per_launch": res[0][0] * 1e3,
+                         "same_acceptance_counts": bool(np.array_equal(res[-1][1], res[0][1]))}
+    out["saem_estep_1e4x100"]["adaptive_default_mode"] = dict(
+        ad, note="n_steps = 0 (adaptive Tsit5, abstol 1e-6, reltol 1e-3): keys = subjects; speculative rounds put the "
+                 "2^d - 1 candidate states of d steps into one adaptive launch + a resolver launch")
     return out
 
 

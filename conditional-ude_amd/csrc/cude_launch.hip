@@ -1175,6 +1175,21 @@ int mh_spec_depth(const cude_ctx* c, int n_mc) {
     if (d > n_mc) d = n_mc;
     return d >= 2 ? d : 0;
 }
+
+// The same speculation for the contexts whose forward solve is ONE launch over lanes = subjects (the adaptive solve -- the
+// API mirrors' default --, the one-lane fixed-step kernel): a Metropolis step there is a wave's whole solve (84 us for
+// 57 ... 1 000 subjects in the adaptive mode) on a chip that a small population leaves empty, so the 2^d - 1 candidate
+// states run side by side as parameter sets of the launch (grid rows) and mh_spec_kernel resolves the d decisions.
+// Depth while the candidates' workgroups still have a SIMD each (profiles/r05/estep_speculative.txt, adaptive mode, 100
+// steps, ms per E-step plain -> depth 2 / 3 / 4: 57 subjects 10.4 -> 5.6 / 4.0 / 3.1, 1 000: 12.1 -> 6.3 / 4.5 / 3.5,
+// 4 000: 12.4 -> - / 6.0 / 4.7, 1e4: 12.6 -> 8.7 / 8.3 / -).
+int mh_spec_depth_one_launch(const cude_ctx* c, int n_mc) {
+    int d = c->opt.mh_spec;
+    if (d < 0) d = 15 * c->nblocks <= 1024 ? 4 : (7 * c->nblocks <= 1100 ? 3 : (3 * c->nblocks <= 1024 ? 2 : 0));
+    d = std::min(d, cude::kMhSpecMaxDepth);
+    if (d > n_mc) d = n_mc;
+    return d >= 2 ? d : 0;
+}
 }  // namespace
 
 extern "C" {
@@ -1279,6 +1294,48 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
             if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
             k += d;
         }
+        if (samples)
+            HIP_TRY(hipMemcpyAsync(samples, d_z.p, (size_t)n_mc * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (device_rng) c->rng_step += n_mc;
+        return CUDE_OK;
+    }
+    const int spec1 = (!fused && m.carry_sse && is_cpep(c) && (adaptive(c) || c->chunks <= 1) && !c->net.generic())
+                          ? mh_spec_depth_one_launch(c, n_mc) : 0;
+    if (spec1 >= 2) {
+        const int P = c->P;
+        const int64_t nb = c->nblocks, max_sets = (1 << spec1) - 1;
+        DevBuf<double> d_cand, d_sse_sets, d_part;
+        HIP_TRY(d_cand.resize((size_t)max_sets * N));
+        HIP_TRY(d_sse_sets.resize((size_t)max_sets * N));
+        HIP_TRY(d_part.resize((size_t)max_sets * nb * (P + 2)));
+        cude::MhSpecArgs sa{};
+        sa.mh = m;
+        sa.mh.key = cude::RngKey{c->rng_seed, c->rng_offset, 0};
+        sa.cand = d_cand.p; sa.sse_sets = d_sse_sets.p; sa.proposal_std = proposal_std;
+        sa.depth_resolve = 0; sa.depth_next = std::min(spec1, n_mc);
+        sa.step_resolve = sa.step_next = c->rng_step;
+        sa.z_rows = device_rng ? nullptr : d_z.p;
+        HIP_TRY(cude::launch_mh_spec(sa, c->stream));                 // the first round's candidates
+        for (int k = 0; k < n_mc;) {
+            const int d = std::min(spec1, n_mc - k), sets = (1 << d) - 1;
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = d_cand.p; a.nn = c->nn.p; a.sse = d_sse_sets.p; a.traj = nullptr; a.auc = nullptr;
+            a.g_cond = c->g_cond.p; a.partials = d_part.p;
+            a.n_sets = sets; a.set_stride_nn = 0; a.set_stride_cond = N;       // one network, `sets` candidate states
+            HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
+            sa.depth_resolve = d;
+            sa.depth_next = std::min(spec1, n_mc - k - d);
+            sa.step_resolve = c->rng_step + k;
+            sa.step_next = c->rng_step + k + d;
+            sa.u_rows = device_rng ? nullptr : d_u.p + (size_t)k * N;
+            sa.z_rows = device_rng ? nullptr : d_z.p + (size_t)(k + d) * N;
+            sa.samples = samples ? d_z.p + (size_t)k * N : nullptr;            // (as in the time-split rounds above)
+            HIP_TRY(cude::launch_mh_spec(sa, c->stream));
+            k += d;
+        }
+        if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }      // (step counts of the last round's set 0)
         if (samples)
             HIP_TRY(hipMemcpyAsync(samples, d_z.p, (size_t)n_mc * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));

@@ -224,14 +224,18 @@ def test_saem_loop_with_device_draws_equals_the_same_loop_fed_those_draws():
     assert 0.0 < a.acceptance_rates[-1] < 1.0
 
 
+@pytest.mark.parametrize("mode", ["time-split", "adaptive", "one-lane"])
 @pytest.mark.parametrize("N", [48, 1300])
-def test_speculative_metropolis_is_the_same_chain_bit_for_bit(N):
+def test_speculative_metropolis_is_the_same_chain_bit_for_bit(N, mode):
     """Option "mh_spec" (csrc/cude_kernels.h MhSpecArgs): d steps of every subject's chain per dependent launch chain --
     the 2^d - 1 states the d steps can propose from are evaluated as parameter sets of one launch and the decisions
     resolved afterwards.  Same draws (the caller's rows, or the counter-based device stream: a draw depends on (seed,
     subject, step) only), same arithmetic per decision: states, acceptance counts and every intermediate sample equal
     the step-by-step path's (src/saem.jl:86-108,177-186) bit for bit, for every depth, when the step count is not a
-    multiple of the depth, and with a subject whose solve fails."""
+    multiple of the depth, and with a subject whose solve fails.  Modes: the time-split fixed-step path (candidates in the
+    forward chunks' grid, resolved inside the scan launch), and the contexts whose solve is one launch over the subjects --
+    the adaptive solve (the mirrors' default; at these sizes the team kernel) and the one-lane fixed-step kernel --
+    where the candidates are grid rows of that launch and a resolver launch follows (round 5)."""
     from cude.engine import Engine
     arch, steps = (2, 4, 2), 11
     c = make_cpep_case(N, arch)
@@ -241,7 +245,9 @@ def test_speculative_metropolis_is_the_same_chain_bit_for_bit(N):
     start[N // 3] = 800.0                      # exp overflows: this subject's likelihood is -Inf throughout
 
     def run(depth, device_draws):
-        eng = Engine("cpep", arch, n_steps=30)
+        eng = Engine("cpep", arch, n_steps=0 if mode == "adaptive" else 30)
+        if mode == "one-lane":
+            eng.set_option("cpep_path", "1")
         eng.set_option("mh_spec", depth)
         eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
         eng.set_params(c["nn"], start)
