@@ -352,6 +352,33 @@ __global__ void mh_accept_kernel(MhArgs a) {
     mh_accept_one(a, i, a.prop[i], a.sse_new[i]);
 }
 
+// gamma < 1: the next state is a BLEND of the current state with the proposal (accepted) or with itself (rejected) -- in
+// either case a point whose likelihood is not known yet, which is why every step used to solve twice (the proposal, then
+// the current state again).  Both blends depend on nothing but (p, q, gamma), so they are formed BEFORE the decision and
+// solved in the SAME launch as the proposal (three parameter sets: on a chip that a small population leaves mostly empty
+// three sets cost what one costs); the decision then picks state and carried SSE.  cand / sse: [3][N] = proposal, blend
+// if accepted, blend if rejected.  The same expressions on the same values as the two-launch form: the same chain.
+__global__ void mh_blend_candidates_kernel(int64_t N, const double* __restrict__ p, const double* __restrict__ z, RngKey key,
+                                           double proposal_std, double gamma, double* __restrict__ cand) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double pi = p[i], q = mh_proposal(p, z, key, proposal_std, i);
+    cand[i] = q;
+    cand[N + i] = mh_blend(gamma, pi, q);
+    cand[2 * N + i] = mh_blend(gamma, pi, pi);
+}
+__global__ void mh_accept_blend_kernel(MhArgs a, const double* __restrict__ cand, const double* __restrict__ sse) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    const double p = a.p[i];
+    const double u = a.u != nullptr ? a.u[i] : rng_uniform(a.key, i);
+    const bool acc = mh_decide(a, p, cand[i], a.sse_cur[i], sse[i], u);
+    a.p[i] = acc ? cand[N + i] : cand[2 * N + i];
+    a.sse_cur[i] = acc ? sse[N + i] : sse[2 * N + i];
+    if (acc) a.accepted[i] += 1;
+}
+
 // One lane per subject: walks the candidate heap of the round just evaluated (depth_resolve levels), leaves the chain
 // where the sequential steps would have left it, and writes the next round's candidates (MhSpecArgs, cude_kernels.h).
 // Everything that does not depend on the path -- the draws, log(u), every candidate's prior term and tempered
@@ -360,12 +387,13 @@ __global__ void mh_accept_kernel(MhArgs a) {
 __global__ void mh_spec_kernel(MhSpecArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.mh.N) return;
-    mh_spec_resolve(a, i);
+    if (a.blend) mh_spec_resolve_blend(a, i);
+    else mh_spec_resolve(a, i);
 }
 
 hipError_t launch_mh_spec(const MhSpecArgs& a, hipStream_t s) {
-    if (a.depth_resolve < 0 || a.depth_resolve > kMhSpecMaxDepth || a.depth_next < 0 || a.depth_next > kMhSpecMaxDepth)
-        return hipErrorInvalidValue;
+    const int dmax = a.blend ? kMhSpecMaxDepthBlend : kMhSpecMaxDepth;
+    if (a.depth_resolve < 0 || a.depth_resolve > dmax || a.depth_next < 0 || a.depth_next > dmax) return hipErrorInvalidValue;
     const int bs = 64;
     hipLaunchKernelGGL(mh_spec_kernel, dim3((unsigned)((a.mh.N + bs - 1) / bs)), dim3(bs), 0, s, a);
     return hipGetLastError();
@@ -388,6 +416,20 @@ hipError_t launch_rng_draws(int64_t N, RngKey key, double* normals, double* unif
 hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s) {
     const int bs = 256;
     hipLaunchKernelGGL(mh_accept_kernel, dim3((unsigned)((a.N + bs - 1) / bs)), dim3(bs), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mh_blend_candidates(int64_t N, const double* p, const double* z, RngKey key, double proposal_std, double gamma,
+                                      double* cand, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(mh_blend_candidates_kernel, dim3((unsigned)((N + bs - 1) / bs)), dim3(bs), 0, s, N, p, z, key,
+                       proposal_std, gamma, cand);
+    return hipGetLastError();
+}
+
+hipError_t launch_mh_accept_blend(const MhArgs& a, const double* cand, const double* sse, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(mh_accept_blend_kernel, dim3((unsigned)((a.N + bs - 1) / bs)), dim3(bs), 0, s, a, cand, sse);
     return hipGetLastError();
 }
 

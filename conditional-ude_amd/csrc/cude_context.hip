@@ -195,6 +195,7 @@ const OptionEntry kOptions[] = {
     {"scan_map", "CUDE_NO_SCAN_MAP", &Options::scan_map, true, true},
     {"scan_bulk", "CUDE_NO_SCAN_BULK", &Options::scan_bulk, true, true},
     {"mh_fuse", "CUDE_NO_MH_FUSE", &Options::mh_fuse, true, true},
+    {"mh_pair", "CUDE_NO_MH_PAIR", &Options::mh_pair, true, true},
     {"graph", "CUDE_NO_GRAPH", &Options::graph, true, true},
     {"graph_unroll", "CUDE_GRAPH_UNROLL", &Options::graph_unroll, false, true},
     {"prio_shift", "CUDE_PRIO_SHIFT", &Options::prio_shift, false, true},

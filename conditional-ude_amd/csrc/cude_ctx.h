@@ -91,6 +91,7 @@ struct Options {
     int scan_bulk = 1;          // CUDE_NO_SCAN_BULK: small scan launches fetch every row through LDS up front (round 5)
     int scan_map = 1;           // CUDE_NO_SCAN_MAP: the scan's adjoint recursion as a per-subject linear map (round 5)
     int mh_fuse = 1;            // CUDE_NO_MH_FUSE
+    int mh_pair = 1;            // CUDE_NO_MH_PAIR: gamma < 1 -- the proposal and both possible next states in one launch (round 5)
     int graph = 1;              // CUDE_NO_GRAPH
     int graph_unroll = 8;       // CUDE_GRAPH_UNROLL
     int prio_shift = -1;        // CUDE_PRIO_SHIFT (-1 = the rule in prio_shift_for)

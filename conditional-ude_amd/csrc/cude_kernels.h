@@ -148,6 +148,7 @@ struct MhArgs {
 // Candidates form a binary heap: node v (1-based; level l = floor(log2 v)) proposes q(v) = s(v) + std * z_l from its
 // state s(v); s(1) = the chain state, s(2v) = s(v) (rejected), s(2v + 1) = q(v) (accepted).  cand / sse_sets: [v - 1][N].
 constexpr int kMhSpecMaxDepth = 4;
+constexpr int kMhSpecMaxDepthBlend = 3;     // gamma < 1 (MhSpecArgs::blend): two parameter sets per node
 struct MhSpecArgs {
     MhArgs mh;                 // p, sse_cur, accepted, the prior and likelihood constants; key.step is NOT used (steps below)
     int32_t depth_resolve;     // levels of `cand` / `sse_sets` to resolve into the chain now (0: none -- the first call)
@@ -159,6 +160,8 @@ struct MhSpecArgs {
     const double* u_rows;      // caller's uniforms of the steps being RESOLVED, likewise
     double proposal_std;
     double* samples;           // chain state after every resolved step, row l at samples + l * N; or nullptr
+    int32_t blend;             // gamma < 1: every node carries its state AND its proposal (mh_spec_resolve_blend, cude_rng.h):
+                               //   cand / sse_sets rows [v - 1] = state of node v, [nodes + v - 1] = its proposal; depth <= 3
 };
 hipError_t launch_mh_spec(const MhSpecArgs& a, hipStream_t s);
 
@@ -407,6 +410,10 @@ hipError_t launch_mh_propose(int64_t N, const double* p, const double* z, RngKey
 // the draws themselves (normals[N], uniforms[N] of one step), for reproducing a device-generated chain elsewhere
 hipError_t launch_rng_draws(int64_t N, RngKey key, double* normals, double* uniforms, hipStream_t s);
 hipError_t launch_mh_accept(const MhArgs& a, hipStream_t s);
+// gamma < 1: proposal and the two possible next states as three parameter sets [3][N]; the decision behind their solves
+hipError_t launch_mh_blend_candidates(int64_t N, const double* p, const double* z, RngKey key, double proposal_std, double gamma,
+                                      double* cand, hipStream_t s);
+hipError_t launch_mh_accept_blend(const MhArgs& a, const double* cand, const double* sse, hipStream_t s);
 // per-subject 1-D fits (cude_fit_conditional): device-resident search state, all arrays [N]
 struct FitArgs {
     int64_t N;

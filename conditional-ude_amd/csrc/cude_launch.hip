@@ -1343,6 +1343,121 @@ int32_t cude_mh_chain(cude_ctx* c, int32_t n_mc, const double* normals, const do
         if (device_rng) c->rng_step += n_mc;
         return CUDE_OK;
     }
+    // gamma < 1 (the stochastic-approximation phase): the next state is a blend whose likelihood is not known, so a step
+    // needed two solves one after the other (the proposal, then the current state again).  The two possible next states
+    // depend on (p, q, gamma) alone: they are solved in the SAME launch as the proposal, as three parameter sets, and the
+    // decision picks state and SSE (mh_accept_blend_kernel) -- one solve launch per step, the same chain.
+    if (!m.carry_sse && is_cpep(c) && !c->net.generic() && c->opt.mh_pair) {
+        const int P = c->P, sets = 3;
+        const int64_t nb = c->nblocks;
+        const bool split = !adaptive(c) && c->chunks > 1;
+        DevBuf<double> d_cand, d_sse3, d_part;
+        HIP_TRY(d_cand.resize((size_t)sets * N));
+        HIP_TRY(d_sse3.resize((size_t)sets * N));
+        if (split) {
+            const int Lf = (c->chunks_f > 1 ? c->chunks_f : c->chunks);
+            HIP_TRY(c->ms_fsum.reserve((size_t)sets * Lf * (3 + c->T) * N));
+            HIP_TRY(c->ms_part.reserve((size_t)sets * nb * (P + 2)));
+        } else {
+            HIP_TRY(d_part.resize((size_t)sets * nb * (P + 2)));
+        }
+        // ... and d such steps per launch by speculation (MhSpecArgs::blend: a node of the candidate heap is its state AND
+        // its proposal, 2 (2^d - 1) parameter sets) while the sets' waves still have a SIMD each
+        int spec3 = c->opt.mh_spec;
+        {
+            const int64_t waves1 = nb * (split ? (c->chunks_f > 1 ? c->chunks_f : c->chunks) : 1);
+            // (profiles/r05/estep_speculative.txt, gamma = 0.25, 100 steps, ms per E-step two launches per step -> one -> depth
+            //  2 / 3: adaptive 57 subjects 20.3 -> 11.0 -> 5.6 / 4.0, 4 000: 24.0 -> 12.8 -> 8.7 / 6.0, 1e4: 24.3 -> 17.3 -> 8.7 /
+            //  11.5; fixed 30 steps (time-split) 57: 4.10 -> 2.39 -> 1.27 / 1.01, 1 000: 4.06 -> 2.39 -> 1.51 / 1.57, 4 000:
+            //  4.28 -> 3.68 -> 3.02 / 3.61, 1e4: 5.94 -> 6.17 -> 5.10 / 6.62)
+            if (spec3 < 0) {
+                if (split) spec3 = 14 * waves1 <= 2048 ? 3 : (6 * waves1 <= 6000 ? 2 : 0);
+                else spec3 = 14 * waves1 <= 1024 ? 3 : (6 * waves1 <= 1024 ? 2 : 0);
+            }
+            spec3 = std::min(std::min(spec3, (int)cude::kMhSpecMaxDepthBlend), (int)n_mc);
+            if (spec3 < 2) spec3 = 0;
+        }
+        if (spec3 >= 2) {
+            const int64_t max_sets = 2 * ((1 << spec3) - 1);
+            HIP_TRY(d_cand.resize((size_t)max_sets * N));
+            HIP_TRY(d_sse3.resize((size_t)max_sets * N));
+            if (split) {
+                const int Lf = (c->chunks_f > 1 ? c->chunks_f : c->chunks);
+                HIP_TRY(c->ms_fsum.reserve((size_t)max_sets * Lf * (3 + c->T) * N));
+                HIP_TRY(c->ms_part.reserve((size_t)max_sets * nb * (P + 2)));
+            } else {
+                HIP_TRY(d_part.resize((size_t)max_sets * nb * (P + 2)));
+            }
+            cude::MhSpecArgs sa{};
+            sa.mh = m;
+            sa.mh.key = cude::RngKey{c->rng_seed, c->rng_offset, 0};
+            sa.blend = 1;
+            sa.cand = d_cand.p; sa.sse_sets = d_sse3.p; sa.proposal_std = proposal_std;
+            sa.depth_resolve = 0; sa.depth_next = std::min(spec3, n_mc);
+            sa.step_resolve = sa.step_next = c->rng_step;
+            sa.z_rows = device_rng ? nullptr : d_z.p;
+            HIP_TRY(cude::launch_mh_spec(sa, c->stream));             // the first round's candidates
+            for (int k = 0; k < n_mc;) {
+                const int d = std::min(spec3, n_mc - k), nsets = 2 * ((1 << d) - 1);
+                cude::CpepArgs a = cpep_args(c);
+                a.cond = d_cand.p; a.nn = c->nn.p; a.sse = d_sse3.p; a.traj = nullptr; a.auc = nullptr;
+                a.g_cond = c->g_cond.p; a.partials = split ? c->ms_part.p : d_part.p;
+                a.n_sets = nsets; a.set_stride_nn = 0; a.set_stride_cond = N;
+                if (split) {
+                    cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true, /*forward_only=*/true);
+                    a2.fsum = c->ms_fsum.p;
+                    HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, false, a2, c->stream));
+                } else {
+                    HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
+                }
+                sa.depth_resolve = d;
+                sa.depth_next = std::min(spec3, n_mc - k - d);
+                sa.step_resolve = c->rng_step + k;
+                sa.step_next = c->rng_step + k + d;
+                sa.u_rows = device_rng ? nullptr : d_u.p + (size_t)k * N;
+                sa.z_rows = device_rng ? nullptr : d_z.p + (size_t)(k + d) * N;
+                sa.samples = samples ? d_z.p + (size_t)k * N : nullptr;
+                HIP_TRY(cude::launch_mh_spec(sa, c->stream));
+                k += d;
+            }
+            if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }
+            if (samples)
+                HIP_TRY(hipMemcpyAsync(samples, d_z.p, (size_t)n_mc * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (device_rng) c->rng_step += n_mc;
+            return CUDE_OK;
+        }
+        if ((rc = run_ensemble(c, false, nullptr, true, c->cond.p, d_sc.p))) return rc;      // SSE of the starting state
+        for (int k = 0; k < n_mc; k++) {
+            m.key = cude::RngKey{c->rng_seed, c->rng_offset, c->rng_step + k};
+            HIP_TRY(cude::launch_mh_blend_candidates(N, c->cond.p, device_rng ? nullptr : d_z.p + (size_t)k * N, m.key,
+                                                     proposal_std, gamma, d_cand.p, c->stream));
+            cude::CpepArgs a = cpep_args(c);
+            a.cond = d_cand.p; a.nn = c->nn.p; a.sse = d_sse3.p; a.traj = nullptr; a.auc = nullptr;
+            a.g_cond = c->g_cond.p; a.partials = split ? c->ms_part.p : d_part.p;
+            a.n_sets = sets; a.set_stride_nn = 0; a.set_stride_cond = N;       // one network, three candidate states
+            if (split) {
+                cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true, /*forward_only=*/true);
+                a2.fsum = c->ms_fsum.p;
+                HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, false, a2, c->stream));
+            } else {
+                HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
+            }
+            m.u = device_rng ? nullptr : d_u.p + (size_t)k * N;
+            HIP_TRY(cude::launch_mh_accept_blend(m, d_cand.p, d_sse3.p, c->stream));
+            if (samples)
+                HIP_TRY(hipMemcpyAsync(d_z.p + (size_t)k * N, c->cond.p, N * sizeof(double), hipMemcpyDeviceToDevice,
+                                       c->stream));
+        }
+        if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }
+        if (samples)
+            HIP_TRY(hipMemcpyAsync(samples, d_z.p, (size_t)n_mc * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (accepted) HIP_TRY(hipMemcpyAsync(accepted, d_acc.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (device_rng) c->rng_step += n_mc;
+        return CUDE_OK;
+    }
     for (int k = 0; k < n_mc; k++) {          // everything is queued on the stream; one sync at the end
         m.key = cude::RngKey{c->rng_seed, c->rng_offset, c->rng_step + k};
         if (fused) {

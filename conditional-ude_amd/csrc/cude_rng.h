@@ -75,13 +75,18 @@ __device__ __forceinline__ bool mh_decide(const MhArgs& a, double p, double q, d
     return mh_decide_terms(log(u), mh_prior_term(a, p), mh_prior_term(a, q), mh_tempered_ll(a, sc), mh_tempered_ll(a, sn));
 }
 
+// the stochastic-approximation update of the state (src/saem.jl:177-186): (1 - gamma) p + gamma x, x = the proposal when it was
+// accepted, else p itself (which does NOT give p back bit for bit when gamma < 1).  One explicit form: the kernels that
+// evaluate the two possible next states before the decision (mh_blend_candidates_kernel) must form the same bits.
+__device__ __forceinline__ double mh_blend(double gamma, double p, double x) { return fma(gamma, x, (1.0 - gamma) * p); }
+
 // accept / reject of one Metropolis-Hastings step for subject i (src/saem.jl:86-108 and the stochastic-approximation
 // update :177-186): q = proposal, sn = its SSE
 __device__ __forceinline__ void mh_accept_one(const MhArgs& a, int64_t i, double q, double sn) {
     const double p = a.p[i];
     const double u = a.u != nullptr ? a.u[i] : rng_uniform(a.key, i);
     const bool acc = mh_decide(a, p, q, a.sse_cur[i], sn, u);
-    a.p[i] = (1.0 - a.gamma) * p + a.gamma * (acc ? q : p);
+    a.p[i] = mh_blend(a.gamma, p, acc ? q : p);
     if (acc) {
         a.accepted[i] += 1;
         if (a.carry_sse) a.sse_cur[i] = sn;
@@ -140,7 +145,7 @@ __device__ __forceinline__ void mh_spec_resolve(const MhSpecArgs& a, int64_t i) 
                 for (int w = (1 << l); w < (2 << l); w++)
                     if (w == v) { qv = q[w - 1]; snv = sn[w - 1]; priv = pri[w - 1]; lltv = llt[w - 1]; }
                 const bool acc = mh_decide_terms(logu[l], pri_s, priv, llt_s, lltv);
-                s = (1.0 - m.gamma) * s + m.gamma * (acc ? qv : s);      // (gamma == 1: the statement of mh_accept_one)
+                s = mh_blend(m.gamma, s, acc ? qv : s);                  // (gamma == 1: the statement of mh_accept_one)
                 if (acc) { nacc++; sc = snv; pri_s = priv; llt_s = lltv; }
                 v = 2 * v + (acc ? 1 : 0);
                 if (a.samples != nullptr) a.samples[(int64_t)l * N + i] = s;
@@ -161,6 +166,80 @@ __device__ __forceinline__ void mh_spec_resolve(const MhSpecArgs& a, int64_t i) 
                     const double qn = fma(zn[l], a.proposal_std, st[v]);      // (= mh_proposal from that state)
                     a.cand[(int64_t)(v - 1) * N + i] = qn;
                     if (l + 1 < D) { st[2 * v] = st[v]; st[2 * v + 1] = qn; }
+                }
+            }
+        }
+    }
+}
+
+// The same for gamma < 1 (MhSpecArgs::blend): the state after a step is a BLEND -- mh_blend(s, q) if the proposal was
+// accepted, mh_blend(s, s) if not -- whose likelihood is not carried by anything, so every node v of the heap contributes
+// TWO parameter sets: its state s(v) (rows [v - 1]) and its proposal q(v) = s(v) + std z_l (rows [nodes + v - 1]);
+// s(1) = the chain state, s(2v) = mh_blend(s(v), s(v)), s(2v + 1) = mh_blend(s(v), q(v)).  The walk reads both SSEs of the
+// node it stands on.  Same expressions on the same values as mh_accept_one step by step: the same bits.
+__device__ __forceinline__ void mh_spec_resolve_blend(const MhSpecArgs& a, int64_t i) {
+    constexpr int D = kMhSpecMaxDepthBlend, NODES = (1 << D) - 1;
+    const int64_t N = a.mh.N;
+    const MhArgs& m = a.mh;
+    double logu[D], zn[D];
+#pragma unroll
+    for (int l = 0; l < D; l++) {
+        RngKey key = m.key;
+        if (l < a.depth_resolve) {
+            key.step = a.step_resolve + l;
+            logu[l] = log(a.u_rows != nullptr ? a.u_rows[(int64_t)l * N + i] : rng_uniform(key, i));
+        }
+        if (l < a.depth_next) {
+            key.step = a.step_next + l;
+            zn[l] = a.z_rows != nullptr ? a.z_rows[(int64_t)l * N + i] : rng_normal(key, i);
+        }
+    }
+    double s = m.p[i];
+    if (a.depth_resolve > 0) {
+        const int nodes = (1 << a.depth_resolve) - 1;
+        double sv[NODES], q[NODES], pri_s[NODES], pri_q[NODES], llt_s[NODES], llt_q[NODES];
+#pragma unroll
+        for (int v = 0; v < NODES; v++) {
+            if (v < nodes) {
+                sv[v] = a.cand[(int64_t)v * N + i];
+                q[v] = a.cand[(int64_t)(nodes + v) * N + i];
+                pri_s[v] = mh_prior_term(m, sv[v]);
+                pri_q[v] = mh_prior_term(m, q[v]);
+                llt_s[v] = mh_tempered_ll(m, a.sse_sets[(int64_t)v * N + i]);
+                llt_q[v] = mh_tempered_ll(m, a.sse_sets[(int64_t)(nodes + v) * N + i]);
+            }
+        }
+        int v = 1, nacc = 0;
+#pragma unroll
+        for (int l = 0; l < D; l++) {
+            if (l < a.depth_resolve) {
+                double svv = 0.0, qv = 0.0, ps = 0.0, pq = 0.0, ls = 0.0, lq = 0.0;
+#pragma unroll
+                for (int w = (1 << l); w < (2 << l); w++)
+                    if (w == v) { svv = sv[w - 1]; qv = q[w - 1]; ps = pri_s[w - 1]; pq = pri_q[w - 1]; ls = llt_s[w - 1]; lq = llt_q[w - 1]; }
+                const bool acc = mh_decide_terms(logu[l], ps, pq, ls, lq);
+                s = mh_blend(m.gamma, svv, acc ? qv : svv);
+                if (acc) nacc++;
+                v = 2 * v + (acc ? 1 : 0);
+                if (a.samples != nullptr) a.samples[(int64_t)l * N + i] = s;
+            }
+        }
+        m.p[i] = s;
+        if (nacc) m.accepted[i] += nacc;
+    }
+    if (a.depth_next > 0) {
+        const int nodes = (1 << a.depth_next) - 1;
+        double st[1 << D];
+        st[1] = s;
+#pragma unroll
+        for (int l = 0; l < D; l++) {
+            if (l < a.depth_next) {
+#pragma unroll
+                for (int v = 1 << l; v < (2 << l); v++) {
+                    const double qn = fma(zn[l], a.proposal_std, st[v]);      // (= mh_proposal from that state)
+                    a.cand[(int64_t)(v - 1) * N + i] = st[v];
+                    a.cand[(int64_t)(nodes + v - 1) * N + i] = qn;
+                    if (l + 1 < D) { st[2 * v] = mh_blend(m.gamma, st[v], st[v]); st[2 * v + 1] = mh_blend(m.gamma, st[v], qn); }
                 }
             }
         }

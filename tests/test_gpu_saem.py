@@ -268,3 +268,45 @@ def test_speculative_metropolis_is_the_same_chain_bit_for_bit(N, mode):
             got = run(depth, device_draws)
             for a, b in zip(ref, got):
                 assert np.array_equal(a, b), (depth, device_draws)
+
+
+@pytest.mark.parametrize("mode", ["time-split", "adaptive", "one-lane"])
+def test_blend_phase_solves_proposal_and_both_next_states_in_one_launch(mode):
+    """gamma < 1 (the stochastic-approximation phase, src/saem.jl:177-186): the next state is (1 - gamma) p + gamma x with x
+    the accepted proposal or p itself -- either way a point whose likelihood is unknown, which cost a second solve per
+    step.  Both possible next states depend on (p, q, gamma) alone, so they ride in the proposal's launch as parameter
+    sets and the decision picks state and SSE (option "mh_pair" = 0: the two-launch form).  The same chain bit for bit --
+    states, acceptance counts, every intermediate sample --, with the caller's draws and the device's, with a subject
+    whose solve fails."""
+    from cude.engine import Engine
+    arch, N, steps = (2, 4, 2), 150, 9
+    c = make_cpep_case(N, arch)
+    rng = np.random.default_rng(6)
+    normals, uniforms = rng.standard_normal((steps, N)), rng.random((steps, N))
+    start = c["beta"].copy()
+    start[N // 3] = 800.0
+
+    def run(pair, device_draws, depth=0):
+        eng = Engine("cpep", arch, n_steps=0 if mode == "adaptive" else 30)
+        if mode == "one-lane":
+            eng.set_option("cpep_path", "1")
+        eng.set_option("mh_pair", pair)
+        eng.set_option("mh_spec", depth)
+        eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        eng.set_params(c["nn"], start)
+        eng.set_rng(99, 3)
+        if device_draws:
+            acc, samples = eng.mh_chain(None, None, 0.4, -0.6, 0.9, 0.3, 2.0, 0.35, n_mc=steps)
+        else:
+            acc, samples = eng.mh_chain(normals, uniforms, 0.4, -0.6, 0.9, 0.3, 2.0, 0.35)
+        _, p = eng.get_params()
+        eng.close()
+        return acc, samples, p
+    for device_draws in (False, True):
+        ref = run(0, device_draws)
+        assert 0 < ref[0].sum() < steps * N
+        # ... and d such steps per launch by speculation (every node of the candidate heap = its state and its proposal)
+        for depth in (0, 2, 3, -1):
+            got = run(1, device_draws, depth)
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), (device_draws, depth)
