@@ -753,6 +753,21 @@ def extras(Engine, device, steps=20, warm=40):
             eng.close()
         ad[str(n_ad)] = {"ms_per_estep": res[-1][0] * 1e3, "ms_per_estep_one_step_per_launch": res[0][0] * 1e3,
                          "same_acceptance_counts": bool(np.array_equal(res[-1][1], res[0][1]))}
+        # the stochastic-approximation phase (gamma < 1: the next state is a blend whose likelihood nothing carries): the
+        # proposal and both possible next states in one launch, d steps per launch by speculation; fixed-step and adaptive
+        for steps_g, tag in ((N_STEPS, "fixed"), (0, "adaptive")):
+            eng = Engine("cpep", arch, n_steps=steps_g, n_state=2, device=device)
+            eng.set_population_cpep(popd["tp"], popd["G"], popd["obs"], popd["age"], popd["t2dm"])
+            best = 1e9
+            for rep in range(3):
+                eng.set_params(nn4, popd["beta0"])
+                eng.set_rng(20250905)
+                t0_ = time.perf_counter()
+                eng.mh_estep(None, None, 0.5, -0.6, 0.8, 0.3, 1.0, 0.25, n_mc=n_mc)
+                if rep:
+                    best = min(best, time.perf_counter() - t0_)
+            eng.close()
+            ad[str(n_ad)][f"ms_per_estep_gamma_0.25_{tag}"] = best * 1e3
     out["saem_estep_1e4x100"]["adaptive_default_mode"] = dict(
         ad, note="n_steps = 0 (adaptive Tsit5, abstol 1e-6, reltol 1e-3): keys = subjects; speculative rounds put the "
                  "2^d - 1 candidate states of d steps into one adaptive launch + a resolver launch")
