@@ -483,6 +483,61 @@ __global__ void fit_golden_kernel(FitArgs a, int final) {
     }
 }
 
+// ---- the same search with several probes per forward launch (cude_fit_conditional, option "fit_spec"): on a chip that a
+// small population leaves mostly empty a launch of k parameter sets costs what a launch of one costs.
+// Grid scan: all n_grid values as the sets of one launch; the scan's update in the scan's order.
+__global__ void fit_grid_all_kernel(FitArgs a, int k0, int kn, const double* __restrict__ values, const double* __restrict__ sse_sets) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    double fbest = a.fc[i], kbest = a.best[i];
+    for (int k = 0; k < kn; k++) {
+        const double f = fit_objective(sse_sets[(int64_t)k * a.N + i], values[k0 + k], a.w, a.mu);
+        if (k0 + k == 0 || f < fbest) { fbest = f; kbest = (double)(k0 + k); }
+    }
+    a.fc[i] = fbest;
+    a.best[i] = kbest;
+}
+// Golden section: which half survives a step is a binary outcome, so the probes of the next `depth` steps form a heap --
+// node v holds the bracket it would have and its two probes (rows 2 (v - 1) and 2 (v - 1) + 1 of cand), node 2v = the
+// bracket after "left" (fc < fd), 2v + 1 after "right" -- all evaluated in one launch; the walk then takes `depth` steps.
+// The same expressions on the same values as fit_golden_kernel step by step: the same brackets, the same result.
+__global__ void fit_tree_candidates_kernel(FitArgs a, int depth, double* __restrict__ cand) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    constexpr int D = kFitSpecMaxDepth;
+    double lo[1 << D], hi[1 << D];
+    lo[1] = a.a[i];
+    hi[1] = a.b[i];
+#pragma unroll
+    for (int l = 0; l < D; l++) {
+        if (l < depth) {
+#pragma unroll
+            for (int v = 1 << l; v < (2 << l); v++) {
+                const double c = hi[v] - a.gr * (hi[v] - lo[v]), d = lo[v] + a.gr * (hi[v] - lo[v]);
+                cand[(int64_t)(2 * (v - 1)) * a.N + i] = c;
+                cand[(int64_t)(2 * (v - 1) + 1) * a.N + i] = d;
+                if (l + 1 < D) { lo[2 * v] = lo[v]; hi[2 * v] = d; lo[2 * v + 1] = c; hi[2 * v + 1] = hi[v]; }
+            }
+        }
+    }
+}
+__global__ void fit_tree_resolve_kernel(FitArgs a, int depth, int final, const double* __restrict__ cand,
+                                        const double* __restrict__ sse_sets) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    double lo = a.a[i], hi = a.b[i];
+    int v = 1;
+    for (int l = 0; l < depth; l++) {
+        const int64_t rc = (int64_t)(2 * (v - 1)) * a.N + i, rd = rc + a.N;
+        const double c = cand[rc], d = cand[rd];
+        const double fc = fit_objective(sse_sets[rc], c, a.w, a.mu), fd = fit_objective(sse_sets[rd], d, a.w, a.mu);
+        if (fc < fd) { hi = d; v = 2 * v; } else { lo = c; v = 2 * v + 1; }
+    }
+    a.a[i] = lo;
+    a.b[i] = hi;
+    if (final) a.c[i] = 0.5 * (lo + hi);
+}
+
 // objective at the returned point
 __global__ void fit_finish_kernel(FitArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -504,6 +559,20 @@ hipError_t launch_fit(int phase, const FitArgs& a, int k, double x, hipStream_t 
         case 3: hipLaunchKernelGGL(fit_finish_kernel, grid, dim3(bs), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_fit_grid_all(const FitArgs& a, int k0, int kn, const double* values, const double* sse_sets, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(fit_grid_all_kernel, dim3((unsigned)((a.N + bs - 1) / bs)), dim3(bs), 0, s, a, k0, kn, values, sse_sets);
+    return hipGetLastError();
+}
+hipError_t launch_fit_tree(const FitArgs& a, int depth, int resolve, int final, double* cand, const double* sse_sets, hipStream_t s) {
+    if (depth < 1 || depth > kFitSpecMaxDepth) return hipErrorInvalidValue;
+    const int bs = 256;
+    const dim3 grid((unsigned)((a.N + bs - 1) / bs));
+    if (resolve) hipLaunchKernelGGL(fit_tree_resolve_kernel, grid, dim3(bs), 0, s, a, depth, final, cand, sse_sets);
+    else hipLaunchKernelGGL(fit_tree_candidates_kernel, grid, dim3(bs), 0, s, a, depth, cand);
     return hipGetLastError();
 }
 

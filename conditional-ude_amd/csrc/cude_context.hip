@@ -180,6 +180,7 @@ const OptionEntry kOptions[] = {
     {"ms_split", "CUDE_NO_MS_SPLIT", &Options::ms_split, true, false},
     {"train_host", "CUDE_TRAIN_HOST", &Options::train_host, false, false},
     {"mh_spec", "CUDE_MH_SPEC", &Options::mh_spec, false, false},
+    {"fit_spec", "CUDE_FIT_SPEC", &Options::fit_spec, false, false},
     {"adaptive_team", "CUDE_NO_ADAPTIVE_TEAM", &Options::adaptive_team, true, false},
     {"auto_regroup", "CUDE_NO_AUTO_REGROUP", &Options::auto_regroup, true, false},
     {"poll_pinned", "CUDE_NO_POLL_PINNED", &Options::poll_pinned, true, false},

@@ -70,6 +70,9 @@ struct Options {
                                 //   (what a sharded population always does), 2 = the Adam stage on the host as well
     int mh_spec = -1;           // "mh_spec" / CUDE_MH_SPEC: speculative Metropolis steps per launch chain (cude_mh_estep, gamma == 1,
                                 //   time-split forward path): 0 = off, 2 ... 4 = that many, -1 = by population size (mh_spec_depth)
+    int fit_spec = -1;          // "fit_spec" / CUDE_FIT_SPEC: cude_fit_conditional with several probes per forward launch (the grid scan
+                                //   as parameter sets, the next d golden-section steps as a heap of brackets): 0 = one probe per launch,
+                                //   1 ... 4 = that depth, -1 = by population size
     int adaptive_team = 1;      // "adaptive_team" / CUDE_NO_ADAPTIVE_TEAM: adaptive launches of small c-peptide populations put a
                                 //   step's five network evaluations on five waves (cude_adaptive_team.hip)
     int auto_regroup = 1;       // "auto_regroup" / CUDE_NO_AUTO_REGROUP: adaptive launches re-ordered by accepted-step count

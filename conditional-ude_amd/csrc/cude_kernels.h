@@ -427,6 +427,11 @@ struct FitArgs {
 // phase 0: grid scan update (k = grid index, x = its value); 1: bracket; 2: golden step (k = 1 on the last one);
 // 3: objective at the result
 hipError_t launch_fit(int phase, const FitArgs& a, int k, double x, hipStream_t s);
+// several probes per forward launch (cude_common.hip): the grid scan's update over sets [k0, k0 + kn) of one launch; the
+// golden section's next `depth` steps as a heap of brackets, 2 (2^depth - 1) probes in cand / sse_sets [set][N]
+constexpr int kFitSpecMaxDepth = 4;
+hipError_t launch_fit_grid_all(const FitArgs& a, int k0, int kn, const double* values, const double* sse_sets, hipStream_t s);
+hipError_t launch_fit_tree(const FitArgs& a, int depth, int resolve, int final, double* cand, const double* sse_sets, hipStream_t s);
 hipError_t launch_fill(int64_t N, double v, double* out, hipStream_t s);
 hipError_t launch_fill_rows(int64_t N, int n_rows, const double* values, double* out, hipStream_t s);
 // population preparation

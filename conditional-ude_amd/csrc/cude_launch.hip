@@ -1129,6 +1129,89 @@ int32_t cude_fit_conditional(cude_ctx* c, double lower, double upper, int32_t n_
     f.w = penalty_weight; f.mu = penalty_center;
     f.lower = lower; f.step = (upper - lower) / (n_grid - 1); f.gr = (std::sqrt(5.0) - 1.0) / 2.0;
     f.n_grid = n_grid;
+    // Several probes per forward launch (option "fit_spec"): every launch below is one wave's whole solve per 64 subjects,
+    // and a small population leaves the chip empty -- the grid values ride as parameter sets of one launch, and because a
+    // golden-section step has two outcomes, the probes of the next d steps are a heap of 2^d - 1 brackets evaluated together
+    // (cude_common.hip fit_tree_*).  The same expressions on the same values: the same brackets and result as the
+    // one-probe-per-launch form, 138 forward launches -> 1 + 48 / d + 1.
+    int fdepth = c->opt.fit_spec;
+    const bool fsplit = is_cpep(c) && !adaptive(c) && c->chunks > 1;
+    if (fdepth < 0) {
+        const int64_t waves1 = c->nblocks * (fsplit ? (c->chunks_f > 1 ? c->chunks_f : c->chunks) : 1);
+        const int64_t room = fsplit ? 4096 : 1024;
+        fdepth = 30 * waves1 <= room ? 4 : (14 * waves1 <= room ? 3 : (6 * waves1 <= room ? 2 : 1));
+    }
+    if (c->net.generic()) fdepth = 0;
+    fdepth = std::min(fdepth, (int)cude::kFitSpecMaxDepth);
+    if (fdepth >= 1) {
+        const int P = c->P;
+        const int64_t nb = c->nblocks;
+        const int Lf = fsplit ? (c->chunks_f > 1 ? c->chunks_f : c->chunks) : 1;
+        // sets per launch: the tree's, and for the grid scan as many as ~256 MB of per-set scratch allow
+        const int tree_sets = 2 * ((1 << fdepth) - 1);
+        const double per_set = 8.0 * ((double)N * (2 + (fsplit ? (double)Lf * (3 + c->T) : 0.0)) + (double)nb * (P + 2));
+        const int grid_sets = (int)std::max<int64_t>(1, std::min<int64_t>(n_grid, (int64_t)(256e6 / per_set)));
+        const int max_sets = std::max(tree_sets, grid_sets);
+        DevBuf<double> d_cand, d_sse, d_part, d_vals;
+        HIP_TRY(d_cand.resize((size_t)max_sets * N));
+        HIP_TRY(d_sse.resize((size_t)max_sets * N));
+        HIP_TRY(d_vals.resize((size_t)n_grid));
+        if (fsplit) {
+            HIP_TRY(c->ms_fsum.reserve((size_t)max_sets * Lf * (3 + c->T) * N));
+            HIP_TRY(c->ms_part.reserve((size_t)max_sets * nb * (P + 2)));
+        } else {
+            HIP_TRY(d_part.resize((size_t)max_sets * nb * (P + 2)));
+        }
+        auto solve_sets = [&](int n_sets) -> int32_t {           // SSE of every subject at cand[set][subject]
+            if (is_cpep(c)) {
+                cude::CpepArgs a = cpep_args(c);
+                a.cond = d_cand.p; a.nn = c->nn.p; a.sse = d_sse.p; a.traj = nullptr; a.auc = nullptr;
+                a.g_cond = c->g_cond.p; a.partials = fsplit ? c->ms_part.p : d_part.p;
+                a.n_sets = n_sets; a.set_stride_nn = 0; a.set_stride_cond = N;
+                if (fsplit) {
+                    cude::Cpep2Args a2 = chunk_args(c, a, /*all_blocks=*/true, /*forward_only=*/true);
+                    a2.fsum = c->ms_fsum.p;
+                    HIP_TRY(cude::launch_cpep2(c->net, c->cfg.n_state, false, a2, c->stream));
+                } else {
+                    HIP_TRY(cude::launch_cpep(c->net, c->cfg.n_state, false, a, c->stream));
+                }
+            } else {
+                cude::SuppArgs a = supp_args(c);
+                a.cond = d_cand.p; a.nn = c->nn.p; a.sse = d_sse.p; a.traj = nullptr;
+                a.g_cond = c->g_cond.p; a.partials = d_part.p;
+                a.n_sets = n_sets; a.set_stride_nn = 0; a.set_stride_cond = N;
+                HIP_TRY(cude::launch_supp(c->net, false, a, c->stream));
+            }
+            if (adaptive(c)) { c->have_counts = true; c->have_tape = false; }
+            return CUDE_OK;
+        };
+        std::vector<double> vals((size_t)n_grid);
+        for (int k = 0; k < n_grid; k++) vals[k] = (k == n_grid - 1) ? upper : std::fma((double)k, f.step, lower);
+        HIP_TRY(hipMemcpyAsync(d_vals.p, vals.data(), (size_t)n_grid * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        for (int k0 = 0; k0 < n_grid; k0 += grid_sets) {      // coarse scan of the box
+            const int kn = std::min(grid_sets, n_grid - k0);
+            HIP_TRY(cude::launch_fill_rows(N, kn, d_vals.p + k0, d_cand.p, c->stream));
+            if ((rc = solve_sets(kn))) return rc;
+            HIP_TRY(cude::launch_fit_grid_all(f, k0, kn, d_vals.p, d_sse.p, c->stream));
+            if (k0 == 0 && (rc = maybe_regroup(c))) return rc; // (adaptive mode: the first launch has told the step counts)
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));             // vals (host vector) was read by the copy above
+        HIP_TRY(cude::launch_fit(1, f, 0, 0.0, c->stream));
+        for (int it = 0; it < n_iters;) {                     // golden section inside the bracket, d steps per launch
+            const int d = std::min(fdepth, n_iters - it);
+            HIP_TRY(cude::launch_fit_tree(f, d, 0, 0, d_cand.p, d_sse.p, c->stream));
+            if ((rc = solve_sets(2 * ((1 << d) - 1)))) return rc;
+            it += d;
+            HIP_TRY(cude::launch_fit_tree(f, d, 1, it == n_iters ? 1 : 0, d_cand.p, d_sse.p, c->stream));
+        }
+        if ((rc = run_ensemble(c, false, nullptr, true, f.c, sse_c))) return rc;       // at the returned midpoint
+        HIP_TRY(cude::launch_fit(3, f, 0, 0.0, c->stream));
+        HIP_TRY(hipMemcpyAsync(cond_out, f.c, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (objective_out) HIP_TRY(hipMemcpyAsync(objective_out, f.fc, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (sse_out) HIP_TRY(hipMemcpyAsync(sse_out, sse_c, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return CUDE_OK;
+    }
     // everything below is queued on the stream; the only synchronisation is the copy-back at the end
     for (int k = 0; k < n_grid; k++) {                    // coarse scan of the box
         const double x = (k == n_grid - 1) ? upper : std::fma((double)k, f.step, lower);

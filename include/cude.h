@@ -437,10 +437,10 @@ int32_t cude_xchg_info(cude_ctx* ctx, int32_t* n_ranks, int32_t* rank, int32_t* 
  * Implementation switches (cude_ctx.h `Options` lists them): launch-path override of the tests ("cpep_path" = "1" |
  * "2:L" | "3:B:L"), "cpep_keep", "supp_store", "supp_ckpt", "tape_steps", "exp_table", "ms_split", "auto_regroup",
  * "poll_pinned", "debug_selector", "xchg_allow_plain", "xchg_fail_kinds" (tests), "force_fallback" (tests: cude_set_network takes the fallback kernel for tuned shapes too), "adaptive_team" (adaptive mode, small c-peptide
- * populations: a step's five network evaluations on five waves; 0 = the one-wave kernels), "mh_spec" (speculative Metropolis steps per
+ * populations: a step's five network evaluations on five waves; 0 = the one-wave kernels), "fit_spec" (cude_fit_conditional: probes per forward launch, 0 = one, 1 ... 4 = golden-section steps per launch, -1 = by size), "mh_spec" (speculative Metropolis steps per
  * launch pair in cude_mh_estep / cude_mh_chain: 0 off, 2 ... 4, -1 = by population size; the chain is the same bit for bit).  Values are decimal integers as text unless noted.  Every option is also read once
  * at cude_create from its environment variable (CUDE_CPEP_PATH, CUDE_CPEP_KEEP, CUDE_SUPP_STORE, CUDE_SUPP_CKPT,
- * CUDE_TAPE_STEPS, CUDE_NO_EXPTAB, CUDE_NO_MS_SPLIT, CUDE_NO_AUTO_REGROUP, CUDE_NO_POLL_PINNED, CUDE_DEBUG_SELECTOR, CUDE_ALLOW_PLAIN_MAILBOX, CUDE_XCHG_FAIL_KINDS, CUDE_MH_SPEC, CUDE_NO_ADAPTIVE_TEAM).
+ * CUDE_TAPE_STEPS, CUDE_NO_EXPTAB, CUDE_NO_MS_SPLIT, CUDE_NO_AUTO_REGROUP, CUDE_NO_POLL_PINNED, CUDE_DEBUG_SELECTOR, CUDE_ALLOW_PLAIN_MAILBOX, CUDE_XCHG_FAIL_KINDS, CUDE_MH_SPEC, CUDE_FIT_SPEC, CUDE_NO_ADAPTIVE_TEAM).
  * Options that shape the launch path take effect at the next cude_set_population_*.  No reference line: these are
  * properties of this implementation. */
 int32_t cude_set_option(cude_ctx* ctx, const char* name, const char* value);

@@ -142,3 +142,39 @@ def test_fit_and_profile_against_the_oracle(model):
         assert abs(x_dev[i] - r.x) < 2e-6 and f_dev[i] <= r.fun * (1 + 1e-10) + 1e-14, (i, x_dev[i], r.x)
         checked += 1
     assert checked >= N // 2
+
+
+@pytest.mark.parametrize("case", ["cpep-time-split", "cpep-adaptive", "cpep-one-lane", "supp", "supp-adaptive"])
+def test_several_probes_per_launch_give_the_same_search(case):
+    """Option "fit_spec": the grid values of the coarse scan as parameter sets of one launch, and -- a golden-section step
+    has two outcomes -- the probes of the next d steps as a heap of 2^d - 1 brackets evaluated together.  The same
+    expressions on the same values as the one-probe-per-launch form (fit_spec = 0): minimisers, objectives and SSEs bit for
+    bit, for every depth, when the step count is not a multiple of the depth, with and without a penalty."""
+    from cude.engine import Engine
+    if case.startswith("cpep"):
+        N, arch = 150, (2, 4, 2)
+        c = make_cpep_case(N, arch)
+        box = (-4.0, 3.0)
+    else:
+        c = make_supp_case(90)
+        N, arch, box = 90, c["arch"], (-6.0, 4.0)
+    out = []
+    for depth in (0, 1, 2, 3, 4, -1):
+        if case.startswith("cpep"):
+            eng = Engine("cpep", arch, n_steps=0 if case == "cpep-adaptive" else 30, n_state=2)
+            if case == "cpep-one-lane":
+                eng.set_option("cpep_path", "1")
+            eng.set_option("fit_spec", depth)
+            eng.set_population_cpep(c["tp"], c["G"], c["obs"], c["age"], c["t2dm"])
+        else:
+            eng = Engine("supp", arch, n_steps=0 if case == "supp-adaptive" else 30)
+            eng.set_option("fit_spec", depth)
+            eng.set_population_supp(c["tp"], c["data"])
+        eng.set_params(c["nn"], np.zeros(N))
+        r = list(eng.fit_conditional(box[0], box[1], 21, 13)) + list(eng.fit_conditional(box[0], box[1], 41, 24, 0.35, -0.6))
+        out.append(r)
+        eng.close()
+    assert np.all(np.isfinite(out[0][1]))
+    for r in out[1:]:
+        for a, b in zip(out[0], r):
+            assert np.array_equal(a, b)
